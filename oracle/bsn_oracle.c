@@ -1,0 +1,518 @@
+/*
+ * bsn_oracle.c — CPU restatement of bigsnpr's genotype-matrix hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under bigsnpr_amd/ (the product) may
+ * include, link, import or execute this file.  Only tests/, the smoke() check of
+ * __graft_entry__.py and the `cpu_baseline` leg of bench.py use it, and only as
+ * the checker / CPU baseline, never as the thing shipped.
+ *
+ * Each function restates (does not copy) the loop structure of a reference
+ * translation unit; the reference location is given as file:line relative to
+ * the bigsnpr 1.12.21 tree.  Plain C + OpenMP, no R/Rcpp types: indices are
+ * 0-based here (the reference converts R's 1-based indices with `- 1`,
+ * src/bed-acc.h:64-65).
+ *
+ * Parity status: pinned.  tests/test_oracle_golden.py checks this file against
+ * the reference's own golden data (PLINK r2 file tests/testthat/testdata/
+ * example.ld on inst/extdata/example.bed; clumping.rds; the dense identities of
+ * tests/testthat/test-5-bed-prod-vec.R).  The reference itself cannot be built
+ * in this image (it needs Rcpp.h, mio/mmap.hpp and bigstatsr headers, none of
+ * which exist here), so there is no oracle/_ref.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#else
+static int omp_get_thread_num(void) { return 0; }
+#endif
+
+#define ORC_NA 3 /* integer code used for a missing genotype, src/bed-acc.h:22 */
+
+/* ------------------------------------------------------------------------- */
+/* a1: file validation — src/bed-acc-xptr.cpp:14-35                           */
+/* returns 0 ok, 1 bad magic, 2 not variant-major, 3 size mismatch            */
+int orc_bed_check(const uint8_t *file, int64_t file_size, int64_t n, int64_t m) {
+  if (file_size < 3 || !(file[0] == 0x6C && file[1] == 0x1B)) return 1;
+  if (file[2] != 0x01) return 2;
+  int64_t n_byte = (n + 3) / 4;
+  if (3 + n_byte * m != file_size) return 3;
+  return 0;
+}
+
+/* a2: 2-bit decode — src/bed-acc.h:22-37 (table) and :71-75 (element access).
+ * numeric 2-bit value 0,1,2,3 -> 2, NA, 1, 0 */
+static inline int orc_code(const uint8_t *payload, int64_t n_byte, int64_t i2,
+                           int64_t j2) {
+  static const int num[4] = {2, ORC_NA, 1, 0};
+  uint8_t byte = payload[i2 / 4 + j2 * n_byte];
+  return num[(byte >> (2 * (i2 % 4))) & 3];
+}
+
+void orc_decode_lut(int32_t *lut /* 4 x 256, lut[i + 4*k] */, int na_val) {
+  const int num[4] = {2, na_val, 1, 0};
+  int coeff = 1;
+  for (int i = 0; i < 4; i++) {
+    for (int k = 0; k < 256; k++) lut[i + 4 * k] = num[(k / coeff) % 4];
+    coeff *= 4;
+  }
+}
+
+/* src/bed-mat-acc.cpp:8-25 — dense integer sub-matrix, column-major, NA -> na_val */
+void orc_read_bed(const uint8_t *payload, int64_t n_byte, const int64_t *ind_row,
+                  int64_t n, const int64_t *ind_col, int64_t m, int32_t na_val,
+                  int32_t *out) {
+  for (int64_t j = 0; j < m; j++)
+    for (int64_t i = 0; i < n; i++) {
+      int g = orc_code(payload, n_byte, ind_row[i], ind_col[j]);
+      out[i + j * n] = (g == ORC_NA) ? na_val : g;
+    }
+}
+
+/* a3: per-column scaled table — src/bed-acc.h:98-105: (g - center)/scale, NA -> 0 */
+static void orc_scale_lut(const double *center, const double *scale, int64_t m,
+                          double *lut /* 4 x m */) {
+  for (int64_t j = 0; j < m; j++) {
+    for (int g = 0; g < 3; g++) lut[g + 4 * j] = (g - center[j]) / scale[j];
+    lut[3 + 4 * j] = 0.0;
+  }
+}
+
+/* src/bed-mat-acc.cpp:30-49 */
+void orc_read_bed_scaled(const uint8_t *payload, int64_t n_byte,
+                         const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                         int64_t m, const double *center, const double *scale,
+                         double *out) {
+  double *lut = (double *)malloc(sizeof(double) * 4 * (size_t)m);
+  orc_scale_lut(center, scale, m, lut);
+  for (int64_t j = 0; j < m; j++)
+    for (int64_t i = 0; i < n; i++)
+      out[i + j * n] = lut[orc_code(payload, n_byte, ind_row[i], ind_col[j]) + 4 * j];
+  free(lut);
+}
+
+/* a4: y = A~ x — src/bed-prod-vec.cpp:15-54.  Same structure: per-thread partial
+ * vectors, column quads with the (a+b)+(c+d) grouping, then a row sum over
+ * threads (:53). */
+void orc_pMatVec4(const uint8_t *payload, int64_t n_byte, const int64_t *ind_row,
+                  int64_t n, const int64_t *ind_col, int64_t m, const double *center,
+                  const double *scale, const double *x, double *y, int ncores) {
+  double *lut = (double *)malloc(sizeof(double) * 4 * (size_t)m);
+  orc_scale_lut(center, scale, m, lut);
+  double *res = (double *)calloc((size_t)n * (size_t)ncores, sizeof(double));
+#define MACC(i, j) lut[orc_code(payload, n_byte, ind_row[i], ind_col[j]) + 4 * (j)]
+#pragma omp parallel num_threads(ncores)
+  {
+    double *r = res + (size_t)omp_get_thread_num() * (size_t)n;
+    int64_t m2 = m - 3;
+#pragma omp for nowait
+    for (int64_t j = 0; j < m2; j += 4)
+      for (int64_t i = 0; i < n; i++)
+        r[i] += (x[j] * MACC(i, j) + x[j + 1] * MACC(i, j + 1)) +
+                (x[j + 2] * MACC(i, j + 2) + x[j + 3] * MACC(i, j + 3));
+#pragma omp for
+    for (int64_t j = m - m % 4; j < m; j++)
+      for (int64_t i = 0; i < n; i++) r[i] += x[j] * MACC(i, j);
+  }
+  for (int64_t i = 0; i < n; i++) {
+    double s = 0;
+    for (int t = 0; t < ncores; t++) s += res[i + (size_t)t * (size_t)n];
+    y[i] = s;
+  }
+  free(res);
+  free(lut);
+}
+
+/* a5: z = A~' x — src/bed-prod-vec.cpp:59-97 */
+void orc_cpMatVec4(const uint8_t *payload, int64_t n_byte, const int64_t *ind_row,
+                   int64_t n, const int64_t *ind_col, int64_t m, const double *center,
+                   const double *scale, const double *x, double *z, int ncores) {
+  double *lut = (double *)malloc(sizeof(double) * 4 * (size_t)m);
+  orc_scale_lut(center, scale, m, lut);
+#pragma omp parallel for num_threads(ncores)
+  for (int64_t j = 0; j < m; j++) {
+    double tmp = 0;
+    int64_t i = 0, n2 = n - 3;
+    for (; i < n2; i += 4)
+      tmp += (MACC(i, j) * x[i] + MACC(i + 1, j) * x[i + 1]) +
+             (MACC(i + 2, j) * x[i + 2] + MACC(i + 3, j) * x[i + 3]);
+    for (; i < n; i++) tmp += MACC(i, j) * x[i];
+    z[j] = tmp;
+  }
+#undef MACC
+  free(lut);
+}
+
+/* a6: src/bed-fun.cpp:9-46 */
+void orc_bed_colstats(const uint8_t *payload, int64_t n_byte, const int64_t *ind_row,
+                      int64_t n, const int64_t *ind_col, int64_t m, double *sumX,
+                      double *denoX, int32_t *nb_nona_col, int ncores) {
+#pragma omp parallel for num_threads(ncores)
+  for (int64_t j = 0; j < m; j++) {
+    double xSum = 0, xxSum = 0;
+    int c = (int)n;
+    for (int64_t i = 0; i < n; i++) {
+      double x = orc_code(payload, n_byte, ind_row[i], ind_col[j]);
+      if (x != 3) {
+        xSum += x;
+        xxSum += x * x;
+      } else
+        c--;
+    }
+    sumX[j] = xSum;
+    denoX[j] = xxSum - xSum * xSum / c;
+    nb_nona_col[j] = c;
+  }
+}
+
+/* a7: src/bed-fun.cpp:51-69 — res is 4 x m, rows = counts of 0,1,2,NA */
+void orc_bed_col_counts(const uint8_t *payload, int64_t n_byte, const int64_t *ind_row,
+                        int64_t n, const int64_t *ind_col, int64_t m, int32_t *res,
+                        int ncores) {
+  memset(res, 0, sizeof(int32_t) * 4 * (size_t)m);
+#pragma omp parallel for num_threads(ncores)
+  for (int64_t j = 0; j < m; j++)
+    for (int64_t i = 0; i < n; i++)
+      res[orc_code(payload, n_byte, ind_row[i], ind_col[j]) + 4 * j]++;
+}
+
+/* src/bed-fun.cpp:103-133 (the "next" row f1: X V and row sums of squares) */
+void orc_prod_and_rowSumsSq(const uint8_t *payload, int64_t n_byte,
+                            const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                            int64_t m, const double *center, const double *scale,
+                            const double *V /* m x K col-major */, int64_t K,
+                            double *XV /* n x K */, double *rowSumsSq) {
+  double *lut = (double *)malloc(sizeof(double) * 4 * (size_t)m);
+  orc_scale_lut(center, scale, m, lut);
+  memset(XV, 0, sizeof(double) * (size_t)n * (size_t)K);
+  memset(rowSumsSq, 0, sizeof(double) * (size_t)n);
+  for (int64_t j = 0; j < m; j++)
+    for (int64_t i = 0; i < n; i++) {
+      double x = lut[orc_code(payload, n_byte, ind_row[i], ind_col[j]) + 4 * j];
+      rowSumsSq[i] += x * x;
+      for (int64_t k = 0; k < K; k++) XV[i + k * n] += x * V[j + k * m];
+    }
+  free(lut);
+}
+
+/* ------------------------------------------------------------------------- */
+/* FBM.code256 accessor (bigstatsr SubBMCode256Acc, external): one byte per
+ * genotype, column-major n_total x m_total, value = code256[byte].  Layout as
+ * evidenced in-tree by src/read-plink.cpp:17-48. */
+typedef struct {
+  int kind; /* 0 = bed payload, 1 = FBM.code256 */
+  const uint8_t *data;
+  int64_t ld; /* n_byte (bed) or n_total (FBM) */
+  const double *code256;
+} orc_acc;
+
+static inline double orc_get(const orc_acc *a, int64_t i2, int64_t j2) {
+  if (a->kind == 0) return (double)orc_code(a->data, a->ld, i2, j2);
+  return a->code256[a->data[i2 + j2 * a->ld]];
+}
+
+/* a8: src/colstats.cpp:8-35 (no NA handling) */
+void orc_snp_colstats(const uint8_t *fbm, int64_t n_total, const double *code256,
+                      const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                      int64_t m, double *sumX, double *denoX, int ncores) {
+  orc_acc a = {1, fbm, n_total, code256};
+#pragma omp parallel for num_threads(ncores)
+  for (int64_t j = 0; j < m; j++) {
+    double xSum = 0, xxSum = 0;
+    for (int64_t i = 0; i < n; i++) {
+      double x = orc_get(&a, ind_row[i], ind_col[j]);
+      xSum += x;
+      xxSum += x * x;
+    }
+    sumX[j] = xSum;
+    denoX[j] = xxSum - xSum * xSum / n;
+  }
+}
+
+/* a9: FBM.code256 mat-vec (bigstatsr::big_prodVec / big_cprodVec, external, not
+ * in the tree; callers R/PRS.R:5, R/autoSVD.R:129-134).  Restated as the plain
+ * linear-algebra definition y = G x, z = G' x on decoded values. */
+void orc_fbm_prodVec(const uint8_t *fbm, int64_t n_total, const double *code256,
+                     const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                     int64_t m, const double *x, double *y) {
+  orc_acc a = {1, fbm, n_total, code256};
+  memset(y, 0, sizeof(double) * (size_t)n);
+  for (int64_t j = 0; j < m; j++)
+    for (int64_t i = 0; i < n; i++) y[i] += orc_get(&a, ind_row[i], ind_col[j]) * x[j];
+}
+void orc_fbm_cprodVec(const uint8_t *fbm, int64_t n_total, const double *code256,
+                      const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                      int64_t m, const double *x, double *z) {
+  orc_acc a = {1, fbm, n_total, code256};
+  for (int64_t j = 0; j < m; j++) {
+    double s = 0;
+    for (int64_t i = 0; i < n; i++) s += orc_get(&a, ind_row[i], ind_col[j]) * x[i];
+    z[j] = s;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a14: windowed pairwise-complete correlation — src/corr.cpp:11-97.
+ * Output in CSC order exactly as R/corr.R:43-47 assembles it: for column j0 the
+ * kept rows in ascending order, the diagonal (if fill_diag) last.  Two calls:
+ * first with out_i == NULL to get the per-column counts in p[1..m] (then
+ * cumulated by the caller), or — simpler — this function allocates and returns
+ * through *pi, *px (caller frees with orc_free). */
+static void pair_sums(const orc_acc *a, const int64_t *ind_row, int64_t n, int64_t c0,
+                      int64_t c1, double xSum0, double xxSum0, int *nona_, double *num_,
+                      double *dx_, double *dy_) {
+  int nona = 0;
+  double xSum = xSum0, xxSum = xxSum0, ySum = 0, yySum = 0, xySum = 0;
+  for (int64_t i = 0; i < n; i++) {
+    double x = orc_get(a, ind_row[i], c0);
+    if (x == 3) continue;
+    double y = orc_get(a, ind_row[i], c1);
+    if (y == 3) {
+      xSum -= x;
+      xxSum -= x * x;
+    } else {
+      nona++;
+      ySum += y;
+      yySum += y * y;
+      xySum += x * y;
+    }
+  }
+  *nona_ = nona;
+  *num_ = xySum - xSum * ySum / nona;
+  *dx_ = xxSum - xSum * xSum / nona;
+  *dy_ = yySum - ySum * ySum / nona;
+}
+
+static void col_presums(const orc_acc *a, const int64_t *ind_row, int64_t n, int64_t c0,
+                        double *xSum0, double *xxSum0) {
+  double s = 0, ss = 0;
+  for (int64_t i = 0; i < n; i++) {
+    double x = orc_get(a, ind_row[i], c0);
+    if (x != 3) {
+      s += x;
+      ss += x * x;
+    }
+  }
+  *xSum0 = s;
+  *xxSum0 = ss;
+}
+
+void orc_free(void *p) { free(p); }
+
+/* kind/data/ld/code256 describe the accessor; for FBM the caller passes code256
+ * with NA already recoded to 3 (src/corr.cpp:115-116). */
+int64_t orc_corMat(int kind, const uint8_t *data, int64_t ld, const double *code256,
+                   const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                   double size, const double *thr /* n */, const double *pos /* m */,
+                   int fill_diag, int ncores, int32_t *p /* m+1 */, int32_t **pi,
+                   double **px) {
+  orc_acc a = {kind, data, ld, code256};
+  int32_t **ci = (int32_t **)calloc((size_t)m, sizeof(int32_t *));
+  double **cx = (double **)calloc((size_t)m, sizeof(double *));
+  int32_t *cn = (int32_t *)calloc((size_t)m, sizeof(int32_t));
+#pragma omp parallel for schedule(dynamic, 16) num_threads(ncores)
+  for (int64_t j0 = 0; j0 < m; j0++) {
+    int64_t cap = 16, cnt = 0;
+    int32_t *ind = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
+    double *val = (double *)malloc(sizeof(double) * (size_t)cap);
+    if (fill_diag) {
+      ind[cnt] = (int32_t)j0;
+      val[cnt++] = 1.0;
+    }
+    double xSum0, xxSum0;
+    col_presums(&a, ind_row, n, ind_col[j0], &xSum0, &xxSum0);
+    double pos_min = pos[j0] - size;
+    for (int64_t j = j0 - 1; j >= 0 && pos[j] >= pos_min; j--) {
+      int nona;
+      double num, dx, dy;
+      pair_sums(&a, ind_row, n, ind_col[j0], ind_col[j], xSum0, xxSum0, &nona, &num, &dx,
+                &dy);
+      double r = num / sqrt(dx * dy);
+      /* thr[nona - 1] with nona == 0 reads out of bounds in the reference; r is
+       * NaN there (0/0), so the ISNAN branch decides before thr is consulted */
+      if (isnan(r) || fabs(r) > thr[nona - 1]) {
+        if (r > 1) r = 1; else if (r < -1) r = -1;
+        if (cnt == cap) {
+          cap *= 2;
+          ind = (int32_t *)realloc(ind, sizeof(int32_t) * (size_t)cap);
+          val = (double *)realloc(val, sizeof(double) * (size_t)cap);
+        }
+        ind[cnt] = (int32_t)j;
+        val[cnt++] = r;
+      }
+    }
+    /* rev() — src/corr.cpp:90-92 */
+    for (int64_t a0 = 0, b0 = cnt - 1; a0 < b0; a0++, b0--) {
+      int32_t ti = ind[a0]; ind[a0] = ind[b0]; ind[b0] = ti;
+      double tv = val[a0]; val[a0] = val[b0]; val[b0] = tv;
+    }
+    ci[j0] = ind; cx[j0] = val; cn[j0] = (int32_t)cnt;
+  }
+  int64_t nnz = 0;
+  p[0] = 0;
+  for (int64_t j = 0; j < m; j++) { nnz += cn[j]; p[j + 1] = (int32_t)nnz; }
+  int32_t *oi = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
+  double *ox = (double *)malloc(sizeof(double) * (size_t)(nnz ? nnz : 1));
+  for (int64_t j = 0; j < m; j++) {
+    memcpy(oi + p[j], ci[j], sizeof(int32_t) * (size_t)cn[j]);
+    memcpy(ox + p[j], cx[j], sizeof(double) * (size_t)cn[j]);
+    free(ci[j]); free(cx[j]);
+  }
+  free(ci); free(cx); free(cn);
+  *pi = oi; *px = ox;
+  return nnz;
+}
+
+/* a15: src/ld-scores.cpp:11-78.  The reference accumulates with omp atomics in
+ * a schedule-dependent order; this restatement accumulates in j0-major order
+ * (the ncores = 1 order). */
+void orc_ld_scores(int kind, const uint8_t *data, int64_t ld, const double *code256,
+                   const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                   double size, const double *pos, double *res) {
+  orc_acc a = {kind, data, ld, code256};
+  for (int64_t j = 0; j < m; j++) res[j] = 1.0;
+  for (int64_t j0 = 0; j0 < m; j0++) {
+    double xSum0, xxSum0;
+    col_presums(&a, ind_row, n, ind_col[j0], &xSum0, &xxSum0);
+    double pos_min = pos[j0] - size;
+    for (int64_t j = j0 - 1; j >= 0 && pos[j] >= pos_min; j--) {
+      int nona;
+      double num, dx, dy;
+      pair_sums(&a, ind_row, n, ind_col[j0], ind_col[j], xSum0, xxSum0, &nona, &num, &dx,
+                &dy);
+      double r2 = num * num / (dx * dy);
+      if (!isnan(r2)) { res[j0] += r2; res[j] += r2; }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a16: greedy clumping.  src/clumping-utils.h:12-43 (which_to_check),
+ * src/clumping.cpp:10-91 (FBM), src/clumping-bed.cpp:11-91 (bed).
+ * The reference runs the rank-ordered loop with dynamic OpenMP scheduling and
+ * spin-waits on keep[] == -1; the outcome equals the sequential rank-order
+ * sweep (tests/testthat/test-7-OpenMP.R:104-115 asserts identical results), which
+ * is what is restated here. ordInd is 0-based; rankInd[j] = rank of column j. */
+static int which_to_check(int64_t j0, const int32_t *keep, const int32_t *rankInd,
+                          const double *pos, int64_t m, double size, int32_t *out) {
+  int cnt = 0;
+  double pos_min = pos[j0] - size, pos_max = pos[j0] + size;
+  int not_min = 1, not_max = 1;
+  for (int64_t k = 1; not_max || not_min; k++) {
+    if (not_max) {
+      int64_t j = j0 + k;
+      not_max = (j < m) && (pos[j] <= pos_max);
+      if (not_max && rankInd[j0] > rankInd[j] && keep[j] != 0) out[cnt++] = (int32_t)j;
+    }
+    if (not_min) {
+      int64_t j = j0 - k;
+      not_min = (j >= 0) && (pos[j] >= pos_min);
+      if (not_min && rankInd[j0] > rankInd[j] && keep[j] != 0) out[cnt++] = (int32_t)j;
+    }
+  }
+  return cnt;
+}
+
+void orc_clumping_chr(const uint8_t *fbm, int64_t n_total, const double *code256,
+                      const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                      int64_t m, const int32_t *ordInd, const int32_t *rankInd,
+                      const double *pos, const double *sumX, const double *denoX,
+                      double size, double thr, int32_t *keep /* m, init -1 */) {
+  orc_acc a = {1, fbm, n_total, code256};
+  int32_t *chk = (int32_t *)malloc(sizeof(int32_t) * (size_t)(m ? m : 1));
+  for (int64_t k = 0; k < m; k++) {
+    int64_t j0 = ordInd[k];
+    int nb = which_to_check(j0, keep, rankInd, pos, m, size, chk);
+    int keep_j0 = 1;
+    for (int k2 = 0; k2 < nb; k2++) {
+      int64_t j = chk[k2];
+      if (keep[j] == 0) continue;
+      double xySum = 0;
+      for (int64_t i = 0; i < n; i++)
+        xySum += orc_get(&a, ind_row[i], ind_col[j]) * orc_get(&a, ind_row[i], ind_col[j0]);
+      double num = xySum - sumX[j] * sumX[j0] / n;
+      double r2 = num * num / (denoX[j] * denoX[j0]);
+      if (r2 > thr) { keep_j0 = 0; break; }
+    }
+    keep[j0] = keep_j0;
+  }
+  free(chk);
+}
+
+void orc_bed_clumping_chr(const uint8_t *payload, int64_t n_byte, const int64_t *ind_row,
+                          int64_t n, const int64_t *ind_col, int64_t m,
+                          const double *center, const double *scale,
+                          const int32_t *ordInd, const int32_t *rankInd,
+                          const double *pos, double size, double thr,
+                          int32_t *keep /* m, init -1 */) {
+  double *lut = (double *)malloc(sizeof(double) * 4 * (size_t)(m ? m : 1));
+  orc_scale_lut(center, scale, m, lut);
+  int32_t *chk = (int32_t *)malloc(sizeof(int32_t) * (size_t)(m ? m : 1));
+  for (int64_t k = 0; k < m; k++) {
+    int64_t j0 = ordInd[k];
+    int nb = which_to_check(j0, keep, rankInd, pos, m, size, chk);
+    int keep_j0 = 1;
+    for (int k2 = 0; k2 < nb; k2++) {
+      int64_t j = chk[k2];
+      if (keep[j] == 0) continue;
+      double r = 0;
+      for (int64_t i = 0; i < n; i++)
+        r += lut[orc_code(payload, n_byte, ind_row[i], ind_col[j]) + 4 * j] *
+             lut[orc_code(payload, n_byte, ind_row[i], ind_col[j0]) + 4 * j0];
+      if (r * r > thr) { keep_j0 = 0; break; }
+    }
+    keep[j0] = keep_j0;
+  }
+  free(chk);
+  free(lut);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Synthetic .bed payload generator: counter-based, integer
+ * only, so that the device generator (bigsnpr_amd/csrc/generate.hip) produces
+ * the identical bytes.  Not a restatement of reference code (the reference has
+ * no generator for .bed); specified in DESIGN.md §"Synthetic inputs". */
+static inline uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+static inline uint32_t gen_pop(uint32_t seed, uint32_t i, uint32_t npop) {
+  uint32_t u = mix32(i * 0x9E3779B1U + mix32(seed ^ 0xA5A5A5A5U)) >> 8; /* 24 bit */
+  uint32_t u2 = (uint32_t)(((uint64_t)u * u) >> 24);                    /* skewed */
+  return (uint32_t)(((uint64_t)u2 * npop) >> 24);
+}
+static inline uint32_t gen_freq16(uint32_t seed, uint32_t j, uint32_t k) {
+  uint32_t hj = mix32(j * 0x85EBCA6BU + mix32(seed ^ 0x3C6EF372U));
+  int32_t p = 3277 + (int32_t)(((hj & 0xFFFF) * 29491U) >> 16); /* 0.05 .. 0.5 */
+  uint32_t hk = mix32(hj + (k + 1) * 0xC2B2AE35U);
+  int32_t amp = 1311 + 393 * (int32_t)(k % 24);                 /* 0.02 .. 0.16 */
+  int32_t dev = (int32_t)(((int64_t)((int32_t)(hk & 0xFFFF) - 32768) * amp) >> 15);
+  p += dev;
+  if (p < 655) p = 655;
+  if (p > 64880) p = 64880;
+  return (uint32_t)p;
+}
+static inline uint32_t gen_code(uint32_t seed, uint32_t i, uint32_t j, uint32_t p16,
+                                uint32_t na16) {
+  uint32_t r = mix32(i * 0x9E3779B1U + mix32(j * 0x85EBCA6BU + seed));
+  uint32_t r2 = mix32(r ^ 0x68E31DA4U);
+  if ((r2 & 0xFFFF) < na16) return 1; /* missing */
+  uint32_t g = ((r & 0xFFFF) < p16) + ((r >> 16) < p16);
+  return g == 2 ? 0u : (g == 1 ? 2u : 3u); /* PLINK 2-bit: 00 = 2 copies, 10 = 1, 11 = 0 */
+}
+
+void orc_fake_bed(uint8_t *payload, int64_t n, int64_t m, int64_t n_byte, uint32_t seed,
+                  uint32_t npop, uint32_t na16, int64_t j_begin) {
+  for (int64_t j = 0; j < m; j++) {
+    uint32_t jj = (uint32_t)(j + j_begin);
+    uint8_t *col = payload + j * n_byte;
+    memset(col, 0, (size_t)n_byte);
+    for (int64_t i = 0; i < n; i++) {
+      uint32_t k = gen_pop(seed, (uint32_t)i, npop);
+      uint32_t c = gen_code(seed, (uint32_t)i, jj, gen_freq16(seed, jj, k), na16);
+      col[i / 4] |= (uint8_t)(c << (2 * (i % 4)));
+    }
+  }
+}
