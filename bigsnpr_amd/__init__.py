@@ -1,0 +1,22 @@
+"""bigsnpr_amd — MI355X (gfx950) implementation of bigsnpr's genotype-matrix hot path.
+
+The product is libbigsnpr_hip.so (hand-written HIP kernels behind the C ABI of
+include/bigsnpr_hip.h); this package is the host-side mirror of the reference's R API
+used by the tests and the benchmark.  No CPU fallback exists anywhere in this package.
+"""
+from ._lib import BsnError, DeviceArray, load  # noqa: F401
+from .bed import (ERROR_DIM, ScaledOp, bed, bed_colstats, bed_counts, bed_cprodVec,  # noqa: F401
+                  bed_MAF, bed_prodVec, bed_scaleBinom, cols_along, read_bed,
+                  read_bed_scaled, rows_along)
+
+
+def selftest():
+    from ._lib import check
+    check(load().bsn_selftest())
+
+
+def device_count():
+    import ctypes
+    n = ctypes.c_int(0)
+    load().bsn_device_count(ctypes.byref(n))
+    return n.value

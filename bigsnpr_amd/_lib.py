@@ -1,0 +1,136 @@
+"""ctypes binding of libbigsnpr_hip.so (the C ABI in include/bigsnpr_hip.h).
+
+There is no fallback: if the shared library is missing, or a compute entry point is
+called without a HIP device, this raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbigsnpr_hip.so")
+
+u8p = C.POINTER(C.c_uint8)
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+f64p = C.POINTER(C.c_double)
+vp = C.c_void_p
+i64 = C.c_int64
+
+# name -> (restype, argtypes); kept in one table so tests can check that every symbol
+# declared in include/bigsnpr_hip.h is exported and bound.
+SIGNATURES = {
+    "bsn_last_error": (C.c_char_p, []),
+    "bsn_version": (C.c_int, []),
+    "bsn_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "bsn_set_device": (C.c_int, [C.c_int]),
+    "bsn_selftest": (C.c_int, []),
+    "bsn_bed_open": (C.c_int, [C.c_char_p, i64, i64, C.POINTER(vp)]),
+    "bsn_bed_from_host": (C.c_int, [u8p, i64, i64, i64, C.POINTER(vp)]),
+    "bsn_bed_from_fbm": (C.c_int, [u8p, i64, i64, i64, C.POINTER(vp)]),
+    "bsn_bed_synthetic": (C.c_int, [i64, i64, C.c_uint32, C.c_uint32, C.c_uint32, i64, C.POINTER(vp)]),
+    "bsn_bed_close": (C.c_int, [vp]),
+    "bsn_bed_nrow": (i64, [vp]),
+    "bsn_bed_ncol": (i64, [vp]),
+    "bsn_bed_bytes": (i64, [vp]),
+    "bsn_bed_download": (C.c_int, [vp, u8p]),
+    "bsn_bed_prodvec": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, f64p, f64p]),
+    "bsn_bed_cprodvec": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, f64p, f64p]),
+    "bsn_bed_col_counts": (C.c_int, [vp, i64p, i64, i64p, i64, i32p]),
+    "bsn_bed_colstats": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, i32p, i32p]),
+    "bsn_snp_colstats": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p]),
+    "bsn_bed_read": (C.c_int, [vp, i64p, i64, i64p, i64, C.c_int32, i32p]),
+    "bsn_bed_read_scaled": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, f64p]),
+    "bsn_op_create": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, C.POINTER(vp)]),
+    "bsn_op_destroy": (C.c_int, [vp]),
+    "bsn_op_set_slices": (C.c_int, [vp, C.c_int]),
+    "bsn_op_prod": (C.c_int, [vp, vp, i64, C.c_int, vp, i64]),
+    "bsn_op_cprod": (C.c_int, [vp, vp, i64, C.c_int, vp, i64]),
+    "bsn_op_sync": (C.c_int, [vp]),
+    "bsn_malloc": (C.c_int, [C.POINTER(vp), i64]),
+    "bsn_free": (C.c_int, [vp]),
+    "bsn_memcpy_h2d": (C.c_int, [vp, vp, i64]),
+    "bsn_memcpy_d2h": (C.c_int, [vp, vp, i64]),
+    "bsn_device_sync": (C.c_int, []),
+    "bsn_timer_start": (C.c_int, [vp]),
+    "bsn_timer_stop": (C.c_int, [vp, f64p]),
+}
+
+_lib = None
+
+
+class BsnError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s not found: build it with `python -m bigsnpr_amd.build` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise BsnError(load().bsn_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def as_i64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int64)
+
+
+def as_f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+class DeviceArray:
+    """A column-major fp64 matrix in HBM owned by the library (rows x cols)."""
+
+    def __init__(self, rows, cols=1):
+        self.rows, self.cols = int(rows), int(cols)
+        p = vp()
+        check(load().bsn_malloc(C.byref(p), self.rows * self.cols * 8))
+        self.ptr = p
+
+    @classmethod
+    def from_numpy(cls, a):
+        a = np.asarray(a, dtype=np.float64)
+        if a.ndim == 1:
+            a = a[:, None]
+        d = cls(a.shape[0], a.shape[1])
+        h = np.asfortranarray(a)
+        check(load().bsn_memcpy_h2d(d.ptr, h.ctypes.data_as(vp), h.nbytes))
+        return d
+
+    def to_numpy(self):
+        h = np.empty((self.rows, self.cols), dtype=np.float64, order="F")
+        check(load().bsn_memcpy_d2h(h.ctypes.data_as(vp), self.ptr, h.nbytes))
+        return h
+
+    def col_ptr(self, j):
+        return vp(self.ptr.value + 8 * self.rows * j)
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value:
+            load().bsn_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,431 @@
+// api.hip — the extern "C" surface declared in include/bigsnpr_hip.h.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <cstring>
+#include <memory>
+
+#include "bsn_internal.hpp"
+
+namespace bsn {
+
+static thread_local std::string g_err;
+void set_error(const char *msg) { g_err = msg ? msg : ""; }
+void fail(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  throw Error(buf);
+}
+
+static void require_gpu() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    fail("no HIP device available: libbigsnpr_hip has no CPU fallback (%s)",
+         e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+}
+
+static std::vector<int32_t> to_i32(const int64_t *ind, int64_t len, int64_t limit, const char *what) {
+  std::vector<int32_t> v((size_t)len);
+  for (int64_t i = 0; i < len; i++) {
+    if (ind[i] < 0 || ind[i] >= limit)
+      // bigstatsr vec_int_to_size(): "Tested %s < %s. Subscript out of bounds."
+      fail("Tested %lld < %lld. Subscript out of bounds (%s).", (long long)ind[i], (long long)limit,
+           what);
+    v[(size_t)i] = (int32_t)ind[i];
+  }
+  return v;
+}
+
+static void free_bed(bsn_bed *b) {
+  if (!b) return;
+  if (b->d_img) (void)hipFree(b->d_img);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+}
+
+static void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n,
+                    const int64_t *ind_col, int64_t m, const double *center, const double *scale) {
+  if (n <= 0 || m <= 0) fail("'ind.row' and 'ind.col' can't be empty.");
+  if (bed->n >= (int64_t)1 << 31 || bed->m >= (int64_t)1 << 31) fail("dimension too large");
+  BSN_HIP(hipSetDevice(bed->device));
+  op->bed = bed;
+  op->n = n;
+  op->m = m;
+  // rows
+  bool ident = (n == bed->n);
+  if (ind_row) {
+    for (int64_t i = 0; ident && i < n; i++) ident = (ind_row[i] == i);
+  }
+  op->rows_identity = ident;
+  if (!ident) {
+    auto r = to_i32(ind_row, n, bed->n, "ind.row");
+    BSN_HIP(hipMemcpyAsync(op->d_rows.ensure((size_t)n), r.data(), (size_t)n * 4,
+                           hipMemcpyHostToDevice, bed->stream));
+    BSN_HIP(hipStreamSynchronize(bed->stream));
+  }
+  // cols
+  bool contig = true;
+  int64_t c0 = ind_col ? ind_col[0] : 0;
+  if (ind_col)
+    for (int64_t j = 0; contig && j < m; j++) contig = (ind_col[j] == c0 + j);
+  if (c0 < 0 || c0 >= bed->m || (contig && c0 + m > bed->m))
+    fail("Tested %lld < %lld. Subscript out of bounds (ind.col).", (long long)(c0 + m - 1),
+         (long long)bed->m);
+  op->cols_contig = contig;
+  op->col0 = contig ? c0 : 0;
+  if (!contig) {
+    auto c = to_i32(ind_col, m, bed->m, "ind.col");
+    int64_t m_pad = bsn::round_up(m, 64);
+    c.resize((size_t)m_pad, c[0]);
+    BSN_HIP(hipMemcpyAsync(op->d_cols.ensure((size_t)m_pad), c.data(), (size_t)m_pad * 4,
+                           hipMemcpyHostToDevice, bed->stream));
+    BSN_HIP(hipStreamSynchronize(bed->stream));
+  }
+  // centre / scale (defaults 0 / 1, R/bed-mult-vec.R:23-24)
+  std::vector<double> tmp((size_t)m);
+  for (int64_t j = 0; j < m; j++) tmp[(size_t)j] = center ? center[j] : 0.0;
+  BSN_HIP(hipMemcpyAsync(op->d_center.ensure((size_t)m), tmp.data(), (size_t)m * 8,
+                         hipMemcpyHostToDevice, bed->stream));
+  BSN_HIP(hipStreamSynchronize(bed->stream));
+  for (int64_t j = 0; j < m; j++) tmp[(size_t)j] = scale ? scale[j] : 1.0;
+  BSN_HIP(hipMemcpyAsync(op->d_scale.ensure((size_t)m), tmp.data(), (size_t)m * 8,
+                         hipMemcpyHostToDevice, bed->stream));
+  BSN_HIP(hipStreamSynchronize(bed->stream));
+}
+
+// counts for an arbitrary sub-view into a host 4 x m int32 array
+static void counts_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                        int64_t m, int32_t *res) {
+  bsn_op op;
+  fill_op(&op, bed, ind_row, n, ind_col, m, nullptr, nullptr);
+  DevBuf<int32_t> d_counts;
+  d_counts.ensure((size_t)4 * m);
+  if (op.rows_identity) {
+    counts_all_rows(bed, op.cols_contig ? nullptr : op.d_cols.p, op.col0, m, d_counts.p);
+  } else {
+    std::vector<double> w((size_t)bed->n, 0.0);
+    for (int64_t i = 0; i < n; i++) w[(size_t)ind_row[i]] += 1.0;
+    DevBuf<double> d_w;
+    BSN_HIP(hipMemcpyAsync(d_w.ensure((size_t)bed->n), w.data(), (size_t)bed->n * 8,
+                           hipMemcpyHostToDevice, bed->stream));
+    BSN_HIP(hipStreamSynchronize(bed->stream));
+    counts_weighted(&op, d_w.p, n, d_counts.p);
+  }
+  BSN_HIP(hipMemcpyAsync(res, d_counts.p, (size_t)4 * m * 4, hipMemcpyDeviceToHost, bed->stream));
+  BSN_HIP(hipStreamSynchronize(bed->stream));
+}
+
+}  // namespace bsn
+
+using namespace bsn;
+
+extern "C" {
+
+const char *bsn_last_error(void) { return g_err.c_str(); }
+int bsn_version(void) { return 100; }
+
+int bsn_device_count(int *count) {
+  return guarded([&] {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+  });
+}
+
+int bsn_set_device(int device) {
+  return guarded([&] {
+    require_gpu();
+    BSN_HIP(hipSetDevice(device));
+  });
+}
+
+int bsn_selftest(void) {
+  return guarded([&] {
+    require_gpu();
+    selftest();
+  });
+}
+
+int bsn_bed_from_host(const uint8_t *payload, int64_t n, int64_t m, int64_t n_byte, bsn_bed **out) {
+  return guarded([&] {
+    require_gpu();
+    if (n_byte < (n + 3) / 4) fail("n or p does not match the dimensions of the file.");
+    std::unique_ptr<bsn_bed, void (*)(bsn_bed *)> b(new bsn_bed(), free_bed);
+    image_alloc(b.get(), n, m);
+    image_from_host(b.get(), payload, n_byte);
+    *out = b.release();
+  });
+}
+
+int bsn_bed_open(const char *path, int64_t n, int64_t m, bsn_bed **out) {
+  return guarded([&] {
+    // validation order and messages of src/bed-acc-xptr.cpp:14-35
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) fail("Error when mapping file:\n  %s.\n", strerror(errno));
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+      close(fd);
+      fail("Error when mapping file:\n  %s.\n", strerror(errno));
+    }
+    size_t size = (size_t)st.st_size;
+    void *map = size ? mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+    close(fd);
+    if (map == MAP_FAILED) fail("Error when mapping file:\n  %s.\n", strerror(errno));
+    struct Unmap {
+      void *p;
+      size_t s;
+      ~Unmap() { munmap(p, s); }
+    } unmap{map, size};
+    const uint8_t *f = (const uint8_t *)map;
+    if (size < 3 || !(f[0] == 0x6C && f[1] == 0x1B)) fail("File is not a binary PED file.");
+    if (f[2] != 0x01) fail("Variant-major is the only mode supported.");
+    int64_t n_byte = (n + 3) / 4;
+    if (n <= 0 || m <= 0 || (size_t)(3 + n_byte * m) != size)
+      fail("n or p does not match the dimensions of the file.");
+    require_gpu();
+    std::unique_ptr<bsn_bed, void (*)(bsn_bed *)> b(new bsn_bed(), free_bed);
+    image_alloc(b.get(), n, m);
+    image_from_host(b.get(), f + 3, n_byte);
+    *out = b.release();
+  });
+}
+
+int bsn_bed_from_fbm(const uint8_t *bytes, int64_t n, int64_t m, int64_t ld, bsn_bed **out) {
+  return guarded([&] {
+    require_gpu();
+    if (ld < n) fail("Incompatibility between dimensions.");
+    std::unique_ptr<bsn_bed, void (*)(bsn_bed *)> b(new bsn_bed(), free_bed);
+    image_alloc(b.get(), n, m);
+    image_from_fbm(b.get(), bytes, ld);
+    *out = b.release();
+  });
+}
+
+int bsn_bed_synthetic(int64_t n, int64_t m, uint32_t seed, uint32_t npop, uint32_t na16,
+                      int64_t j_begin, bsn_bed **out) {
+  return guarded([&] {
+    require_gpu();
+    std::unique_ptr<bsn_bed, void (*)(bsn_bed *)> b(new bsn_bed(), free_bed);
+    image_alloc(b.get(), n, m);
+    image_generate(b.get(), seed, npop ? npop : 1, na16, j_begin);
+    *out = b.release();
+  });
+}
+
+int bsn_bed_close(bsn_bed *bed) {
+  return guarded([&] {
+    if (bed) {
+      (void)hipSetDevice(bed->device);
+      free_bed(bed);
+    }
+  });
+}
+
+int64_t bsn_bed_nrow(const bsn_bed *bed) { return bed->n; }
+int64_t bsn_bed_ncol(const bsn_bed *bed) { return bed->m; }
+int64_t bsn_bed_bytes(const bsn_bed *bed) { return bed->pitch * bed->m; }
+
+int bsn_bed_download(bsn_bed *bed, uint8_t *payload_out) {
+  return guarded([&] {
+    BSN_HIP(hipSetDevice(bed->device));
+    image_download(bed, payload_out);
+  });
+}
+
+// ---- operator -------------------------------------------------------------------
+int bsn_op_create(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                  int64_t m, const double *center, const double *scale, bsn_op **out) {
+  return guarded([&] {
+    std::unique_ptr<bsn_op> op(new bsn_op());
+    fill_op(op.get(), bed, ind_row, n, ind_col, m, center, scale);
+    *out = op.release();
+  });
+}
+
+int bsn_op_destroy(bsn_op *op) {
+  return guarded([&] {
+    if (op) {
+      (void)hipSetDevice(op->bed->device);
+      delete op;
+    }
+  });
+}
+
+int bsn_op_set_slices(bsn_op *op, int slices) {
+  return guarded([&] {
+    if (slices < 1 || slices > 7) fail("slices must be in 1..7");
+    op->slices = slices;
+  });
+}
+
+int bsn_op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy) {
+  return guarded([&] {
+    BSN_HIP(hipSetDevice(op->bed->device));
+    op_prod(op, d_X, ldx, nvec, d_Y, ldy);
+  });
+}
+
+int bsn_op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z, int64_t ldz) {
+  return guarded([&] {
+    BSN_HIP(hipSetDevice(op->bed->device));
+    op_cprod(op, d_X, ldx, nvec, d_Z, ldz);
+  });
+}
+
+int bsn_op_sync(bsn_op *op) {
+  return guarded([&] { BSN_HIP(hipStreamSynchronize(op->bed->stream)); });
+}
+
+// ---- .Call replacements ------------------------------------------------------------
+static void matvec_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                        int64_t m, const double *center, const double *scale, const double *x,
+                        double *out, bool transpose) {
+  bsn_op op;
+  fill_op(&op, bed, ind_row, n, ind_col, m, center, scale);
+  op.slices = 7;  // 56-bit fixed point: fp64-grade for a single vector, still one MFMA column block
+  int64_t nin = transpose ? n : m, nout = transpose ? m : n;
+  DevBuf<double> d_in, d_out;
+  BSN_HIP(hipMemcpyAsync(d_in.ensure((size_t)nin), x, (size_t)nin * 8, hipMemcpyHostToDevice,
+                         bed->stream));
+  d_out.ensure((size_t)nout);
+  if (transpose)
+    op_cprod(&op, d_in.p, nin, 1, d_out.p, nout);
+  else
+    op_prod(&op, d_in.p, nin, 1, d_out.p, nout);
+  BSN_HIP(hipMemcpyAsync(out, d_out.p, (size_t)nout * 8, hipMemcpyDeviceToHost, bed->stream));
+  BSN_HIP(hipStreamSynchronize(bed->stream));
+}
+
+int bsn_bed_prodvec(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                    int64_t m, const double *center, const double *scale, const double *x,
+                    double *y) {
+  return guarded([&] { matvec_host(bed, ind_row, n, ind_col, m, center, scale, x, y, false); });
+}
+
+int bsn_bed_cprodvec(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                     int64_t m, const double *center, const double *scale, const double *x,
+                     double *z) {
+  return guarded([&] { matvec_host(bed, ind_row, n, ind_col, m, center, scale, x, z, true); });
+}
+
+int bsn_bed_col_counts(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                       int64_t m, int32_t *res) {
+  return guarded([&] { counts_host(bed, ind_row, n, ind_col, m, res); });
+}
+
+int bsn_bed_colstats(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                     int64_t m, double *sumX, double *denoX, int32_t *nb_nona_col,
+                     int32_t *n_bad) {
+  return guarded([&] {
+    // integer-exact restatement of src/bed-fun.cpp:22-38 from the code counts:
+    // xSum = n1 + 2 n2, xxSum = n1 + 4 n2 (both exact in fp64), c = n - nNA
+    std::vector<int32_t> cnt((size_t)4 * m);
+    counts_host(bed, ind_row, n, ind_col, m, cnt.data());
+    int32_t bad = 0;
+    for (int64_t j = 0; j < m; j++) {
+      const int32_t *c = &cnt[(size_t)4 * j];
+      double xSum = (double)c[1] + 2.0 * c[2], xxSum = (double)c[1] + 4.0 * c[2];
+      int32_t nona = (int32_t)(n - c[3]);
+      sumX[j] = xSum;
+      denoX[j] = xxSum - xSum * xSum / nona;
+      nb_nona_col[j] = nona;
+      if (2 * (int64_t)nona < n) bad++;
+    }
+    if (n_bad) *n_bad = bad;
+  });
+}
+
+int bsn_snp_colstats(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                     int64_t m, double *sumX, double *denoX) {
+  return guarded([&] {
+    // src/colstats.cpp:22-32: no NA handling, denominator n; a code-3 byte counts as 3
+    std::vector<int32_t> cnt((size_t)4 * m);
+    counts_host(bed, ind_row, n, ind_col, m, cnt.data());
+    for (int64_t j = 0; j < m; j++) {
+      const int32_t *c = &cnt[(size_t)4 * j];
+      double xSum = (double)c[1] + 2.0 * c[2] + 3.0 * c[3];
+      double xxSum = (double)c[1] + 4.0 * c[2] + 9.0 * c[3];
+      sumX[j] = xSum;
+      denoX[j] = xxSum - xSum * xSum / n;
+    }
+  });
+}
+
+static void read_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                      int64_t m, const double *center, const double *scale, int32_t na_val,
+                      int32_t *out_i, double *out_d) {
+  if (n <= 0 || m <= 0) fail("'ind.row' and 'ind.col' can't be empty.");
+  BSN_HIP(hipSetDevice(bed->device));
+  auto r = to_i32(ind_row, n, bed->n, "ind.row");
+  auto c = to_i32(ind_col, m, bed->m, "ind.col");
+  DevBuf<int32_t> d_r, d_c, d_oi;
+  DevBuf<double> d_ce, d_sc, d_od;
+  BSN_HIP(hipMemcpy(d_r.ensure((size_t)n), r.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  BSN_HIP(hipMemcpy(d_c.ensure((size_t)m), c.data(), (size_t)m * 4, hipMemcpyHostToDevice));
+  if (out_d) {
+    BSN_HIP(hipMemcpy(d_ce.ensure((size_t)m), center, (size_t)m * 8, hipMemcpyHostToDevice));
+    BSN_HIP(hipMemcpy(d_sc.ensure((size_t)m), scale, (size_t)m * 8, hipMemcpyHostToDevice));
+    d_od.ensure((size_t)n * m);
+  } else {
+    d_oi.ensure((size_t)n * m);
+  }
+  read_dense(bed, d_r.p, n, d_c.p, m, d_ce.p, d_sc.p, na_val, d_oi.p, d_od.p);
+  BSN_HIP(hipStreamSynchronize(bed->stream));
+  if (out_d)
+    BSN_HIP(hipMemcpy(out_d, d_od.p, (size_t)n * m * 8, hipMemcpyDeviceToHost));
+  else
+    BSN_HIP(hipMemcpy(out_i, d_oi.p, (size_t)n * m * 4, hipMemcpyDeviceToHost));
+}
+
+int bsn_bed_read(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                 int64_t m, int32_t na_val, int32_t *out) {
+  return guarded([&] { read_host(bed, ind_row, n, ind_col, m, nullptr, nullptr, na_val, out, nullptr); });
+}
+
+int bsn_bed_read_scaled(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                        int64_t m, const double *center, const double *scale, double *out) {
+  return guarded([&] { read_host(bed, ind_row, n, ind_col, m, center, scale, 0, nullptr, out); });
+}
+
+// ---- helpers ---------------------------------------------------------------------------
+int bsn_malloc(void **d_ptr, int64_t bytes) {
+  return guarded([&] {
+    require_gpu();
+    BSN_HIP(hipMalloc(d_ptr, (size_t)bytes));
+  });
+}
+int bsn_free(void *d_ptr) {
+  return guarded([&] { BSN_HIP(hipFree(d_ptr)); });
+}
+int bsn_memcpy_h2d(void *d_dst, const void *src, int64_t bytes) {
+  return guarded([&] { BSN_HIP(hipMemcpy(d_dst, src, (size_t)bytes, hipMemcpyHostToDevice)); });
+}
+int bsn_memcpy_d2h(void *dst, const void *d_src, int64_t bytes) {
+  return guarded([&] { BSN_HIP(hipMemcpy(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost)); });
+}
+int bsn_device_sync(void) {
+  return guarded([&] { BSN_HIP(hipDeviceSynchronize()); });
+}
+int bsn_timer_start(bsn_bed *bed) {
+  return guarded([&] { BSN_HIP(hipEventRecord(bed->ev0, bed->stream)); });
+}
+int bsn_timer_stop(bsn_bed *bed, double *ms) {
+  return guarded([&] {
+    BSN_HIP(hipEventRecord(bed->ev1, bed->stream));
+    BSN_HIP(hipEventSynchronize(bed->ev1));
+    float t = 0;
+    BSN_HIP(hipEventElapsedTime(&t, bed->ev0, bed->ev1));
+    *ms = t;
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+// Internal declarations shared by the translation units of libbigsnpr_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "bigsnpr_hip.h"
+
+namespace bsn {
+
+// ---- errors ----------------------------------------------------------------
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+void set_error(const char *msg);
+[[noreturn]] void fail(const char *fmt, ...);
+
+#define BSN_HIP(expr)                                                             \
+  do {                                                                            \
+    hipError_t e__ = (expr);                                                      \
+    if (e__ != hipSuccess)                                                        \
+      ::bsn::fail("HIP error %s at %s:%d (%s)", hipGetErrorString(e__), __FILE__, \
+                  __LINE__, #expr);                                               \
+  } while (0)
+
+// Every extern "C" entry point body is wrapped with this.
+template <class F>
+int guarded(F &&f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception &ex) {
+    set_error(ex.what());
+    return 1;
+  } catch (...) {
+    set_error("unknown C++ exception");
+    return 1;
+  }
+}
+
+// ---- device buffer ------------------------------------------------------------
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  // grow-only
+  T *ensure(size_t count) {
+    if (count > n) {
+      release();
+      BSN_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+      n = count;
+    }
+    return p;
+  }
+};
+
+constexpr int64_t kPitchAlign = 256;  // bytes; one SNP row = pitch bytes, 1024 samples per 256 B
+
+inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+}  // namespace bsn
+
+// ---- the handle -------------------------------------------------------------
+// HBM layout: variant-major like the file (src/bed-acc.h:71-75): variant j occupies
+// bytes [j*pitch, j*pitch + n_byte); sample i sits in bits 2*(i%4) of byte i/4.
+// pitch = n_byte rounded up to 256 B.  Pad samples (pad bits of the last real byte and
+// all pad bytes) are coded 0b11 (genotype 0, not missing) so that they contribute
+// nothing to any plane product; kernels may therefore run over [0, 4*pitch) samples.
+struct bsn_bed {
+  int64_t n = 0, m = 0, n_byte = 0, pitch = 0;
+  uint8_t *d_img = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct bsn_op {
+  bsn_bed *bed = nullptr;
+  int64_t n = 0, m = 0;        // dimensions of the sub-view
+  bool rows_identity = true;   // ind_row == 0..n_file-1
+  bool cols_contig = true;     // ind_col == col0 .. col0+m-1
+  int64_t col0 = 0;
+  int slices = 4;
+  bsn::DevBuf<int32_t> d_rows;   // n (gather list) when !rows_identity
+  bsn::DevBuf<int32_t> d_cols;   // m_pad (padded by repeating a valid column)
+  bsn::DevBuf<double> d_center, d_scale;  // m
+  // workspaces (grow-only)
+  bsn::DevBuf<double> d_xfull;   // scattered / padded input panel
+  bsn::DevBuf<int8_t> d_q;       // quantised panels
+  bsn::DevBuf<int32_t> d_acc;    // raw int32 MFMA accumulators
+  bsn::DevBuf<double> d_meta;    // per-vector scale, sums
+  bsn::DevBuf<double> d_yfull;   // full-length output before the row gather
+};
+
+namespace bsn {
+
+// image.hip
+void image_alloc(bsn_bed *b, int64_t n, int64_t m);
+void image_from_host(bsn_bed *b, const uint8_t *payload, int64_t n_byte_src);
+void image_from_fbm(bsn_bed *b, const uint8_t *bytes, int64_t ld);
+void image_generate(bsn_bed *b, uint32_t seed, uint32_t npop, uint32_t na16, int64_t j_begin);
+void image_download(bsn_bed *b, uint8_t *payload_out);
+// counts for variants cols[0..m) (device list or contiguous from col0) over all file rows;
+// d_counts: 4 x m int32 column-major (0,1,2,NA)
+void counts_all_rows(bsn_bed *b, const int32_t *d_cols, int64_t col0, int64_t m, int32_t *d_counts);
+void read_dense(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t m,
+                const double *d_center, const double *d_scale, int32_t na_val, int32_t *d_out_i,
+                double *d_out_d);
+
+// matvec.hip
+void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy);
+void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z, int64_t ldz);
+// weighted code counts: d_w = per-file-row integer weights (n_file doubles); out 4 x m
+void counts_weighted(bsn_op *op, const double *d_w, int64_t n_sub, int32_t *d_counts);
+void selftest();
+
+}  // namespace bsn

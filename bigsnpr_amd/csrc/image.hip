@@ -1,0 +1,277 @@
+// image.hip — the HBM-resident 2-bit genotype image: upload, FBM repack, synthetic
+// generator, per-variant code counts, dense read-back.
+//
+// Replaces the storage accessors of the reference: `class bed` / bedAcc
+// (src/bed-acc.h:18-82) and the byte-per-genotype FBM accessor used by the snp_*
+// functions (bigstatsr SubBMCode256Acc; layout per src/read-plink.cpp:17-48).
+#include "bsn_internal.hpp"
+
+namespace bsn {
+
+// ---------------------------------------------------------------------------
+// pad bits of the last real byte and all pad bytes -> 0b11 (genotype 0, non-missing)
+__global__ void k_tailfix(uint8_t *img, int64_t pitch, int64_t n, int64_t n_byte, int64_t m_rows,
+                          int64_t m_real) {
+  int64_t j = blockIdx.x;
+  uint8_t *row = img + j * pitch;
+  if (j >= m_real) {  // pad rows (read by the K-tail of k_prod): all genotype 0
+    for (int64_t b = threadIdx.x; b < pitch; b += blockDim.x) row[b] = 0xFF;
+    return;
+  }
+  for (int64_t b = n_byte + threadIdx.x; b < pitch; b += blockDim.x) row[b] = 0xFF;
+  int rem = (int)(n & 3);
+  if (rem && threadIdx.x == 0) row[n_byte - 1] |= (uint8_t)(0xFF << (2 * rem));
+  (void)m_rows;
+}
+
+constexpr int64_t kPadRows = 64;  // extra all-0xFF rows after the last variant
+
+void image_alloc(bsn_bed *b, int64_t n, int64_t m) {
+  if (n <= 0 || m <= 0) fail("n and p must be positive.");
+  b->n = n;
+  b->m = m;
+  b->n_byte = (n + 3) / 4;
+  b->pitch = round_up(b->n_byte, kPitchAlign);
+  BSN_HIP(hipGetDevice(&b->device));
+  BSN_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  BSN_HIP(hipEventCreate(&b->ev0));
+  BSN_HIP(hipEventCreate(&b->ev1));
+  size_t bytes = (size_t)(m + kPadRows) * (size_t)b->pitch;
+  BSN_HIP(hipMalloc((void **)&b->d_img, bytes));
+}
+
+static void tailfix(bsn_bed *b) {
+  hipLaunchKernelGGL(k_tailfix, dim3((unsigned)(b->m + kPadRows)), dim3(256), 0, b->stream,
+                     b->d_img, b->pitch, b->n, b->n_byte, b->m + kPadRows, b->m);
+  BSN_HIP(hipGetLastError());
+}
+
+void image_from_host(bsn_bed *b, const uint8_t *payload, int64_t n_byte_src) {
+  // Column chunks keep each 2-D copy below 1 GiB so that pageable (mmap'd) sources are
+  // staged piecewise by the runtime.
+  int64_t rows_per = (int64_t)((1ull << 30) / (size_t)n_byte_src);
+  if (rows_per < 1) rows_per = 1;
+  for (int64_t j = 0; j < b->m; j += rows_per) {
+    int64_t cnt = (b->m - j < rows_per) ? b->m - j : rows_per;
+    BSN_HIP(hipMemcpy2DAsync(b->d_img + j * b->pitch, (size_t)b->pitch, payload + j * n_byte_src,
+                             (size_t)n_byte_src, (size_t)b->n_byte, (size_t)cnt,
+                             hipMemcpyHostToDevice, b->stream));
+  }
+  tailfix(b);
+  BSN_HIP(hipStreamSynchronize(b->stream));
+}
+
+// ---------------------------------------------------------------------------
+// FBM.code256 bytes (CODE_012: 0,1,2, else NA) -> 2-bit PLINK codes.
+// genotype 0 -> 0b11, 1 -> 0b10, 2 -> 0b00, NA -> 0b01   (inverse of src/bed-acc.h:22-37)
+__global__ void k_pack_fbm(const uint8_t *src, int64_t ld, int64_t n, int64_t n_byte, uint8_t *img,
+                           int64_t pitch, int64_t ncols) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t j = blockIdx.y;
+  if (b >= n_byte || j >= ncols) return;
+  const uint8_t *col = src + j * ld;
+  uint32_t out = 0;
+  for (int e = 0; e < 4; e++) {
+    int64_t i = b * 4 + e;
+    uint32_t code = 3;
+    if (i < n) {
+      uint8_t v = col[i];
+      code = (v == 0) ? 3u : (v == 1) ? 2u : (v == 2) ? 0u : 1u;
+    }
+    out |= code << (2 * e);
+  }
+  img[j * pitch + b] = (uint8_t)out;
+}
+
+void image_from_fbm(bsn_bed *b, const uint8_t *bytes, int64_t ld) {
+  int64_t cols_per = (int64_t)((256ull << 20) / (size_t)ld);
+  if (cols_per < 1) cols_per = 1;
+  if (cols_per > 65535) cols_per = 65535;
+  DevBuf<uint8_t> tmp;
+  tmp.ensure((size_t)cols_per * (size_t)ld);
+  for (int64_t j = 0; j < b->m; j += cols_per) {
+    int64_t cnt = (b->m - j < cols_per) ? b->m - j : cols_per;
+    BSN_HIP(hipMemcpyAsync(tmp.p, bytes + j * ld, (size_t)cnt * (size_t)ld, hipMemcpyHostToDevice,
+                           b->stream));
+    dim3 grid((unsigned)((b->n_byte + 255) / 256), (unsigned)cnt);
+    hipLaunchKernelGGL(k_pack_fbm, grid, dim3(256), 0, b->stream, tmp.p, ld, b->n, b->n_byte,
+                       b->d_img + j * b->pitch, b->pitch, cnt);
+    BSN_HIP(hipGetLastError());
+    BSN_HIP(hipStreamSynchronize(b->stream));
+  }
+  tailfix(b);
+  BSN_HIP(hipStreamSynchronize(b->stream));
+}
+
+// ---------------------------------------------------------------------------
+// Synthetic generator — must stay bit-identical to oracle/bsn_oracle.c:orc_fake_bed.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t gen_pop(uint32_t seed, uint32_t i, uint32_t npop) {
+  uint32_t u = mix32(i * 0x9E3779B1U + mix32(seed ^ 0xA5A5A5A5U)) >> 8;
+  uint32_t u2 = (uint32_t)(((uint64_t)u * u) >> 24);
+  return (uint32_t)(((uint64_t)u2 * npop) >> 24);
+}
+__device__ __forceinline__ uint32_t gen_freq16(uint32_t seed, uint32_t j, uint32_t k) {
+  uint32_t hj = mix32(j * 0x85EBCA6BU + mix32(seed ^ 0x3C6EF372U));
+  int32_t p = 3277 + (int32_t)(((hj & 0xFFFF) * 29491U) >> 16);
+  uint32_t hk = mix32(hj + (k + 1) * 0xC2B2AE35U);
+  int32_t amp = 1311 + 393 * (int32_t)(k % 24);
+  int32_t dev = (int32_t)(((int64_t)((int32_t)(hk & 0xFFFF) - 32768) * amp) >> 15);
+  p += dev;
+  if (p < 655) p = 655;
+  if (p > 64880) p = 64880;
+  return (uint32_t)p;
+}
+__device__ __forceinline__ uint32_t gen_code(uint32_t seed, uint32_t i, uint32_t j, uint32_t p16,
+                                             uint32_t na16) {
+  uint32_t r = mix32(i * 0x9E3779B1U + mix32(j * 0x85EBCA6BU + seed));
+  uint32_t r2 = mix32(r ^ 0x68E31DA4U);
+  if ((r2 & 0xFFFF) < na16) return 1;
+  uint32_t g = ((r & 0xFFFF) < p16) + ((r >> 16) < p16);
+  return g == 2 ? 0u : (g == 1 ? 2u : 3u);
+}
+
+// one thread = one dword (16 samples) of one variant
+__global__ void k_generate(uint8_t *img, int64_t pitch, int64_t n, int64_t m, uint32_t seed,
+                           uint32_t npop, uint32_t na16, int64_t j_begin) {
+  int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t j = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (d * 4 >= pitch || j >= m) return;
+  uint32_t jj = (uint32_t)(j + j_begin);
+  uint32_t out = 0;
+  for (int e = 0; e < 16; e++) {
+    int64_t i = d * 16 + e;
+    uint32_t code = 3;
+    if (i < n) {
+      uint32_t k = gen_pop(seed, (uint32_t)i, npop);
+      code = gen_code(seed, (uint32_t)i, jj, gen_freq16(seed, jj, k), na16);
+    }
+    out |= code << (2 * e);
+  }
+  *(uint32_t *)(img + j * pitch + d * 4) = out;
+}
+
+void image_generate(bsn_bed *b, uint32_t seed, uint32_t npop, uint32_t na16, int64_t j_begin) {
+  int64_t dwords = b->pitch / 4;
+  int64_t gy = b->m < 65535 ? b->m : 65535;
+  int64_t gz = (b->m + 65534) / 65535;
+  dim3 grid((unsigned)((dwords + 255) / 256), (unsigned)gy, (unsigned)gz);
+  hipLaunchKernelGGL(k_generate, grid, dim3(256), 0, b->stream, b->d_img, b->pitch, b->n, b->m,
+                     seed, npop, na16, j_begin);
+  BSN_HIP(hipGetLastError());
+  // pad rows only (pad samples were already written as 0b11 above)
+  hipLaunchKernelGGL(k_tailfix, dim3((unsigned)kPadRows), dim3(256), 0, b->stream,
+                     b->d_img + b->m * b->pitch, b->pitch, b->n, b->n_byte, kPadRows, (int64_t)0);
+  BSN_HIP(hipGetLastError());
+  BSN_HIP(hipStreamSynchronize(b->stream));
+}
+
+// back to .bed payload layout; pad bits of the last byte are written as 0 like PLINK does
+__global__ void k_unpad(const uint8_t *img, int64_t pitch, int64_t n, int64_t n_byte,
+                        uint8_t *out) {
+  int64_t j = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_byte) return;
+  uint8_t v = img[j * pitch + b];
+  int rem = (int)(n & 3);
+  if (rem && b == n_byte - 1) v &= (uint8_t)((1u << (2 * rem)) - 1);
+  out[j * n_byte + b] = v;
+}
+
+void image_download(bsn_bed *b, uint8_t *payload_out) {
+  int64_t rows_per = (int64_t)((256ull << 20) / (size_t)b->n_byte);
+  if (rows_per < 1) rows_per = 1;
+  if (rows_per > 65535) rows_per = 65535;
+  DevBuf<uint8_t> tmp;
+  tmp.ensure((size_t)rows_per * (size_t)b->n_byte);
+  for (int64_t j = 0; j < b->m; j += rows_per) {
+    int64_t cnt = (b->m - j < rows_per) ? b->m - j : rows_per;
+    dim3 grid((unsigned)((b->n_byte + 255) / 256), (unsigned)cnt, 1);
+    hipLaunchKernelGGL(k_unpad, grid, dim3(256), 0, b->stream, b->d_img + j * b->pitch, b->pitch,
+                       b->n, b->n_byte, tmp.p);
+    BSN_HIP(hipGetLastError());
+    BSN_HIP(hipMemcpyAsync(payload_out + j * b->n_byte, tmp.p, (size_t)cnt * (size_t)b->n_byte,
+                           hipMemcpyDeviceToHost, b->stream));
+    BSN_HIP(hipStreamSynchronize(b->stream));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Per-variant counts of the four codes over ALL file rows: one wave per variant,
+// 16 B per lane per iteration, popcount on the 2-bit planes.  HBM-bound, pure
+// integer; replaces the element loop of src/bed-fun.cpp:51-69.
+__global__ __launch_bounds__(256) void k_counts(const uint8_t *img, int64_t pitch,
+                                                const int32_t *cols, int64_t col0, int64_t m,
+                                                int64_t n_pad_samples, int32_t *counts) {
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int64_t j = (int64_t)blockIdx.x * 4 + wave;
+  if (j >= m) return;
+  int64_t col = cols ? (int64_t)cols[j] : col0 + j;
+  const uint4 *row = (const uint4 *)(img + col * pitch);
+  int64_t nvec = pitch / 16;
+  uint32_t c1 = 0, c2 = 0, c3 = 0;
+  for (int64_t t = lane; t < nvec; t += 64) {
+    uint4 v = row[t];
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      uint32_t lo = w[q] & 0x55555555u, hi = (w[q] >> 1) & 0x55555555u;
+      c3 += __popc(lo & hi);   // 0b11 -> genotype 0
+      c1 += __popc(lo & ~hi);  // 0b01 -> missing
+      c2 += __popc(hi & ~lo);  // 0b10 -> genotype 1
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    c1 += __shfl_down(c1, off);
+    c2 += __shfl_down(c2, off);
+    c3 += __shfl_down(c3, off);
+  }
+  if (lane == 0) {
+    int64_t total = pitch * 4;
+    int32_t n0 = (int32_t)(c3 - n_pad_samples);
+    int32_t n2 = (int32_t)(total - c1 - c2 - c3);
+    counts[4 * j + 0] = n0;
+    counts[4 * j + 1] = (int32_t)c2;
+    counts[4 * j + 2] = n2;
+    counts[4 * j + 3] = (int32_t)c1;
+  }
+}
+
+void counts_all_rows(bsn_bed *b, const int32_t *d_cols, int64_t col0, int64_t m,
+                     int32_t *d_counts) {
+  hipLaunchKernelGGL(k_counts, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, b->stream, b->d_img,
+                     b->pitch, d_cols, col0, m, b->pitch * 4 - b->n, d_counts);
+  BSN_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// Dense read-back (src/bed-mat-acc.cpp:8-49): the test ground truth and the block
+// loader of bed_tcrossprodSelf.
+__global__ void k_read_dense(const uint8_t *img, int64_t pitch, const int32_t *rows, int64_t n,
+                             const int32_t *cols, int64_t m, const double *center,
+                             const double *scale, int32_t na_val, int32_t *out_i, double *out_d) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t j = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (i >= n || j >= m) return;
+  int64_t i2 = rows ? rows[i] : i, j2 = cols ? cols[j] : j;
+  uint32_t code = (img[j2 * pitch + (i2 >> 2)] >> (2 * (i2 & 3))) & 3;
+  int g = code == 0 ? 2 : code == 2 ? 1 : code == 3 ? 0 : -1;
+  if (out_i) out_i[i + j * n] = g < 0 ? na_val : g;
+  if (out_d) out_d[i + j * n] = g < 0 ? 0.0 : ((double)g - center[j]) / scale[j];
+}
+
+void read_dense(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t m,
+                const double *d_center, const double *d_scale, int32_t na_val, int32_t *d_out_i,
+                double *d_out_d) {
+  int64_t gy = m < 65535 ? m : 65535, gz = (m + 65534) / 65535;
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)gy, (unsigned)gz);
+  hipLaunchKernelGGL(k_read_dense, grid, dim3(256), 0, b->stream, b->d_img, b->pitch, d_rows, n,
+                     d_cols, m, d_center, d_scale, na_val, d_out_i, d_out_d);
+  BSN_HIP(hipGetLastError());
+}
+
+}  // namespace bsn

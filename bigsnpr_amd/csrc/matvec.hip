@@ -1,0 +1,649 @@
+// matvec.hip — the streaming products of the scaled genotype matrix on gfx950.
+//
+//   op_prod : Y = A~ X   (replaces bed_pMatVec4,  src/bed-prod-vec.cpp:15-54)
+//   op_cprod: Z = A~' X  (replaces bed_cpMatVec4, src/bed-prod-vec.cpp:59-97)
+//   with A~[i,j] = (g - center_j)/scale_j, missing -> 0 (src/bed-acc.h:98-111).
+//
+// Design: both products are HBM-bound on the 2-bit image but a
+// fp64 VALU formulation needs ~7 lane-ops per genotype, 2x what the chip can issue at
+// 6 TB/s.  So the multiply-accumulate is moved to the i8 MFMA pipe, exactly:
+//   - the fp64 panel is scaled per vector to a fixed-point integer of 8*S bits and split
+//     into S balanced base-256 digits (int8 "slices");
+//   - each 2-bit code is expanded with v_perm_b32 byte look-ups into int8 planes
+//     g0 in {0,1,2} (missing -> 0) and na in {0,1};
+//   - v_mfma_i32_16x16x64_i8 accumulates  sum g0*digit  and  sum na*digit  in int32,
+//     which is exact; the digits are recombined in fp64 in a finalize kernel together
+//     with the centre/scale algebra
+//         A~' x = (P - c (Sx - Q)) / s,      P = sum g0 x, Q = sum na x, Sx = sum x
+//         A~ x  = sum_j g0 w_j + sum_j na (c w)_j - sum_j (c w)_j,   w = x / s.
+//   Results are bit-reproducible (integer sums are order-independent).
+#include <cmath>
+
+#include "bsn_internal.hpp"
+
+namespace bsn {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// byte look-up: result byte k = lut byte (sel byte k), sel bytes in 0..3.  The LUT is
+// given as both sources so the result does not depend on the S0/S1 order of v_perm_b32.
+__device__ __forceinline__ uint32_t lut4(uint32_t lut, uint32_t sel) {
+  return __builtin_amdgcn_perm(lut, lut, sel);
+}
+// byte permute of the 8 bytes {hi:lo}; selector k picks lo.byte[k] for k<4, hi.byte[k-4]
+// otherwise (verified by bsn_selftest)
+__device__ __forceinline__ uint32_t perm8(uint32_t hi, uint32_t lo, uint32_t sel) {
+  return __builtin_amdgcn_perm(hi, lo, sel);
+}
+
+// PLINK 2-bit code -> plane value.  code 0 = two copies, 1 = missing, 2 = one copy, 3 = none
+constexpr uint32_t kLutG0 = 0x00010002u;   // {2,0,1,0}
+constexpr uint32_t kLutNA = 0x00000100u;   // {0,1,0,0}
+constexpr uint32_t kLutHom2 = 0x00000001u; // {1,0,0,0}
+constexpr uint32_t kLutHet = 0x00010000u;  // {0,0,1,0}
+
+// ---- per-vector metadata -------------------------------------------------------
+struct VecMeta {
+  unsigned long long absmax_bits;  // bits of max |value| (non-negative doubles order like u64)
+  long long sum_hi, sum_lo;        // sum of the fixed-point integers, split at bit 24
+  long long sum2_hi, sum2_lo;      // same for the second plane (c*w) in op_prod
+  unsigned long long nonfinite;    // count of non-finite inputs
+  double qscale;                   // fixed-point scale actually used
+  double pad;
+};
+static_assert(sizeof(VecMeta) == 64, "VecMeta layout");
+
+__global__ void k_meta_clear(VecMeta *meta, int nvec) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < nvec) {
+    VecMeta z = {};
+    meta[v] = z;
+  }
+}
+
+// rows scatter: xfull[rows[i], v] += x[i, v]   (duplicates allowed -> atomics)
+__global__ void k_scatter_rows(const double *X, int64_t ldx, const int32_t *rows, int64_t n,
+                               double *xfull, int64_t ldf) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int v = blockIdx.y;
+  if (i >= n) return;
+  atomicAdd(&xfull[(int64_t)rows[i] + v * ldf], X[i + v * ldx]);
+}
+
+// mode 0 (cprod): value = X[k, v]                       for k < len
+// mode 1 (prod) : value = X[k, v]/scale[k] and c*value  for k < len
+__global__ void k_absmax(const double *X, int64_t ldx, int64_t len, const double *center,
+                         const double *scale, int mode, VecMeta *meta) {
+  int v = blockIdx.y;
+  double mx = 0;
+  unsigned long long bad = 0;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < len;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    double a = X[k + v * ldx];
+    if (mode == 1) {
+      double s = scale ? scale[k] : 1.0, c = center ? center[k] : 0.0;
+      a = a / s;
+      double b = fabs(c * a);
+      if (!(b <= 1.79e308)) bad++; else mx = fmax(mx, b);
+    }
+    a = fabs(a);
+    if (!(a <= 1.79e308)) bad++; else mx = fmax(mx, a);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    mx = fmax(mx, __shfl_down(mx, off));
+    bad += __shfl_down(bad, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&meta[v].absmax_bits, (unsigned long long)__double_as_longlong(mx));
+    if (bad) atomicAdd(&meta[v].nonfinite, bad);
+  }
+}
+
+__global__ void k_set_qscale(VecMeta *meta, int nvec, int slices, int exact_int) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nvec) return;
+  double mx = __longlong_as_double((long long)meta[v].absmax_bits);
+  double lim = ldexp(0.99, 8 * slices - 1);
+  double qs = exact_int ? 1.0 : (mx > 0 ? lim / mx : 0.0);
+  if (!exact_int && mx > 0) {  // power-of-two scale: x*qs is then exact, only the rounding to integer errs
+    int e;
+    frexp(qs, &e);
+    qs = ldexp(1.0, e - 1);
+  }
+  meta[v].qscale = qs;
+}
+
+__device__ __forceinline__ void digits_of(long long X, int S, int8_t *d) {
+  for (int s = 0; s < S; s++) {
+    int8_t b = (int8_t)(X & 0xFF);
+    d[s] = b;
+    X = (X - b) >> 8;
+  }
+}
+
+// One thread quantises 16 consecutive k of one vector into S digit rows of 16 bytes.
+// Layout: q[(k/16) * (nplanes*ncol) + plane*ncol + col][16 B], col = v*S + s.
+// permute = 1 (cprod operand): sample e of the 16 is stored at byte (e%4)*4 + e/4, the
+// order in which k_cprod's decode emits them;  permute = 0 (prod operand): natural.
+__global__ void k_quant(const double *X, int64_t ldx, int64_t len, int64_t len_pad,
+                        const double *center, const double *scale, int mode, int S, int ncol,
+                        int permute, VecMeta *meta, int8_t *q) {
+  int64_t kb = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // 16-block index
+  int v = blockIdx.y;
+  int nplanes = mode == 1 ? 2 : 1;
+  long long shi = 0, slo = 0, shi2 = 0, slo2 = 0;
+  if (kb * 16 < len_pad) {
+    double qs = meta[v].qscale;
+    int8_t dg[2][8][16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      int64_t k = kb * 16 + e;
+      double a = 0, b = 0;
+      if (k < len) {
+        a = X[k + v * ldx];
+        if (mode == 1) {
+          double s = scale ? scale[k] : 1.0, c = center ? center[k] : 0.0;
+          a = a / s;
+          b = c * a;
+        }
+      }
+      if (!(fabs(a) <= 1.79e308)) a = 0;
+      if (!(fabs(b) <= 1.79e308)) b = 0;
+      long long A = llrint(a * qs), B = llrint(b * qs);
+      shi += A >> 24; slo += A & 0xFFFFFF;
+      shi2 += B >> 24; slo2 += B & 0xFFFFFF;
+      int pos = permute ? ((e & 3) * 4 + (e >> 2)) : e;
+      int8_t d[8];
+      digits_of(A, S, d);
+      for (int s = 0; s < S; s++) dg[0][s][pos] = d[s];
+      if (mode == 1) {
+        digits_of(B, S, d);
+        for (int s = 0; s < S; s++) dg[1][s][pos] = d[s];
+      }
+    }
+    for (int p = 0; p < nplanes; p++)
+      for (int s = 0; s < S; s++) {
+        int8_t *dst = q + ((kb * nplanes + p) * ncol + (v * S + s)) * 16;
+        *(uint4 *)dst = *(const uint4 *)dg[p][s];
+      }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    shi += __shfl_down(shi, off); slo += __shfl_down(slo, off);
+    shi2 += __shfl_down(shi2, off); slo2 += __shfl_down(slo2, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd((unsigned long long *)&meta[v].sum_hi, (unsigned long long)shi);
+    atomicAdd((unsigned long long *)&meta[v].sum_lo, (unsigned long long)slo);
+    if (mode == 1) {
+      atomicAdd((unsigned long long *)&meta[v].sum2_hi, (unsigned long long)shi2);
+      atomicAdd((unsigned long long *)&meta[v].sum2_lo, (unsigned long long)slo2);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_cprod: contraction over samples.  One wave owns 32 variants (two 16-row MFMA tiles)
+// for the whole sample range; the 8 waves of a workgroup share the digit panel of the
+// current sample chunk through LDS.  Per 16 B of a variant row a lane does 4 K-steps of
+// {decode 15 VALU, NPLANE*NB MFMA, NB ds_read_b128}.
+//   A operand: lane l -> variant row (l&15), k-group (l>>4): 16 samples of that variant
+//   B operand: lane l -> digit column (l&15), same 16 samples (from LDS)
+//   D        : lane l -> column (l&15), rows 4*(l>>4)+r
+template <int NB, int NPLANE, int KC>
+__global__ __launch_bounds__(512) void k_cprod(const uint8_t *__restrict__ img, int64_t pitch,
+                                               const int32_t *__restrict__ cols, int64_t col0,
+                                               int64_t m, const int8_t *__restrict__ xq,
+                                               int32_t *__restrict__ acc_out, int64_t m_out,
+                                               uint32_t lutA, uint32_t lutB, uint32_t lutC) {
+  constexpr int NCOL = 16 * NB;
+  constexpr int LD = KC / 256;             // 16-B loads per variant row per chunk per lane
+  constexpr int XS = KC / 16 * NCOL;       // uint4 entries per LDS buffer
+  __shared__ uint4 xs[2][XS];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int c = lane & 15, g = lane >> 4;
+  const int64_t snp_base = ((int64_t)blockIdx.x * 8 + wave) * 32;
+  const uint8_t *rowp[2];
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    int64_t j = snp_base + t * 16 + c;
+    if (j > m - 1) j = m - 1;
+    int64_t col = cols ? (int64_t)cols[j] : col0 + j;
+    rowp[t] = img + col * pitch + g * 16;
+  }
+  const int nchunks = (int)(pitch * 4 / KC);
+  const uint4 *xq4 = (const uint4 *)xq;
+
+  v4i acc[2][NPLANE][NB];
+#pragma unroll
+  for (int t = 0; t < 2; t++)
+#pragma unroll
+    for (int p = 0; p < NPLANE; p++)
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) acc[t][p][nb] = v4i{0, 0, 0, 0};
+
+  uint4 a_cur[2][LD], a_nxt[2][LD];
+  // prologue
+#pragma unroll
+  for (int t = 0; t < 2; t++)
+#pragma unroll
+    for (int it = 0; it < LD; it++) a_cur[t][it] = *(const uint4 *)(rowp[t] + it * 64);
+  for (int e = tid; e < XS; e += 512) xs[0][e] = xq4[e];
+  __syncthreads();
+
+  for (int ch = 0; ch < nchunks; ch++) {
+    const int cur = ch & 1;
+    if (ch + 1 < nchunks) {
+      const int64_t off = (int64_t)(ch + 1) * (KC / 4);
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int it = 0; it < LD; it++)
+          a_nxt[t][it] = *(const uint4 *)(rowp[t] + off + it * 64);
+      const uint4 *src = xq4 + (int64_t)(ch + 1) * XS;
+      for (int e = tid; e < XS; e += 512) xs[cur ^ 1][e] = src[e];
+    }
+#pragma unroll
+    for (int it = 0; it < LD; it++) {
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        uint4 bv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) bv[nb] = xs[cur][(it * 16 + g * 4 + d) * NCOL + nb * 16 + c];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          const uint32_t w = d == 0 ? a_cur[t][it].x : d == 1 ? a_cur[t][it].y
+                             : d == 2 ? a_cur[t][it].z : a_cur[t][it].w;
+          uint32_t s0 = w & 0x03030303u, s1 = (w >> 2) & 0x03030303u,
+                   s2 = (w >> 4) & 0x03030303u, s3 = (w >> 6) & 0x03030303u;
+#pragma unroll
+          for (int p = 0; p < NPLANE; p++) {
+            const uint32_t lut = p == 0 ? lutA : p == 1 ? lutB : lutC;
+            v4i a = {(int)lut4(lut, s0), (int)lut4(lut, s1), (int)lut4(lut, s2),
+                     (int)lut4(lut, s3)};
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) {
+              v4i b = {(int)bv[nb].x, (int)bv[nb].y, (int)bv[nb].z, (int)bv[nb].w};
+              acc[t][p][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[t][p][nb], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int it = 0; it < LD; it++) a_cur[t][it] = a_nxt[t][it];
+  }
+
+  // raw accumulators: acc_out[plane][variant][NCOL]
+#pragma unroll
+  for (int t = 0; t < 2; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      int64_t j = snp_base + t * 16 + g * 4 + r;
+      if (j < m) {
+#pragma unroll
+        for (int p = 0; p < NPLANE; p++)
+#pragma unroll
+          for (int nb = 0; nb < NB; nb++)
+            acc_out[((int64_t)p * m_out + j) * NCOL + nb * 16 + c] = acc[t][p][nb][r];
+      }
+    }
+}
+
+__device__ __forceinline__ double horner(const int32_t *a, int S) {
+  double r = 0;
+  for (int s = S - 1; s >= 0; s--) r = r * 256.0 + (double)a[s];
+  return r;
+}
+
+// z[j, v] = (P - c_j (Sx - Q)) / (s_j qs)
+__global__ void k_cprod_final(const int32_t *acc, int64_t m, int ncol, int S, const VecMeta *meta,
+                              const double *center, const double *scale, double *Z, int64_t ldz) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int v = blockIdx.y;
+  if (j >= m) return;
+  double P = horner(acc + j * ncol + v * S, S);
+  double Q = horner(acc + (m + j) * ncol + v * S, S);
+  double Sx = (double)meta[v].sum_hi * 16777216.0 + (double)meta[v].sum_lo;
+  double c = center ? center[j] : 0.0, s = scale ? scale[j] : 1.0;
+  double qs = meta[v].qscale;
+  double z = qs > 0 ? (P - c * (Sx - Q)) / (s * qs) : 0.0 / s;
+  if (meta[v].nonfinite) z = __longlong_as_double(0x7ff8000000000000LL);
+  Z[j + v * ldz] = z;
+}
+
+// ---------------------------------------------------------------------------
+// k_prod: contraction over variants on the variant-major image.  One wave owns 256
+// samples (16 sample groups x 16) and walks a range of variants 64 at a time:
+//   16 dword loads/lane (16 variants x 16 samples), four 4x4 byte transposes so that a
+//   register holds the same sample quad of 4 variants, then per sample: 2 VALU for the
+//   selector, 2 v_perm for the planes, 2 MFMA (g0 x w-digits, na x (c w)-digits) into
+//   one accumulator.
+//   A operand: lane l -> digit column (l&15), k-group (l>>4): 16 variants' digits
+//   B operand: lane l -> sample group (l&15), same 16 variants, sample u of the group
+//   D        : lane l -> sample group (l&15), digit columns 4*(l>>4)+r
+template <int NB, bool CONTIG>
+__global__ __launch_bounds__(256) void k_prod(const uint8_t *__restrict__ img, int64_t pitch,
+                                              const int32_t *__restrict__ cols, int64_t col0,
+                                              int64_t m_pad, int64_t mc,
+                                              const int8_t *__restrict__ wq,
+                                              int32_t *__restrict__ acc_out, int64_t n_pad) {
+  constexpr int NCOL = 16 * NB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int sg = lane & 15, g = lane >> 4;
+  const int64_t wbase = ((int64_t)blockIdx.x * 4 + wave) * 256;  // first sample of this wave
+  const int64_t wbyte = wbase / 4 + sg * 4;
+  const int64_t j0 = (int64_t)blockIdx.y * mc;
+  int64_t j1 = j0 + mc;
+  if (j1 > m_pad) j1 = m_pad;
+  const uint4 *wq4 = (const uint4 *)wq;
+
+  v4i acc[16][NB];
+#pragma unroll
+  for (int u = 0; u < 16; u++)
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) acc[u][nb] = v4i{0, 0, 0, 0};
+
+  uint32_t X[16], Xn[16];
+  auto load = [&](int64_t jb, uint32_t *dst) {
+    if (CONTIG) {
+      const uint8_t *base = img + (col0 + jb + g * 16) * pitch + wbyte;
+#pragma unroll
+      for (int r = 0; r < 16; r++) dst[r] = *(const uint32_t *)(base + r * pitch);
+    } else {
+      const int4 *ip = (const int4 *)(cols + jb + g * 16);
+#pragma unroll
+      for (int r4 = 0; r4 < 4; r4++) {
+        int4 id = ip[r4];
+        dst[r4 * 4 + 0] = *(const uint32_t *)(img + (int64_t)id.x * pitch + wbyte);
+        dst[r4 * 4 + 1] = *(const uint32_t *)(img + (int64_t)id.y * pitch + wbyte);
+        dst[r4 * 4 + 2] = *(const uint32_t *)(img + (int64_t)id.z * pitch + wbyte);
+        dst[r4 * 4 + 3] = *(const uint32_t *)(img + (int64_t)id.w * pitch + wbyte);
+      }
+    }
+  };
+  if (j0 < j1) load(j0, X);
+  for (int64_t jb = j0; jb < j1; jb += 64) {
+    if (jb + 64 < j1) load(jb + 64, Xn);
+    v4i aw[NB], awc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      uint4 t0 = wq4[((jb / 16 + g) * 2 + 0) * NCOL + nb * 16 + sg];
+      uint4 t1 = wq4[((jb / 16 + g) * 2 + 1) * NCOL + nb * 16 + sg];
+      aw[nb] = v4i{(int)t0.x, (int)t0.y, (int)t0.z, (int)t0.w};
+      awc[nb] = v4i{(int)t1.x, (int)t1.y, (int)t1.z, (int)t1.w};
+    }
+    // T[q][r4]: byte b = byte q of X[4*r4 + b]
+    uint32_t T[4][4];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; r4++) {
+      const uint32_t x0 = X[4 * r4], x1 = X[4 * r4 + 1], x2 = X[4 * r4 + 2], x3 = X[4 * r4 + 3];
+      const uint32_t lo01 = perm8(x1, x0, 0x05010400u);  // x0.b0 x1.b0 x0.b1 x1.b1
+      const uint32_t hi01 = perm8(x1, x0, 0x07030602u);  // x0.b2 x1.b2 x0.b3 x1.b3
+      const uint32_t lo23 = perm8(x3, x2, 0x05010400u);
+      const uint32_t hi23 = perm8(x3, x2, 0x07030602u);
+      T[0][r4] = perm8(lo23, lo01, 0x05040100u);  // lo01.b0 lo01.b1 lo23.b0 lo23.b1
+      T[1][r4] = perm8(lo23, lo01, 0x07060302u);
+      T[2][r4] = perm8(hi23, hi01, 0x05040100u);
+      T[3][r4] = perm8(hi23, hi01, 0x07060302u);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int uu = 0; uu < 4; uu++) {
+        v4i g0, na;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+          const uint32_t sel = (T[q][r4] >> (2 * uu)) & 0x03030303u;
+          g0[r4] = (int)lut4(kLutG0, sel);
+          na[r4] = (int)lut4(kLutNA, sel);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+          acc[q * 4 + uu][nb] =
+              __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[nb], g0, acc[q * 4 + uu][nb], 0, 0, 0);
+          acc[q * 4 + uu][nb] =
+              __builtin_amdgcn_mfma_i32_16x16x64_i8(awc[nb], na, acc[q * 4 + uu][nb], 0, 0, 0);
+        }
+      }
+#pragma unroll
+    for (int r = 0; r < 16; r++) X[r] = Xn[r];
+  }
+  // raw accumulators: acc_out[ky][sample][NCOL], lane holds columns nb*16 + 4g .. +3
+#pragma unroll
+  for (int u = 0; u < 16; u++) {
+    const int64_t i = wbase + sg * 16 + u;
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++)
+      *(v4i *)(acc_out + (((int64_t)blockIdx.y * n_pad + i) * NCOL + nb * 16 + 4 * g)) = acc[u][nb];
+  }
+}
+
+// y[i, v] = (sum_ky value(i) - C_v) / qs_v, gathered through rows[]
+__global__ void k_prod_final(const int32_t *acc, int64_t n_pad, int ky, int ncol, int S,
+                             const VecMeta *meta, const int32_t *rows, int64_t n, double *Y,
+                             int64_t ldy) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int v = blockIdx.y;
+  if (i >= n) return;
+  int64_t i2 = rows ? (int64_t)rows[i] : i;
+  long long d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int k = 0; k < ky; k++) {
+    const int32_t *a = acc + ((int64_t)k * n_pad + i2) * ncol + v * S;
+    for (int s = 0; s < S; s++) d[s] += a[s];
+  }
+  double r = 0;
+  for (int s = S - 1; s >= 0; s--) r = r * 256.0 + (double)d[s];
+  double C = (double)meta[v].sum2_hi * 16777216.0 + (double)meta[v].sum2_lo;
+  double qs = meta[v].qscale;
+  double y = qs > 0 ? (r - C) / qs : 0.0;
+  if (meta[v].nonfinite) y = __longlong_as_double(0x7ff8000000000000LL);
+  Y[i + v * ldy] = y;
+}
+
+// ---------------------------------------------------------------------------
+static int pick_nb(int ncols_needed) { return ncols_needed <= 16 ? 1 : 2; }
+
+static void quantise(bsn_op *op, const double *d_X, int64_t ldx, int64_t len, int64_t len_pad,
+                     int nvec, int mode, int S, int ncol, int permute, int exact_int,
+                     VecMeta *meta, int8_t *q) {
+  hipStream_t st = op->bed->stream;
+  hipLaunchKernelGGL(k_meta_clear, dim3(1), dim3(64), 0, st, meta, nvec);
+  if (!exact_int) {
+    int gx = (int)((len + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(k_absmax, dim3(gx, nvec), dim3(256), 0, st, d_X, ldx, len,
+                       mode == 1 ? op->d_center.p : nullptr, mode == 1 ? op->d_scale.p : nullptr,
+                       mode, meta);
+  }
+  hipLaunchKernelGGL(k_set_qscale, dim3(1), dim3(64), 0, st, meta, nvec, S, exact_int);
+  int nplanes = mode == 1 ? 2 : 1;
+  BSN_HIP(hipMemsetAsync(q, 0, (size_t)(len_pad / 16) * nplanes * ncol * 16, st));
+  int64_t nblk = len_pad / 16;
+  hipLaunchKernelGGL(k_quant, dim3((unsigned)((nblk + 63) / 64), nvec), dim3(64), 0, st, d_X, ldx,
+                     len, len_pad, mode == 1 ? op->d_center.p : nullptr,
+                     mode == 1 ? op->d_scale.p : nullptr, mode, S, ncol, permute, meta, q);
+  BSN_HIP(hipGetLastError());
+}
+
+static const double *scatter_rows_if_needed(bsn_op *op, const double *d_X, int64_t *ldx,
+                                            int nvec) {
+  if (op->rows_identity) return d_X;
+  bsn_bed *b = op->bed;
+  double *xf = op->d_xfull.ensure((size_t)b->n * nvec);
+  BSN_HIP(hipMemsetAsync(xf, 0, (size_t)b->n * nvec * sizeof(double), b->stream));
+  hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((op->n + 255) / 256), nvec), dim3(256), 0,
+                     b->stream, d_X, *ldx, op->d_rows.p, op->n, xf, b->n);
+  BSN_HIP(hipGetLastError());
+  *ldx = b->n;
+  return xf;
+}
+
+template <int NPLANE>
+static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint32_t l0,
+                         uint32_t l1, uint32_t l2) {
+  bsn_bed *b = op->bed;
+  constexpr int KC = 512;
+  dim3 grid((unsigned)((op->m + 255) / 256));
+  const int32_t *cols = op->cols_contig ? nullptr : op->d_cols.p;
+  if (NB == 1)
+    hipLaunchKernelGGL((k_cprod<1, NPLANE, KC>), grid, dim3(512), 0, b->stream, b->d_img, b->pitch,
+                       cols, op->col0, op->m, q, acc, op->m, l0, l1, l2);
+  else
+    hipLaunchKernelGGL((k_cprod<2, NPLANE, KC>), grid, dim3(512), 0, b->stream, b->d_img, b->pitch,
+                       cols, op->col0, op->m, q, acc, op->m, l0, l1, l2);
+  BSN_HIP(hipGetLastError());
+}
+
+void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z, int64_t ldz) {
+  bsn_bed *b = op->bed;
+  const int S = op->slices;
+  const int vmax = 32 / S;  // vectors per launch (NB <= 2)
+  if (nvec <= 0) return;
+  const double *xsrc = scatter_rows_if_needed(op, d_X, &ldx, nvec);
+  const int64_t npad = b->pitch * 4;
+  VecMeta *meta = (VecMeta *)op->d_meta.ensure(8 * 64);
+  for (int v0 = 0; v0 < nvec; v0 += vmax) {
+    int nv = nvec - v0 < vmax ? nvec - v0 : vmax;
+    int NB = pick_nb(nv * S), ncol = 16 * NB;
+    int8_t *q = op->d_q.ensure((size_t)npad * 32 * 2);
+    int32_t *acc = op->d_acc.ensure((size_t)2 * op->m * 32);
+    quantise(op, xsrc + (int64_t)v0 * ldx, ldx, b->n, npad, nv, 0, S, ncol, 1, 0, meta, q);
+    launch_cprod<2>(op, NB, q, acc, kLutG0, kLutNA, 0);
+    hipLaunchKernelGGL(k_cprod_final, dim3((unsigned)((op->m + 255) / 256), nv), dim3(256), 0,
+                       b->stream, acc, op->m, ncol, S, meta, op->d_center.p, op->d_scale.p,
+                       d_Z + (int64_t)v0 * ldz, ldz);
+    BSN_HIP(hipGetLastError());
+  }
+}
+
+void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy) {
+  bsn_bed *b = op->bed;
+  const int S = op->slices;
+  const int vmax = 32 / S;
+  if (nvec <= 0) return;
+  const int64_t npad = b->pitch * 4;
+  const int64_t m_pad = round_up(op->m, 64);
+  VecMeta *meta = (VecMeta *)op->d_meta.ensure(8 * 64);
+  // K split so that the grid has a few thousand workgroups
+  int64_t wgx = npad / 1024;
+  int ky = (int)((4096 + wgx - 1) / wgx);
+  int64_t steps = m_pad / 64;
+  if (ky > steps) ky = (int)steps;
+  if (ky > 64) ky = 64;
+  if (ky < 1) ky = 1;
+  int64_t mc = round_up((steps + ky - 1) / ky, 1) * 64;
+  ky = (int)((m_pad + mc - 1) / mc);
+  for (int v0 = 0; v0 < nvec; v0 += vmax) {
+    int nv = nvec - v0 < vmax ? nvec - v0 : vmax;
+    int NB = pick_nb(nv * S), ncol = 16 * NB;
+    int8_t *q = op->d_q.ensure((size_t)npad * 32 * 2 > (size_t)m_pad * 32 * 2 ? (size_t)npad * 64
+                                                                             : (size_t)m_pad * 64);
+    size_t acc_need = (size_t)ky * npad * ncol;
+    if (acc_need < (size_t)2 * op->m * 32) acc_need = (size_t)2 * op->m * 32;
+    int32_t *acc = op->d_acc.ensure(acc_need);
+    quantise(op, d_X + (int64_t)v0 * ldx, ldx, op->m, m_pad, nv, 1, S, ncol, 0, 0, meta, q);
+    dim3 grid((unsigned)wgx, (unsigned)ky);
+    const int32_t *cols = op->d_cols.p;
+    if (op->cols_contig) {
+      if (NB == 1)
+        hipLaunchKernelGGL((k_prod<1, true>), grid, dim3(256), 0, b->stream, b->d_img, b->pitch,
+                           cols, op->col0, m_pad, mc, q, acc, npad);
+      else
+        hipLaunchKernelGGL((k_prod<2, true>), grid, dim3(256), 0, b->stream, b->d_img, b->pitch,
+                           cols, op->col0, m_pad, mc, q, acc, npad);
+    } else {
+      if (NB == 1)
+        hipLaunchKernelGGL((k_prod<1, false>), grid, dim3(256), 0, b->stream, b->d_img, b->pitch,
+                           cols, op->col0, m_pad, mc, q, acc, npad);
+      else
+        hipLaunchKernelGGL((k_prod<2, false>), grid, dim3(256), 0, b->stream, b->d_img, b->pitch,
+                           cols, op->col0, m_pad, mc, q, acc, npad);
+    }
+    BSN_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_prod_final, dim3((unsigned)((op->n + 255) / 256), nv), dim3(256), 0,
+                       b->stream, acc, npad, ky, ncol, S, meta,
+                       op->rows_identity ? nullptr : op->d_rows.p, op->n,
+                       d_Y + (int64_t)v0 * ldy, ldy);
+    BSN_HIP(hipGetLastError());
+  }
+}
+
+// counts of codes weighted by integer row multiplicities (general ind_row):
+// three planes (hom2, het, na) against the multiplicity vector, exact.
+__global__ void k_counts_final(const int32_t *acc, int64_t m, int ncol, int S, int64_t n_sub,
+                               int32_t *counts) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  long long n2 = (long long)horner(acc + j * ncol, S);
+  long long n1 = (long long)horner(acc + (m + j) * ncol, S);
+  long long na = (long long)horner(acc + (2 * m + j) * ncol, S);
+  counts[4 * j + 0] = (int32_t)(n_sub - n1 - n2 - na);
+  counts[4 * j + 1] = (int32_t)n1;
+  counts[4 * j + 2] = (int32_t)n2;
+  counts[4 * j + 3] = (int32_t)na;
+}
+
+void counts_weighted(bsn_op *op, const double *d_w, int64_t n_sub, int32_t *d_counts) {
+  bsn_bed *b = op->bed;
+  const int S = 4;
+  const int64_t npad = b->pitch * 4;
+  VecMeta *meta = (VecMeta *)op->d_meta.ensure(8 * 64);
+  int8_t *q = op->d_q.ensure((size_t)npad * 64);
+  int32_t *acc = op->d_acc.ensure((size_t)3 * op->m * 16);
+  quantise(op, d_w, b->n, b->n, npad, 1, 0, S, 16, 1, 1, meta, q);
+  launch_cprod<3>(op, 1, q, acc, kLutHom2, kLutHet, kLutNA);
+  hipLaunchKernelGGL(k_counts_final, dim3((unsigned)((op->m + 255) / 256)), dim3(256), 0, b->stream,
+                     acc, op->m, 16, S, n_sub, d_counts);
+  BSN_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// Instruction-level self test: v_perm_b32 source order and i8 MFMA layouts.
+__global__ void k_selftest(int *out) {
+  int lane = threadIdx.x;
+  // perm8: selector 0..3 must pick from `lo`, 4..7 from `hi`
+  uint32_t r = perm8(0x77665544u, 0x33221100u, 0x07040300u);
+  int ok_perm = (r == 0x77443300u);
+  // mfma: A[row=l&15][k], B[k][col=l&15], k-slots paired by (lane>>4, byte)
+  // A[i][k] = (i + 1) if k == 5*i+3 (mod 64) else 0 ; B[k][j] = (k % 7) - 3 + j
+  v4i a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+  int i = lane & 15, gq = lane >> 4;
+  for (int e = 0; e < 16; e++) {
+    int k = gq * 16 + e;
+    int av = (k == (5 * i + 3) % 64) ? (i + 1) : 0;
+    int bv = (k % 7) - 3 + i;  // column index of B is also lane&15
+    a[e >> 2] |= (av & 0xFF) << (8 * (e & 3));
+    b[e >> 2] |= (bv & 0xFF) << (8 * (e & 3));
+  }
+  v4i c = {0, 0, 0, 0};
+  c = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
+  int ok_mfma = 1;
+  for (int rr = 0; rr < 4; rr++) {
+    int row = 4 * gq + rr, col = lane & 15;
+    int k = (5 * row + 3) % 64;
+    int want = (row + 1) * ((k % 7) - 3 + col);
+    if (c[rr] != want) ok_mfma = 0;
+  }
+  int all_perm = __all(ok_perm), all_mfma = __all(ok_mfma);
+  if (lane == 0) {
+    out[0] = all_perm;
+    out[1] = all_mfma;
+    out[2] = (int)r;
+  }
+}
+
+void selftest() {
+  DevBuf<int> d;
+  d.ensure(4);
+  hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, 0, d.p);
+  BSN_HIP(hipGetLastError());
+  int h[4] = {0, 0, 0, 0};
+  BSN_HIP(hipMemcpy(h, d.p, sizeof(h), hipMemcpyDeviceToHost));
+  if (!h[0]) fail("selftest: v_perm_b32 byte order differs from the assumed {hi:lo} (got %08x)", h[2]);
+  if (!h[1]) fail("selftest: v_mfma_i32_16x16x64_i8 operand/accumulator layout differs");
+}
+
+}  // namespace bsn

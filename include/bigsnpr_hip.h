@@ -1,0 +1,125 @@
+/*
+ * bigsnpr_hip.h — C ABI of libbigsnpr_hip.so: the MI355X (gfx950) implementation of
+ * bigsnpr's genotype-matrix hot path.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one `.Call` target of
+ * the reference package (bigsnpr 1.12.21, registration table
+ * src/RcppExports.cpp:597-640) or one operator that the reference hands to
+ * bigstatsr::big_randomSVD (R/autoSVD.R:216-218).  The reference-side binding (an R
+ * `.Call` shim) is shown in INTEGRATION.md and bindings/R/.
+ *
+ * Conventions
+ *  - plain C types only; no R, Rcpp, torch or HIP types in any signature;
+ *  - all functions return 0 on success, non-zero on error; bsn_last_error() then
+ *    returns a thread-local message whose text matches the reference's
+ *    Rcpp::stop() strings where the reference has one;
+ *  - indices are 0-based int64 (the R shim subtracts 1 exactly where the reference
+ *    does, src/bed-acc.h:64-65); arbitrary order, duplicates allowed;
+ *  - `*_host` style pointers are borrowed host buffers (never freed, never kept);
+ *    `d_*` pointers are device (HBM) pointers on the handle's device;
+ *  - a handle owns the device image of one genotype matrix; it is created on the
+ *    current device (bsn_set_device) and all work is issued on its own HIP stream.
+ *  - There is NO CPU fallback: without a gfx950 device every compute call fails.
+ */
+#ifndef BIGSNPR_HIP_H
+#define BIGSNPR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bsn_bed bsn_bed; /* packed 2-bit genotype matrix resident in HBM */
+typedef struct bsn_op bsn_op;   /* scaled sub-view  A~ = ((G - center)/scale)[ind_row, ind_col] */
+
+/* ---- runtime ------------------------------------------------------------- */
+const char *bsn_last_error(void);
+int bsn_version(void);
+int bsn_device_count(int *count);
+int bsn_set_device(int device);
+/* verifies the gfx950 instruction-level assumptions the kernels rely on
+ * (v_perm_b32 byte order, i8 MFMA operand/accumulator layout) on the device */
+int bsn_selftest(void);
+
+/* ---- genotype image (replaces `class bed` + bedXPtr) ----------------------
+ * src/bed-acc.h:18-48, src/bed-acc-xptr.cpp:14-53 (_bigsnpr_bedXPtr, 3 args).
+ * Error strings: "Error when mapping file:\n  %s.\n", "File is not a binary PED
+ * file.", "Variant-major is the only mode supported.", "n or p does not match the
+ * dimensions of the file." */
+int bsn_bed_open(const char *path, int64_t n, int64_t m, bsn_bed **out);
+/* same, from a payload already in host memory (n_byte = bytes per variant, >= ceil(n/4)) */
+int bsn_bed_from_host(const uint8_t *payload, int64_t n, int64_t m, int64_t n_byte, bsn_bed **out);
+/* FBM.code256 (bigstatsr, one byte per genotype, column-major, n_total rows) with the
+ * CODE_012 coding (R/bigSNP-class.R:7: 0,1,2, everything else NA) repacked to 2 bits
+ * on the device; the FBM twin of bedXPtr for snp_* functions (src/colstats.cpp:13-14). */
+int bsn_bed_from_fbm(const uint8_t *bytes, int64_t n, int64_t m, int64_t ld, bsn_bed **out);
+/* synthetic matrix generated directly in HBM (DESIGN.md "Synthetic inputs");
+ * byte-identical to oracle/bsn_oracle.c:orc_fake_bed */
+int bsn_bed_synthetic(int64_t n, int64_t m, uint32_t seed, uint32_t npop, uint32_t na16,
+                      int64_t j_begin, bsn_bed **out);
+int bsn_bed_close(bsn_bed *bed);
+int64_t bsn_bed_nrow(const bsn_bed *bed);
+int64_t bsn_bed_ncol(const bsn_bed *bed);
+int64_t bsn_bed_bytes(const bsn_bed *bed); /* HBM bytes held by the image */
+/* copies the image back in .bed payload layout (ceil(n/4) bytes per variant) */
+int bsn_bed_download(bsn_bed *bed, uint8_t *payload_out);
+
+/* ---- .Call replacements (host buffers in, host buffers out) --------------- */
+/* _bigsnpr_bed_pMatVec4 (7 args) src/bed-prod-vec.cpp:15-54 — R: bed_prodVec.
+ * y[n] = A~ x[m].  "Incompatibility between dimensions" is raised by the caller
+ * layer (lengths are explicit here). `ncores` of the reference is dropped. */
+int bsn_bed_prodvec(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                    int64_t m, const double *center, const double *scale, const double *x,
+                    double *y);
+/* _bigsnpr_bed_cpMatVec4 (7 args) src/bed-prod-vec.cpp:59-97 — R: bed_cprodVec. z[m] = A~' x[n] */
+int bsn_bed_cprodvec(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                     int64_t m, const double *center, const double *scale, const double *x,
+                     double *z);
+/* _bigsnpr_bed_col_counts_cpp (4 args) src/bed-fun.cpp:51-69: res is 4 x m column-major
+ * (rows: counts of 0, 1, 2, NA) */
+int bsn_bed_col_counts(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                       int64_t m, int32_t *res);
+/* _bigsnpr_bed_colstats (4 args) src/bed-fun.cpp:9-46; *n_bad = number of variants with
+ * more than 50 % missing values (the reference warns "%d variants have >50%% missing values.") */
+int bsn_bed_colstats(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                     int64_t m, double *sumX, double *denoX, int32_t *nb_nona_col, int32_t *n_bad);
+/* _bigsnpr_snp_colstats (4 args) src/colstats.cpp:8-35 (no NA handling: NA counts as 3
+ * exactly as code256[3] would if it were 3; callers assert no NA, R/utils-assert.R:31) */
+int bsn_snp_colstats(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                     int64_t m, double *sumX, double *denoX);
+/* _bigsnpr_read_bed (3 args) / _bigsnpr_read_bed_scaled (5 args) src/bed-mat-acc.cpp:8-49:
+ * dense n x m column-major; read_bed codes NA as na_val */
+int bsn_bed_read(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                 int64_t m, int32_t na_val, int32_t *out);
+int bsn_bed_read_scaled(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                        int64_t m, const double *center, const double *scale, double *out);
+
+/* ---- device-resident operator (the fun.prod / fun.cprod seam of big_randomSVD,
+ *      R/autoSVD.R:216-218, kept on the device so vectors never cross PCIe) ----- */
+int bsn_op_create(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                  int64_t m, const double *center, const double *scale, bsn_op **out);
+int bsn_op_destroy(bsn_op *op);
+/* number of 8-bit slices the fp64 panels are split into (exact int8 MFMA arithmetic on
+ * a fixed-point image of the vectors; 4 = 32-bit, 7 = 56-bit).  Default 4. */
+int bsn_op_set_slices(bsn_op *op, int slices);
+/* Y[n x nvec] = A~ X[m x nvec];  Z[m x nvec] = A~' X[n x nvec]; column-major, leading
+ * dimensions ldx / ldy in elements; all pointers are DEVICE pointers */
+int bsn_op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy);
+int bsn_op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z, int64_t ldz);
+int bsn_op_sync(bsn_op *op);
+
+/* ---- device memory + timing helpers for hosts without a HIP binding -------- */
+int bsn_malloc(void **d_ptr, int64_t bytes);
+int bsn_free(void *d_ptr);
+int bsn_memcpy_h2d(void *d_dst, const void *src, int64_t bytes);
+int bsn_memcpy_d2h(void *dst, const void *d_src, int64_t bytes);
+int bsn_device_sync(void);
+/* HIP events on the handle's stream (bench.py roofline timing) */
+int bsn_timer_start(bsn_bed *bed);
+int bsn_timer_stop(bsn_bed *bed, double *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIGSNPR_HIP_H */

@@ -1,0 +1,85 @@
+"""CPU-only checks of the drop-in boundary: the shared library builds, loads, and exports
+every symbol that include/bigsnpr_hip.h declares; compute calls fail loudly without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from bigsnpr_amd import build
+    build.build()
+    from bigsnpr_amd import _lib
+    return _lib
+
+
+def test_header_symbols_exported_and_bound(lib):
+    hdr = open(os.path.join(ROOT, "include", "bigsnpr_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(bsn_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) > 25
+    L = lib.load()
+    for name in declared:
+        assert hasattr(L, name), "missing export " + name
+    assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
+
+
+def test_no_torch_or_r_types_in_abi():
+    hdr = open(os.path.join(ROOT, "include", "bigsnpr_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    for banned in ("SEXP", "Rcpp", "at::", "torch", "hipStream_t", "std::"):
+        assert banned not in hdr
+
+
+def test_product_never_imports_oracle():
+    for dp, _, files in os.walk(os.path.join(ROOT, "bigsnpr_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+\S*oracle", src, flags=re.M), f
+                assert not re.search(r"#\s*include.*oracle", src), f
+                assert "libbsn_oracle" not in src and "orc_" not in src.replace("orc_fake_bed", ""), f
+
+
+def test_fails_loudly_without_gpu(lib, golden_dir):
+    import bigsnpr_amd as ba
+    if ba.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(ba.BsnError, match="no CPU fallback"):
+        ba.bed(os.path.join(golden_dir, "example.bed"))
+    with pytest.raises(ba.BsnError, match="no CPU fallback"):
+        ba.selftest()
+
+
+def test_open_error_strings_match_reference(lib, golden_dir, tmp_path):
+    """src/bed-acc-xptr.cpp:19-34 messages; these checks run before any GPU work."""
+    import ctypes as C
+    L = lib.load()
+    raw = np.fromfile(os.path.join(golden_dir, "example-missing.bed"), dtype=np.uint8)
+
+    def err(path, n, m):
+        h = C.c_void_p()
+        rc = L.bsn_bed_open(str(path).encode(), n, m, C.byref(h))
+        assert rc != 0
+        return L.bsn_last_error().decode()
+
+    assert "Error when mapping file" in err(tmp_path / "nope.bed", 200, 500)
+    p = tmp_path / "a.bed"
+    bad = raw.copy(); bad[1] = 0; bad.tofile(p)
+    assert err(p, 200, 500) == "File is not a binary PED file."
+    bad = raw.copy(); bad[2] = 0; bad.tofile(p)
+    assert err(p, 200, 500) == "Variant-major is the only mode supported."
+    raw.tofile(p)
+    assert err(p, 196, 500) == "n or p does not match the dimensions of the file."
+
+
+def test_host_api_argument_checks(lib):
+    import bigsnpr_amd as ba
+    with pytest.raises(TypeError, match="is not of class 'bed' or 'bed_light'"):
+        ba.bed_prodVec(object(), np.zeros(3))
+    with pytest.raises(ValueError, match="must have 'bed' extension"):
+        ba.bed("foo.txt")

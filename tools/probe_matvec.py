@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Times the streaming kernels on a synthetic matrix (run on the GPU box)."""
+import argparse, json, sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
+import numpy as np
+import bigsnpr_amd as ba
+from bigsnpr_amd import _lib
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=400000)
+ap.add_argument("--m", type=int, default=100000)
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--nvecs", type=str, default="1,4,8")
+ap.add_argument("--slices", type=int, default=4)
+a = ap.parse_args()
+L = _lib.load()
+ba.selftest()
+t0 = time.time()
+gb = ba.bed.synthetic(a.n, a.m)
+L.bsn_device_sync()
+print("generate %.2fs, image %.2f GB" % (time.time() - t0, gb.hbm_bytes() / 1e9), flush=True)
+bytes_pass = ((a.n + 3) // 4) * a.m
+
+def timed(fn, reps):
+    fn(); L.bsn_device_sync()
+    ms = C.c_double()
+    L.bsn_timer_start(gb.handle)
+    for _ in range(reps):
+        fn()
+    L.bsn_timer_stop(gb.handle, C.byref(ms))
+    return ms.value / reps
+
+t = timed(lambda: ba.bed_counts(gb), 1)
+print(json.dumps(dict(kernel="counts(host api)", ms=t, GBps=bytes_pass / t / 1e6)), flush=True)
+sc = ba.bed_scaleBinom(gb)
+op = ba.ScaledOp(gb, None, None, sc["center"], sc["scale"], slices=a.slices)
+rng = np.random.default_rng(0)
+for nv in [int(v) for v in a.nvecs.split(",")]:
+    X = ba.DeviceArray.from_numpy(rng.normal(size=(a.m, nv)))
+    R = ba.DeviceArray.from_numpy(rng.normal(size=(a.n, nv)))
+    Y = ba.DeviceArray(a.n, nv); Z = ba.DeviceArray(a.m, nv)
+    t = timed(lambda: op.cprod(R, Z), a.reps)
+    print(json.dumps(dict(kernel="cprod", nvec=nv, ms=t, GBps=bytes_pass / t / 1e6)), flush=True)
+    t = timed(lambda: op.prod(X, Y), a.reps)
+    print(json.dumps(dict(kernel="prod", nvec=nv, ms=t, GBps=bytes_pass / t / 1e6)), flush=True)
