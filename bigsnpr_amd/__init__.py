@@ -8,6 +8,7 @@ from ._lib import BsnError, DeviceArray, load  # noqa: F401
 from .bed import (ERROR_DIM, ScaledOp, bed, bed_colstats, bed_counts, bed_cprodVec,  # noqa: F401
                   bed_MAF, bed_prodVec, bed_scaleBinom, cols_along, read_bed,
                   read_bed_scaled, rows_along)
+from .svd import bed_randomSVD  # noqa: F401,E402
 
 
 def selftest():

@@ -18,6 +18,21 @@ f64p = C.POINTER(C.c_double)
 vp = C.c_void_p
 i64 = C.c_int64
 
+ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class SvdOptions(C.Structure):
+    _fields_ = [("k", C.c_int32), ("tol", C.c_double), ("block", C.c_int32),
+                ("slices", C.c_int32), ("max_basis", C.c_int32), ("seed", C.c_uint32),
+                ("verbose", C.c_int32), ("m_total", C.c_int64), ("allreduce", ALLREDUCE_FN),
+                ("allreduce_ctx", C.c_void_p)]
+
+
+class SvdInfo(C.Structure):
+    _fields_ = [("niter", C.c_int32), ("nops", C.c_int32), ("basis", C.c_int32),
+                ("converged", C.c_int32), ("max_rel_resid", C.c_double), ("gpu_ms", C.c_double)]
+
+
 # name -> (restype, argtypes); kept in one table so tests can check that every symbol
 # declared in include/bigsnpr_hip.h is exported and bound.
 SIGNATURES = {
@@ -48,6 +63,8 @@ SIGNATURES = {
     "bsn_op_prod": (C.c_int, [vp, vp, i64, C.c_int, vp, i64]),
     "bsn_op_cprod": (C.c_int, [vp, vp, i64, C.c_int, vp, i64]),
     "bsn_op_sync": (C.c_int, [vp]),
+    "bsn_bed_randomsvd": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, C.POINTER(SvdOptions),
+                                    f64p, f64p, f64p, C.POINTER(SvdInfo)]),
     "bsn_malloc": (C.c_int, [C.POINTER(vp), i64]),
     "bsn_free": (C.c_int, [vp]),
     "bsn_memcpy_h2d": (C.c_int, [vp, vp, i64]),

@@ -95,6 +95,7 @@ struct bsn_op {
   bool cols_contig = true;     // ind_col == col0 .. col0+m-1
   int64_t col0 = 0;
   int slices = 4;
+  int64_t passes = 0;         // streaming launches over the image issued so far
   bsn::DevBuf<int32_t> d_rows;   // n (gather list) when !rows_identity
   bsn::DevBuf<int32_t> d_cols;   // m_pad (padded by repeating a valid column)
   bsn::DevBuf<double> d_center, d_scale;  // m

@@ -512,6 +512,7 @@ void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z,
     int32_t *acc = op->d_acc.ensure((size_t)2 * op->m * 32);
     quantise(op, xsrc + (int64_t)v0 * ldx, ldx, b->n, npad, nv, 0, S, ncol, 1, 0, meta, q);
     launch_cprod<2>(op, NB, q, acc, kLutG0, kLutNA, 0);
+    op->passes++;
     hipLaunchKernelGGL(k_cprod_final, dim3((unsigned)((op->m + 255) / 256), nv), dim3(256), 0,
                        b->stream, acc, op->m, ncol, S, meta, op->d_center.p, op->d_scale.p,
                        d_Z + (int64_t)v0 * ldz, ldz);
@@ -563,6 +564,7 @@ void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, 
                            cols, op->col0, m_pad, mc, q, acc, npad);
     }
     BSN_HIP(hipGetLastError());
+    op->passes++;
     hipLaunchKernelGGL(k_prod_final, dim3((unsigned)((op->n + 255) / 256), nv), dim3(256), 0,
                        b->stream, acc, npad, ky, ncol, S, meta,
                        op->rows_identity ? nullptr : op->d_rows.p, op->n,

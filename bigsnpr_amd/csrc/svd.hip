@@ -1,0 +1,290 @@
+// svd.hip — HIP backend of the block-Lanczos partial SVD (svd_driver.hpp) and the
+// bsn_bed_randomsvd entry point (replaces bed_randomSVD -> bigstatsr::big_randomSVD,
+// R/autoSVD.R:205-219).  The two matrix passes per step are op_cprod / op_prod
+// (matvec.hip); the tall-skinny fp64 panel algebra below is memory-bound on the basis Q
+// (n x p doubles) and is a few percent of a step.
+#include <memory>
+
+#include "bsn_internal.hpp"
+#include "svd_driver.hpp"
+
+namespace bsn {
+
+constexpr int kMaxB = 8;
+
+__device__ __forceinline__ uint32_t hmix(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+
+__global__ void k_random(double *W, int64_t ld, int64_t n, int b, uint32_t seed) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int j = blockIdx.y;
+  if (i >= n || j >= b) return;
+  uint32_t h = hmix((uint32_t)i * 0x9E3779B1U + hmix(seed * 0x85EBCA6BU + (uint32_t)j + 0x1234567U));
+  uint32_t h2 = hmix(h ^ 0xDEADBEEFU);
+  // uniform in (-1, 1) with 53 random bits
+  double x = ((double)(((uint64_t)h << 21) ^ (uint64_t)h2) + 0.5) * (1.0 / 9007199254740992.0);
+  W[i + j * ld] = 2.0 * x - 1.0;
+}
+
+// partial[rc][pt*4 + a][j] = sum over the row chunk of Q[i, pt*4+a] * W[i, j]
+__global__ __launch_bounds__(256) void k_gemm_tn_part(const double *__restrict__ Q, int64_t ldq,
+                                                      int p, const double *__restrict__ W,
+                                                      int64_t ldw, int cb, int64_t n,
+                                                      int64_t rows_per, double *partial) {
+  const int pt = blockIdx.x, rc = blockIdx.y, tid = threadIdx.x;
+  const int64_t r0 = (int64_t)rc * rows_per;
+  int64_t r1 = r0 + rows_per;
+  if (r1 > n) r1 = n;
+  double acc[4][kMaxB];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int j = 0; j < kMaxB; j++) acc[a][j] = 0;
+  const int pc = pt * 4;
+  for (int64_t i = r0 + tid; i < r1; i += 256) {
+    double w[kMaxB];
+#pragma unroll
+    for (int j = 0; j < kMaxB; j++) w[j] = j < cb ? W[i + j * ldw] : 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+      double q = (pc + a) < p ? Q[i + (int64_t)(pc + a) * ldq] : 0.0;
+#pragma unroll
+      for (int j = 0; j < kMaxB; j++) acc[a][j] += q * w[j];
+    }
+  }
+  __shared__ double red[4][4 * kMaxB];
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int j = 0; j < kMaxB; j++) {
+      double v = acc[a][j];
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+      if (lane == 0) red[wave][a * kMaxB + j] = v;
+    }
+  __syncthreads();
+  if (tid < 4 * kMaxB) {
+    double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    int a = tid / kMaxB, j = tid % kMaxB;
+    if (pc + a < p && j < cb) partial[((int64_t)rc * p + pc + a) * kMaxB + j] = v;
+  }
+}
+
+__global__ void k_gemm_tn_reduce(const double *partial, int nrc, int p, int cb, double *C) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p * cb) return;
+  int a = t % p, j = t / p;
+  double s = 0;
+  for (int rc = 0; rc < nrc; rc++) s += partial[((int64_t)rc * p + a) * kMaxB + j];
+  C[a + (int64_t)j * p] = s;
+}
+
+// Out[i, j] = alpha * In[i, j] + beta * sum_a Q[i, a] S[a, j],  j < nc <= 8; S (p x nc) in global
+__global__ __launch_bounds__(256) void k_gemm_nn(const double *__restrict__ Q, int64_t ldq, int p,
+                                                 const double *__restrict__ S, int nc,
+                                                 const double *In, int64_t ldi, double alpha,
+                                                 double beta, double *Out, int64_t ldo, int64_t n) {
+  extern __shared__ __attribute__((aligned(16))) double sS[];  // tile of S: TP x kMaxB
+  constexpr int TP = 512;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double acc[kMaxB];
+#pragma unroll
+  for (int j = 0; j < kMaxB; j++) acc[j] = 0;
+  for (int a0 = 0; a0 < p; a0 += TP) {
+    int ta = p - a0 < TP ? p - a0 : TP;
+    __syncthreads();
+    for (int t = threadIdx.x; t < ta * kMaxB; t += blockDim.x) {
+      int a = t / kMaxB, j = t % kMaxB;
+      sS[t] = j < nc ? S[(a0 + a) + (int64_t)j * p] : 0.0;
+    }
+    __syncthreads();
+    if (i < n) {
+      for (int a = 0; a < ta; a++) {
+        double q = Q[i + (int64_t)(a0 + a) * ldq];
+#pragma unroll
+        for (int j = 0; j < kMaxB; j++) acc[j] += q * sS[a * kMaxB + j];
+      }
+    }
+  }
+  if (i < n) {
+#pragma unroll
+    for (int j = 0; j < kMaxB; j++)
+      if (j < nc) {
+        double base = alpha != 0.0 ? alpha * In[i + (int64_t)j * ldi] : 0.0;
+        Out[i + (int64_t)j * ldo] = base + beta * acc[j];
+      }
+  }
+}
+
+// in place W[:, :r] = W[:, :cb] * M (cb x r), one thread per row
+__global__ void k_right_mult(double *W, int64_t ld, int64_t n, int cb, int r, const double *M) {
+  __shared__ double sM[kMaxB * kMaxB];
+  if (threadIdx.x < cb * r) sM[threadIdx.x] = M[threadIdx.x];
+  __syncthreads();
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double w[kMaxB], o[kMaxB];
+#pragma unroll
+  for (int j = 0; j < kMaxB; j++) w[j] = j < cb ? W[i + j * ld] : 0.0;
+#pragma unroll
+  for (int c = 0; c < kMaxB; c++) {
+    double s = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxB; j++)
+      if (j < cb && c < r) s += w[j] * sM[j + c * cb];
+    o[c] = s;
+  }
+#pragma unroll
+  for (int c = 0; c < kMaxB; c++)
+    if (c < r) W[i + c * ld] = o[c];
+}
+
+struct HipSvdBackend : SvdBackend {
+  bsn_op *op = nullptr;
+  hipStream_t st = nullptr;
+  bsn_allreduce_fn allreduce = nullptr;
+  void *ctx = nullptr;
+  DevBuf<double> Q, Z, W, partial, dsmall, tmp;
+  int cap = 0, b = 0;
+  int64_t rows_per = 0;
+  int nrc = 0;
+
+  void alloc(int cap_, int b_) override {
+    if (b_ > kMaxB) fail("block size must be <= %d", kMaxB);
+    cap = cap_;
+    b = b_;
+    Q.ensure((size_t)n * cap);
+    Z.ensure((size_t)m_local * cap);
+    W.ensure((size_t)n * kMaxB);
+    rows_per = 4096;
+    nrc = (int)((n + rows_per - 1) / rows_per);
+    partial.ensure((size_t)nrc * (cap + 4) * kMaxB);
+    dsmall.ensure((size_t)(cap + 4) * 64);
+  }
+  void random_W(int bb, uint32_t seed) override {
+    hipLaunchKernelGGL(k_random, dim3((unsigned)((n + 255) / 256), bb), dim3(256), 0, st, W.p, n, n,
+                       bb, seed);
+    BSN_HIP(hipGetLastError());
+  }
+  void At_Qblock(int p0, int cb) override {
+    op_cprod(op, Q.p + (int64_t)p0 * n, n, cb, Z.p + (int64_t)p0 * m_local, m_local);
+  }
+  void A_Zblock(int p0, int cb) override {
+    op_prod(op, Z.p + (int64_t)p0 * m_local, m_local, cb, W.p, n);
+    if (allreduce) {
+      BSN_HIP(hipStreamSynchronize(st));
+      allreduce(W.p, n * cb, ctx);
+    }
+  }
+  void gemm_tn(const double *A, int p, int cb, double *C_host) {
+    dim3 grid((unsigned)((p + 3) / 4), (unsigned)nrc);
+    hipLaunchKernelGGL(k_gemm_tn_part, grid, dim3(256), 0, st, A, n, p, W.p, n, cb, n, rows_per,
+                       partial.p);
+    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((p * cb + 255) / 256)), dim3(256), 0, st,
+                       partial.p, nrc, p, cb, dsmall.p);
+    BSN_HIP(hipGetLastError());
+    BSN_HIP(hipMemcpyAsync(C_host, dsmall.p, (size_t)p * cb * 8, hipMemcpyDeviceToHost, st));
+    BSN_HIP(hipStreamSynchronize(st));
+  }
+  void QtW(int p, int cb, double *C) override { gemm_tn(Q.p, p, cb, C); }
+  void WtW(int cb, double *G) override { gemm_tn(W.p, cb, cb, G); }
+  void W_minus_QC(int p, int cb, const double *C) override {
+    BSN_HIP(hipMemcpyAsync(dsmall.p, C, (size_t)p * cb * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((n + 255) / 256)), dim3(256), 512 * kMaxB * 8, st,
+                       Q.p, n, p, dsmall.p, cb, W.p, n, 1.0, -1.0, W.p, n, n);
+    BSN_HIP(hipGetLastError());
+    BSN_HIP(hipStreamSynchronize(st));  // C is a host vector that may be reused
+  }
+  void W_times(int cb, int r, const double *M) override {
+    BSN_HIP(hipMemcpyAsync(dsmall.p, M, (size_t)cb * r * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_right_mult, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W.p, n, n,
+                       cb, r, dsmall.p);
+    BSN_HIP(hipGetLastError());
+    BSN_HIP(hipStreamSynchronize(st));
+  }
+  void W_to_Q(int p0, int r) override {
+    BSN_HIP(hipMemcpyAsync(Q.p + (int64_t)p0 * n, W.p, (size_t)n * r * 8, hipMemcpyDeviceToDevice, st));
+  }
+  void finalize(int pp, int k, const double *S, const double *dinv, double *u, double *v) override {
+    std::vector<double> Sv((size_t)pp * k);
+    for (int t = 0; t < k; t++)
+      for (int i = 0; i < pp; i++) Sv[(size_t)i + (size_t)t * pp] = S[(size_t)i + (size_t)t * pp] * dinv[t];
+    DevBuf<double> dS, dU, dV;
+    dS.ensure((size_t)pp * k * 2 + 16);
+    dU.ensure((size_t)n * k);
+    dV.ensure((size_t)m_local * k);
+    BSN_HIP(hipMemcpyAsync(dS.p, S, (size_t)pp * k * 8, hipMemcpyHostToDevice, st));
+    BSN_HIP(hipMemcpyAsync(dS.p + (size_t)pp * k, Sv.data(), (size_t)pp * k * 8, hipMemcpyHostToDevice, st));
+    for (int c0 = 0; c0 < k && pp > 0; c0 += kMaxB) {
+      int nc = k - c0 < kMaxB ? k - c0 : kMaxB;
+      hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((n + 255) / 256)), dim3(256), 512 * kMaxB * 8, st,
+                         Q.p, n, pp, dS.p + (size_t)c0 * pp, nc, (const double *)nullptr, (int64_t)0,
+                         0.0, 1.0, dU.p + (int64_t)c0 * n, n, n);
+      hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((m_local + 255) / 256)), dim3(256),
+                         512 * kMaxB * 8, st, Z.p, m_local, pp, dS.p + (size_t)pp * k + (size_t)c0 * pp,
+                         nc, (const double *)nullptr, (int64_t)0, 0.0, 1.0,
+                         dV.p + (int64_t)c0 * m_local, m_local, m_local);
+    }
+    BSN_HIP(hipGetLastError());
+    if (pp == 0) {
+      BSN_HIP(hipMemsetAsync(dU.p, 0, (size_t)n * k * 8, st));
+      BSN_HIP(hipMemsetAsync(dV.p, 0, (size_t)m_local * k * 8, st));
+    }
+    if (u) BSN_HIP(hipMemcpyAsync(u, dU.p, (size_t)n * k * 8, hipMemcpyDeviceToHost, st));
+    if (v) BSN_HIP(hipMemcpyAsync(v, dV.p, (size_t)m_local * k * 8, hipMemcpyDeviceToHost, st));
+    BSN_HIP(hipStreamSynchronize(st));
+  }
+};
+
+}  // namespace bsn
+
+using namespace bsn;
+
+extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n,
+                                 const int64_t *ind_col, int64_t m, const double *center,
+                                 const double *scale, const bsn_svd_options *o, double *d, double *u,
+                                 double *v, bsn_svd_info *info) {
+  return guarded([&] {
+    if (!o) fail("options must not be NULL");
+    if (o->k < 1) fail("'k' must be at least 1.");
+    bsn_op *op = nullptr;
+    if (bsn_op_create(bed, ind_row, n, ind_col, m, center, scale, &op) != 0)
+      throw Error(bsn_last_error());
+    std::unique_ptr<bsn_op> guard(op);
+    op->slices = o->slices > 0 ? o->slices : 4;
+    if (op->slices > 7) fail("slices must be in 1..7");
+    HipSvdBackend bk;
+    bk.op = op;
+    bk.st = bed->stream;
+    bk.n = n;
+    bk.m_local = m;
+    bk.m_total = o->m_total > 0 ? o->m_total : m;
+    bk.allreduce = o->allreduce;
+    bk.ctx = o->allreduce_ctx;
+    int64_t dim = bk.n < bk.m_total ? bk.n : bk.m_total;
+    if (o->k > dim) fail("'k' is larger than the dimensions of the matrix.");
+    SvdOptions so;
+    so.k = o->k;
+    so.tol = o->tol > 0 ? o->tol : 1e-4;
+    so.block = o->block > 0 ? (o->block > kMaxB ? kMaxB : o->block) : kMaxB;
+    so.max_basis = o->max_basis;
+    so.seed = o->seed ? o->seed : 1;
+    so.verbose = o->verbose;
+    BSN_HIP(hipEventRecord(bed->ev0, bed->stream));
+    SvdResult r = block_lanczos_svd(bk, so, d, u, v);
+    BSN_HIP(hipEventRecord(bed->ev1, bed->stream));
+    BSN_HIP(hipEventSynchronize(bed->ev1));
+    float ms = 0;
+    BSN_HIP(hipEventElapsedTime(&ms, bed->ev0, bed->ev1));
+    if (info) {
+      info->niter = r.niter;
+      info->nops = (int32_t)op->passes;
+      info->basis = r.basis;
+      info->converged = r.converged;
+      info->max_rel_resid = r.max_rel_resid;
+      info->gpu_ms = ms;
+    }
+  });
+}

@@ -1,0 +1,48 @@
+"""bed_randomSVD — host mirror of R/autoSVD.R:205-219.
+
+The reference forwards to bigstatsr::big_randomSVD(obj.bed$light, fun.scaling, ind.row,
+ind.col, k, tol, verbose, ncores, bed_prodVec, bed_cprodVec); here the whole solve runs in
+libbigsnpr_hip (bsn_bed_randomsvd): scaling statistics, block-Lanczos passes and panel
+algebra all stay on the GPU.  The result mirrors class "big_SVD": d, u, v, niter, nops,
+center, scale.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, f64p, i64p, ptr
+from .bed import _args, assert_bed, bed_scaleBinom
+
+
+def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=None, k=10,
+                  tol=1e-4, verbose=False, ncores=1, block=8, slices=4, max_basis=0, seed=1,
+                  allreduce=None, m_total=0, return_uv=True):
+    """Partial SVD of the scaled matrix.  Extra (non-reference) arguments: ``block``
+    (vectors per streaming pass), ``slices`` (int8 slices per fp64 value), ``allreduce``
+    (callable(ptr, count) summing a device buffer over ranks; column-sharded multi-GPU),
+    ``m_total`` (columns over all ranks)."""
+    assert_bed(obj_bed)
+    ir, ic = _args(obj_bed, ind_row, ind_col)
+    ms = fun_scaling(obj_bed, ind_row=ir, ind_col=ic, ncores=ncores)
+    center = np.ascontiguousarray(ms["center"], dtype=np.float64)
+    scale = np.ascontiguousarray(ms["scale"], dtype=np.float64)
+    opts = _lib.SvdOptions()
+    opts.k, opts.tol, opts.block, opts.slices = int(k), float(tol), int(block), int(slices)
+    opts.max_basis, opts.seed, opts.verbose, opts.m_total = int(max_basis), int(seed), int(bool(verbose)), int(m_total)
+    cb = None
+    if allreduce is not None:
+        cb = _lib.ALLREDUCE_FN(lambda p, count, ctx: allreduce(p, count))
+        opts.allreduce = cb
+    info = _lib.SvdInfo()
+    d = np.empty(k)
+    u = np.empty((k, ir.size)) if return_uv else None
+    v = np.empty((k, ic.size)) if return_uv else None
+    check(_lib.load().bsn_bed_randomsvd(obj_bed.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p),
+                                        ic.size, ptr(center, f64p), ptr(scale, f64p),
+                                        C.byref(opts), ptr(d, f64p), ptr(u, f64p), ptr(v, f64p),
+                                        C.byref(info)))
+    return dict(d=d, u=None if u is None else u.T, v=None if v is None else v.T,
+                niter=info.niter, nops=info.nops, center=center, scale=scale,
+                basis=info.basis, converged=bool(info.converged),
+                max_rel_resid=info.max_rel_resid, gpu_ms=info.gpu_ms)

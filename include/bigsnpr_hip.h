@@ -109,6 +109,40 @@ int bsn_op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_
 int bsn_op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z, int64_t ldz);
 int bsn_op_sync(bsn_op *op);
 
+/* ---- partial SVD (replaces bed_randomSVD -> bigstatsr::big_randomSVD -> RSpectra::svds,
+ *      R/autoSVD.R:205-219; result fields of class "big_SVD": d, u, v, niter, nops) --------
+ * Block Lanczos with full re-orthogonalisation on A~ A~' driven entirely on the device.
+ * `center`/`scale` are what fun.scaling returned (bed_scaleBinom, R/binom-scaling.R:133-142).
+ * Multi-GPU: every rank calls this on its own column shard (ind_col local to its image),
+ * passes m_total and an all-reduce hook that sums a device buffer of `count` doubles over
+ * ranks in place (RCCL); u (n x k) is then identical on all ranks and v (m x k) is the
+ * rank's own shard.  u / v may be NULL. */
+typedef void (*bsn_allreduce_fn)(void *d_buf, int64_t count, void *ctx);
+typedef struct bsn_svd_options {
+  int32_t k;          /* number of singular triplets (R default 10) */
+  double tol;         /* relative residual on eigenvalues of A~A~' (R default 1e-4) */
+  int32_t block;      /* vectors per pass, 1..8 (0 -> 8) */
+  int32_t slices;     /* int8 slices of the fp64 panels, 1..7 (0 -> 4) */
+  int32_t max_basis;  /* cap on the Krylov basis (0 -> automatic) */
+  uint32_t seed;      /* start block seed (0 -> 1) */
+  int32_t verbose;
+  int64_t m_total;    /* total number of columns over all ranks (0 -> m) */
+  bsn_allreduce_fn allreduce;
+  void *allreduce_ctx;
+} bsn_svd_options;
+typedef struct bsn_svd_info {
+  int32_t niter;      /* block steps */
+  int32_t nops;       /* streaming passes over the genotype image (A~ or A~' applications) */
+  int32_t basis;      /* Krylov basis size at exit */
+  int32_t converged;
+  double max_rel_resid;
+  double gpu_ms;      /* HIP-event time of the whole solve on the handle's stream */
+} bsn_svd_info;
+int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                      int64_t m, const double *center, const double *scale,
+                      const bsn_svd_options *options, double *d, double *u, double *v,
+                      bsn_svd_info *info);
+
 /* ---- device memory + timing helpers for hosts without a HIP binding -------- */
 int bsn_malloc(void **d_ptr, int64_t bytes);
 int bsn_free(void *d_ptr);

@@ -1,0 +1,147 @@
+// Test-only shared library: runs the product's backend-independent host code
+// (bigsnpr_amd/csrc/svd_driver.hpp, dense_small.hpp) on CPU with a dense host backend so
+// that the driver logic — including the column-sharded multi-rank path with an all-reduce
+// hook — can be tested without a GPU (gloo, world_size 2).  Not part of the product.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "svd_driver.hpp"
+
+using namespace bsn;
+
+typedef void (*allreduce_fn)(double *buf, int64_t count, void *ctx);
+
+struct HostBackend : SvdBackend {
+  const double *A = nullptr;  // n x m_local dense scaled matrix, column-major
+  allreduce_fn ar = nullptr;
+  void *ctx = nullptr;
+  std::vector<double> Q, Z, W;
+  void alloc(int cap, int b) override {
+    Q.assign((size_t)n * cap, 0.0);
+    Z.assign((size_t)m_local * cap, 0.0);
+    W.assign((size_t)n * b, 0.0);
+  }
+  void random_W(int b, uint32_t seed) override {
+    uint64_t s = 0x9E3779B97F4A7C15ull * (seed + 1);
+    for (size_t t = 0; t < (size_t)n * b; t++) {
+      s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+      W[t] = (double)(s >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
+    }
+  }
+  void At_Qblock(int p0, int cb) override {
+    for (int c = 0; c < cb; c++)
+      for (int64_t j = 0; j < m_local; j++) {
+        double s = 0;
+        for (int64_t i = 0; i < n; i++) s += A[i + j * n] * Q[i + (size_t)(p0 + c) * n];
+        Z[j + (size_t)(p0 + c) * m_local] = s;
+      }
+  }
+  void A_Zblock(int p0, int cb) override {
+    std::fill(W.begin(), W.begin() + (size_t)n * cb, 0.0);
+    for (int c = 0; c < cb; c++)
+      for (int64_t j = 0; j < m_local; j++) {
+        double z = Z[j + (size_t)(p0 + c) * m_local];
+        for (int64_t i = 0; i < n; i++) W[i + (size_t)c * n] += A[i + j * n] * z;
+      }
+    if (ar) ar(W.data(), n * cb, ctx);
+  }
+  void QtW(int p, int cb, double *C) override {
+    for (int c = 0; c < cb; c++)
+      for (int a = 0; a < p; a++) {
+        double s = 0;
+        for (int64_t i = 0; i < n; i++) s += Q[i + (size_t)a * n] * W[i + (size_t)c * n];
+        C[a + (size_t)c * p] = s;
+      }
+  }
+  void W_minus_QC(int p, int cb, const double *C) override {
+    for (int c = 0; c < cb; c++)
+      for (int a = 0; a < p; a++) {
+        double f = C[a + (size_t)c * p];
+        for (int64_t i = 0; i < n; i++) W[i + (size_t)c * n] -= Q[i + (size_t)a * n] * f;
+      }
+  }
+  void WtW(int cb, double *G) override {
+    for (int c = 0; c < cb; c++)
+      for (int a = 0; a < cb; a++) {
+        double s = 0;
+        for (int64_t i = 0; i < n; i++) s += W[i + (size_t)a * n] * W[i + (size_t)c * n];
+        G[a + (size_t)c * cb] = s;
+      }
+  }
+  void W_times(int cb, int r, const double *M) override {
+    std::vector<double> row(cb), out(r);
+    for (int64_t i = 0; i < n; i++) {
+      for (int j = 0; j < cb; j++) row[j] = W[i + (size_t)j * n];
+      for (int c = 0; c < r; c++) {
+        double s = 0;
+        for (int j = 0; j < cb; j++) s += row[j] * M[j + (size_t)c * cb];
+        out[c] = s;
+      }
+      for (int c = 0; c < r; c++) W[i + (size_t)c * n] = out[c];
+    }
+  }
+  void W_to_Q(int p0, int r) override {
+    std::memcpy(&Q[(size_t)p0 * n], W.data(), sizeof(double) * (size_t)n * r);
+  }
+  void finalize(int pp, int k, const double *S, const double *dinv, double *u, double *v) override {
+    for (int t = 0; t < k; t++) {
+      for (int64_t i = 0; i < n; i++) {
+        double s = 0;
+        for (int a = 0; a < pp; a++) s += Q[i + (size_t)a * n] * S[a + (size_t)t * pp];
+        u[i + (size_t)t * n] = s;
+      }
+      for (int64_t j = 0; j < m_local; j++) {
+        double s = 0;
+        for (int a = 0; a < pp; a++) s += Z[j + (size_t)a * m_local] * S[a + (size_t)t * pp];
+        v[j + (size_t)t * m_local] = s * dinv[t];
+      }
+    }
+  }
+};
+
+extern "C" {
+
+void nt_eig_sym(int n, double *A, double *d) {
+  std::vector<double> V(A, A + (size_t)n * n), w;
+  eig_sym(n, V, w);
+  std::memcpy(A, V.data(), sizeof(double) * (size_t)n * n);
+  std::memcpy(d, w.data(), sizeof(double) * (size_t)n);
+}
+
+int nt_chol_inv(int b, const double *G, double *R, double *Ri) {
+  std::vector<double> g(G, G + (size_t)b * b), r, ri;
+  int rk = chol_upper(b, g, r, 1e-22);
+  if (rk == b) {
+    inv_upper(b, r, ri);
+    std::memcpy(R, r.data(), sizeof(double) * (size_t)b * b);
+    std::memcpy(Ri, ri.data(), sizeof(double) * (size_t)b * b);
+  }
+  return rk;
+}
+
+// info: niter, nops, basis, converged
+void nt_svd_host(const double *A, int64_t n, int64_t m_local, int64_t m_total, int k, double tol,
+                 int block, int max_basis, uint32_t seed, allreduce_fn ar, void *ctx, double *d,
+                 double *u, double *v, int32_t *info, double *resid) {
+  HostBackend bk;
+  bk.A = A;
+  bk.n = n;
+  bk.m_local = m_local;
+  bk.m_total = m_total;
+  bk.ar = ar;
+  bk.ctx = ctx;
+  SvdOptions o;
+  o.k = k;
+  o.tol = tol;
+  o.block = block;
+  o.max_basis = max_basis;
+  o.seed = seed;
+  SvdResult r = block_lanczos_svd(bk, o, d, u, v);
+  info[0] = r.niter;
+  info[1] = r.nops;
+  info[2] = r.basis;
+  info[3] = r.converged;
+  *resid = r.max_rel_resid;
+}
+}

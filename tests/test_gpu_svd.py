@@ -1,0 +1,83 @@
+"""GPU parity of bed_randomSVD (through bsn_bed_randomsvd) against the oracle's dense SVD.
+Mirrors tests/testthat/test-2-bed-clumping-SVD.R:41-79.  Tolerances: d within 1e-6
+relative (north_star); u, v within 1e-6 after sign alignment when solved to a tight
+tolerance with 56-bit slices."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ba():
+    import bigsnpr_amd
+    return bigsnpr_amd
+
+
+def _align(a, ref):
+    s = np.sign(np.sum(a * ref, axis=0))
+    return a * s
+
+
+def test_example_bed_svd(ba, orc, golden_dir, example_bed):
+    gb = ba.bed(os.path.join(golden_dir, "example.bed"))
+    ref = orc.dense_svd(example_bed, k=10)
+    # reference defaults (k = 10, tol = 1e-4): singular values within 1e-6
+    res = ba.bed_randomSVD(gb, k=10)
+    assert res["converged"]
+    np.testing.assert_allclose(res["d"], ref["d"], rtol=1e-6)
+    np.testing.assert_array_equal(res["center"], ref["center"])
+    np.testing.assert_array_equal(res["scale"], ref["scale"])
+    assert np.abs(res["u"].mean(0)).max() < 1e-6          # colMeans(u) ~ 0 (:53)
+    # tight solve: vectors too
+    res = ba.bed_randomSVD(gb, k=10, tol=1e-11, slices=7)
+    np.testing.assert_allclose(res["d"], ref["d"], rtol=1e-10)
+    assert np.abs(_align(res["u"], ref["u"]) - ref["u"]).max() < 1e-6
+    assert np.abs(_align(res["v"], ref["v"]) - ref["v"]).max() < 1e-6
+    # u, v orthonormal and consistent: A v = u d
+    np.testing.assert_allclose(res["u"].T @ res["u"], np.eye(10), atol=1e-9)
+    np.testing.assert_allclose(res["v"].T @ res["v"], np.eye(10), atol=1e-9)
+
+
+def test_subset_with_missing_values(ba, orc, golden_dir, missing_bed):
+    gb = ba.bed(os.path.join(golden_dir, "example-missing.bed"))
+    rng = np.random.default_rng(0)
+    ir = np.sort(rng.choice(missing_bed.n, 150, replace=False))
+    ic = np.sort(rng.choice(missing_bed.m, 400, replace=False))
+    sc = orc.bed_scaleBinom(missing_bed, ir, ic)
+    ic = ic[sc["scale"] > 0]
+    ref = orc.dense_svd(missing_bed, ir, ic, k=5)
+    res = ba.bed_randomSVD(gb, ind_row=ir, ind_col=ic, k=5, tol=1e-11, slices=7)
+    np.testing.assert_allclose(res["d"], ref["d"], rtol=1e-9)
+    assert np.abs(_align(res["u"], ref["u"]) - ref["u"]).max() < 1e-6
+    assert np.abs(_align(res["v"], ref["v"]) - ref["v"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("n,m,k", [(1500, 4000, 20), (3000, 900, 10)])
+def test_synthetic_structured(ba, orc, n, m, k):
+    ob = orc.fake_bed(n, m, seed=21)
+    gb = ba.bed.synthetic(n, m, seed=21)
+    sc = orc.bed_scaleBinom(ob)
+    ic = np.nonzero(sc["scale"] > 0)[0]
+    ref = orc.dense_svd(ob, None, ic, k=k)
+    res = ba.bed_randomSVD(gb, ind_col=ic, k=k)                  # defaults: 32-bit slices, tol 1e-4
+    assert res["converged"]
+    np.testing.assert_allclose(res["d"], ref["d"], rtol=1e-6)
+    res7 = ba.bed_randomSVD(gb, ind_col=ic, k=k, tol=1e-11, slices=7)
+    np.testing.assert_allclose(res7["d"], ref["d"], rtol=1e-10)
+    gap_ok = np.r_[True, np.diff(-ref["d"]) / ref["d"][0] > 1e-4] & np.r_[np.diff(-ref["d"]) / ref["d"][0] > 1e-4, True]
+    U = _align(res7["u"], ref["u"]); V = _align(res7["v"], ref["v"])
+    assert np.abs(U - ref["u"])[:, gap_ok].max() < 1e-6
+    assert np.abs(V - ref["v"])[:, gap_ok].max() < 1e-6
+    # run-to-run bit reproducibility
+    res_b = ba.bed_randomSVD(gb, ind_col=ic, k=k)
+    np.testing.assert_array_equal(res["d"], res_b["d"])
+    np.testing.assert_array_equal(res["u"], res_b["u"])
+
+
+def test_k_too_large_and_errors(ba, golden_dir):
+    gb = ba.bed(os.path.join(golden_dir, "example-missing.bed"))
+    with pytest.raises(ba.BsnError, match="larger than the dimensions"):
+        ba.bed_randomSVD(gb, k=300)

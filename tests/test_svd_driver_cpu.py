@@ -1,0 +1,145 @@
+"""CPU tests of the backend-independent SVD driver (bigsnpr_amd/csrc/svd_driver.hpp) with
+a dense host backend, including the column-sharded world_size-2 path over gloo."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "native"))
+
+AR_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int64, C.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def nt():
+    import build_native
+    lib = C.CDLL(build_native.build())
+    return lib
+
+
+def host_svd(nt, A, k, tol=1e-10, block=8, m_total=None, ar=None, max_basis=0, seed=1):
+    A = np.asfortranarray(A, dtype=np.float64)
+    n, m = A.shape
+    d = np.empty(k); u = np.empty((k, n)); v = np.empty((k, m))
+    info = np.zeros(4, dtype=np.int32); resid = C.c_double()
+    cb = AR_FN(ar) if ar is not None else AR_FN()
+    nt.nt_svd_host(A.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(n), C.c_int64(m),
+                   C.c_int64(m_total or m), k, C.c_double(tol), block, max_basis, C.c_uint32(seed),
+                   cb, None, d.ctypes.data_as(C.POINTER(C.c_double)),
+                   u.ctypes.data_as(C.POINTER(C.c_double)), v.ctypes.data_as(C.POINTER(C.c_double)),
+                   info.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(resid))
+    return dict(d=d, u=u.T, v=v.T, niter=info[0], nops=info[1], basis=info[2],
+                converged=bool(info[3]), resid=resid.value)
+
+
+def test_eig_sym_matches_numpy(nt):
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 5, 37, 120):
+        B = rng.normal(size=(n, n)); S = B + B.T
+        if n == 37:  # block tridiagonal like the Lanczos matrix, with repeated eigenvalues
+            S = np.kron(np.eye(n // 2 + 1), np.ones((2, 2)))[:n, :n] + np.diag(np.ones(n - 2), 2) + np.diag(np.ones(n - 2), -2)
+        A = np.asfortranarray(S.copy()); d = np.empty(n)
+        nt.nt_eig_sym(n, A.ctypes.data_as(C.POINTER(C.c_double)), d.ctypes.data_as(C.POINTER(C.c_double)))
+        w = np.linalg.eigvalsh(S)
+        np.testing.assert_allclose(d, w, atol=1e-12 * max(1, np.abs(w).max()))
+        np.testing.assert_allclose(A @ np.diag(d) @ A.T, S, atol=1e-11 * max(1, np.abs(w).max()))
+        np.testing.assert_allclose(A.T @ A, np.eye(n), atol=1e-12)
+
+
+def _check_svd(res, A, k, tol_d=1e-8, tol_vec=1e-6):
+    U, d, Vt = np.linalg.svd(A, full_matrices=False)
+    np.testing.assert_allclose(res["d"], d[:k], rtol=tol_d)
+    for t in range(k):
+        if t + 1 < len(d) and (d[t] - d[t + 1]) / d[0] < 1e-6:
+            continue
+        s = np.sign(res["u"][:, t] @ U[:, t])
+        assert np.abs(s * res["u"][:, t] - U[:, t]).max() < tol_vec
+        assert np.abs(s * res["v"][:, t] - Vt[t]).max() < tol_vec
+
+
+@pytest.mark.parametrize("n,m,k,block", [(200, 500, 10, 8), (300, 120, 10, 8), (60, 45, 10, 4),
+                                         (33, 70, 10, 8), (500, 400, 20, 8), (150, 150, 3, 1),
+                                         (12, 40, 10, 8)])
+def test_block_lanczos_dense(nt, n, m, k, block):
+    rng = np.random.default_rng(n + m)
+    r = min(n, m)
+    A = rng.normal(size=(n, r)) @ np.diag(np.linspace(1, 30, r) ** 1.5) @ rng.normal(size=(r, m)) / np.sqrt(r)
+    res = host_svd(nt, A, k, tol=1e-12, block=block)
+    assert res["converged"]
+    _check_svd(res, A, k)
+
+
+def test_genotype_matrix_matches_oracle_dense_svd(nt, orc, example_bed):
+    # tests/testthat/test-2-bed-clumping-SVD.R:52-54,76-79 through the oracle's dense SVD
+    ic = np.arange(0, example_bed.m, 3)
+    ref = orc.dense_svd(example_bed, None, ic, k=10)
+    A = orc.read_bed_scaled(example_bed, None, ic, ref["center"], ref["scale"])
+    res = host_svd(nt, A, 10, tol=1e-12)
+    np.testing.assert_allclose(res["d"], ref["d"], rtol=1e-9)
+    assert np.abs(res["u"].mean(0)).max() < 1e-8
+    # default tolerance of the reference (1e-4): d still within 1e-6
+    res2 = host_svd(nt, A, 10, tol=1e-4)
+    np.testing.assert_allclose(res2["d"], ref["d"], rtol=1e-6)
+    assert res2["nops"] <= res["nops"]
+
+
+def test_rank_deficient_and_tiny(nt):
+    rng = np.random.default_rng(5)
+    A = rng.normal(size=(80, 6)) @ rng.normal(size=(6, 50))   # rank 6 < k
+    res = host_svd(nt, A, 10, tol=1e-10)
+    d = np.linalg.svd(A, compute_uv=False)
+    np.testing.assert_allclose(res["d"][:6], d[:6], rtol=1e-8)
+    assert np.all(res["d"][6:] < 1e-6 * d[0])
+
+
+_WORKER = r'''
+import ctypes as C, os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from test_svd_driver_cpu import host_svd, AR_FN
+import build_native
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+rank = dist.get_rank()
+nt = C.CDLL(build_native.build())
+rng = np.random.default_rng(42)
+n, m, k = 180, 260, 10
+A = rng.normal(size=(n, 40)) @ np.diag(np.linspace(1, 20, 40)) @ rng.normal(size=(40, m)) + 0.01 * rng.normal(size=(n, m))
+cols = np.arange(m)[rank::2] if False else np.arange(rank * m // 2, (rank + 1) * m // 2)
+def ar(buf, count, ctx):
+    a = np.ctypeslib.as_array(buf, shape=(count,))
+    t = torch.from_numpy(a)
+    dist.all_reduce(t)
+res = host_svd(nt, A[:, cols], k, tol=1e-12, m_total=m, ar=ar)
+U, d, Vt = np.linalg.svd(A, full_matrices=False)
+assert res["converged"]
+np.testing.assert_allclose(res["d"], d[:k], rtol=1e-9)
+for t in range(k):
+    s = np.sign(res["u"][:, t] @ U[:, t])
+    assert np.abs(s * res["u"][:, t] - U[:, t]).max() < 1e-7
+    assert np.abs(s * res["v"][:, t] - Vt[t, cols]).max() < 1e-7
+# u identical on both ranks (bitwise): gather and compare
+t = torch.from_numpy(np.ascontiguousarray(res["u"]))
+out = [torch.empty_like(t) for _ in range(2)]
+dist.all_gather(out, t)
+assert torch.equal(out[0], out[1])
+dist.barrier()
+print("rank", rank, "ok", res["niter"])
+'''
+
+
+def test_sharded_two_ranks_gloo(tmp_path):
+    """N>1 path: columns sharded over 2 ranks, W all-reduced (gloo on CPU); both ranks must
+    converge to the global SVD and hold identical u."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "tests", "native"))
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
