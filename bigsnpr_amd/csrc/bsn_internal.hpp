@@ -96,6 +96,14 @@ struct bsn_op {
   int64_t col0 = 0;
   int slices = 4;
   int64_t passes = 0;         // streaming launches over the image issued so far
+  // per-launch HIP-event timing of the two streaming kernels (kind 0 = k_cprod, 1 = k_prod)
+  bool profile = false;
+  std::vector<hipEvent_t> ev_begin, ev_end;
+  std::vector<int> ev_kind;
+  ~bsn_op() {
+    for (auto e : ev_begin) (void)hipEventDestroy(e);
+    for (auto e : ev_end) (void)hipEventDestroy(e);
+  }
   bsn::DevBuf<int32_t> d_rows;   // n (gather list) when !rows_identity
   bsn::DevBuf<int32_t> d_cols;   // m_pad (padded by repeating a valid column)
   bsn::DevBuf<double> d_center, d_scale;  // m
@@ -128,5 +136,10 @@ void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z,
 // weighted code counts: d_w = per-file-row integer weights (n_file doubles); out 4 x m
 void counts_weighted(bsn_op *op, const double *d_w, int64_t n_sub, int32_t *d_counts);
 void selftest();
+// event helpers around a streaming launch (no-ops unless op->profile)
+void prof_begin(bsn_op *op, int kind);
+void prof_end(bsn_op *op);
+// sums the recorded launches: ms[kind], count[kind]; clears the records
+void prof_collect(bsn_op *op, double ms[2], int count[2]);
 
 }  // namespace bsn

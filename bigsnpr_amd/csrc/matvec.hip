@@ -444,6 +444,37 @@ __global__ void k_prod_final(const int32_t *acc, int64_t n_pad, int ky, int ncol
 }
 
 // ---------------------------------------------------------------------------
+void prof_begin(bsn_op *op, int kind) {
+  if (!op->profile) return;
+  hipEvent_t a, b;
+  BSN_HIP(hipEventCreate(&a));
+  BSN_HIP(hipEventCreate(&b));
+  op->ev_begin.push_back(a);
+  op->ev_end.push_back(b);
+  op->ev_kind.push_back(kind);
+  BSN_HIP(hipEventRecord(a, op->bed->stream));
+}
+void prof_end(bsn_op *op) {
+  if (!op->profile) return;
+  BSN_HIP(hipEventRecord(op->ev_end.back(), op->bed->stream));
+}
+void prof_collect(bsn_op *op, double ms[2], int count[2]) {
+  ms[0] = ms[1] = 0;
+  count[0] = count[1] = 0;
+  for (size_t i = 0; i < op->ev_begin.size(); i++) {
+    BSN_HIP(hipEventSynchronize(op->ev_end[i]));
+    float t = 0;
+    BSN_HIP(hipEventElapsedTime(&t, op->ev_begin[i], op->ev_end[i]));
+    ms[op->ev_kind[i]] += t;
+    count[op->ev_kind[i]]++;
+    (void)hipEventDestroy(op->ev_begin[i]);
+    (void)hipEventDestroy(op->ev_end[i]);
+  }
+  op->ev_begin.clear();
+  op->ev_end.clear();
+  op->ev_kind.clear();
+}
+
 static int pick_nb(int ncols_needed) { return ncols_needed <= 16 ? 1 : 2; }
 
 static void quantise(bsn_op *op, const double *d_X, int64_t ldx, int64_t len, int64_t len_pad,
@@ -511,7 +542,9 @@ void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z,
     int8_t *q = op->d_q.ensure((size_t)npad * 32 * 2);
     int32_t *acc = op->d_acc.ensure((size_t)2 * op->m * 32);
     quantise(op, xsrc + (int64_t)v0 * ldx, ldx, b->n, npad, nv, 0, S, ncol, 1, 0, meta, q);
+    prof_begin(op, 0);
     launch_cprod<2>(op, NB, q, acc, kLutG0, kLutNA, 0);
+    prof_end(op);
     op->passes++;
     hipLaunchKernelGGL(k_cprod_final, dim3((unsigned)((op->m + 255) / 256), nv), dim3(256), 0,
                        b->stream, acc, op->m, ncol, S, meta, op->d_center.p, op->d_scale.p,
@@ -548,6 +581,7 @@ void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, 
     quantise(op, d_X + (int64_t)v0 * ldx, ldx, op->m, m_pad, nv, 1, S, ncol, 0, 0, meta, q);
     dim3 grid((unsigned)wgx, (unsigned)ky);
     const int32_t *cols = op->d_cols.p;
+    prof_begin(op, 1);
     if (op->cols_contig) {
       if (NB == 1)
         hipLaunchKernelGGL((k_prod<1, true>), grid, dim3(256), 0, b->stream, b->d_img, b->pitch,
@@ -564,6 +598,7 @@ void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, 
                            cols, op->col0, m_pad, mc, q, acc, npad);
     }
     BSN_HIP(hipGetLastError());
+    prof_end(op);
     op->passes++;
     hipLaunchKernelGGL(k_prod_final, dim3((unsigned)((op->n + 255) / 256), nv), dim3(256), 0,
                        b->stream, acc, npad, ky, ncol, S, meta,

@@ -254,6 +254,7 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       throw Error(bsn_last_error());
     std::unique_ptr<bsn_op> guard(op);
     op->slices = o->slices > 0 ? o->slices : 4;
+    op->profile = true;
     if (op->slices > 7) fail("slices must be in 1..7");
     HipSvdBackend bk;
     bk.op = op;
@@ -285,6 +286,13 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       info->converged = r.converged;
       info->max_rel_resid = r.max_rel_resid;
       info->gpu_ms = ms;
+      double pms[2];
+      int pc[2];
+      prof_collect(op, pms, pc);
+      info->cprod_ms = pms[0];
+      info->prod_ms = pms[1];
+      info->n_cprod = pc[0];
+      info->n_prod = pc[1];
     }
   });
 }

@@ -45,4 +45,6 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
     return dict(d=d, u=None if u is None else u.T, v=None if v is None else v.T,
                 niter=info.niter, nops=info.nops, center=center, scale=scale,
                 basis=info.basis, converged=bool(info.converged),
-                max_rel_resid=info.max_rel_resid, gpu_ms=info.gpu_ms)
+                max_rel_resid=info.max_rel_resid, gpu_ms=info.gpu_ms,
+                cprod_ms=info.cprod_ms, prod_ms=info.prod_ms, n_cprod=info.n_cprod,
+                n_prod=info.n_prod)

@@ -137,6 +137,10 @@ typedef struct bsn_svd_info {
   int32_t converged;
   double max_rel_resid;
   double gpu_ms;      /* HIP-event time of the whole solve on the handle's stream */
+  /* per-launch HIP-event time of the two streaming kernels inside this solve */
+  double cprod_ms;    /* total over n_cprod launches of k_cprod (A~' panel) */
+  double prod_ms;     /* total over n_prod launches of k_prod (A~ panel) */
+  int32_t n_cprod, n_prod;
 } bsn_svd_info;
 int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
                       int64_t m, const double *center, const double *scale,
