@@ -190,7 +190,7 @@ __global__ void k_quant(const double *X, int64_t ldx, int64_t len, int64_t len_p
 //   B operand: lane l -> digit column (l&15), same 16 samples (from LDS)
 //   D        : lane l -> column (l&15), rows 4*(l>>4)+r
 template <int NB, int NPLANE, int KC>
-__global__ __launch_bounds__(512) void k_cprod(const uint8_t *__restrict__ img, int64_t pitch,
+__global__ __launch_bounds__(512, 4) void k_cprod(const uint8_t *__restrict__ img, int64_t pitch,
                                                const int32_t *__restrict__ cols, int64_t col0,
                                                int64_t m, const int8_t *__restrict__ xq,
                                                int32_t *__restrict__ acc_out, int64_t m_out,
@@ -221,26 +221,36 @@ __global__ __launch_bounds__(512) void k_cprod(const uint8_t *__restrict__ img, 
 #pragma unroll
       for (int nb = 0; nb < NB; nb++) acc[t][p][nb] = v4i{0, 0, 0, 0};
 
+  static_assert(XS % 512 == 0, "digit chunk must be a multiple of the workgroup");
+  constexpr int NX = XS / 512;             // staged uint4 per thread per chunk
+  static_assert(NX <= 2, "NB <= 2");
   uint4 a_cur[2][LD], a_nxt[2][LD];
+  uint4 xr0 = {0, 0, 0, 0}, xr1 = {0, 0, 0, 0};
   // prologue
 #pragma unroll
   for (int t = 0; t < 2; t++)
 #pragma unroll
     for (int it = 0; it < LD; it++) a_cur[t][it] = *(const uint4 *)(rowp[t] + it * 64);
-  for (int e = tid; e < XS; e += 512) xs[0][e] = xq4[e];
+#pragma unroll
+  for (int e = 0; e < NX; e++)
+    xs[0][tid + e * 512] = xq4[tid + e * 512];
   __syncthreads();
 
   for (int ch = 0; ch < nchunks; ch++) {
     const int cur = ch & 1;
-    if (ch + 1 < nchunks) {
+    const bool has_next = ch + 1 < nchunks;
+    if (has_next) {
+      // issue order matters: the digit panel first, so that waiting for it later does not
+      // also wait for the (younger) genotype loads of the next chunk
+      const uint4 *src = xq4 + (int64_t)(ch + 1) * XS;
+      xr0 = src[tid];
+      if constexpr (NX > 1) xr1 = src[tid + 512];
       const int64_t off = (int64_t)(ch + 1) * (KC / 4);
 #pragma unroll
       for (int t = 0; t < 2; t++)
 #pragma unroll
         for (int it = 0; it < LD; it++)
           a_nxt[t][it] = *(const uint4 *)(rowp[t] + off + it * 64);
-      const uint4 *src = xq4 + (int64_t)(ch + 1) * XS;
-      for (int e = tid; e < XS; e += 512) xs[cur ^ 1][e] = src[e];
     }
 #pragma unroll
     for (int it = 0; it < LD; it++) {
@@ -268,6 +278,10 @@ __global__ __launch_bounds__(512) void k_cprod(const uint8_t *__restrict__ img, 
           }
         }
       }
+    }
+    if (has_next) {
+      xs[cur ^ 1][tid] = xr0;
+      if constexpr (NX > 1) xs[cur ^ 1][tid + 512] = xr1;
     }
     __syncthreads();
 #pragma unroll
@@ -346,7 +360,12 @@ __global__ __launch_bounds__(256) void k_prod(const uint8_t *__restrict__ img, i
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) acc[u][nb] = v4i{0, 0, 0, 0};
 
+  // digit operands of one 64-variant step: (4 k-groups) x (2 planes) x NCOL entries of 16 B,
+  // contiguous in wq; shared by the 4 waves through LDS, double-buffered
+  constexpr int WS = 8 * NCOL;
+  __shared__ uint4 ws[2][WS];
   uint32_t X[16], Xn[16];
+  uint4 wreg = {0, 0, 0, 0};
   auto load = [&](int64_t jb, uint32_t *dst) {
     if (CONTIG) {
       const uint8_t *base = img + (col0 + jb + g * 16) * pitch + wbyte;
@@ -364,14 +383,23 @@ __global__ __launch_bounds__(256) void k_prod(const uint8_t *__restrict__ img, i
       }
     }
   };
-  if (j0 < j1) load(j0, X);
+  if (j0 < j1) {
+    if (tid < WS) ws[0][tid] = wq4[(j0 / 16) * 2 * NCOL + tid];
+    load(j0, X);
+  }
+  __syncthreads();
+  int cur = 0;
   for (int64_t jb = j0; jb < j1; jb += 64) {
-    if (jb + 64 < j1) load(jb + 64, Xn);
+    const bool has_next = jb + 64 < j1;
+    if (has_next) {
+      if (tid < WS) wreg = wq4[((jb + 64) / 16) * 2 * NCOL + tid];  // first: see k_cprod
+      load(jb + 64, Xn);
+    }
     v4i aw[NB], awc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
-      uint4 t0 = wq4[((jb / 16 + g) * 2 + 0) * NCOL + nb * 16 + sg];
-      uint4 t1 = wq4[((jb / 16 + g) * 2 + 1) * NCOL + nb * 16 + sg];
+      uint4 t0 = ws[cur][(g * 2 + 0) * NCOL + nb * 16 + sg];
+      uint4 t1 = ws[cur][(g * 2 + 1) * NCOL + nb * 16 + sg];
       aw[nb] = v4i{(int)t0.x, (int)t0.y, (int)t0.z, (int)t0.w};
       awc[nb] = v4i{(int)t1.x, (int)t1.y, (int)t1.z, (int)t1.w};
     }
@@ -408,6 +436,9 @@ __global__ __launch_bounds__(256) void k_prod(const uint8_t *__restrict__ img, i
               __builtin_amdgcn_mfma_i32_16x16x64_i8(awc[nb], na, acc[q * 4 + uu][nb], 0, 0, 0);
         }
       }
+    if (has_next && tid < WS) ws[cur ^ 1][tid] = wreg;
+    __syncthreads();
+    cur ^= 1;
 #pragma unroll
     for (int r = 0; r < 16; r++) X[r] = Xn[r];
   }
