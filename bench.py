@@ -36,8 +36,9 @@ def parse():
     ap.add_argument("--n", type=int, default=400000)
     ap.add_argument("--m", type=int, default=1000000, help="total SNP columns over all ranks")
     ap.add_argument("--k", type=int, default=20)
-    ap.add_argument("--block", type=int, default=8)
+    ap.add_argument("--block", type=int, default=5)
     ap.add_argument("--tol", type=float, default=1e-4)
+    ap.add_argument("--slices", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cols", type=int, default=0)
     return ap.parse_args()
@@ -97,7 +98,7 @@ def main():
             torch.cuda.synchronize()
 
     def step():
-        return ba.bed_randomSVD(gb, k=a.k, tol=a.tol, block=a.block, allreduce=allreduce,
+        return ba.bed_randomSVD(gb, k=a.k, tol=a.tol, block=a.block, slices=a.slices, allreduce=allreduce,
                                 m_total=m_total, return_uv=False)
 
     for _ in range(a.warmup):
@@ -116,7 +117,8 @@ def main():
     value = m_total * passes / wall                           # whole job, all ranks
     bytes_per_launch = ((n + 3) // 4) * m_local               # algorithmic: 2-bit payload of the shard
     kern = {}
-    for key, name in (("prod", "k_prod<2,true> (A~ panel)"), ("cprod", "k_cprod<2,2,512> (A~' panel)")):
+    for key, name in (("prod", "k_prod (A~ panel, contraction over variants)"),
+                      ("cprod", "k_cprod (A~' panel, contraction over samples)")):
         ms = sum(r[key + "_ms"] for r in infos)
         cnt = sum(r["n_" + key] for r in infos)
         kern[key] = dict(name=name, total_ms=ms, launches=cnt, avg_ms=ms / max(cnt, 1))

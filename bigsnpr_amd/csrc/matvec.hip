@@ -18,6 +18,7 @@
 //         A~ x  = sum_j g0 w_j + sum_j na (c w)_j - sum_j (c w)_j,   w = x / s.
 //   Results are bit-reproducible (integer sums are order-independent).
 #include <cmath>
+#include <cstdlib>
 
 #include "bsn_internal.hpp"
 
@@ -189,7 +190,7 @@ __global__ void k_quant(const double *X, int64_t ldx, int64_t len, int64_t len_p
 //   A operand: lane l -> variant row (l&15), k-group (l>>4): 16 samples of that variant
 //   B operand: lane l -> digit column (l&15), same 16 samples (from LDS)
 //   D        : lane l -> column (l&15), rows 4*(l>>4)+r
-template <int NB, int NPLANE, int KC>
+template <int NB, int NPLANE, int KC, int ABL = 0>
 __global__ __launch_bounds__(512, 4) void k_cprod(const uint8_t *__restrict__ img, int64_t pitch,
                                                const int32_t *__restrict__ cols, int64_t col0,
                                                int64_t m, const int8_t *__restrict__ xq,
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(512, 4) void k_cprod(const uint8_t *__restrict__ im
 
   static_assert(XS % 512 == 0, "digit chunk must be a multiple of the workgroup");
   constexpr int NX = XS / 512;             // staged uint4 per thread per chunk
-  static_assert(NX <= 2, "NB <= 2");
+  static_assert(NX <= 2, "staging registers");
   uint4 a_cur[2][LD], a_nxt[2][LD];
   uint4 xr0 = {0, 0, 0, 0}, xr1 = {0, 0, 0, 0};
   // prologue
@@ -252,13 +253,20 @@ __global__ __launch_bounds__(512, 4) void k_cprod(const uint8_t *__restrict__ im
         for (int it = 0; it < LD; it++)
           a_nxt[t][it] = *(const uint4 *)(rowp[t] + off + it * 64);
     }
+    uint4 bv[NB], bn[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) bv[nb] = xs[cur][(g * 4) * NCOL + nb * 16 + c];
 #pragma unroll
     for (int it = 0; it < LD; it++) {
 #pragma unroll
       for (int d = 0; d < 4; d++) {
-        uint4 bv[NB];
+        // prefetch the digit operand of the next K-step so that its LDS latency hides
+        // under this step's decode + MFMA
+        if (it * 4 + d + 1 < LD * 4) {
+          const int itn = (it * 4 + d + 1) / 4, dn = (it * 4 + d + 1) % 4;
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++) bv[nb] = xs[cur][(it * 16 + g * 4 + d) * NCOL + nb * 16 + c];
+          for (int nb = 0; nb < NB; nb++) bn[nb] = xs[cur][(itn * 16 + g * 4 + dn) * NCOL + nb * 16 + c];
+        }
 #pragma unroll
         for (int t = 0; t < 2; t++) {
           const uint32_t w = d == 0 ? a_cur[t][it].x : d == 1 ? a_cur[t][it].y
@@ -268,15 +276,25 @@ __global__ __launch_bounds__(512, 4) void k_cprod(const uint8_t *__restrict__ im
 #pragma unroll
           for (int p = 0; p < NPLANE; p++) {
             const uint32_t lut = p == 0 ? lutA : p == 1 ? lutB : lutC;
-            v4i a = {(int)lut4(lut, s0), (int)lut4(lut, s1), (int)lut4(lut, s2),
-                     (int)lut4(lut, s3)};
+            v4i a;
+            if (ABL & 2) {  // ablation: no decode, raw bits as operand
+              a = v4i{(int)w, (int)(w ^ lut), (int)s1, (int)s3};
+            } else {
+              a = v4i{(int)lut4(lut, s0), (int)lut4(lut, s1), (int)lut4(lut, s2), (int)lut4(lut, s3)};
+            }
 #pragma unroll
             for (int nb = 0; nb < NB; nb++) {
               v4i b = {(int)bv[nb].x, (int)bv[nb].y, (int)bv[nb].z, (int)bv[nb].w};
-              acc[t][p][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[t][p][nb], 0, 0, 0);
+              if (ABL & 1) {  // ablation: no MFMA, keep the operands alive
+                asm volatile("" ::"v"(a), "v"(b));
+              } else {
+                acc[t][p][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[t][p][nb], 0, 0, 0);
+              }
             }
           }
         }
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) bv[nb] = bn[nb];
       }
     }
     if (has_next) {
@@ -349,6 +367,7 @@ __global__ __launch_bounds__(256) void k_prod(const uint8_t *__restrict__ img, i
   const int sg = lane & 15, g = lane >> 4;
   const int64_t wbase = ((int64_t)blockIdx.x * 4 + wave) * 256;  // first sample of this wave
   const int64_t wbyte = wbase / 4 + sg * 4;
+  const uint32_t lane_off = (uint32_t)(g * 16 * pitch + wbyte);
   const int64_t j0 = (int64_t)blockIdx.y * mc;
   int64_t j1 = j0 + mc;
   if (j1 > m_pad) j1 = m_pad;
@@ -368,9 +387,9 @@ __global__ __launch_bounds__(256) void k_prod(const uint8_t *__restrict__ img, i
   uint4 wreg = {0, 0, 0, 0};
   auto load = [&](int64_t jb, uint32_t *dst) {
     if (CONTIG) {
-      const uint8_t *base = img + (col0 + jb + g * 16) * pitch + wbyte;
+      const uint8_t *sbase = img + (col0 + jb) * pitch;
 #pragma unroll
-      for (int r = 0; r < 16; r++) dst[r] = *(const uint32_t *)(base + r * pitch);
+      for (int r = 0; r < 16; r++) dst[r] = *(const uint32_t *)(sbase + (int64_t)r * pitch + lane_off);
     } else {
       const int4 *ip = (const int4 *)(cols + jb + g * 16);
 #pragma unroll
@@ -452,26 +471,43 @@ __global__ __launch_bounds__(256) void k_prod(const uint8_t *__restrict__ img, i
   }
 }
 
-// y[i, v] = (sum_ky value(i) - C_v) / qs_v, gathered through rows[]
-__global__ void k_prod_final(const int32_t *acc, int64_t n_pad, int ky, int ncol, int S,
+// y[i, v] = (sum_ky value(i) - C_v) / qs_v, gathered through rows[].  One thread per output
+// row reads its NCOL contiguous int32 per K-chunk (16 B loads, consecutive rows adjacent).
+template <int NCOL>
+__global__ void k_prod_final(const int32_t *__restrict__ acc, int64_t n_pad, int ky, int S, int nv,
                              const VecMeta *meta, const int32_t *rows, int64_t n, double *Y,
                              int64_t ldy) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int v = blockIdx.y;
   if (i >= n) return;
   int64_t i2 = rows ? (int64_t)rows[i] : i;
-  long long d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long d[NCOL];
+#pragma unroll
+  for (int c = 0; c < NCOL; c++) d[c] = 0;
   for (int k = 0; k < ky; k++) {
-    const int32_t *a = acc + ((int64_t)k * n_pad + i2) * ncol + v * S;
-    for (int s = 0; s < S; s++) d[s] += a[s];
+    const int4 *a = (const int4 *)(acc + ((int64_t)k * n_pad + i2) * NCOL);
+#pragma unroll
+    for (int c4 = 0; c4 < NCOL / 4; c4++) {
+      int4 t = a[c4];
+      d[4 * c4 + 0] += t.x;
+      d[4 * c4 + 1] += t.y;
+      d[4 * c4 + 2] += t.z;
+      d[4 * c4 + 3] += t.w;
+    }
   }
-  double r = 0;
-  for (int s = S - 1; s >= 0; s--) r = r * 256.0 + (double)d[s];
-  double C = (double)meta[v].sum2_hi * 16777216.0 + (double)meta[v].sum2_lo;
-  double qs = meta[v].qscale;
-  double y = qs > 0 ? (r - C) / qs : 0.0;
-  if (meta[v].nonfinite) y = __longlong_as_double(0x7ff8000000000000LL);
-  Y[i + v * ldy] = y;
+  for (int v = 0; v < nv; v++) {
+    double r = 0;
+    for (int s = S - 1; s >= 0; s--) {
+      long long dv = 0;
+#pragma unroll
+      for (int c = 0; c < NCOL; c++) dv = (c == v * S + s) ? d[c] : dv;
+      r = r * 256.0 + (double)dv;
+    }
+    double C = (double)meta[v].sum2_hi * 16777216.0 + (double)meta[v].sum2_lo;
+    double qs = meta[v].qscale;
+    double y = qs > 0 ? (r - C) / qs : 0.0;
+    if (meta[v].nonfinite) y = __longlong_as_double(0x7ff8000000000000LL);
+    Y[i + v * ldy] = y;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -543,6 +579,16 @@ static const double *scatter_rows_if_needed(bsn_op *op, const double *d_X, int64
   return xf;
 }
 
+// BSN_TUNE selects profiling builds of k_cprod (see launch_cprod); default 0 = the product
+static int tune_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("BSN_TUNE");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 template <int NPLANE>
 static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint32_t l0,
                          uint32_t l1, uint32_t l2) {
@@ -550,12 +596,24 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
   constexpr int KC = 512;
   dim3 grid((unsigned)((op->m + 255) / 256));
   const int32_t *cols = op->cols_contig ? nullptr : op->d_cols.p;
-  if (NB == 1)
-    hipLaunchKernelGGL((k_cprod<1, NPLANE, KC>), grid, dim3(512), 0, b->stream, b->d_img, b->pitch,
-                       cols, op->col0, op->m, q, acc, op->m, l0, l1, l2);
-  else
-    hipLaunchKernelGGL((k_cprod<2, NPLANE, KC>), grid, dim3(512), 0, b->stream, b->d_img, b->pitch,
-                       cols, op->col0, op->m, q, acc, op->m, l0, l1, l2);
+  // BSN_TUNE = 11 / 12 / 13 select the ablation builds (no MFMA / no decode / neither) used
+  // for profiles/r01_ablation.txt; they produce wrong numbers by construction.
+  const int abl = tune_variant();
+#define BSN_LAUNCH_CPROD(NBV, ABLV)                                                              \
+  hipLaunchKernelGGL((k_cprod<NBV, NPLANE, KC, ABLV>), grid, dim3(512), 0, b->stream, b->d_img, \
+                     b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2)
+  if (NB == 1) {
+    if (abl == 11) BSN_LAUNCH_CPROD(1, 1);
+    else if (abl == 12) BSN_LAUNCH_CPROD(1, 2);
+    else if (abl == 13) BSN_LAUNCH_CPROD(1, 3);
+    else BSN_LAUNCH_CPROD(1, 0);
+  } else {
+    if (abl == 11) BSN_LAUNCH_CPROD(2, 1);
+    else if (abl == 12) BSN_LAUNCH_CPROD(2, 2);
+    else if (abl == 13) BSN_LAUNCH_CPROD(2, 3);
+    else BSN_LAUNCH_CPROD(2, 0);
+  }
+#undef BSN_LAUNCH_CPROD
   BSN_HIP(hipGetLastError());
 }
 
@@ -631,10 +689,14 @@ void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, 
     BSN_HIP(hipGetLastError());
     prof_end(op);
     op->passes++;
-    hipLaunchKernelGGL(k_prod_final, dim3((unsigned)((op->n + 255) / 256), nv), dim3(256), 0,
-                       b->stream, acc, npad, ky, ncol, S, meta,
-                       op->rows_identity ? nullptr : op->d_rows.p, op->n,
-                       d_Y + (int64_t)v0 * ldy, ldy);
+    if (NB == 1)
+      hipLaunchKernelGGL((k_prod_final<16>), dim3((unsigned)((op->n + 255) / 256)), dim3(256), 0, b->stream,
+                         acc, npad, ky, S, nv, meta, op->rows_identity ? nullptr : op->d_rows.p, op->n,
+                         d_Y + (int64_t)v0 * ldy, ldy);
+    else
+      hipLaunchKernelGGL((k_prod_final<32>), dim3((unsigned)((op->n + 255) / 256)), dim3(256), 0, b->stream,
+                         acc, npad, ky, S, nv, meta, op->rows_identity ? nullptr : op->d_rows.p, op->n,
+                         d_Y + (int64_t)v0 * ldy, ldy);
     BSN_HIP(hipGetLastError());
   }
 }

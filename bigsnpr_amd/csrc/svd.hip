@@ -10,7 +10,8 @@
 
 namespace bsn {
 
-constexpr int kMaxB = 8;
+constexpr int kMaxB = 12;
+constexpr int kDefaultB = 5;
 
 __device__ __forceinline__ uint32_t hmix(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
@@ -253,9 +254,8 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     if (bsn_op_create(bed, ind_row, n, ind_col, m, center, scale, &op) != 0)
       throw Error(bsn_last_error());
     std::unique_ptr<bsn_op> guard(op);
-    op->slices = o->slices > 0 ? o->slices : 4;
     op->profile = true;
-    if (op->slices > 7) fail("slices must be in 1..7");
+    if (o->slices > 7) fail("slices must be in 1..7");
     HipSvdBackend bk;
     bk.op = op;
     bk.st = bed->stream;
@@ -269,7 +269,15 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     SvdOptions so;
     so.k = o->k;
     so.tol = o->tol > 0 ? o->tol : 1e-4;
-    so.block = o->block > 0 ? (o->block > kMaxB ? kMaxB : o->block) : kMaxB;
+    so.block = o->block > 0 ? (o->block > kMaxB ? kMaxB : o->block) : kDefaultB;
+    // digit slices per fp64 value: as many as fit the MFMA column blocks the block size
+    // needs anyway (16 columns per block): b <= 4 -> 4 slices, b = 5 -> 3 (15 columns),
+    // 6..8 -> 4 (two blocks), 9..10 -> 3
+    {
+      int bb = so.block;
+      int autos = bb * 4 <= 16 ? 4 : bb * 3 <= 16 ? 3 : bb * 4 <= 32 ? 4 : bb * 3 <= 32 ? 3 : 2;
+      op->slices = o->slices > 0 ? o->slices : autos;
+    }
     so.max_basis = o->max_basis;
     so.seed = o->seed ? o->seed : 1;
     so.verbose = o->verbose;

@@ -64,7 +64,7 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
   const int64_t dim = bk.n < bk.m_total ? bk.n : bk.m_total;
   int b = opt.block;
   if (b > dim) b = (int)dim;
-  int cap = opt.max_basis > 0 ? opt.max_basis : std::max(6 * k + 4 * b, 40 * b);
+  int cap = opt.max_basis > 0 ? opt.max_basis : std::max(8 * k + 4 * b, 320);
   if (cap > dim) cap = (int)dim;
   if (cap < k) cap = k;
   bk.alloc(cap + b, b);

@@ -16,7 +16,7 @@ from .bed import _args, assert_bed, bed_scaleBinom
 
 
 def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=None, k=10,
-                  tol=1e-4, verbose=False, ncores=1, block=8, slices=4, max_basis=0, seed=1,
+                  tol=1e-4, verbose=False, ncores=1, block=0, slices=0, max_basis=0, seed=1,
                   allreduce=None, m_total=0, return_uv=True):
     """Partial SVD of the scaled matrix.  Extra (non-reference) arguments: ``block``
     (vectors per streaming pass), ``slices`` (int8 slices per fp64 value), ``allreduce``

@@ -121,8 +121,8 @@ typedef void (*bsn_allreduce_fn)(void *d_buf, int64_t count, void *ctx);
 typedef struct bsn_svd_options {
   int32_t k;          /* number of singular triplets (R default 10) */
   double tol;         /* relative residual on eigenvalues of A~A~' (R default 1e-4) */
-  int32_t block;      /* vectors per pass, 1..8 (0 -> 8) */
-  int32_t slices;     /* int8 slices of the fp64 panels, 1..7 (0 -> 4) */
+  int32_t block;      /* vectors per pass, 1..12 (0 -> 5) */
+  int32_t slices;     /* int8 slices of the fp64 panels, 1..7 (0 -> chosen from block: 5 -> 3) */
   int32_t max_basis;  /* cap on the Krylov basis (0 -> automatic) */
   uint32_t seed;      /* start block seed (0 -> 1) */
   int32_t verbose;

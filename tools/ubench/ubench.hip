@@ -8,7 +8,8 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k(unsigned *out, int iters, unsigned seed) {
+__global__ __launch_bounds__(256) void k(unsigned *out, int iters, unsigned seed, unsigned long long *clk) {
+  unsigned long long t_begin = clock64();
   unsigned w = seed + threadIdx.x * 2654435761u, acc0 = 0;
   v4i a = {(int)w, (int)(w * 3), (int)(w * 5), (int)(w * 7)}, b = a;
   v4i c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
@@ -62,25 +63,28 @@ __global__ __launch_bounds__(256) void k(unsigned *out, int iters, unsigned seed
   }
   unsigned r = acc0 ^ c0[0] ^ c1[1] ^ c2[2] ^ c3[3] ^ d0[0] ^ d1[5] ^ w;
   if (r == 0x12345678u) out[threadIdx.x] = r;
+  if (blockIdx.x == 0 && threadIdx.x == 0) clk[0] = clock64() - t_begin;
 }
 
 template <int MODE>
 void run(const char *name, int waves_per_simd, double genos_per_iter_per_wave) {
   unsigned *d; CK(hipMalloc(&d, 4096));
+  unsigned long long *dclk; CK(hipMalloc(&dclk, 8));
   int iters = 20000;
   int blocks = 256 * waves_per_simd;  // 256 CUs x (4 waves per block = 1 per SIMD) x waves_per_simd
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 100, 1u);
+  hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 100, 1u, dclk);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters, 1u);
+  hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters, 1u, dclk);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   double ns_per_iter = ms * 1e6 / iters / waves_per_simd;   // per wave-iteration per SIMD
   double genos = genos_per_iter_per_wave * 1024.0 * waves_per_simd * iters;  // whole chip
   printf("%-34s waves/SIMD %d: %8.3f ms  %7.2f ns per wave-iter per SIMD", name, waves_per_simd, ms, ns_per_iter);
   if (genos_per_iter_per_wave > 0) printf("  -> %.2f Tgeno/s = %.2f TB/s of 2-bit image", genos / ms / 1e9, genos / 4 / ms / 1e9);
-  printf("\n");
+  unsigned long long hc = 0; CK(hipMemcpy(&hc, dclk, 8, hipMemcpyDeviceToHost));
+  printf("  [shader clock %.0f MHz]\n", hc / (ms * 1e3));
   CK(hipFree(d));
 }
 
