@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--tol", type=float, default=1e-4)
     ap.add_argument("--slices", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="exercise the RCCL all-reduce hook even with one rank (self-test)")
     ap.add_argument("--cpu-sample-cols", type=int, default=0)
     return ap.parse_args()
 
@@ -60,11 +62,14 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
     dist = None
     torch = None
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         # torch first: the library then binds to the same HIP runtime as torch / RCCL
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29511"
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     import numpy as np
@@ -84,7 +89,7 @@ def main():
     gen_s = time.time() - t0
 
     allreduce = None
-    if world > 1:
+    if use_dist:
         def allreduce(ptr, count):
             t = torch.as_tensor(_DevPtr(ptr, count), device="cuda")
             dist.all_reduce(t)
@@ -92,7 +97,7 @@ def main():
 
     def sync():
         L.bsn_device_sync()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -108,7 +113,7 @@ def main():
     infos = [step() for _ in range(a.steps)]
     sync()
     wall = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([wall], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
@@ -152,7 +157,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(ba, gb, n, a.cpu_sample_cols)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

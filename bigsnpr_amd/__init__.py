@@ -9,6 +9,8 @@ from .bed import (ERROR_DIM, ScaledOp, bed, bed_colstats, bed_counts, bed_cprodV
                   bed_MAF, bed_prodVec, bed_scaleBinom, cols_along, read_bed,
                   read_bed_scaled, rows_along)
 from .svd import bed_randomSVD  # noqa: F401,E402
+from .ld import (FBM_code256, bed_clumping, bed_cor, bed_ld_scores, snp_clumping,  # noqa: F401,E402
+                 snp_colstats, snp_cor, snp_ld_scores)
 
 
 def selftest():

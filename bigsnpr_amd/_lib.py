@@ -67,6 +67,13 @@ SIGNATURES = {
     "bsn_op_sync": (C.c_int, [vp]),
     "bsn_bed_randomsvd": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, C.POINTER(SvdOptions),
                                     f64p, f64p, f64p, C.POINTER(SvdInfo)]),
+    "bsn_cormat": (C.c_int, [vp, i64p, i64, i64p, i64, C.c_double, f64p, f64p, C.c_int, i32p,
+                             C.POINTER(C.c_int64), C.POINTER(vp)]),
+    "bsn_cormat_fetch": (C.c_int, [vp, i32p, f64p]),
+    "bsn_cormat_free": (C.c_int, [vp]),
+    "bsn_ld_scores": (C.c_int, [vp, i64p, i64, i64p, i64, C.c_double, f64p, f64p]),
+    "bsn_clumping_chr": (C.c_int, [vp, i64p, i64, i64p, i64, C.c_int, f64p, f64p, i32p, i32p, f64p,
+                                   C.c_double, C.c_double, i32p]),
     "bsn_malloc": (C.c_int, [C.POINTER(vp), i64]),
     "bsn_free": (C.c_int, [vp]),
     "bsn_memcpy_h2d": (C.c_int, [vp, vp, i64]),

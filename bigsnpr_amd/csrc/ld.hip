@@ -1,0 +1,472 @@
+// ld.hip — windowed pairwise-complete correlation, LD scores and clumping on gfx950.
+//
+// Replaces corMat0 (src/corr.cpp:11-97), ld_scores0 (src/ld-scores.cpp:11-78),
+// clumping_chr (src/clumping.cpp:10-91) and bed_clumping_chr (src/clumping-bed.cpp:11-91).
+//
+// The reference walks every (j0, j) pair of the position window and every sample with a
+// branchy scalar loop.  Here the six pairwise-complete sums of a 64 x 64 block of variant
+// pairs are six exact integer GEMMs over the samples on the i8 MFMA pipe, on three planes
+// decoded from the 2-bit codes: X = genotype (missing -> 0), X2 = X^2, M = non-missing:
+//     sum xy = X.X      sum_{both} x = X.M     sum_{both} x^2 = X2.M
+//     nona   = M.M      sum_{both} y = M.X     sum_{both} y^2 = M.X2
+// (values <= 4n < 2^31, so int32 accumulation is exact, as are the reference's fp64 sums of
+// small integers).  The fp64 epilogue then repeats the reference's expressions in the
+// reference's operation order on identical integer inputs.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+#include "bsn_internal.hpp"
+
+namespace bsn {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t lut4b(uint32_t lut, uint32_t sel) {
+  return __builtin_amdgcn_perm(lut, lut, sel);
+}
+constexpr uint32_t kLX = 0x00010002u;   // code 0,1,2,3 -> 2, 0(NA), 1, 0
+constexpr uint32_t kLX2 = 0x00010004u;  //               -> 4, 0,     1, 0
+constexpr uint32_t kLM = 0x01010001u;   //               -> 1, 0,     1, 1
+constexpr int TB = 64;                  // variants per tile side
+
+struct Planes {
+  v4i x, x2, m;
+};
+__device__ __forceinline__ Planes decode3(uint32_t w) {
+  const uint32_t s0 = w & 0x03030303u, s1 = (w >> 2) & 0x03030303u, s2 = (w >> 4) & 0x03030303u,
+                 s3 = (w >> 6) & 0x03030303u;
+  Planes p;
+  p.x = v4i{(int)lut4b(kLX, s0), (int)lut4b(kLX, s1), (int)lut4b(kLX, s2), (int)lut4b(kLX, s3)};
+  p.x2 = v4i{(int)lut4b(kLX2, s0), (int)lut4b(kLX2, s1), (int)lut4b(kLX2, s2), (int)lut4b(kLX2, s3)};
+  p.m = v4i{(int)lut4b(kLM, s0), (int)lut4b(kLM, s1), (int)lut4b(kLM, s2), (int)lut4b(kLM, s3)};
+  return p;
+}
+
+// stats[pair][prod][row][col], prod: 0 xy, 1 x(both), 2 xx(both), 3 y(both), 4 yy(both), 5 nona
+// row = variant of tile I (the "x" / j0 side), col = variant of tile J (the "y" / j side).
+// rowmask (optional): 2 bits per sample, 11 = keep; dropped samples are turned into code 01
+// (missing) so that they vanish from all six sums.
+__global__ __launch_bounds__(256) void k_pair_stats(const uint8_t *__restrict__ img, int64_t pitch,
+                                                    const int32_t *__restrict__ cols,
+                                                    const int2 *__restrict__ pairs,
+                                                    const uint32_t *__restrict__ rowmask,
+                                                    int64_t kbytes_per_split,
+                                                    int32_t *__restrict__ stats, int use_atomic) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int2 pr = pairs[blockIdx.x];
+  const uint8_t *pa[2], *pb[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    pa[s] = img + (int64_t)cols[pr.x * TB + wr * 32 + s * 16 + r16] * pitch + g * 16;
+    pb[s] = img + (int64_t)cols[pr.y * TB + wc * 32 + s * 16 + r16] * pitch + g * 16;
+  }
+  int64_t b0 = (int64_t)blockIdx.y * kbytes_per_split, b1 = b0 + kbytes_per_split;
+  if (b1 > pitch) b1 = pitch;
+
+  v4i acc[2][2][6];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int p = 0; p < 6; p++) acc[i][j][p] = v4i{0, 0, 0, 0};
+
+  for (int64_t kb = b0; kb < b1; kb += 64) {  // 64 B per row = 256 samples per iteration
+    uint4 a[2], b[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      a[s] = *(const uint4 *)(pa[s] + kb);
+      b[s] = *(const uint4 *)(pb[s] + kb);
+    }
+    uint4 mk = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (rowmask) mk = *(const uint4 *)((const uint8_t *)rowmask + kb + g * 16);
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const uint32_t mw = d == 0 ? mk.x : d == 1 ? mk.y : d == 2 ? mk.z : mk.w;
+      Planes A[2], B[2];
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        uint32_t wa = d == 0 ? a[s].x : d == 1 ? a[s].y : d == 2 ? a[s].z : a[s].w;
+        uint32_t wb = d == 0 ? b[s].x : d == 1 ? b[s].y : d == 2 ? b[s].z : b[s].w;
+        wa = (wa & mw) | (0x55555555u & ~mw);
+        wb = (wb & mw) | (0x55555555u & ~mw);
+        A[s] = decode3(wa);
+        B[s] = decode3(wb);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          acc[i][j][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].x, B[j].x, acc[i][j][0], 0, 0, 0);
+          acc[i][j][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].x, B[j].m, acc[i][j][1], 0, 0, 0);
+          acc[i][j][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].x2, B[j].m, acc[i][j][2], 0, 0, 0);
+          acc[i][j][3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].m, B[j].x, acc[i][j][3], 0, 0, 0);
+          acc[i][j][4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].m, B[j].x2, acc[i][j][4], 0, 0, 0);
+          acc[i][j][5] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].m, B[j].m, acc[i][j][5], 0, 0, 0);
+        }
+    }
+  }
+  int32_t *out = stats + (int64_t)blockIdx.x * 6 * TB * TB;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int p = 0; p < 6; p++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = wr * 32 + i * 16 + 4 * g + r, col = wc * 32 + j * 16 + r16;
+          int32_t *dst = out + (p * TB + row) * TB + col;
+          if (use_atomic)
+            atomicAdd(dst, acc[i][j][p][r]);
+          else
+            *dst = acc[i][j][p][r];
+        }
+}
+
+// mode 0: r of corMat0 with threshold (dropped -> 2.0);  mode 1: r2 of ld_scores0;
+// mode 2: r2 of clumping_chr (raw formula with cached sumX/denoX, n rows);
+// mode 3: r2 of bed_clumping_chr (mean-imputed scaled values)
+#pragma clang fp contract(off)
+__global__ void k_band_fill(const int32_t *__restrict__ stats, const int2 *__restrict__ pairs,
+                            int npairs, int64_t m, const int64_t *__restrict__ lo, int64_t W,
+                            const double *__restrict__ thr, int mode, const double *__restrict__ v1,
+                            const double *__restrict__ v2, double nrows, double *__restrict__ band) {
+  const int pi = blockIdx.x;
+  if (pi >= npairs) return;
+  const int2 pr = pairs[pi];
+  const int32_t *st = stats + (int64_t)pi * 6 * TB * TB;
+  for (int e = threadIdx.x; e < TB * TB; e += blockDim.x) {
+    const int row = e / TB, col = e % TB;
+    const int64_t j0 = (int64_t)pr.x * TB + row, j = (int64_t)pr.y * TB + col;
+    if (j0 >= m || j >= j0 || j < lo[j0]) continue;
+    const double xySum = st[(0 * TB + row) * TB + col], xSum = st[(1 * TB + row) * TB + col],
+                 xxSum = st[(2 * TB + row) * TB + col], ySum = st[(3 * TB + row) * TB + col],
+                 yySum = st[(4 * TB + row) * TB + col];
+    const int nona = st[(5 * TB + row) * TB + col];
+    double val;
+    if (mode == 0 || mode == 1) {
+      const double num = xySum - xSum * ySum / nona;
+      const double deno_x = xxSum - xSum * xSum / nona;
+      const double deno_y = yySum - ySum * ySum / nona;
+      if (mode == 0) {
+        double r = num / sqrt(deno_x * deno_y);
+        // src/corr.cpp:82-86; thr[nona - 1] is only read when r is not NaN (nona >= 1 then)
+        if (isnan(r) || fabs(r) > thr[nona > 0 ? nona - 1 : 0]) {
+          if (r > 1) r = 1; else if (r < -1) r = -1;
+          val = r;
+        } else {
+          val = 2.0;
+        }
+      } else {
+        val = num * num / (deno_x * deno_y);
+      }
+    } else if (mode == 2) {
+      // src/clumping.cpp:72-73 ; v1 = sumX, v2 = denoX (per position in ind_col)
+      const double num = xySum - v1[j] * v1[j0] / nrows;
+      val = num * num / (v2[j] * v2[j0]);
+    } else {
+      // src/clumping-bed.cpp:69-73 on mean-imputed scaled values: v1 = center, v2 = scale.
+      // sum_i x~ y~ over rows where both are present (missing -> 0)
+      const double cx = v1[j0], cy = v1[j], sx = v2[j0], sy = v2[j];
+      const double s = xySum - cx * ySum - cy * xSum + cx * cy * (double)nona;
+      const double r = s / (sx * sy);
+      val = r * r;
+    }
+    band[j0 * W + (j0 - j - 1)] = val;
+  }
+}
+
+// one wave per column j0: counts kept entries (ascending j), + diagonal
+__global__ void k_cor_count(const double *__restrict__ band, const int64_t *__restrict__ lo, int64_t W,
+                            int64_t m, int fill_diag, int32_t *__restrict__ cnt) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t j0 = (int64_t)blockIdx.x * 4 + wave;
+  if (j0 >= m) return;
+  const int64_t width = j0 - lo[j0];
+  int c = 0;
+  for (int64_t w = lane; w < width; w += 64) c += band[j0 * W + w] != 2.0;
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+  if (lane == 0) cnt[j0] = c + (fill_diag ? 1 : 0);
+}
+
+__global__ void k_cor_fill(const double *__restrict__ band, const int64_t *__restrict__ lo, int64_t W,
+                           int64_t m, int fill_diag, const int32_t *__restrict__ p,
+                           int32_t *__restrict__ oi, double *__restrict__ ox) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t j0 = (int64_t)blockIdx.x * 4 + wave;
+  if (j0 >= m) return;
+  const int64_t width = j0 - lo[j0];
+  int64_t base = p[j0];
+  // ascending j = descending w
+  for (int64_t t0 = 0; t0 < width; t0 += 64) {
+    const int64_t t = t0 + lane;  // t-th smallest j: w = width - 1 - t
+    double v = 2.0;
+    if (t < width) v = band[j0 * W + (width - 1 - t)];
+    const bool keep = (t < width) && (v != 2.0);
+    const unsigned long long mask = __ballot(keep);
+    if (keep) {
+      const int off = __popcll(mask & ((1ull << lane) - 1ull));
+      oi[base + off] = (int32_t)(lo[j0] + t);
+      ox[base + off] = v;
+    }
+    base += __popcll(mask);
+  }
+  if (fill_diag && lane == 0) {
+    oi[base] = (int32_t)j0;
+    ox[base] = 1.0;
+  }
+}
+
+// ld[j] = 1 + sum over pairs containing j of r2 (NaN skipped), deterministic order:
+// own row first (j' < j, descending j'), then later columns j0 > j in ascending order.
+__global__ void k_ld_sum(const double *__restrict__ band, const int64_t *__restrict__ lo, int64_t W,
+                         int64_t m, double *__restrict__ ld) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  double s = 1.0;
+  const int64_t width = j - lo[j];
+  for (int64_t w = 0; w < width; w++) {
+    const double v = band[j * W + w];
+    if (!isnan(v)) s += v;
+  }
+  for (int64_t j0 = j + 1; j0 < m && lo[j0] <= j; j0++) {
+    const double v = band[j0 * W + (j0 - j - 1)];
+    if (!isnan(v)) s += v;
+  }
+  ld[j] = s;
+}
+
+// ---------------------------------------------------------------------------------------
+struct BandJob {
+  bsn_bed *bed = nullptr;
+  int64_t n = 0, m = 0, W = 1;
+  std::vector<int64_t> lo;
+  DevBuf<int32_t> d_cols, d_stats;
+  DevBuf<int2> d_pairs;
+  DevBuf<int64_t> d_lo;
+  DevBuf<uint32_t> d_mask;
+  DevBuf<double> d_band, d_thr, d_v1, d_v2;
+  bool use_mask = false;
+  int64_t npairs = 0;
+};
+
+// lo[j0] = first j with pos[j] >= pos[j0] - size (src/corr.cpp:52-53).  For clumping the
+// window is two-sided (src/clumping-utils.h:21-22); by symmetry the pair (j0, j), j < j0, is
+// needed iff pos[j] >= pos[j0] - size, the same lower bound.
+static void window_bounds(const double *pos, int64_t m, double size, bool two_sided,
+                          std::vector<int64_t> &lo) {
+  lo.resize((size_t)m);
+  int64_t l = 0;
+  for (int64_t j0 = 0; j0 < m; j0++) {
+    if (j0 > 0 && pos[j0] < pos[j0 - 1]) fail("'pos' is not sorted.");
+    const double pos_min = pos[j0] - size;
+    // pos is sorted, so the reference's downward walk from j0-1 stops exactly at the first
+    // j with pos[j] < pos_min.  For clumping the pair is also reached from j's side with
+    // `pos[j0] <= pos[j] + size`; both spellings are honoured so that rounding cannot make
+    // the host sweep ask for a pair outside the band.
+    while (l < j0 && pos[l] < pos_min && !(two_sided && pos[j0] <= pos[l] + size)) l++;
+    lo[(size_t)j0] = l;
+  }
+}
+
+static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t n,
+                       const int64_t *ind_col, int64_t m, const double *pos, double size,
+                       bool two_sided = false) {
+  if (n <= 0 || m <= 0) fail("'ind.row' and 'ind.col' can't be empty.");
+  BSN_HIP(hipSetDevice(bed->device));
+  J.bed = bed;
+  J.n = n;
+  J.m = m;
+  window_bounds(pos, m, size, two_sided, J.lo);
+  int64_t W = 1;
+  for (int64_t j0 = 0; j0 < m; j0++) W = std::max(W, j0 - J.lo[(size_t)j0]);
+  J.W = W;
+  if ((double)m * (double)W * 8.0 > 64e9) fail("LD band of %lld x %lld does not fit the 64 GB budget",
+                                               (long long)m, (long long)W);
+  // columns (padded to the tile size with a valid column)
+  const int64_t mt = (m + TB - 1) / TB, m_pad = mt * TB;
+  std::vector<int32_t> cols((size_t)m_pad);
+  for (int64_t j = 0; j < m_pad; j++) {
+    int64_t c = ind_col ? ind_col[j < m ? j : m - 1] : (j < m ? j : m - 1);
+    if (c < 0 || c >= bed->m) fail("Tested %lld < %lld. Subscript out of bounds (ind.col).", (long long)c, (long long)bed->m);
+    cols[(size_t)j] = (int32_t)c;
+  }
+  BSN_HIP(hipMemcpyAsync(J.d_cols.ensure((size_t)m_pad), cols.data(), (size_t)m_pad * 4, hipMemcpyHostToDevice, bed->stream));
+  // rows: keep-mask, 2 bits per sample (also removes the pad samples, which are coded as
+  // non-missing genotype 0 in the image).  Duplicated rows are not supported on this path.
+  J.use_mask = true;
+  {
+    std::vector<uint32_t> mask((size_t)(bed->pitch / 4), 0u);
+    for (int64_t i = 0; i < n; i++) {
+      int64_t r = ind_row ? ind_row[i] : i;
+      if (r < 0 || r >= bed->n) fail("Tested %lld < %lld. Subscript out of bounds (ind.row).", (long long)r, (long long)bed->n);
+      uint32_t bit = 3u << (2 * (r & 15));
+      if (mask[(size_t)(r >> 4)] & bit) fail("duplicated 'ind.row' are not supported by the GPU LD path");
+      mask[(size_t)(r >> 4)] |= bit;
+    }
+    BSN_HIP(hipMemcpyAsync(J.d_mask.ensure(mask.size()), mask.data(), mask.size() * 4, hipMemcpyHostToDevice, bed->stream));
+    BSN_HIP(hipStreamSynchronize(bed->stream));
+  }
+  // tile pairs of the band
+  std::vector<int2> pairs;
+  for (int64_t I = 0; I < mt; I++) {
+    int64_t Jlo = J.lo[(size_t)(I * TB)] / TB;
+    for (int64_t Jt = Jlo; Jt <= I; Jt++) pairs.push_back(int2{(int)I, (int)Jt});
+  }
+  J.npairs = (int64_t)pairs.size();
+  BSN_HIP(hipMemcpyAsync(J.d_pairs.ensure(pairs.size()), pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice, bed->stream));
+  BSN_HIP(hipMemcpyAsync(J.d_lo.ensure((size_t)m), J.lo.data(), (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
+  BSN_HIP(hipStreamSynchronize(bed->stream));  // host vectors go out of scope
+  // statistics in batches of tile pairs (bounded scratch)
+  J.d_band.ensure((size_t)m * (size_t)W);
+}
+
+// runs the statistics + band fill in batches; fill_mode / aux as in k_band_fill
+static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_v1, const double *d_v2,
+                     double nrows) {
+  bsn_bed *bed = J.bed;
+  const int64_t batch = 4096;  // 4096 x 6 x 64 x 64 x 4 B = 403 MB of int32 statistics
+  J.d_stats.ensure((size_t)std::min(batch, J.npairs) * 6 * TB * TB);
+  // K split: enough workgroups to fill the chip when there are few tile pairs
+  for (int64_t p0 = 0; p0 < J.npairs; p0 += batch) {
+    const int64_t np = std::min(batch, J.npairs - p0);
+    int ksplit = (int)std::min<int64_t>(std::max<int64_t>(1, 2048 / np), bed->pitch / 256);
+    if (ksplit < 1) ksplit = 1;
+    int64_t kbytes = round_up((bed->pitch + ksplit - 1) / ksplit, 64);
+    ksplit = (int)((bed->pitch + kbytes - 1) / kbytes);
+    if (ksplit > 1) BSN_HIP(hipMemsetAsync(J.d_stats.p, 0, (size_t)np * 6 * TB * TB * 4, bed->stream));
+    hipLaunchKernelGGL(k_pair_stats, dim3((unsigned)np, (unsigned)ksplit), dim3(256), 0, bed->stream,
+                       bed->d_img, bed->pitch, J.d_cols.p, J.d_pairs.p + p0,
+                       J.use_mask ? J.d_mask.p : nullptr, kbytes, J.d_stats.p, ksplit > 1 ? 1 : 0);
+    BSN_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_band_fill, dim3((unsigned)np), dim3(256), 0, bed->stream, J.d_stats.p,
+                       J.d_pairs.p + p0, (int)np, J.m, J.d_lo.p, J.W, d_thr, mode, d_v1, d_v2, nrows,
+                       J.d_band.p);
+    BSN_HIP(hipGetLastError());
+  }
+}
+
+}  // namespace bsn
+
+using namespace bsn;
+
+struct bsn_cor {
+  BandJob job;
+  DevBuf<int32_t> d_p, d_i;
+  DevBuf<double> d_x;
+  int64_t nnz = 0;
+};
+
+extern "C" {
+
+int bsn_cormat(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+               double size, const double *thr, const double *pos, int fill_diag, int32_t *p_out,
+               int64_t *nnz_out, bsn_cor **out) {
+  return guarded([&] {
+    std::unique_ptr<bsn_cor> C(new bsn_cor());
+    BandJob &J = C->job;
+    band_stats(J, bed, ind_row, n, ind_col, m, pos, size);
+    BSN_HIP(hipMemcpyAsync(J.d_thr.ensure((size_t)n), thr, (size_t)n * 8, hipMemcpyHostToDevice, bed->stream));
+    band_run(J, 0, J.d_thr.p, nullptr, nullptr, (double)n);
+    DevBuf<int32_t> d_cnt;
+    d_cnt.ensure((size_t)m);
+    hipLaunchKernelGGL(k_cor_count, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, bed->stream, J.d_band.p,
+                       J.d_lo.p, J.W, m, fill_diag, d_cnt.p);
+    BSN_HIP(hipGetLastError());
+    std::vector<int32_t> cnt((size_t)m);
+    BSN_HIP(hipMemcpyAsync(cnt.data(), d_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost, bed->stream));
+    BSN_HIP(hipStreamSynchronize(bed->stream));
+    int64_t nnz = 0;
+    p_out[0] = 0;
+    for (int64_t j = 0; j < m; j++) {
+      nnz += cnt[(size_t)j];
+      if (nnz > 0x7fffffffLL) fail("more than 2^31 - 1 non-zero correlations");
+      p_out[j + 1] = (int32_t)nnz;
+    }
+    C->nnz = nnz;
+    BSN_HIP(hipMemcpyAsync(C->d_p.ensure((size_t)m + 1), p_out, (size_t)(m + 1) * 4, hipMemcpyHostToDevice, bed->stream));
+    C->d_i.ensure((size_t)std::max<int64_t>(nnz, 1));
+    C->d_x.ensure((size_t)std::max<int64_t>(nnz, 1));
+    hipLaunchKernelGGL(k_cor_fill, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, bed->stream, J.d_band.p,
+                       J.d_lo.p, J.W, m, fill_diag, C->d_p.p, C->d_i.p, C->d_x.p);
+    BSN_HIP(hipGetLastError());
+    BSN_HIP(hipStreamSynchronize(bed->stream));
+    J.d_band.release();
+    J.d_stats.release();
+    *nnz_out = nnz;
+    *out = C.release();
+  });
+}
+
+int bsn_cormat_fetch(bsn_cor *c, int32_t *i_out, double *x_out) {
+  return guarded([&] {
+    BSN_HIP(hipSetDevice(c->job.bed->device));
+    if (c->nnz > 0) {
+      BSN_HIP(hipMemcpy(i_out, c->d_i.p, (size_t)c->nnz * 4, hipMemcpyDeviceToHost));
+      BSN_HIP(hipMemcpy(x_out, c->d_x.p, (size_t)c->nnz * 8, hipMemcpyDeviceToHost));
+    }
+  });
+}
+
+int bsn_cormat_free(bsn_cor *c) {
+  return guarded([&] { delete c; });
+}
+
+int bsn_ld_scores(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                  double size, const double *pos, double *out) {
+  return guarded([&] {
+    BandJob J;
+    band_stats(J, bed, ind_row, n, ind_col, m, pos, size);
+    band_run(J, 1, nullptr, nullptr, nullptr, (double)n);
+    DevBuf<double> d_ld;
+    d_ld.ensure((size_t)m);
+    hipLaunchKernelGGL(k_ld_sum, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, bed->stream, J.d_band.p,
+                       J.d_lo.p, J.W, m, d_ld.p);
+    BSN_HIP(hipGetLastError());
+    BSN_HIP(hipMemcpyAsync(out, d_ld.p, (size_t)m * 8, hipMemcpyDeviceToHost, bed->stream));
+    BSN_HIP(hipStreamSynchronize(bed->stream));
+  });
+}
+
+// Greedy clumping inside one chromosome.  mode 0: FBM formula (aux1 = sumX, aux2 = denoX);
+// mode 1: bed formula (aux1 = center, aux2 = scale).  keep[] is written with 0 / 1.
+int bsn_clumping_chr(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                     int64_t m, int mode, const double *aux1, const double *aux2,
+                     const int32_t *ordInd, const int32_t *rankInd, const double *pos, double size,
+                     double thr, int32_t *keep) {
+  return guarded([&] {
+    BandJob J;
+    band_stats(J, bed, ind_row, n, ind_col, m, pos, size, true);
+    BSN_HIP(hipMemcpyAsync(J.d_v1.ensure((size_t)m), aux1, (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
+    BSN_HIP(hipMemcpyAsync(J.d_v2.ensure((size_t)m), aux2, (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
+    band_run(J, mode == 0 ? 2 : 3, nullptr, J.d_v1.p, J.d_v2.p, (double)n);
+    std::vector<double> band((size_t)m * (size_t)J.W);
+    BSN_HIP(hipMemcpyAsync(band.data(), J.d_band.p, band.size() * 8, hipMemcpyDeviceToHost, bed->stream));
+    BSN_HIP(hipStreamSynchronize(bed->stream));
+    // the rank-ordered sweep of src/clumping.cpp:33-88 (sequential order == the reference's
+    // result for any ncores, tests/testthat/test-7-OpenMP.R:104-115)
+    auto r2_of = [&](int64_t a, int64_t b) {  // a != b
+      int64_t hi = a > b ? a : b, lo_ = a > b ? b : a;
+      return band[(size_t)hi * (size_t)J.W + (size_t)(hi - lo_ - 1)];
+    };
+    for (int64_t j = 0; j < m; j++) keep[j] = -1;
+    for (int64_t k = 0; k < m; k++) {
+      const int64_t j0 = ordInd[k];
+      const double pos_min = pos[j0] - size, pos_max = pos[j0] + size;
+      bool keep_j0 = true;
+      // which_to_check (src/clumping-utils.h:12-43): neighbours inside the window with a
+      // better rank that are still kept
+      for (int64_t j = j0 + 1; keep_j0 && j < m && pos[j] <= pos_max; j++)
+        if (rankInd[j0] > rankInd[j] && keep[j] != 0 && r2_of(j0, j) > thr) keep_j0 = false;
+      for (int64_t j = j0 - 1; keep_j0 && j >= 0 && pos[j] >= pos_min; j--)
+        if (rankInd[j0] > rankInd[j] && keep[j] != 0 && r2_of(j0, j) > thr) keep_j0 = false;
+      keep[j0] = keep_j0 ? 1 : 0;
+    }
+  });
+}
+
+}  // extern "C"

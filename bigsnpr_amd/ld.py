@@ -1,0 +1,238 @@
+"""Windowed LD on the GPU: snp_cor / bed_cor, snp_ld_scores / bed_ld_scores,
+snp_clumping / bed_clumping — host mirror of R/corr.R, R/ld-scores.R, R/clumping.R,
+R/bed-clumping.R over bsn_cormat / bsn_ld_scores / bsn_clumping_chr.
+
+`Gna` / `G` may be a `bed` (PLINK file on the device) or an `FBM_code256` (byte matrix with
+the CODE_012 coding, repacked to the same 2-bit image), the dispatch of src/corr.cpp:113-125.
+Indices are 0-based.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import as_f64, check, f64p, i32p, i64p, ptr, vp
+from .bed import (_check_ind, assert_lengths, bed, bed_colstats, cols_along, rows_along)
+
+CODE_012 = np.array([0, 1, 2] + [np.nan] * 253)  # R/bigSNP-class.R:7
+
+
+class FBM_code256:
+    """bigstatsr's FBM.code256 with CODE_012, held on the device as a 2-bit image."""
+
+    def __init__(self, bytes_nm, code=CODE_012):
+        a = np.asarray(bytes_nm, dtype=np.uint8)
+        if a.ndim != 2:
+            raise ValueError("a genotype FBM is a matrix")
+        code = np.asarray(code, dtype=np.float64)
+        ok = (code[:3] == np.array([0, 1, 2])).all() and np.isnan(code[3:]).all()
+        if not ok:
+            raise NotImplementedError("only the CODE_012 coding is supported on the GPU path")
+        self.code256 = code
+        self.nrow, self.ncol = a.shape
+        self._bed = bed.from_fbm(a)
+        self._has_na = bool((a > 2).any())
+
+    @property
+    def handle(self):
+        return self._bed.handle
+
+    @property
+    def shape(self):
+        return (self.nrow, self.ncol)
+
+
+def snp_fake(n, m, rng=None):
+    """R/fake.R:27-54: a bigSNP-like dict with an all-NA FBM.code256; fill
+    `obj["genotypes_bytes"]` and call `snp_attach_bytes` to upload."""
+    seq_m = np.arange(1, m + 1)
+    return dict(genotypes=None, fam=dict(sample_ID=["ind_%d" % i for i in range(1, n + 1)]),
+                map=dict(chromosome=np.ones(m, dtype=np.int64), physical_pos=seq_m * 1000))
+
+
+def _image(obj):
+    if isinstance(obj, FBM_code256):
+        return obj._bed
+    if isinstance(obj, bed):
+        return obj
+    raise TypeError("'Gna' is not of class 'FBM.code256' (or 'bed').")
+
+
+def _ind(obj, ind_row, ind_col):
+    im = _image(obj)
+    ir = rows_along(im) if ind_row is None else _check_ind("ind.row", ind_row, im.nrow)
+    ic = cols_along(im) if ind_col is None else _check_ind("ind.col", ind_col, im.ncol)
+    return im, ir, ic
+
+
+def assert_sorted(x):
+    if np.any(np.diff(x) < 0):
+        raise ValueError("'infos.pos' is not sorted.")
+
+
+def _cor_thresholds(n, alpha, thr_r2):
+    """R/corr.R:18-23,29: |r| threshold per number of non-missing pairs"""
+    from scipy import stats
+    df = np.arange(1, n + 1, dtype=np.float64) - 2
+    with np.errstate(all="ignore"):
+        q = stats.t.isf(alpha / 2, df=np.where(df > 0, df, np.nan))
+        THR = q / np.sqrt(df + q * q)
+    return np.maximum(THR, np.sqrt(thr_r2))
+
+
+class CorResult:
+    """upper-triangular dsCMatrix slots (R/corr.R:43-47): i, p, x, Dim"""
+
+    def __init__(self, i, p, x, m):
+        self.i, self.p, self.x, self.Dim = i, p, x, (m, m)
+        self.uplo = "U"
+
+    def tocsc(self):
+        from scipy import sparse
+        return sparse.csc_matrix((self.x, self.i, self.p), shape=self.Dim)
+
+
+def _cor0(obj, ind_row, ind_col, size, alpha, thr_r2, fill_diag, infos_pos):
+    im, ir, ic = _ind(obj, ind_row, ind_col)
+    pos = 1000.0 * np.arange(1, ic.size + 1) if infos_pos is None else as_f64(np.ravel(infos_pos))
+    assert_lengths(pos, ic)
+    assert_sorted(pos)
+    thr = as_f64(_cor_thresholds(ir.size, alpha, thr_r2))
+    p = np.empty(ic.size + 1, dtype=np.int32)
+    nnz = C.c_int64(0)
+    h = vp()
+    L = _lib.load()
+    check(L.bsn_cormat(im.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p), ic.size, float(size) * 1000.0,
+                       ptr(thr, f64p), ptr(pos, f64p), int(bool(fill_diag)), ptr(p, i32p),
+                       C.byref(nnz), C.byref(h)))
+    try:
+        i = np.empty(nnz.value, dtype=np.int32)
+        x = np.empty(nnz.value, dtype=np.float64)
+        check(L.bsn_cormat_fetch(h, ptr(i, i32p), ptr(x, f64p)))
+    finally:
+        L.bsn_cormat_free(h)
+    if np.isnan(x).any():
+        import warnings
+        warnings.warn("NA or NaN values in the resulting correlation matrix.")  # R/corr.R:53-54
+    return CorResult(i, p, x, ic.size)
+
+
+def snp_cor(Gna, ind_row=None, ind_col=None, size=500, alpha=1, thr_r2=0, fill_diag=True,
+            infos_pos=None, ncores=1):
+    """R/corr.R:95-110"""
+    return _cor0(Gna, ind_row, ind_col, size, alpha, thr_r2, fill_diag, infos_pos)
+
+
+def bed_cor(obj_bed, ind_row=None, ind_col=None, size=500, alpha=1, thr_r2=0, fill_diag=True,
+            infos_pos=None, ncores=1):
+    """R/corr.R:116-132"""
+    return _cor0(obj_bed, ind_row, ind_col, size, alpha, thr_r2, fill_diag, infos_pos)
+
+
+def _ld0(obj, ind_row, ind_col, size, infos_pos):
+    im, ir, ic = _ind(obj, ind_row, ind_col)
+    pos = 1000.0 * np.arange(1, ic.size + 1) if infos_pos is None else as_f64(np.ravel(infos_pos))
+    assert_lengths(pos, ic)
+    assert_sorted(pos)
+    out = np.empty(ic.size)
+    check(_lib.load().bsn_ld_scores(im.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p), ic.size,
+                                    float(size) * 1000.0, ptr(pos, f64p), ptr(out, f64p)))
+    return out
+
+
+def snp_ld_scores(Gna, ind_row=None, ind_col=None, size=500, infos_pos=None, ncores=1):
+    """R/ld-scores.R:41-53"""
+    return _ld0(Gna, ind_row, ind_col, size, infos_pos)
+
+
+def bed_ld_scores(obj_bed, ind_row=None, ind_col=None, size=500, infos_pos=None, ncores=1):
+    """R/ld-scores.R:59-72"""
+    return _ld0(obj_bed, ind_row, ind_col, size, infos_pos)
+
+
+def _r_order_decreasing(S):
+    """R's order(S, decreasing = TRUE): stable w.r.t. the original index"""
+    return np.argsort(-np.asarray(S, dtype=np.float64), kind="stable")
+
+
+def snp_colstats(G, ind_row=None, ind_col=None, ncores=1):
+    """src/colstats.cpp:8-35 on the device image of an FBM.code256"""
+    im, ir, ic = _ind(G, ind_row, ind_col)
+    sumX, denoX = np.empty(ic.size), np.empty(ic.size)
+    check(_lib.load().bsn_snp_colstats(im.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p), ic.size,
+                                       ptr(sumX, f64p), ptr(denoX, f64p)))
+    return dict(sumX=sumX, denoX=denoX)
+
+
+def _clump_chr(im, ir, ind_chr, mode, aux1, aux2, S_chr, pos_chr, size, thr_r2):
+    ord_ = _r_order_decreasing(S_chr).astype(np.int32)
+    rank = np.empty(ord_.size, dtype=np.int32)
+    rank[ord_] = np.arange(ord_.size, dtype=np.int32)
+    keep = np.empty(ind_chr.size, dtype=np.int32)
+    aux1, aux2, pos_chr = as_f64(aux1), as_f64(aux2), as_f64(pos_chr)
+    assert_sorted(pos_chr)
+    check(_lib.load().bsn_clumping_chr(im.handle, ptr(ir, i64p), ir.size, ptr(ind_chr, i64p),
+                                       ind_chr.size, mode, ptr(aux1, f64p), ptr(aux2, f64p),
+                                       ptr(ord_, i32p), ptr(rank, i32p), ptr(pos_chr, f64p),
+                                       float(size), float(thr_r2), ptr(keep, i32p)))
+    assert np.all((keep == 0) | (keep == 1))  # stopifnot(all(keep[] %in% 0:1)), R/clumping.R:134
+    return ind_chr[keep == 1]
+
+
+def snp_clumping(G, infos_chr, ind_row=None, S=None, thr_r2=0.2, size=None, infos_pos=None,
+                 exclude=None, ncores=1):
+    """R/clumping.R:62-137 (snp_clumping + clumpingChr)"""
+    im, ir, _ = _ind(G, ind_row, None)
+    infos_chr = np.asarray(infos_chr)
+    assert_lengths(infos_chr, cols_along(im))
+    size = 100.0 / thr_r2 if size is None else size
+    if infos_pos is not None:
+        assert_lengths(infos_pos, infos_chr)
+    if S is not None:
+        assert_lengths(S, infos_chr)
+    excl = np.zeros(im.ncol, dtype=bool)
+    if exclude is not None and len(exclude):
+        excl[np.asarray(exclude, dtype=np.int64)] = True
+    kept = []
+    for chrom in np.unique(infos_chr[~excl]):
+        ind_chr = np.nonzero((infos_chr == chrom) & ~excl)[0].astype(np.int64)
+        st = snp_colstats(G, ir, ind_chr)
+        if S is None:
+            af = st["sumX"] / (2.0 * ir.size)
+            S_chr = np.minimum(af, 1 - af)
+        else:
+            S_chr = np.asarray(S, dtype=np.float64)[ind_chr]
+        if infos_pos is None:
+            pos_chr, sz = np.arange(1, ind_chr.size + 1, dtype=np.float64), float(size)
+        else:
+            pos_chr, sz = np.asarray(infos_pos, dtype=np.float64)[ind_chr], float(size) * 1000.0
+        kept.append(_clump_chr(im, ir, ind_chr, 0, st["sumX"], st["denoX"], S_chr, pos_chr, sz, thr_r2))
+    return np.sort(np.concatenate(kept)) if kept else np.zeros(0, dtype=np.int64)
+
+
+def bed_clumping(obj_bed, ind_row=None, S=None, thr_r2=0.2, size=None, exclude=None, ncores=1,
+                 infos_chr=None, infos_pos=None):
+    """R/bed-clumping.R:7-74; chromosome / position default to the .bim columns"""
+    im, ir, _ = _ind(obj_bed, ind_row, None)
+    infos_chr = np.asarray(obj_bed.map["chromosome"] if infos_chr is None else infos_chr)
+    infos_pos = np.asarray(obj_bed.map["physical_pos"] if infos_pos is None else infos_pos, dtype=np.float64)
+    size = 100.0 / thr_r2 if size is None else size
+    if S is not None:
+        assert_lengths(infos_chr, S)
+    excl = np.zeros(im.ncol, dtype=bool)
+    if exclude is not None and len(exclude):
+        excl[np.asarray(exclude, dtype=np.int64)] = True
+    kept = []
+    for chrom in np.unique(infos_chr[~excl]):
+        ind_chr = np.nonzero((infos_chr == chrom) & ~excl)[0].astype(np.int64)
+        st = bed_colstats(obj_bed, ir, ind_chr)
+        with np.errstate(all="ignore"):
+            center = st["sumX"] / st["nb_nona_col"]
+            scale = np.sqrt(st["denoX"])
+        if S is None:
+            S_chr = np.minimum(st["sumX"], 2.0 * st["nb_nona_col"] - st["sumX"])  # MAC
+        else:
+            S_chr = np.asarray(S, dtype=np.float64)[ind_chr]
+        kept.append(_clump_chr(im, ir, ind_chr, 1, center, scale, S_chr, infos_pos[ind_chr],
+                               float(size) * 1000.0, thr_r2))
+    return np.sort(np.concatenate(kept)) if kept else np.zeros(0, dtype=np.int64)

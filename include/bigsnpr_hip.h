@@ -147,6 +147,33 @@ int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int
                       const bsn_svd_options *options, double *d, double *u, double *v,
                       bsn_svd_info *info);
 
+/* ---- windowed LD (replaces corMat, ld_scores, clumping_chr, bed_clumping_chr) -----------
+ * The handle may come from bsn_bed_open (.bed) or bsn_bed_from_fbm (FBM.code256 with NA),
+ * which is the dispatch of src/corr.cpp:113-125.  `pos` has length m and must be sorted;
+ * `size` is already in position units (R multiplies by 1000, R/corr.R:29).  Rows must not be
+ * duplicated on this path. */
+typedef struct bsn_cor bsn_cor;
+/* _bigsnpr_corMat (8 args) src/corr.cpp:102-126.  Two-phase: this call computes everything
+ * on the device, fills p_out[m+1] (CSC column pointers exactly as R/corr.R:43-47 builds
+ * them) and *nnz_out; bsn_cormat_fetch copies @i (ascending row index, diagonal last in each
+ * column) and @x; thr has length n (thr[nona-1], src/corr.cpp:82). */
+int bsn_cormat(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+               double size, const double *thr, const double *pos, int fill_diag, int32_t *p_out,
+               int64_t *nnz_out, bsn_cor **out);
+int bsn_cormat_fetch(bsn_cor *cor, int32_t *i_out, double *x_out);
+int bsn_cormat_free(bsn_cor *cor);
+/* _bigsnpr_ld_scores (6 args) src/ld-scores.cpp:83-105 */
+int bsn_ld_scores(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                  double size, const double *pos, double *out);
+/* _bigsnpr_clumping_chr (12 args) src/clumping.cpp:10-91 (mode 0: aux1 = sumX, aux2 = denoX)
+ * and _bigsnpr_bed_clumping_chr (12 args) src/clumping-bed.cpp:11-91 (mode 1: aux1 = center,
+ * aux2 = scale).  ordInd / rankInd are 0-based; keep[m] receives 0 / 1 (the reference's
+ * `keep` FBM, R/clumping.R:116). */
+int bsn_clumping_chr(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                     int64_t m, int mode, const double *aux1, const double *aux2,
+                     const int32_t *ordInd, const int32_t *rankInd, const double *pos, double size,
+                     double thr, int32_t *keep);
+
 /* ---- device memory + timing helpers for hosts without a HIP binding -------- */
 int bsn_malloc(void **d_ptr, int64_t bytes);
 int bsn_free(void *d_ptr);

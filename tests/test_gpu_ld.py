@@ -1,0 +1,144 @@
+"""GPU parity of snp_cor / bed_cor / ld_scores / clumping against the oracle (which is
+itself pinned to PLINK's golden files).  Mirrors tests/testthat/test-2-corr.R,
+test-2-ld-scores.R and test-2-bed-clumping-SVD.R:33-48.  Bars: sparsity pattern (@i, @p) and
+clumping indices bit-exact; @x and LD scores within 1e-6 relative (asserted much tighter)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ba():
+    import bigsnpr_amd
+    return bigsnpr_amd
+
+
+def _plink_pairs(golden_dir):
+    rows = [l.split() for l in open(os.path.join(golden_dir, "example.ld"))][1:]
+    a = np.array([int(r[2][3:]) for r in rows]); b = np.array([int(r[5][3:]) for r in rows])
+    return a, b, np.array([float(r[6]) for r in rows])
+
+
+def _same_cor(res, ref, tol=1e-12):
+    i, p, x = ref
+    np.testing.assert_array_equal(res.p, p)
+    np.testing.assert_array_equal(res.i, i)
+    both_nan = np.isnan(res.x) & np.isnan(x)
+    assert np.all(np.isnan(res.x) == np.isnan(x))
+    np.testing.assert_allclose(res.x[~both_nan], x[~both_nan], rtol=0, atol=tol)
+
+
+def test_cor_vs_plink_golden(ba, golden_dir):
+    """test-2-corr.R:21-58 directly against PLINK's file, all 1431 pairs"""
+    gb = ba.bed(os.path.join(golden_dir, "example.bed"))
+    a, b, r2 = _plink_pairs(golden_dir)
+    res = ba.bed_cor(gb, size=1e6, thr_r2=0.2, fill_diag=False)
+    j = np.repeat(np.arange(gb.ncol), np.diff(res.p))
+    want = dict(zip(zip(a, b), r2)); got = dict(zip(zip(res.i, j), res.x ** 2))
+    assert set(want) == set(got)
+    assert max(abs(want[k] - got[k]) for k in want) < 1e-6
+
+
+@pytest.mark.parametrize("size", [0.037, 0.2, 2.5])
+def test_cor_bed_matches_oracle(ba, orc, golden_dir, example_bed, size):
+    gb = ba.bed(os.path.join(golden_dir, "example.bed"))
+    res = ba.bed_cor(gb, size=size, thr_r2=0.2, fill_diag=False)
+    _same_cor(res, orc.snp_cor(example_bed, size=size, thr_r2=0.2, fill_diag=False, ncores=8))
+    res = ba.bed_cor(gb, size=size, ind_col=np.arange(300, 1500))
+    _same_cor(res, orc.snp_cor(example_bed, size=size, ind_col=np.arange(300, 1500), ncores=8))
+
+
+def test_cor_missing_values_subsets_alpha(ba, orc, golden_dir, missing_bed):
+    """test-2-corr.R:77-116,148-159: NA, row/column subsets, alpha thresholds, FBM == bed"""
+    gb = ba.bed(os.path.join(golden_dir, "example-missing.bed"))
+    G_o = orc.fbm_from_bed(missing_bed)
+    G = ba.FBM_code256(G_o.bytes)
+    rng = np.random.default_rng(0)
+    ir = rng.choice(missing_bed.n, 100, replace=False)
+    ic = np.sort(rng.choice(missing_bed.m, 250, replace=False))
+    for kw in (dict(size=30), dict(size=0.05, alpha=0.1), dict(size=1e3, thr_r2=0.05, fill_diag=False),
+               dict(size=3, alpha=0.05, thr_r2=0.01)):
+        ref = orc.snp_cor(missing_bed, ir, ic, ncores=8, **kw)
+        _same_cor(ba.bed_cor(gb, ir, ic, **kw), ref)
+        _same_cor(ba.snp_cor(G, ir, ic, **kw), ref)
+    # positions in other units (test-2-corr.R:120-144)
+    pos = np.cumsum(rng.uniform(0.5, 3, ic.size))
+    _same_cor(ba.snp_cor(G, ir, ic, size=0.004, infos_pos=pos),
+              orc.snp_cor(missing_bed, ir, ic, size=0.004, infos_pos=pos))
+
+
+def test_cor_nan_for_constant_column(ba, orc):
+    """test-2-corr.R:163-171: zero-variance column -> NaN + warning"""
+    rng = np.random.default_rng(1)
+    g = rng.integers(0, 4, size=(200, 40)).astype(np.uint8)
+    g[:, 7] = 1
+    G = ba.FBM_code256(g); Go = orc.FBM256(g)
+    with pytest.warns(UserWarning, match="NA or NaN values"):
+        res = ba.snp_cor(G, size=1e3)
+    _same_cor(res, orc.snp_cor(Go, size=1e3))
+    assert np.isnan(res.x).any()
+
+
+def test_ld_scores(ba, orc, golden_dir, missing_bed, example_bed):
+    """test-2-ld-scores.R:15-64"""
+    gb = ba.bed(os.path.join(golden_dir, "example-missing.bed"))
+    for size in (25, 0.004, 300):
+        np.testing.assert_allclose(ba.bed_ld_scores(gb, size=size), orc.ld_scores(missing_bed, size=size),
+                                   rtol=1e-12)
+    np.testing.assert_array_equal(ba.bed_ld_scores(gb, size=0.0005), np.ones(missing_bed.m))
+    ge = ba.bed(os.path.join(golden_dir, "example.bed"))
+    ic = np.arange(1000, 2200)
+    ld = ba.bed_ld_scores(ge, ind_col=ic, size=50)
+    np.testing.assert_allclose(ld, orc.ld_scores(example_bed, ind_col=ic, size=50), rtol=1e-12)
+    # == colSums(cor^2)
+    c = ba.bed_cor(ge, ind_col=ic, size=50).tocsc()
+    full = c + c.T - __import__("scipy.sparse", fromlist=["x"]).diags(c.diagonal())
+    np.testing.assert_allclose(ld, np.asarray(full.multiply(full).sum(0)).ravel(), rtol=1e-10)
+
+
+def test_clumping_identical_to_oracle(ba, orc, golden_dir, example_bed):
+    """test-2-bed-clumping-SVD.R:33-48,70 and test-6-PRS.R:24-31: indices bit-exact"""
+    path = os.path.join(golden_dir, "example.bed")
+    gb = ba.bed(path)
+    chrom, pos = orc.read_bim(path)
+    Go = orc.fbm_from_bed(example_bed)
+    G = ba.FBM_code256(Go.bytes)
+    ref = orc.snp_clumping(Go, chrom, infos_pos=pos, thr_r2=0.2)
+    np.testing.assert_array_equal(ba.snp_clumping(G, chrom, infos_pos=pos, thr_r2=0.2), ref)
+    np.testing.assert_array_equal(ba.bed_clumping(gb, thr_r2=0.2), ref)          # bed == FBM
+    np.testing.assert_array_equal(ba.snp_clumping(G, chrom, infos_pos=pos / 1000, size=0.5), ref)
+    # other thresholds, window in SNP units, exclusions, row subset, custom statistic
+    rng = np.random.default_rng(2)
+    ir = np.sort(rng.choice(example_bed.n, 300, replace=False))
+    excl = rng.choice(example_bed.m, 500, replace=False)
+    S = rng.uniform(size=example_bed.m)
+    for kw in (dict(thr_r2=0.05, size=200), dict(thr_r2=0.5, infos_pos=pos, size=100),
+               dict(thr_r2=0.2, infos_pos=pos, ind_row=ir, exclude=excl),
+               dict(thr_r2=0.1, infos_pos=pos, S=S)):
+        np.testing.assert_array_equal(ba.snp_clumping(G, chrom, **kw), orc.snp_clumping(Go, chrom, **kw))
+    np.testing.assert_array_equal(ba.bed_clumping(gb, ind_row=ir, exclude=excl, thr_r2=0.3),
+                                  orc.bed_clumping(example_bed, chrom, pos, ind_row=ir, exclude=excl, thr_r2=0.3))
+    # PLINK golden: > 98 % overlap when prioritising by the stored p-values
+    pval = orc.read_rds(os.path.join(golden_dir, "pval.rds"))
+    keep2 = orc.read_rds(os.path.join(golden_dir, "clumping.rds")) - 1
+    keep = ba.snp_clumping(G, chrom, S=-np.log10(pval), size=250, infos_pos=pos)
+    assert np.isin(keep, keep2).mean() > 0.98
+
+
+def test_clumping_with_missing_values(ba, orc, golden_dir, missing_bed):
+    path = os.path.join(golden_dir, "example-missing.bed")
+    gb = ba.bed(path)
+    chrom, pos = orc.read_bim(path)
+    np.testing.assert_array_equal(ba.bed_clumping(gb, thr_r2=0.1),
+                                  orc.bed_clumping(missing_bed, chrom, pos, thr_r2=0.1))
+
+
+def test_ld_errors(ba, golden_dir):
+    gb = ba.bed(os.path.join(golden_dir, "example-missing.bed"))
+    with pytest.raises(ValueError, match="not sorted"):
+        ba.bed_cor(gb, infos_pos=np.arange(gb.ncol)[::-1])
+    with pytest.raises(ba.BsnError, match="duplicated"):
+        ba.bed_cor(gb, ind_row=np.array([0, 1, 1, 2]))
