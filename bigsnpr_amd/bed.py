@@ -107,7 +107,7 @@ class bed:
                 for line in f:
                     t = line.split()
                     chrom.append(t[0]); snp.append(t[1]); gd.append(float(t[2]))
-                    pos.append(int(t[3])); a1.append(t[4]); a2.append(t[5])
+                    pos.append(int(float(t[3]))); a1.append(t[4]); a2.append(t[5])
             try:
                 chrom = np.array([int(c) for c in chrom])
             except ValueError:

@@ -108,7 +108,7 @@ def read_bim(bedpath):
         for line in f:
             t = line.split()
             chrom.append(int(t[0]))
-            pos.append(int(t[3]))
+            pos.append(int(float(t[3])))
     return np.array(chrom, dtype=np.int64), np.array(pos, dtype=np.float64)
 
 
