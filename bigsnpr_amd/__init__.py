@@ -11,6 +11,7 @@ from .bed import (ERROR_DIM, ScaledOp, bed, bed_colstats, bed_counts, bed_cprodV
 from .svd import bed_randomSVD  # noqa: F401,E402
 from .ld import (FBM_code256, bed_clumping, bed_cor, bed_ld_scores, snp_clumping,  # noqa: F401,E402
                  snp_colstats, snp_cor, snp_ld_scores)
+from .prs import bed_tcrossprodSelf, prodVecRev, snp_PRS  # noqa: F401,E402
 
 
 def selftest():

@@ -67,6 +67,7 @@ SIGNATURES = {
     "bsn_op_sync": (C.c_int, [vp]),
     "bsn_bed_randomsvd": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, C.POINTER(SvdOptions),
                                     f64p, f64p, f64p, C.POINTER(SvdInfo)]),
+    "bsn_bed_tcrossprod": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, i64, f64p]),
     "bsn_cormat": (C.c_int, [vp, i64p, i64, i64p, i64, C.c_double, f64p, f64p, C.c_int, i32p,
                              C.POINTER(C.c_int64), C.POINTER(vp)]),
     "bsn_cormat_fetch": (C.c_int, [vp, i32p, f64p]),

@@ -1,0 +1,65 @@
+"""snp_PRS and bed_tcrossprodSelf — host mirrors of R/PRS.R and R/bed-tcrossprodSelf.R."""
+import numpy as np
+
+from . import _lib
+from ._lib import as_f64, check, f64p, i64p, ptr
+from .bed import _args, assert_lengths, bed_prodVec, bed_scaleBinom
+from .ld import _ind, _r_order_decreasing
+
+
+def prodVecRev(G, betas_col, same_col, ind_row, ind_col):
+    """R/PRS.R:3-7: big_prodVec(G, (2 * same - 1) * beta, ind.row, ind.col) + 2 * sum(beta[!same]).
+    big_prodVec is bigstatsr's unscaled FBM product (external); here the same streaming
+    kernel as bed_prodVec with center 0 / scale 1 on the FBM's 2-bit image."""
+    im, ir, ic = _ind(G, ind_row, ind_col)
+    betas_col = as_f64(betas_col)
+    same_col = np.asarray(same_col, dtype=bool)
+    if ic.size == 0:
+        return np.zeros(ir.size)
+    mod = (2.0 * same_col - 1.0) * betas_col
+    return bed_prodVec(im, mod, ir, ic) + 2.0 * betas_col[~same_col].sum()
+
+
+def snp_PRS(G, betas_keep, ind_test=None, ind_keep=None, same_keep=None, lpS_keep=None, thr_list=0):
+    """R/PRS.R:36-76.  Returns an n x T matrix; T thresholds cost one pass over the kept
+    columns in total (scores are accumulated from the highest threshold down)."""
+    im, ind_test, ind_keep = _ind(G, ind_test, ind_keep)
+    betas_keep = as_f64(np.ravel(betas_keep))
+    same_keep = np.ones(ind_keep.size, dtype=bool) if same_keep is None else np.asarray(same_keep)
+    if same_keep.dtype != np.bool_:
+        raise TypeError("'same.keep' is not of type 'logical'.")
+    assert_lengths(same_keep, ind_keep)
+    assert_lengths(betas_keep, ind_keep)
+    thr_arr = np.atleast_1d(np.asarray(thr_list, dtype=np.float64))
+    if lpS_keep is None or (thr_arr.size == 1 and thr_arr[0] == 0):
+        import warnings
+        warnings.warn("'lpS.keep' or 'thr.list' was not specified. Thresholding disabled.")
+        return prodVecRev(G, betas_keep, same_keep, ind_test, ind_keep)[:, None]
+    lpS_keep = as_f64(np.ravel(lpS_keep))
+    assert_lengths(lpS_keep, ind_keep)
+    if np.any(lpS_keep < 0):
+        raise ValueError("'lpS.keep' should have only positive values.")
+    scores = np.full((ind_test.size, thr_arr.size), np.nan)
+    ind_rem = np.arange(ind_keep.size)
+    last = np.zeros(ind_test.size)
+    for i in _r_order_decreasing(thr_arr):
+        pass_thr = lpS_keep[ind_rem] > thr_arr[i]
+        ind = ind_rem[pass_thr]
+        last = last + prodVecRev(G, betas_keep[ind], same_keep[ind], ind_test, ind_keep[ind])
+        scores[:, i] = last
+        ind_rem = ind_rem[~pass_thr]
+    return scores
+
+
+def bed_tcrossprodSelf(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=None,
+                       block_size=0):
+    """R/bed-tcrossprodSelf.R:21-52: returns (K, dict(center, scale)); fun.scaling is applied
+    per column block there, which is the same as applying it to all columns at once."""
+    ir, ic = _args(obj_bed, ind_row, ind_col)
+    ms = fun_scaling(obj_bed, ind_row=ir, ind_col=ic)
+    center, scale = as_f64(ms["center"]), as_f64(ms["scale"])
+    K = np.empty((ir.size, ir.size), dtype=np.float64, order="F")
+    check(_lib.load().bsn_bed_tcrossprod(obj_bed.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p),
+                                         ic.size, ptr(center, f64p), ptr(scale, f64p),
+                                         int(block_size), K.ctypes.data_as(f64p)))
+    return K, dict(center=center, scale=scale)

@@ -147,6 +147,13 @@ int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int
                       const bsn_svd_options *options, double *d, double *u, double *v,
                       bsn_svd_info *info);
 
+/* bed_tcrossprodSelf (R/bed-tcrossprodSelf.R:21-52): K[n x n] = A~ A~' accumulated over column
+ * blocks of block_size (0 -> 1024) variants; center / scale of length m as returned by
+ * fun.scaling.  K is column-major (symmetric). */
+int bsn_bed_tcrossprod(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                       int64_t m, const double *center, const double *scale, int64_t block_size,
+                       double *K);
+
 /* ---- windowed LD (replaces corMat, ld_scores, clumping_chr, bed_clumping_chr) -----------
  * The handle may come from bsn_bed_open (.bed) or bsn_bed_from_fbm (FBM.code256 with NA),
  * which is the dispatch of src/corr.cpp:113-125.  `pos` has length m and must be sorted;
