@@ -356,8 +356,8 @@ __global__ void k_cprod_final(const int32_t *acc, int64_t m, int ncol, int S, co
 //   A operand: lane l -> digit column (l&15), k-group (l>>4): 16 variants' digits
 //   B operand: lane l -> sample group (l&15), same 16 variants, sample u of the group
 //   D        : lane l -> sample group (l&15), digit columns 4*(l>>4)+r
-template <int NB, bool CONTIG>
-__global__ __launch_bounds__(256) void k_prod(const uint8_t *__restrict__ img, int64_t pitch,
+template <int NB, bool CONTIG, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__ img, int64_t pitch,
                                               const int32_t *__restrict__ cols, int64_t col0,
                                               int64_t m_pad, int64_t mc,
                                               const int8_t *__restrict__ wq,
@@ -365,7 +365,9 @@ __global__ __launch_bounds__(256) void k_prod(const uint8_t *__restrict__ img, i
   constexpr int NCOL = 16 * NB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int sg = lane & 15, g = lane >> 4;
-  const int64_t wbase = ((int64_t)blockIdx.x * 4 + wave) * 256;  // first sample of this wave
+  int64_t wbase = ((int64_t)blockIdx.x * WAVES + wave) * 256;  // first sample of this wave
+  const bool active = wbase < n_pad;  // WAVES = 8: the last workgroup may be half empty
+  if (!active) wbase = 0;
   const int64_t wbyte = wbase / 4 + sg * 4;
   const uint32_t lane_off = (uint32_t)(g * 16 * pitch + wbyte);
   const int64_t j0 = (int64_t)blockIdx.y * mc;
@@ -462,12 +464,14 @@ __global__ __launch_bounds__(256) void k_prod(const uint8_t *__restrict__ img, i
     for (int r = 0; r < 16; r++) X[r] = Xn[r];
   }
   // raw accumulators: acc_out[ky][sample][NCOL], lane holds columns nb*16 + 4g .. +3
+  if (active) {
 #pragma unroll
-  for (int u = 0; u < 16; u++) {
-    const int64_t i = wbase + sg * 16 + u;
+    for (int u = 0; u < 16; u++) {
+      const int64_t i = wbase + sg * 16 + u;
 #pragma unroll
-    for (int nb = 0; nb < NB; nb++)
-      *(v4i *)(acc_out + (((int64_t)blockIdx.y * n_pad + i) * NCOL + nb * 16 + 4 * g)) = acc[u][nb];
+      for (int nb = 0; nb < NB; nb++)
+        *(v4i *)(acc_out + (((int64_t)blockIdx.y * n_pad + i) * NCOL + nb * 16 + 4 * g)) = acc[u][nb];
+    }
   }
 }
 

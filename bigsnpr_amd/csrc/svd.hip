@@ -3,6 +3,7 @@
 // R/autoSVD.R:205-219).  The two matrix passes per step are op_cprod / op_prod
 // (matvec.hip); the tall-skinny fp64 panel algebra below is memory-bound on the basis Q
 // (n x p doubles) and is a few percent of a step.
+#include <chrono>
 #include <memory>
 
 #include "bsn_internal.hpp"
@@ -250,9 +251,14 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
   return guarded([&] {
     if (!o) fail("options must not be NULL");
     if (o->k < 1) fail("'k' must be at least 1.");
+    auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&]() {
+      return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    };
     bsn_op *op = nullptr;
     if (bsn_op_create(bed, ind_row, n, ind_col, m, center, scale, &op) != 0)
       throw Error(bsn_last_error());
+    const double t_create = since();
     std::unique_ptr<bsn_op> guard(op);
     op->profile = true;
     if (o->slices > 7) fail("slices must be in 1..7");
@@ -283,6 +289,9 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     so.verbose = o->verbose;
     BSN_HIP(hipEventRecord(bed->ev0, bed->stream));
     SvdResult r = block_lanczos_svd(bk, so, d, u, v);
+    if (o->verbose > 1)
+      std::fprintf(stderr, "[bsn svd] host wall: op_create %.2f ms, solve %.2f ms\n", t_create,
+                   since() - t_create);
     BSN_HIP(hipEventRecord(bed->ev1, bed->stream));
     BSN_HIP(hipEventSynchronize(bed->ev1));
     float ms = 0;

@@ -29,7 +29,7 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
     scale = np.ascontiguousarray(ms["scale"], dtype=np.float64)
     opts = _lib.SvdOptions()
     opts.k, opts.tol, opts.block, opts.slices = int(k), float(tol), int(block), int(slices)
-    opts.max_basis, opts.seed, opts.verbose, opts.m_total = int(max_basis), int(seed), int(bool(verbose)), int(m_total)
+    opts.max_basis, opts.seed, opts.verbose, opts.m_total = int(max_basis), int(seed), int(verbose), int(m_total)
     cb = None
     if allreduce is not None:
         cb = _lib.ALLREDUCE_FN(lambda p, count, ctx: allreduce(p, count))

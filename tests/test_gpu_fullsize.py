@@ -1,0 +1,60 @@
+"""Size-independent properties at BASELINE.json's full sizes (the oracle cannot run there):
+C2 = 50K x 200K through the FBM-style products, C3 = 400K x 1M bed_randomSVD k = 20.
+The matrix is generated in HBM; each test takes a few seconds on MI355X."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ba():
+    import bigsnpr_amd
+    return bigsnpr_amd
+
+
+def test_c2_products_linearity_adjointness_counts(ba):
+    n, m = 50000, 200000
+    gb = ba.bed.synthetic(n, m, seed=77)
+    counts = ba.bed_counts(gb)
+    assert np.all(counts.sum(0) == n) and counts.min() >= 0           # checksum of checksums
+    st = ba.bed_colstats(gb)
+    np.testing.assert_array_equal(st["sumX"], counts[1] + 2.0 * counts[2])
+    np.testing.assert_array_equal(st["nb_nona_col"], n - counts[3])
+    sc = ba.bed_scaleBinom(gb)
+    rng = np.random.default_rng(0)
+    x1, x2, y = rng.normal(size=m), rng.normal(size=m), rng.normal(size=n)
+    kw = dict(center=sc["center"], scale=sc["scale"])
+    a1, a2 = ba.bed_prodVec(gb, x1, **kw), ba.bed_prodVec(gb, x2, **kw)
+    a3 = ba.bed_prodVec(gb, 3 * x1 - x2, **kw)
+    assert np.abs(a3 - (3 * a1 - a2)).max() <= 1e-9 * np.abs(a3).max()
+    z = ba.bed_cprodVec(gb, y, **kw)
+    assert abs(a1 @ y - x1 @ z) <= 1e-10 * np.linalg.norm(a1) * np.linalg.norm(y)
+    # mean-imputed scaling => every scaled column sums to 0:  A~' 1 = 0
+    z1 = ba.bed_cprodVec(gb, np.ones(n), **kw)
+    assert np.abs(z1).max() <= 1e-7 * np.sqrt(n)
+    # a column subset of the product equals the product on the subset (gather paths)
+    ic = np.sort(rng.choice(m, 5000, replace=False))
+    np.testing.assert_allclose(ba.bed_cprodVec(gb, y, ind_col=ic, center=sc["center"][ic], scale=sc["scale"][ic]),
+                               z[ic], rtol=0, atol=1e-9 * np.abs(z).max())
+
+
+def test_c3_randomsvd_full_size_properties(ba):
+    n, m, k = 400000, 1000000, 20
+    gb = ba.bed.synthetic(n, m)
+    res = ba.bed_randomSVD(gb, k=k)                                   # reference defaults (tol 1e-4)
+    assert res["converged"] and res["u"].shape == (n, k) and res["v"].shape == (m, k)
+    d, u, v = res["d"], res["u"], res["v"]
+    assert np.all(np.diff(d) < 0) and d[-1] > 0
+    np.testing.assert_allclose(u.T @ u, np.eye(k), atol=1e-6)
+    np.testing.assert_allclose(v.T @ v, np.eye(k), atol=1e-4)
+    assert np.abs(u.mean(0)).max() < 1e-5                            # colMeans(u) ~ 0
+    # singular triplets: || A~ v_t - d_t u_t || <= ~sqrt(tol) d_t, checked through the 56-bit products
+    for t in (0, k - 1):
+        av = ba.bed_prodVec(gb, v[:, t], center=res["center"], scale=res["scale"])
+        assert np.linalg.norm(av - d[t] * u[:, t]) <= 2e-2 * d[t]
+        atu = ba.bed_cprodVec(gb, u[:, t], center=res["center"], scale=res["scale"])
+        assert np.linalg.norm(atu - d[t] * v[:, t]) <= 2e-2 * d[t]
+    # reproducible and insensitive to the panel precision at the 1e-6 level
+    res2 = ba.bed_randomSVD(gb, k=k, block=8, slices=4, return_uv=False)
+    np.testing.assert_allclose(res2["d"], d, rtol=1e-6)
