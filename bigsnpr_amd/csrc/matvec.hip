@@ -190,8 +190,8 @@ __global__ void k_quant(const double *X, int64_t ldx, int64_t len, int64_t len_p
 //   A operand: lane l -> variant row (l&15), k-group (l>>4): 16 samples of that variant
 //   B operand: lane l -> digit column (l&15), same 16 samples (from LDS)
 //   D        : lane l -> column (l&15), rows 4*(l>>4)+r
-template <int NB, int NPLANE, int KC, int ABL = 0>
-__global__ __launch_bounds__(512, 4) void k_cprod(const uint8_t *__restrict__ img, int64_t pitch,
+template <int NB, int NPLANE, int KC, int ABL = 0, int TILES = 2, int WAVES = 8>
+__global__ __launch_bounds__(64 * WAVES) void k_cprod(const uint8_t *__restrict__ img, int64_t pitch,
                                                const int32_t *__restrict__ cols, int64_t col0,
                                                int64_t m, const int8_t *__restrict__ xq,
                                                int32_t *__restrict__ acc_out, int64_t m_out,
@@ -202,10 +202,11 @@ __global__ __launch_bounds__(512, 4) void k_cprod(const uint8_t *__restrict__ im
   __shared__ uint4 xs[2][XS];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int c = lane & 15, g = lane >> 4;
-  const int64_t snp_base = ((int64_t)blockIdx.x * 8 + wave) * 32;
-  const uint8_t *rowp[2];
+  constexpr int NT = 64 * WAVES;
+  const int64_t snp_base = ((int64_t)blockIdx.x * WAVES + wave) * (16 * TILES);
+  const uint8_t *rowp[TILES];
 #pragma unroll
-  for (int t = 0; t < 2; t++) {
+  for (int t = 0; t < TILES; t++) {
     int64_t j = snp_base + t * 16 + c;
     if (j > m - 1) j = m - 1;
     int64_t col = cols ? (int64_t)cols[j] : col0 + j;
@@ -214,27 +215,26 @@ __global__ __launch_bounds__(512, 4) void k_cprod(const uint8_t *__restrict__ im
   const int nchunks = (int)(pitch * 4 / KC);
   const uint4 *xq4 = (const uint4 *)xq;
 
-  v4i acc[2][NPLANE][NB];
+  v4i acc[TILES][NPLANE][NB];
 #pragma unroll
-  for (int t = 0; t < 2; t++)
+  for (int t = 0; t < TILES; t++)
 #pragma unroll
     for (int p = 0; p < NPLANE; p++)
 #pragma unroll
       for (int nb = 0; nb < NB; nb++) acc[t][p][nb] = v4i{0, 0, 0, 0};
 
-  static_assert(XS % 512 == 0, "digit chunk must be a multiple of the workgroup");
-  constexpr int NX = XS / 512;             // staged uint4 per thread per chunk
+  constexpr int NX = (XS + NT - 1) / NT;   // staged uint4 per thread per chunk
   static_assert(NX <= 2, "staging registers");
-  uint4 a_cur[2][LD], a_nxt[2][LD];
+  constexpr bool XFULL = (XS % NT == 0);   // every thread stages NX entries
+  uint4 a_cur[TILES][LD], a_nxt[TILES][LD];
   uint4 xr0 = {0, 0, 0, 0}, xr1 = {0, 0, 0, 0};
   // prologue
 #pragma unroll
-  for (int t = 0; t < 2; t++)
+  for (int t = 0; t < TILES; t++)
 #pragma unroll
     for (int it = 0; it < LD; it++) a_cur[t][it] = *(const uint4 *)(rowp[t] + it * 64);
-#pragma unroll
-  for (int e = 0; e < NX; e++)
-    xs[0][tid + e * 512] = xq4[tid + e * 512];
+  if (XFULL || tid < XS) xs[0][tid] = xq4[tid];
+  if constexpr (NX > 1) xs[0][tid + NT] = xq4[tid + NT];
   __syncthreads();
 
   for (int ch = 0; ch < nchunks; ch++) {
@@ -244,11 +244,11 @@ __global__ __launch_bounds__(512, 4) void k_cprod(const uint8_t *__restrict__ im
       // issue order matters: the digit panel first, so that waiting for it later does not
       // also wait for the (younger) genotype loads of the next chunk
       const uint4 *src = xq4 + (int64_t)(ch + 1) * XS;
-      xr0 = src[tid];
-      if constexpr (NX > 1) xr1 = src[tid + 512];
+      if (XFULL || tid < XS) xr0 = src[tid];
+      if constexpr (NX > 1) xr1 = src[tid + NT];
       const int64_t off = (int64_t)(ch + 1) * (KC / 4);
 #pragma unroll
-      for (int t = 0; t < 2; t++)
+      for (int t = 0; t < TILES; t++)
 #pragma unroll
         for (int it = 0; it < LD; it++)
           a_nxt[t][it] = *(const uint4 *)(rowp[t] + off + it * 64);
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(512, 4) void k_cprod(const uint8_t *__restrict__ im
           for (int nb = 0; nb < NB; nb++) bn[nb] = xs[cur][(itn * 16 + g * 4 + dn) * NCOL + nb * 16 + c];
         }
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
+        for (int t = 0; t < TILES; t++) {
           const uint32_t w = d == 0 ? a_cur[t][it].x : d == 1 ? a_cur[t][it].y
                              : d == 2 ? a_cur[t][it].z : a_cur[t][it].w;
           uint32_t s0 = w & 0x03030303u, s1 = (w >> 2) & 0x03030303u,
@@ -298,19 +298,19 @@ __global__ __launch_bounds__(512, 4) void k_cprod(const uint8_t *__restrict__ im
       }
     }
     if (has_next) {
-      xs[cur ^ 1][tid] = xr0;
-      if constexpr (NX > 1) xs[cur ^ 1][tid + 512] = xr1;
+      if (XFULL || tid < XS) xs[cur ^ 1][tid] = xr0;
+      if constexpr (NX > 1) xs[cur ^ 1][tid + NT] = xr1;
     }
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 2; t++)
+    for (int t = 0; t < TILES; t++)
 #pragma unroll
       for (int it = 0; it < LD; it++) a_cur[t][it] = a_nxt[t][it];
   }
 
   // raw accumulators: acc_out[plane][variant][NCOL]
 #pragma unroll
-  for (int t = 0; t < 2; t++)
+  for (int t = 0; t < TILES; t++)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       int64_t j = snp_base + t * 16 + g * 4 + r;
