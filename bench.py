@@ -127,7 +127,17 @@ def main():
         ms = sum(r[key + "_ms"] for r in infos)
         cnt = sum(r["n_" + key] for r in infos)
         kern[key] = dict(name=name, total_ms=ms, launches=cnt, avg_ms=ms / max(cnt, 1))
-    dom = max(kern.values(), key=lambda d: d["total_ms"])
+    dom_key = max(kern, key=lambda k_: kern[k_]["total_ms"])
+    dom = kern[dom_key]
+    # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside
+    # the process, so this is the committed rocprofv3 measurement of the same workload
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if pm["workload"] == {"n": n, "m_per_gpu": m_local} and a.block == 5:
+            traffic = pm["kernels"][dom_key]["hbm_read_bytes"]
+    except Exception:
+        traffic = None
     achieved = bytes_per_launch / (dom["avg_ms"] * 1e-3) / 1e9
     out = {
         "metric": "SNP-cols/sec for bed_randomSVD k=%d (m*passes/wall)" % a.k,
@@ -145,7 +155,8 @@ def main():
         "sigma": [float(x) for x in infos[-1]["d"][:5]],
         "generate_s": gen_s,
         "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2, bytes per launch)" if traffic else None,
                      "bytes_per_launch": bytes_per_launch, "avg_launch_ms": dom["avg_ms"],
                      "launches": dom["launches"],
                      "other": {k: {"avg_ms": v["avg_ms"], "launches": v["launches"],

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage: tools/pmc_run.sh <tag> <bench args...>   (run on the GPU box from the repo root)
-# One rocprofv3 invocation per counter group (PMC slots: SQ 8, TCC 4 with FETCH_SIZE=3).
+# One rocprofv3 invocation per counter group (PMC slots: SQ 8, TCC 4 with FETCH_SIZE=3);
+# counters are collected on their own (kernel-trace only), as the profiling guide prescribes.
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_$TAG
