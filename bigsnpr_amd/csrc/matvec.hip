@@ -224,10 +224,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_cprod(const uint8_t *__restrict_
       for (int nb = 0; nb < NB; nb++) acc[t][p][nb] = v4i{0, 0, 0, 0};
 
   constexpr int NX = (XS + NT - 1) / NT;   // staged uint4 per thread per chunk
-  static_assert(NX <= 2, "staging registers");
+  static_assert(NX <= 4, "staging registers");
   constexpr bool XFULL = (XS % NT == 0);   // every thread stages NX entries
   uint4 a_cur[TILES][LD], a_nxt[TILES][LD];
-  uint4 xr0 = {0, 0, 0, 0}, xr1 = {0, 0, 0, 0};
+  uint4 xr0 = {0, 0, 0, 0}, xr1 = {0, 0, 0, 0}, xr2 = {0, 0, 0, 0}, xr3 = {0, 0, 0, 0};
   // prologue
 #pragma unroll
   for (int t = 0; t < TILES; t++)
@@ -235,6 +235,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_cprod(const uint8_t *__restrict_
     for (int it = 0; it < LD; it++) a_cur[t][it] = *(const uint4 *)(rowp[t] + it * 64);
   if (XFULL || tid < XS) xs[0][tid] = xq4[tid];
   if constexpr (NX > 1) xs[0][tid + NT] = xq4[tid + NT];
+  if constexpr (NX > 2) xs[0][tid + 2 * NT] = xq4[tid + 2 * NT];
+  if constexpr (NX > 3) xs[0][tid + 3 * NT] = xq4[tid + 3 * NT];
   __syncthreads();
 
   for (int ch = 0; ch < nchunks; ch++) {
@@ -246,6 +248,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_cprod(const uint8_t *__restrict_
       const uint4 *src = xq4 + (int64_t)(ch + 1) * XS;
       if (XFULL || tid < XS) xr0 = src[tid];
       if constexpr (NX > 1) xr1 = src[tid + NT];
+      if constexpr (NX > 2) xr2 = src[tid + 2 * NT];
+      if constexpr (NX > 3) xr3 = src[tid + 3 * NT];
       const int64_t off = (int64_t)(ch + 1) * (KC / 4);
 #pragma unroll
       for (int t = 0; t < TILES; t++)
@@ -256,13 +260,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_cprod(const uint8_t *__restrict_
     uint4 bv[NB], bn[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) bv[nb] = xs[cur][(g * 4) * NCOL + nb * 16 + c];
+    if (ABL & 4) {  // ablation: digit operand read once per chunk instead of once per K-step
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) bn[nb] = bv[nb];
+    }
 #pragma unroll
     for (int it = 0; it < LD; it++) {
 #pragma unroll
       for (int d = 0; d < 4; d++) {
         // prefetch the digit operand of the next K-step so that its LDS latency hides
         // under this step's decode + MFMA
-        if (it * 4 + d + 1 < LD * 4) {
+        if (!(ABL & 4) && it * 4 + d + 1 < LD * 4) {
           const int itn = (it * 4 + d + 1) / 4, dn = (it * 4 + d + 1) % 4;
 #pragma unroll
           for (int nb = 0; nb < NB; nb++) bn[nb] = xs[cur][(itn * 16 + g * 4 + dn) * NCOL + nb * 16 + c];
@@ -300,6 +308,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_cprod(const uint8_t *__restrict_
     if (has_next) {
       if (XFULL || tid < XS) xs[cur ^ 1][tid] = xr0;
       if constexpr (NX > 1) xs[cur ^ 1][tid + NT] = xr1;
+      if constexpr (NX > 2) xs[cur ^ 1][tid + 2 * NT] = xr2;
+      if constexpr (NX > 3) xs[cur ^ 1][tid + 3 * NT] = xr3;
     }
     __syncthreads();
 #pragma unroll
@@ -600,7 +610,8 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
   constexpr int KC = 512;
   dim3 grid((unsigned)((op->m + 255) / 256));
   const int32_t *cols = op->cols_contig ? nullptr : op->d_cols.p;
-  // BSN_TUNE = 11 / 12 / 13 select the ablation builds (no MFMA / no decode / neither) used
+  // BSN_TUNE = 11 / 12 / 13 / 14 select the ablation builds (no MFMA / no decode / neither /
+  // digit operand read once per chunk) used
   // for profiles/r01_ablation.txt; they produce wrong numbers by construction.
   const int abl = tune_variant();
 #define BSN_LAUNCH_CPROD(NBV, ABLV)                                                              \
@@ -615,6 +626,7 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
     if (abl == 11) BSN_LAUNCH_CPROD(2, 1);
     else if (abl == 12) BSN_LAUNCH_CPROD(2, 2);
     else if (abl == 13) BSN_LAUNCH_CPROD(2, 3);
+    else if (abl == 14) BSN_LAUNCH_CPROD(2, 4);
     else BSN_LAUNCH_CPROD(2, 0);
   }
 #undef BSN_LAUNCH_CPROD
