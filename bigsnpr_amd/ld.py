@@ -236,3 +236,43 @@ def bed_clumping(obj_bed, ind_row=None, S=None, thr_r2=0.2, size=None, exclude=N
         kept.append(_clump_chr(im, ir, ind_chr, 1, center, scale, S_chr, infos_pos[ind_chr],
                                float(size) * 1000.0, thr_r2))
     return np.sort(np.concatenate(kept)) if kept else np.zeros(0, dtype=np.int64)
+
+
+# ---- FBM.code256 scaling helpers and SVD (R/binom-scaling.R:12-106, R/autoSVD.R:129-134) ----
+def snp_scaleBinom(nploidy=2):
+    """R/binom-scaling.R:62-77: returns fun.scaling(X, ind.row, ind.col, ncores)"""
+    def fun(X, ind_row=None, ind_col=None, ncores=1):
+        im, ir, ic = _ind(X, ind_row, ind_col)
+        af = snp_colstats(X, ir, ic)["sumX"] / (ir.size * nploidy)
+        with np.errstate(all="ignore"):
+            return dict(center=nploidy * af, scale=np.sqrt(nploidy * af * (1 - af)))
+    return fun
+
+
+def snp_scaleAlpha(alpha=-1):
+    """R/binom-scaling.R:12-27"""
+    def fun(X, ind_row=None, ind_col=None, ncores=1):
+        im, ir, ic = _ind(X, ind_row, ind_col)
+        af = snp_colstats(X, ir, ic)["sumX"] / (2 * ir.size)
+        with np.errstate(all="ignore"):
+            return dict(center=2 * af, scale=(2 * af * (1 - af)) ** (-alpha / 2))
+    return fun
+
+
+def snp_MAF(G, ind_row=None, ind_col=None, nploidy=2, ncores=1):
+    """R/binom-scaling.R:94-106"""
+    im, ir, ic = _ind(G, ind_row, ind_col)
+    af = snp_colstats(G, ir, ic)["sumX"] / (ir.size * nploidy)
+    return np.minimum(af, 1 - af)
+
+
+def big_randomSVD(X, fun_scaling=None, ind_row=None, ind_col=None, k=10, tol=1e-4, verbose=False,
+                  ncores=1, **kw):
+    """The FBM entry of the partial SVD as snp_autoSVD calls it (R/autoSVD.R:129-134;
+    bigstatsr::big_randomSVD is external): same device solver as bed_randomSVD, on the
+    FBM's 2-bit image."""
+    from .svd import bed_randomSVD
+    im, ir, ic = _ind(X, ind_row, ind_col)
+    fs = snp_scaleBinom() if fun_scaling is None else fun_scaling
+    return bed_randomSVD(im, fun_scaling=lambda obj, ind_row, ind_col, ncores=1: fs(X, ind_row, ind_col, ncores),
+                         ind_row=ir, ind_col=ic, k=k, tol=tol, verbose=verbose, ncores=ncores, **kw)

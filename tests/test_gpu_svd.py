@@ -81,3 +81,24 @@ def test_k_too_large_and_errors(ba, golden_dir):
     gb = ba.bed(os.path.join(golden_dir, "example-missing.bed"))
     with pytest.raises(ba.BsnError, match="larger than the dimensions"):
         ba.bed_randomSVD(gb, k=300)
+
+
+def test_bed_svd_equals_fbm_svd(ba, orc, golden_dir, example_bed):
+    """test-2-bed-clumping-SVD.R:41,52-54: bed_randomSVD(obj.bed, ind.col = keep) equals
+    big_randomSVD(G, snp_scaleBinom(), ind.col = keep) — all fields"""
+    gb = ba.bed(os.path.join(golden_dir, "example.bed"))
+    G = ba.FBM_code256(orc.fbm_from_bed(example_bed).bytes)
+    keep = np.arange(0, example_bed.m, 2)
+    a = ba.bed_randomSVD(gb, ind_col=keep, k=10)
+    b = ba.big_randomSVD(G, ba.snp_scaleBinom(), ind_col=keep, k=10)
+    for f in ("d", "u", "v", "center", "scale"):
+        np.testing.assert_array_equal(a[f], b[f])
+    assert (a["niter"], a["nops"]) == (b["niter"], b["nops"])
+    # scaling helpers (R/binom-scaling.R): snp_MAF / snp_scaleBinom against the oracle
+    Go = orc.fbm_from_bed(example_bed)
+    st = orc.snp_colstats(Go)
+    af = st["sumX"] / (2 * example_bed.n)
+    np.testing.assert_array_equal(ba.snp_MAF(G), np.minimum(af, 1 - af))
+    sc = ba.snp_scaleBinom()(G)
+    np.testing.assert_array_equal(sc["center"], 2 * af)
+    np.testing.assert_array_equal(ba.snp_colstats(G)["denoX"], st["denoX"])
