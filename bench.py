@@ -63,6 +63,10 @@ def main():
     dist = None
     torch = None
     use_dist = world > 1 or a.force_dist
+    # RCCL prints a version banner through C stdio on stdout; keep the real stdout for the one
+    # JSON line and send everything else (fd 1) to stderr.
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if use_dist:
         # torch first: the library then binds to the same HIP runtime as torch / RCCL
         import torch
@@ -89,11 +93,19 @@ def main():
     gen_s = time.time() - t0
 
     allreduce = None
+    ar_stats = {"calls": 0, "seconds": 0.0}
     if use_dist:
+        views = {}
+
         def allreduce(ptr, count):
-            t = torch.as_tensor(_DevPtr(ptr, count), device="cuda")
+            t0 = time.perf_counter()
+            t = views.get((ptr, count))
+            if t is None:  # alias of the library's device buffer, created once per (ptr, count)
+                t = views[(ptr, count)] = torch.as_tensor(_DevPtr(ptr, count), device="cuda")
             dist.all_reduce(t)
-            torch.cuda.synchronize()
+            torch.cuda.current_stream().synchronize()
+            ar_stats["calls"] += 1
+            ar_stats["seconds"] += time.perf_counter() - t0
 
     def sync():
         L.bsn_device_sync()
@@ -154,6 +166,8 @@ def main():
         "hbm_GBps_whole_solve": passes * ((n + 3) // 4) * m_total / wall / 1e9,
         "sigma": [float(x) for x in infos[-1]["d"][:5]],
         "generate_s": gen_s,
+        "allreduce": {"calls": ar_stats["calls"], "ms_per_call": 1e3 * ar_stats["seconds"] / max(ar_stats["calls"], 1),
+                      "bytes_per_call": 8 * n * a.block} if use_dist else None,
         "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2, bytes per launch)" if traffic else None,
@@ -166,11 +180,13 @@ def main():
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ba, gb, n, a.cpu_sample_cols)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stderr.flush()
+    if rank == 0:
+        real_stdout.write(json.dumps(out) + "\n")   # the ONE stdout line
+        real_stdout.flush()
 
 
 def cpu_baseline(ba, gb, n, sample_cols):

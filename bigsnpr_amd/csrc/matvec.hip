@@ -352,6 +352,9 @@ __global__ void k_cprod_final(const int32_t *acc, int64_t m, int ncol, int S, co
   double c = center ? center[j] : 0.0, s = scale ? scale[j] : 1.0;
   double qs = meta[v].qscale;
   double z = qs > 0 ? (P - c * (Sx - Q)) / (s * qs) : 0.0 / s;
+  // a variant with no non-missing genotype contributes only bedAccScaled's NA entry (0),
+  // whatever its centre / scale are (src/bed-acc.h:104); P and Sx - Q are exact integers
+  if (P == 0.0 && Sx - Q == 0.0 && qs > 0) z = 0.0;
   if (meta[v].nonfinite) z = __longlong_as_double(0x7ff8000000000000LL);
   Z[j + v * ldz] = z;
 }

@@ -61,9 +61,14 @@ struct SvdResult {
 inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double *d, double *u,
                                    double *v) {
   const int k = opt.k;
-  const int64_t dim = bk.n < bk.m_total ? bk.n : bk.m_total;
   int b = opt.block;
-  if (b > dim) b = (int)dim;
+  {
+    const int64_t small = bk.n < bk.m_total ? bk.n : bk.m_total;
+    if (b > small) b = (int)small;
+  }
+  // The Krylov space of A A' started from a random block of R^n has dimension at most
+  // rank(A) + b: the start block is not in range(A) when n > m.
+  const int64_t dim = bk.n < bk.m_total + b ? bk.n : bk.m_total + b;
   int cap = opt.max_basis > 0 ? opt.max_basis : std::max(8 * k + 4 * b, 320);
   if (cap > dim) cap = (int)dim;
   if (cap < k) cap = k;

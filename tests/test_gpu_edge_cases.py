@@ -1,0 +1,129 @@
+"""Edge cases the reference's tests touch (ragged / tiny shapes, all-missing or constant
+columns, duplicated indices, empty selections) through the C ABI on the GPU."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ba():
+    import bigsnpr_amd
+    return bigsnpr_amd
+
+
+def _bed_from_matrix(ba, orc, g):
+    """g: n x m int matrix with values 0,1,2 and 3 = missing"""
+    n, m = g.shape
+    code = np.array([3, 2, 0, 1], dtype=np.uint8)[g]          # genotype -> PLINK 2-bit code
+    n_byte = (n + 3) // 4
+    payload = np.zeros((m, n_byte), dtype=np.uint8)
+    for i in range(n):
+        payload[:, i // 4] |= (code[i] << (2 * (i % 4))).astype(np.uint8)
+    ob = orc.BedFile.from_payload(payload.ravel(), n, m)
+    return ob, ba.bed.from_payload(payload.ravel(), n, m)
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (3, 5), (4, 64), (5, 63), (17, 65), (255, 129), (1025, 3)])
+def test_tiny_and_ragged_shapes(ba, orc, n, m):
+    rng = np.random.default_rng(n * 1000 + m)
+    g = rng.integers(0, 4, size=(n, m))
+    ob, gb = _bed_from_matrix(ba, orc, g)
+    np.testing.assert_array_equal(gb.download(), ob.payload)
+    np.testing.assert_array_equal(ba.bed_counts(gb), orc.bed_col_counts(ob))
+    np.testing.assert_array_equal(ba.read_bed(gb, None, None), orc.read_bed(ob))
+    x, y = rng.normal(size=m), rng.normal(size=n)
+    c, s = rng.normal(size=m), rng.uniform(0.5, 2, size=m)
+    ref = orc.bed_prodVec(ob, x, None, None, c, s)
+    np.testing.assert_allclose(ba.bed_prodVec(gb, x, center=c, scale=s), ref, rtol=0,
+                               atol=1e-9 * max(np.abs(ref).max(), 1e-300))
+    ref = orc.bed_cprodVec(ob, y, None, None, c, s)
+    np.testing.assert_allclose(ba.bed_cprodVec(gb, y, center=c, scale=s), ref, rtol=0,
+                               atol=1e-9 * max(np.abs(ref).max(), 1e-300))
+    # duplicated + unsorted rows and columns (test-7-OpenMP.R:31-32)
+    ir, ic = rng.integers(0, n, size=2 * n + 1), rng.integers(0, m, size=2 * m + 3)
+    np.testing.assert_array_equal(ba.bed_counts(gb, ir, ic), orc.bed_col_counts(ob, ir, ic))
+    xx, yy = rng.normal(size=ic.size), rng.normal(size=ir.size)
+    ref = orc.bed_prodVec(ob, xx, ir, ic, c[ic], s[ic])
+    np.testing.assert_allclose(ba.bed_prodVec(gb, xx, ir, ic, c[ic], s[ic]), ref, rtol=0,
+                               atol=1e-9 * max(np.abs(ref).max(), 1e-300))
+    ref = orc.bed_cprodVec(ob, yy, ir, ic, c[ic], s[ic])
+    np.testing.assert_allclose(ba.bed_cprodVec(gb, yy, ir, ic, c[ic], s[ic]), ref, rtol=0,
+                               atol=1e-9 * max(np.abs(ref).max(), 1e-300))
+
+
+def test_all_missing_and_constant_columns(ba, orc):
+    rng = np.random.default_rng(5)
+    g = rng.integers(0, 3, size=(120, 10))
+    g[:, 2] = 3      # all missing
+    g[:, 4] = 1      # constant
+    g[:70, 6] = 3    # > 50 % missing -> warning of bed_colstats (src/bed-fun.cpp:40-41)
+    ob, gb = _bed_from_matrix(ba, orc, g)
+    with pytest.warns(UserWarning, match="2 variants have >50% missing values"):
+        st = ba.bed_colstats(gb)
+    ref = orc.bed_colstats(ob)
+    for k in st:
+        np.testing.assert_array_equal(st[k], ref[k])          # incl. NaN in denoX of column 2
+    with pytest.warns(UserWarning):
+        sc = ba.bed_scaleBinom(gb)
+    scr = orc.bed_scaleBinom(ob)
+    np.testing.assert_array_equal(sc["center"], scr["center"])
+    np.testing.assert_array_equal(sc["scale"], scr["scale"])
+    # the all-missing column has NaN centre / scale but only ever uses the NA entry (0) of
+    # bedAccScaled's table (src/bed-acc.h:104): cprodVec is finite and 0 there
+    y = rng.normal(size=120)
+    z = ba.bed_cprodVec(gb, y, center=sc["center"], scale=sc["scale"])
+    zr = orc.bed_cprodVec(ob, y, None, None, scr["center"], scr["scale"])
+    assert np.isfinite(zr).all() and zr[2] == 0 and z[2] == 0
+    np.testing.assert_allclose(z, zr, rtol=0, atol=1e-9 * np.abs(zr).max())
+    # a zero scale (monomorphic column under a user-supplied scaling) is non-finite in that column only
+    s0 = np.where(np.arange(10) == 4, 0.0, 1.0)
+    z0 = ba.bed_cprodVec(gb, y, center=np.ones(10), scale=s0)
+    z0r = orc.bed_cprodVec(ob, y, None, None, np.ones(10), s0)
+    assert np.array_equal(np.isfinite(z0), np.isfinite(z0r)) and not np.isfinite(z0[4])
+
+
+def test_ld_small_and_edge_windows(ba, orc):
+    rng = np.random.default_rng(6)
+    for n, m in ((30, 3), (64, 64), (65, 130), (200, 1)):
+        g = rng.integers(0, 4, size=(n, m))
+        ob, gb = _bed_from_matrix(ba, orc, g)
+        for size in (0.0005, 0.002, 1e3):
+            ref = orc.snp_cor(ob, size=size)
+            with np.errstate(all="ignore"):
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    res = ba.bed_cor(gb, size=size)
+            np.testing.assert_array_equal(res.p, ref[1])
+            np.testing.assert_array_equal(res.i, ref[0])
+            ok = ~np.isnan(ref[2])
+            assert np.array_equal(np.isnan(res.x), ~ok)
+            np.testing.assert_allclose(res.x[ok], ref[2][ok], rtol=0, atol=1e-12)
+            np.testing.assert_allclose(ba.bed_ld_scores(gb, size=size), orc.ld_scores(ob, size=size), rtol=1e-12)
+
+
+def test_svd_tiny_matrices(ba, orc):
+    rng = np.random.default_rng(7)
+    for n, m, k in ((40, 25, 5), (12, 300, 10), (300, 11, 10), (9, 9, 3)):
+        g = rng.integers(0, 3, size=(n, m))
+        g[rng.uniform(size=(n, m)) < 0.03] = 3
+        ob, gb = _bed_from_matrix(ba, orc, g)
+        sc = orc.bed_scaleBinom(ob)
+        ic = np.nonzero(np.nan_to_num(sc["scale"]) > 0)[0]
+        if min(n, ic.size) < k:
+            continue
+        ref = orc.dense_svd(ob, None, ic, k=k)
+        res = ba.bed_randomSVD(gb, ind_col=ic, k=k, tol=1e-12, slices=7)
+        np.testing.assert_allclose(res["d"], ref["d"], rtol=1e-8, atol=1e-8 * ref["d"][0])
+
+
+def test_empty_selection_errors(ba, orc):
+    g = np.random.default_rng(8).integers(0, 3, size=(20, 8))
+    ob, gb = _bed_from_matrix(ba, orc, g)
+    with pytest.raises(ba.BsnError, match="can't be empty"):
+        ba.bed_counts(gb, ind_col=np.zeros(0, dtype=np.int64))
+    with pytest.raises(IndexError):
+        ba.bed_counts(gb, ind_col=np.array([8]))
+    with pytest.raises(IndexError):
+        ba.bed_prodVec(gb, np.zeros(1), ind_col=np.array([-1]))

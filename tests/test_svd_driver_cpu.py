@@ -63,7 +63,7 @@ def _check_svd(res, A, k, tol_d=1e-8, tol_vec=1e-6):
 
 @pytest.mark.parametrize("n,m,k,block", [(200, 500, 10, 8), (300, 120, 10, 8), (60, 45, 10, 4),
                                          (33, 70, 10, 8), (500, 400, 20, 8), (150, 150, 3, 1),
-                                         (12, 40, 10, 8)])
+                                         (12, 40, 10, 8), (40, 25, 5, 5), (300, 11, 10, 5)])
 def test_block_lanczos_dense(nt, n, m, k, block):
     rng = np.random.default_rng(n + m)
     r = min(n, m)
