@@ -13,6 +13,7 @@ from .ld import (FBM_code256, bed_clumping, bed_cor, bed_ld_scores, big_randomSV
                  snp_clumping, snp_colstats, snp_cor, snp_ld_scores, snp_MAF, snp_scaleAlpha,
                  snp_scaleBinom)
 from .prs import bed_tcrossprodSelf, prodVecRev, snp_PRS  # noqa: F401,E402
+from .autosvd import bed_autoSVD, snp_autoSVD  # noqa: F401,E402
 
 
 def selftest():

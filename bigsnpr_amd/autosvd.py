@@ -1,0 +1,304 @@
+"""snp_autoSVD / bed_autoSVD — host mirror of R/autoSVD.R:67-186,226-339.
+
+Everything that touches genotypes (MAF/MAC counts, clumping, the partial SVD) runs on the
+GPU through the C ABI.  The outer loop also needs three functions of the external package
+bigutilsr (>= 0.3.3, not in the reference tree and without golden data there):
+``dist_ogk`` (robust Mahalanobis distance with the orthogonalised Gnanadesikan-Kettenring
+estimator of Maronna & Zamar 2002, as implemented by robustbase::covOGK with scaleTau2 and
+hard rejection at beta = 0.9), ``rollmean`` (Gaussian-weighted rolling mean with renormalised
+edge windows) and ``tukey_mc_up`` (upper Tukey fence adjusted for skewness with the medcouple,
+Hubert & Vandervieren 2008, with the coefficient chosen for a family-wise type-I error
+``alpha`` under normality).  They are restated below from their published descriptions.
+
+PARITY STATUS of this module: **unpinned** — neither the reference tree nor this image holds
+bigutilsr or outputs of it, so `attr(, "subset")` cannot be compared with the reference here;
+the tests assert the behavioural properties of tests/testthat/test-2-autoSVD.R instead.
+"""
+import numpy as np
+
+from .bed import ERROR_DIM, assert_lengths, bed_MAF, bed_scaleBinom, cols_along, rows_along
+from .ld import _ind, bed_clumping, big_randomSVD, snp_clumping, snp_MAF, snp_scaleBinom
+from .svd import bed_randomSVD
+
+
+# ---- bigutilsr restatements (host, O(m k^2) / O(m log m)) ---------------------------------
+def _erho(b):
+    from scipy.stats import norm
+    return 2 * ((1 - b * b) * norm.cdf(b) - b * norm.pdf(b) + b * b) - 1
+
+
+def scale_tau2(x, c1=4.5, c2=3.0, mu_too=False):
+    """robustbase::scaleTau2 (Maronna & Zamar 2002), consistency = TRUE."""
+    x = np.asarray(x, dtype=np.float64)
+    n = x.size
+    med = np.median(x)
+    xa = np.abs(x - med)
+    sigma0 = np.median(xa)
+    if sigma0 <= 0:
+        return (med, 0.0) if mu_too else 0.0
+    w = np.maximum(0.0, 1.0 - (xa / (sigma0 * c1)) ** 2) ** 2
+    mu = np.sum(x * w) / np.sum(w)
+    rho = np.minimum(((x - mu) / sigma0) ** 2, c2 * c2)
+    from scipy.stats import norm
+    q = norm.ppf(0.75)                      # sigma0 is the raw MAD: Es2(c2) = Erho(c2 * qnorm(3/4))
+    s = sigma0 * np.sqrt(np.sum(rho) / (n * _erho(c2 * q)))
+    return (mu, s) if mu_too else s
+
+
+def covrob_ogk(U, niter=2, beta=0.9):
+    """Orthogonalised Gnanadesikan-Kettenring estimate with reweighting (hard rejection)."""
+    from scipy.stats import chi2
+    U = np.asarray(U, dtype=np.float64)
+    n, p = U.shape
+    Z = U.copy()
+    A = []
+    for _ in range(niter):
+        d = np.array([scale_tau2(Z[:, j]) for j in range(p)])
+        d[d <= 0] = 1.0
+        Z = Z / d
+        R = np.eye(p)
+        for i in range(p):
+            for j in range(i):
+                R[i, j] = R[j, i] = (scale_tau2(Z[:, i] + Z[:, j]) ** 2 -
+                                     scale_tau2(Z[:, i] - Z[:, j]) ** 2) / 4
+        _, E = np.linalg.eigh(R)
+        E = E[:, ::-1]
+        A.append(d[:, None] * E)
+        Z = Z @ E
+    ms = [scale_tau2(Z[:, j], mu_too=True) for j in range(p)]
+    mu = np.array([t[0] for t in ms]); sig = np.array([t[1] for t in ms])
+    sig[sig <= 0] = 1.0
+    wdist = np.sum(((Z - mu) / sig) ** 2, axis=1)
+    d0 = np.median(wdist) * chi2.ppf(beta, p) / chi2.ppf(0.5, p)
+    keep = wdist <= d0
+    center = U[keep].mean(0)
+    cov = np.cov(U[keep], rowvar=False).reshape(p, p)
+    return dict(center=center, cov=cov, weights=keep)
+
+
+def dist_ogk(U, niter=2, beta=0.9):
+    """squared robust Mahalanobis distances (bigutilsr::dist_ogk)"""
+    U = np.asarray(U, dtype=np.float64)
+    est = covrob_ogk(U, niter, beta)
+    Xc = U - est["center"]
+    return np.einsum("ij,ij->i", Xc @ np.linalg.pinv(est["cov"]), Xc)
+
+
+def rollmean(x, size):
+    """bigutilsr::rollmean: Gaussian weights over 2*floor(size)+1 points, edge windows
+    renormalised by the weights they contain."""
+    from scipy.stats import norm
+    x = np.asarray(x, dtype=np.float64)
+    if size == 0:
+        return x
+    half = int(np.floor(size))
+    length = 2 * half + 1
+    if length >= x.size:
+        raise ValueError("Parameter 'size' is too large.")
+    a = 3.0 / 8 if length <= 10 else 0.5                       # stats::ppoints
+    pp = (np.arange(1, length + 1) - a) / (length + 1 - 2 * a)
+    lims = norm.ppf([pp[0], pp[-1]])
+    w = norm.pdf(np.linspace(lims[0], lims[1], length))
+    num = np.convolve(x, w[::-1], mode="full")[half:half + x.size]
+    den = np.convolve(np.ones_like(x), w[::-1], mode="full")[half:half + x.size]
+    return num / den
+
+
+def medcouple(x):
+    """Medcouple (Brys, Hubert & Struyf 2004) by bisection on the kernel value: the kernel
+    h(xi, xj) = ((xi - med) - (med - xj)) / (xi - xj), xi >= med >= xj, is monotone in both
+    arguments, so #{h <= t} is a sum of searchsorted counts."""
+    x = np.sort(np.asarray(x, dtype=np.float64))
+    n = x.size
+    if n < 3:
+        return 0.0
+    med = np.median(x)
+    up = x[x >= med] - med          # >= 0, ascending
+    lo = (med - x[x <= med])[::-1]  # >= 0, ascending
+    if up[-1] == 0 or lo[-1] == 0:
+        return 0.0 if up[-1] == lo[-1] else (1.0 if lo[-1] == 0 else -1.0)
+    total = up.size * lo.size
+
+    upp = up[up > 0]
+    n0u, n0l = int(np.sum(up == 0)), int(np.sum(lo == 0))   # elements equal to the median
+
+    def count_le(t):  # pairs with (u - l) / (u + l) <= t  <=>  l >= u (1 - t) / (1 + t)
+        thr = upp * (1 - t) / (1 + t)
+        c = int(np.sum(lo.size - np.searchsorted(lo, thr, side="left")))
+        # rows with u == med: h = -1 against every l > 0, and 0 against l == med (the kernel
+        # of tied medians is taken as 0, exact for the single tie of an odd-length sample)
+        c += n0u * (lo.size - n0l) + (n0u * n0l if t >= 0 else 0)
+        return c
+
+    k = (total + 1) // 2  # lower median rank
+    a, b = -1.0, 1.0
+    for _ in range(100):
+        mid = 0.5 * (a + b)
+        if count_le(mid) >= k:
+            b = mid
+        else:
+            a = mid
+        if b - a < 1e-14:
+            break
+    if total % 2 == 1:
+        return b
+    # even number of pairs: average the two middle order statistics
+    a2, b2 = b, 1.0
+    for _ in range(100):
+        mid = 0.5 * (a2 + b2)
+        if count_le(mid) >= k + 1:
+            b2 = mid
+        else:
+            a2 = mid
+        if b2 - a2 < 1e-14:
+            break
+    return 0.5 * (b + b2)
+
+
+def tukey_mc_up(x, coef=None, alpha=0.05, a=-4.0, b=3.0):
+    """Upper fence Q3 + coef * exp(b MC | -a MC) * IQR.  With coef = NULL the coefficient is
+    the one for which a sample of m = length(x) normal values has probability `alpha` of
+    containing at least one value above the fence: per-value tail p = 1 - (1 - alpha)^(1/m),
+    coef = (qnorm(1 - p) - q75) / (2 q75).  (This family-wise form is what makes
+    alpha.tukey -> 1 flag outliers at every iteration, tests/testthat/test-2-autoSVD.R:60-62.)"""
+    from scipy.stats import norm
+    x = np.asarray(x, dtype=np.float64)
+    x = x[~np.isnan(x)]
+    q1, q3 = np.quantile(x, [0.25, 0.75])   # R's default quantile type 7 == numpy's default
+    iqr = q3 - q1
+    if coef is None:
+        q75 = norm.ppf(0.75)
+        p = -np.expm1(np.log1p(-alpha) / x.size)
+        coef = (norm.isf(p) - q75) / (2 * q75)
+    mc = medcouple(x)
+    return q3 + coef * iqr * (np.exp(b * mc) if mc >= 0 else np.exp(-a * mc))
+
+
+def getIntervals(x, n=2):
+    """R/autoSVD.R:4-12: regroup consecutive integers into [start, stop] intervals of
+    length >= n"""
+    x = np.asarray(x)
+    if x.size < 2:
+        return np.zeros((0, 2), dtype=x.dtype)
+    dx = np.diff(x)
+    # rle(diff(x))
+    change = np.r_[True, dx[1:] != dx[:-1]]
+    starts = np.nonzero(change)[0]
+    lengths = np.diff(np.r_[starts, dx.size])
+    values = dx[starts]
+    ind = np.nonzero((values == 1) & (lengths >= (n - 1)))[0]
+    pos = np.cumsum(lengths)            # 0-based index of the last element of each run in x
+    first = np.r_[0, pos][ind]
+    last = pos[ind]
+    return np.column_stack([x[first], x[last]])
+
+
+# ---- the outer loop ---------------------------------------------------------------------
+def _auto_svd(svd_fun, clump_fun, maf_nok, ind_col, infos_chr, infos_pos, thr_r2, k, roll_size,
+              int_min_size, alpha_tukey, max_iter, verbose, n_all_cols):
+    def printf2(fmt, *a):
+        if verbose:
+            print(fmt % a, end="")
+
+    if maf_nok is None:
+        raise ValueError("You cannot use variants with no variation; set min.mac > 0 and min.maf > 0.")
+    ns = int(maf_nok[0].sum())
+    printf2("Discarding %d variant%s with MAC < %s or MAF < %s.\n", ns, "s" if ns > 1 else "",
+            maf_nok[1], maf_nok[2])
+    ind_keep = ind_col[~maf_nok[0]]
+    if thr_r2 is None or (isinstance(thr_r2, float) and np.isnan(thr_r2)):
+        printf2("\nSkipping clumping.\n")
+    else:
+        printf2("\nPhase of clumping (on %s) at r^2 > %s.. ", maf_nok[3], thr_r2)
+        excl = np.setdiff1d(np.arange(n_all_cols), ind_keep)
+        ind_keep = clump_fun(excl)
+        printf2("keep %d variants.\n", ind_keep.size)
+
+    it = 0
+    lrldr = dict(Chr=[], Start=[], Stop=[], Iter=[])
+    while True:
+        it += 1
+        printf2("\nIteration %d:\n", it)
+        printf2("Computing SVD..\n")
+        obj = svd_fun(ind_keep)
+        if it > max_iter:
+            printf2("Maximum number of iterations reached.\n")
+            break
+        S = np.sqrt(dist_ogk(obj["v"]))
+        S2 = np.full(S.size, np.nan)
+        chr_keep = infos_chr[ind_keep]
+        for c in np.unique(chr_keep):
+            idx = np.nonzero(chr_keep == c)[0]
+            S2[idx] = rollmean(S[idx], roll_size)
+        thr = tukey_mc_up(S2, alpha=alpha_tukey)
+        excl = np.nonzero(S2 > thr)[0]
+        printf2("%d outlier variant%s detected..\n", excl.size, "s" if excl.size > 1 else "")
+        if excl.size > 0:
+            if infos_pos is not None:
+                rng = getIntervals(excl, n=int_min_size)
+                printf2("%d long-range LD region%s detected..\n", len(rng), "s" if len(rng) > 1 else "")
+                for lo, hi in rng:
+                    seq = np.arange(lo, hi + 1)
+                    seq_chr = infos_chr[ind_keep[seq]]
+                    vals, cnts = np.unique(seq_chr, return_counts=True)
+                    mode = vals[np.argmax(cnts)]     # sort(table(.), decreasing = TRUE)[1]
+                    in_chr = seq_chr == mode
+                    p = infos_pos[ind_keep[seq[in_chr]]]
+                    lrldr["Chr"].append(mode); lrldr["Start"].append(p.min())
+                    lrldr["Stop"].append(p.max()); lrldr["Iter"].append(it)
+            ind_keep = np.delete(ind_keep, excl)
+        else:
+            printf2("\nConverged!\n")
+            break
+    order = np.lexsort((lrldr["Stop"], lrldr["Start"], lrldr["Chr"])) if lrldr["Chr"] else []
+    obj = dict(obj)
+    obj["subset"] = ind_keep
+    obj["lrldr"] = {key: np.asarray(val)[order] if len(order) else np.asarray(val)
+                    for key, val in lrldr.items()}
+    return obj
+
+
+def snp_autoSVD(G, infos_chr, infos_pos=None, ind_row=None, ind_col=None, fun_scaling=None,
+                thr_r2=0.2, size=None, k=10, roll_size=50, int_min_size=20, alpha_tukey=0.05,
+                min_mac=10, min_maf=0.02, max_iter=5, ncores=1, verbose=True):
+    """R/autoSVD.R:67-186.  Returns the last big_SVD dict with keys `subset` (kept column
+    indices, 0-based) and `lrldr`."""
+    im, ir, ic = _ind(G, ind_row, ind_col)
+    infos_chr = np.asarray(infos_chr)
+    if infos_chr.size != im.ncol:
+        raise ValueError(ERROR_DIM)
+    if infos_pos is not None:
+        infos_pos = np.asarray(infos_pos)
+        if infos_pos.size != im.ncol:
+            raise ValueError(ERROR_DIM)
+    fun_scaling = snp_scaleBinom() if fun_scaling is None else fun_scaling
+    size = (100.0 / thr_r2 if thr_r2 is not None and not np.isnan(thr_r2) else 500.0) if size is None else size
+    maf_nok = None
+    if min_mac > 0 and min_maf > 0:
+        maf = snp_MAF(G, ir, ic)
+        maf_nok = (maf < max(min_maf, min_mac / (2.0 * ir.size)), min_mac, min_maf, "MAF")
+    return _auto_svd(
+        lambda keep: big_randomSVD(G, fun_scaling, ind_row=ir, ind_col=keep, k=k),
+        lambda excl: snp_clumping(G, infos_chr, ind_row=ir, exclude=excl, thr_r2=thr_r2, size=size,
+                                  infos_pos=infos_pos),
+        maf_nok, ic, infos_chr, infos_pos, thr_r2, k, roll_size, int_min_size, alpha_tukey,
+        max_iter, verbose, im.ncol)
+
+
+def bed_autoSVD(obj_bed, ind_row=None, ind_col=None, fun_scaling=bed_scaleBinom, thr_r2=0.2,
+                size=None, k=10, roll_size=50, int_min_size=20, alpha_tukey=0.05, min_mac=10,
+                min_maf=0.02, max_iter=5, ncores=1, verbose=True):
+    """R/autoSVD.R:226-339"""
+    im, ir, ic = _ind(obj_bed, ind_row, ind_col)
+    infos_chr = np.asarray(obj_bed.map["chromosome"])
+    infos_pos = np.asarray(obj_bed.map["physical_pos"])
+    size = (100.0 / thr_r2 if thr_r2 is not None and not np.isnan(thr_r2) else 500.0) if size is None else size
+    maf_nok = None
+    if min_mac > 0 and min_maf > 0:
+        info = bed_MAF(obj_bed, ir, ic)
+        maf_nok = ((info["mac"] < min_mac) | (info["maf"] < min_maf), min_mac, min_maf, "MAC")
+    return _auto_svd(
+        lambda keep: bed_randomSVD(obj_bed, fun_scaling=fun_scaling, ind_row=ir, ind_col=keep, k=k),
+        lambda excl: bed_clumping(obj_bed, ind_row=ir, exclude=excl, thr_r2=thr_r2, size=size),
+        maf_nok, ic, infos_chr, infos_pos, thr_r2, k, roll_size, int_min_size, alpha_tukey,
+        max_iter, verbose, im.ncol)

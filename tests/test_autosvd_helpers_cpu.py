@@ -1,0 +1,94 @@
+"""CPU tests of the host-side statistics that snp_autoSVD / bed_autoSVD need (restatements of
+bigutilsr::dist_ogk / rollmean / tukey_mc_up, see bigsnpr_amd/autosvd.py — unpinned against
+the reference, so they are checked against independent definitions)."""
+import numpy as np
+import pytest
+
+from bigsnpr_amd import autosvd as A
+
+
+def test_scale_tau2_is_consistent_for_normal_data():
+    rng = np.random.default_rng(0)
+    x = rng.normal(3.0, 2.5, size=200000)
+    mu, s = A.scale_tau2(x, mu_too=True)
+    assert abs(mu - 3.0) < 0.03 and abs(s / 2.5 - 1) < 0.02
+    x[:2000] = 1e6                       # 1 % gross outliers barely move it
+    assert abs(A.scale_tau2(x) / 2.5 - 1) < 0.05
+
+
+def test_dist_ogk_matches_mahalanobis_on_clean_data_and_flags_outliers():
+    rng = np.random.default_rng(1)
+    L = np.array([[2.0, 0, 0], [0.8, 1.0, 0], [-0.5, 0.3, 0.7]])
+    X = rng.normal(size=(20000, 3)) @ L.T + np.array([1.0, -2.0, 0.5])
+    d = A.dist_ogk(X)
+    Xc = X - X.mean(0)
+    dm = np.einsum("ij,ij->i", Xc @ np.linalg.inv(np.cov(X, rowvar=False)), Xc)
+    # the reweighted covariance (hard rejection at beta = 0.9) is not rescaled, as in
+    # robustbase::covOGK: distances are a constant multiple of the classical ones
+    ratio = d / dm
+    assert np.corrcoef(d, dm)[0, 1] > 0.999 and ratio.std() / ratio.mean() < 0.05 and 1.0 < ratio.mean() < 1.5
+    X[:50] += 25.0
+    d2 = A.dist_ogk(X)
+    assert d2[:50].min() > np.quantile(d2[50:], 0.999)
+
+
+def test_rollmean_matches_naive_definition():
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=300)
+    for size in (0, 1, 7, 50):
+        got = A.rollmean(x, size)
+        if size == 0:
+            assert got is x or np.array_equal(got, x)
+            continue
+        from scipy.stats import norm
+        L = 2 * size + 1
+        a = 3 / 8 if L <= 10 else 0.5
+        pp = (np.arange(1, L + 1) - a) / (L + 1 - 2 * a)
+        w = norm.pdf(np.linspace(norm.ppf(pp[0]), norm.ppf(pp[-1]), L))
+        ref = np.empty_like(x)
+        for i in range(x.size):
+            lo, hi = max(0, i - size), min(x.size, i + size + 1)
+            ww = w[lo - (i - size):hi - (i - size)]
+            ref[i] = np.sum(x[lo:hi] * ww) / ww.sum()
+        np.testing.assert_allclose(got, ref, rtol=1e-12)
+    with pytest.raises(ValueError, match="too large"):
+        A.rollmean(x, 150)
+
+
+def test_medcouple_matches_naive():
+    rng = np.random.default_rng(3)
+    for n, gen in ((201, rng.normal), (500, lambda size: rng.exponential(size=size)),
+                   (333, lambda size: -rng.lognormal(size=size))):
+        x = gen(size=n)
+        med = np.median(x)
+        up, lo = x[x >= med], x[x <= med]
+        with np.errstate(all="ignore"):
+            H = ((up[:, None] - med) - (med - lo[None, :])) / (up[:, None] - lo[None, :])
+        H[np.isnan(H)] = 0.0                       # the (med, med) pair
+        assert abs(A.medcouple(x) - np.median(H)) < 1e-9
+    assert A.medcouple(rng.exponential(size=5000)) > 0.2 > 0 > A.medcouple(-rng.exponential(size=5000))
+
+
+def test_tukey_mc_up_behaviour():
+    rng = np.random.default_rng(4)
+    x = rng.normal(size=20000)
+    # family-wise calibration under normality: the fence sits near qnorm(1 - alpha/m)
+    from scipy.stats import norm
+    thr = A.tukey_mc_up(x, alpha=0.05)
+    assert abs(thr - norm.ppf(1 - 0.05 / x.size)) < 0.35
+    assert (x > thr).sum() <= 1
+    assert A.tukey_mc_up(x, alpha=0.999) < thr                 # larger alpha -> lower fence
+    assert abs(A.tukey_mc_up(x, coef=1.5) - (np.quantile(x, .75) + 1.5 * np.subtract(*np.quantile(x, [.75, .25])))) < 0.15
+    skew = rng.exponential(size=20000)
+    q1, q3 = np.quantile(skew, [.25, .75])
+    assert A.tukey_mc_up(skew, coef=1.5) > q3 + 1.5 * (q3 - q1)  # right-skew widens the upper fence
+
+
+def test_get_intervals():
+    # R: getIntervals(c(1,2,3, 7, 9,10, 20,21,22,23), n = 3) -> rows (1,3), (20,23)
+    np.testing.assert_array_equal(A.getIntervals(np.array([1, 2, 3, 7, 9, 10, 20, 21, 22, 23]), n=3),
+                                  [[1, 3], [20, 23]])
+    np.testing.assert_array_equal(A.getIntervals(np.array([1, 2, 3, 7, 9, 10, 20, 21, 22, 23]), n=2),
+                                  [[1, 3], [9, 10], [20, 23]])
+    assert A.getIntervals(np.array([5]), n=2).shape == (0, 2)
+    assert A.getIntervals(np.array([1, 3, 5]), n=2).shape == (0, 2)

@@ -1,0 +1,91 @@
+"""snp_autoSVD / bed_autoSVD: the behavioural properties asserted by
+tests/testthat/test-2-autoSVD.R (errors, messages, monotonicity of the kept subset in `size`,
+`roll.size`, `alpha.tukey`, MAC/MAF thresholds).  The outlier statistics are restatements of
+external bigutilsr functions (parity unpinned, see bigsnpr_amd/autosvd.py)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env(orc, golden_dir, example_bed):
+    import bigsnpr_amd as ba
+    path = os.path.join(golden_dir, "example.bed")
+    gb = ba.bed(path)
+    G = ba.FBM_code256(orc.fbm_from_bed(example_bed).bytes)
+    chrom, pos = orc.read_bim(path)
+    return ba, gb, G, chrom, pos / 10, np.round(pos / 10 + 1)
+
+
+def test_snp_autosvd_properties(env, capsys):
+    ba, gb, G, CHR, POS, POS2 = env
+    with pytest.raises(ValueError, match="Incompatibility between dimensions"):
+        ba.snp_autoSVD(G, CHR[1:], POS2)
+    with pytest.raises(ValueError, match="Incompatibility between dimensions"):
+        ba.snp_autoSVD(G, CHR, POS2[1:])
+    with pytest.raises(ValueError, match="no variation; set min.mac > 0"):
+        ba.snp_autoSVD(G, CHR, min_mac=0)
+    ba.snp_autoSVD(G, CHR, POS2, thr_r2=float("nan"))
+    assert "Skipping clumping." in capsys.readouterr().out
+
+    s1 = ba.snp_autoSVD(G, CHR, verbose=False)
+    assert set(s1) >= {"d", "u", "v", "center", "scale", "subset", "lrldr"}
+    assert len(s1["lrldr"]["Chr"]) == 0 and s1["u"].shape == (G.nrow, 10)
+    s2 = ba.snp_autoSVD(G, CHR, size=5, verbose=False)
+    assert s2["subset"].size > s1["subset"].size
+    s3 = ba.snp_autoSVD(G, CHR, POS2, size=5, verbose=False)
+    assert s3["subset"].size < s2["subset"].size
+    s4 = ba.snp_autoSVD(G, CHR, roll_size=0, verbose=False)
+    assert s4["subset"].size < s1["subset"].size
+    s5 = ba.snp_autoSVD(G, CHR, thr_r2=1, roll_size=0, verbose=False)
+    c = [abs(np.corrcoef(s5["u"][:, t], s1["u"][:, t])[0, 1]) for t in range(3)]
+    assert min(c) ** 2 > 0.98
+    s6 = ba.snp_autoSVD(G, CHR, thr_r2=float("nan"), roll_size=0, verbose=False)
+    np.testing.assert_array_equal(s6["subset"], s5["subset"])
+    np.testing.assert_allclose(s6["d"], s5["d"], rtol=1e-6)
+    s7 = ba.snp_autoSVD(G, CHR, alpha_tukey=0.999, roll_size=0, verbose=False)
+    assert s7["subset"].size < s6["subset"].size
+    s8 = ba.snp_autoSVD(G, CHR, POS, alpha_tukey=0.9999, roll_size=0, int_min_size=0, verbose=False)
+    assert s8["subset"].size < s6["subset"].size
+    if len(s8["lrldr"]["Iter"]):          # the reference only checks types and Iter >= 1
+        assert s8["lrldr"]["Iter"].min() >= 1
+        assert np.all(s8["lrldr"]["Start"] <= s8["lrldr"]["Stop"])
+    ba.snp_autoSVD(G, CHR, alpha_tukey=0.999999999, roll_size=0, verbose=True)
+    assert "Maximum number of iterations reached." in capsys.readouterr().out
+
+
+def test_bed_autosvd_properties(env, capsys):
+    ba, gb, G, CHR, POS, POS2 = env
+    with pytest.raises(ValueError, match="no variation; set min.mac > 0"):
+        ba.bed_autoSVD(gb, min_mac=0)
+    ba.bed_autoSVD(gb, thr_r2=float("nan"))
+    assert "Skipping clumping." in capsys.readouterr().out
+    s1 = ba.bed_autoSVD(gb, verbose=False)
+    s2 = ba.bed_autoSVD(gb, size=5, verbose=False)
+    assert s2["subset"].size > s1["subset"].size
+    s4 = ba.bed_autoSVD(gb, roll_size=0, verbose=False)
+    assert s4["subset"].size < s1["subset"].size
+    s5 = ba.bed_autoSVD(gb, thr_r2=1, roll_size=0, verbose=False)
+    s6 = ba.bed_autoSVD(gb, thr_r2=float("nan"), roll_size=0, verbose=False)
+    np.testing.assert_array_equal(s6["subset"], s5["subset"])
+    s7 = ba.bed_autoSVD(gb, alpha_tukey=0.999, roll_size=0, verbose=False)
+    assert s7["subset"].size < s6["subset"].size
+
+
+def test_mac_maf_thresholds(env):
+    """test-2-autoSVD.R:100-121"""
+    ba, gb, G, CHR, POS, POS2 = env
+    info = ba.bed_MAF(gb)
+    rng = np.random.default_rng(0)
+    for _ in range(4):
+        min_mac = int(rng.integers(1, 41))
+        min_maf = float(rng.uniform(0.01, 0.1))
+        for res in (ba.snp_autoSVD(G, CHR, size=5, min_mac=min_mac, min_maf=min_maf,
+                                   thr_r2=float("nan"), max_iter=0, verbose=False),
+                    ba.bed_autoSVD(gb, min_mac=min_mac, min_maf=min_maf, thr_r2=float("nan"),
+                                   max_iter=0, verbose=False)):
+            ind = res["subset"]
+            assert np.all(info["maf"][ind] >= min_maf) and np.all(info["mac"][ind] >= min_mac)
