@@ -14,6 +14,7 @@ from .ld import (FBM_code256, bed_clumping, bed_cor, bed_ld_scores, big_randomSV
                  snp_scaleBinom)
 from .prs import bed_tcrossprodSelf, prodVecRev, snp_PRS  # noqa: F401,E402
 from .autosvd import bed_autoSVD, snp_autoSVD  # noqa: F401,E402
+from .plink_io import bed_to_bytes, snp_readBed, snp_writeBed  # noqa: F401,E402
 
 
 def selftest():

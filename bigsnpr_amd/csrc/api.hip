@@ -396,6 +396,36 @@ int bsn_bed_read_scaled(bsn_bed *bed, const int64_t *ind_row, int64_t n, const i
   return guarded([&] { read_host(bed, ind_row, n, ind_col, m, center, scale, 0, nullptr, out); });
 }
 
+static void convert_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                         int64_t m, uint8_t *out, bool packed) {
+  if (n <= 0 || m <= 0) fail("'ind.row' and 'ind.col' can't be empty.");
+  BSN_HIP(hipSetDevice(bed->device));
+  auto r = to_i32(ind_row, n, bed->n, "ind.row");
+  auto c = to_i32(ind_col, m, bed->m, "ind.col");
+  DevBuf<int32_t> d_r, d_c;
+  DevBuf<uint8_t> d_o;
+  BSN_HIP(hipMemcpy(d_r.ensure((size_t)n), r.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  BSN_HIP(hipMemcpy(d_c.ensure((size_t)m), c.data(), (size_t)m * 4, hipMemcpyHostToDevice));
+  const size_t bytes = packed ? (size_t)((n + 3) / 4) * m : (size_t)n * m;
+  d_o.ensure(bytes);
+  if (packed)
+    subset_pack(bed, d_r.p, n, d_c.p, m, d_o.p);
+  else
+    to_bytes(bed, d_r.p, n, d_c.p, m, d_o.p);
+  BSN_HIP(hipMemcpyAsync(out, d_o.p, bytes, hipMemcpyDeviceToHost, bed->stream));
+  BSN_HIP(hipStreamSynchronize(bed->stream));
+}
+
+int bsn_bed_to_fbm(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                   uint8_t *out) {
+  return guarded([&] { convert_host(bed, ind_row, n, ind_col, m, out, false); });
+}
+
+int bsn_bed_subset_payload(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                           int64_t m, uint8_t *payload_out) {
+  return guarded([&] { convert_host(bed, ind_row, n, ind_col, m, payload_out, true); });
+}
+
 // ---- helpers ---------------------------------------------------------------------------
 int bsn_malloc(void **d_ptr, int64_t bytes) {
   return guarded([&] {

@@ -130,6 +130,11 @@ void read_dense(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_c
                 const double *d_center, const double *d_scale, int32_t na_val, int32_t *d_out_i,
                 double *d_out_d);
 
+void to_bytes(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t m,
+              uint8_t *d_out);
+void subset_pack(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t m,
+                 uint8_t *d_out);
+
 // matvec.hip
 void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy);
 void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z, int64_t ldz);

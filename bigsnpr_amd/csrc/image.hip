@@ -274,4 +274,53 @@ void read_dense(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_c
   BSN_HIP(hipGetLastError());
 }
 
+
+// ---------------------------------------------------------------------------
+// .bed <-> FBM.code256 conversions (src/read-plink.cpp:13-80, src/write-plink.cpp:13-52).
+// bytes out: decoded genotype 0/1/2 and 3 for missing, one byte each, column-major n x m
+__global__ void k_to_bytes(const uint8_t *img, int64_t pitch, const int32_t *rows, int64_t n,
+                           const int32_t *cols, int64_t m, uint8_t *out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t j = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (i >= n || j >= m) return;
+  int64_t i2 = rows ? rows[i] : i, j2 = cols ? cols[j] : j;
+  uint32_t code = (img[j2 * pitch + (i2 >> 2)] >> (2 * (i2 & 3))) & 3;
+  out[i + j * n] = (uint8_t)(code == 0 ? 2 : code == 2 ? 1 : code == 3 ? 0 : 3);
+}
+
+// packed .bed payload of the sub-matrix [rows, cols]: ceil(n/4) bytes per variant, pad bits 0
+__global__ void k_subset_pack(const uint8_t *img, int64_t pitch, const int32_t *rows, int64_t n,
+                              const int32_t *cols, int64_t m, int64_t n_byte_out, uint8_t *out) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t j = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (b >= n_byte_out || j >= m) return;
+  int64_t j2 = cols ? cols[j] : j;
+  uint32_t v = 0;
+  for (int e = 0; e < 4; e++) {
+    int64_t i = b * 4 + e;
+    if (i < n) {
+      int64_t i2 = rows ? rows[i] : i;
+      v |= ((img[j2 * pitch + (i2 >> 2)] >> (2 * (i2 & 3))) & 3u) << (2 * e);
+    }
+  }
+  out[j * n_byte_out + b] = (uint8_t)v;
+}
+
+void to_bytes(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t m,
+              uint8_t *d_out) {
+  int64_t gy = m < 65535 ? m : 65535, gz = (m + 65534) / 65535;
+  hipLaunchKernelGGL(k_to_bytes, dim3((unsigned)((n + 255) / 256), (unsigned)gy, (unsigned)gz), dim3(256),
+                     0, b->stream, b->d_img, b->pitch, d_rows, n, d_cols, m, d_out);
+  BSN_HIP(hipGetLastError());
+}
+
+void subset_pack(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t m,
+                 uint8_t *d_out) {
+  int64_t nb = (n + 3) / 4;
+  int64_t gy = m < 65535 ? m : 65535, gz = (m + 65534) / 65535;
+  hipLaunchKernelGGL(k_subset_pack, dim3((unsigned)((nb + 255) / 256), (unsigned)gy, (unsigned)gz),
+                     dim3(256), 0, b->stream, b->d_img, b->pitch, d_rows, n, d_cols, m, nb, d_out);
+  BSN_HIP(hipGetLastError());
+}
+
 }  // namespace bsn

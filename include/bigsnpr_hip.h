@@ -95,6 +95,18 @@ int bsn_bed_read(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t 
 int bsn_bed_read_scaled(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
                         int64_t m, const double *center, const double *scale, double *out);
 
+/* ---- .bed <-> FBM.code256 (the data formats either side of the path) ------
+ * _bigsnpr_readbina2 (5 args) src/read-plink.cpp:61-80: decoded genotypes of the sub-matrix,
+ * one byte each (0, 1, 2, 3 = missing), n x m column-major — the content of the .bk file that
+ * snp_readBed / snp_readBed2 create (R/read-plink.R:27-111). */
+int bsn_bed_to_fbm(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                   uint8_t *out);
+/* _bigsnpr_writebina (5 args) src/write-plink.cpp:13-52: the .bed payload (ceil(n/4) bytes per
+ * variant, pad bits 0, no magic header) of the sub-matrix [ind_row, ind_col] of the image;
+ * snp_writeBed (R/write-plink.R:15-44) writes magic + this + .bim/.fam. */
+int bsn_bed_subset_payload(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                           int64_t m, uint8_t *payload_out);
+
 /* ---- device-resident operator (the fun.prod / fun.cprod seam of big_randomSVD,
  *      R/autoSVD.R:216-218, kept on the device so vectors never cross PCIe) ----- */
 int bsn_op_create(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
