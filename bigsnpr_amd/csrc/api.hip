@@ -396,6 +396,27 @@ int bsn_bed_read_scaled(bsn_bed *bed, const int64_t *ind_row, int64_t n, const i
   return guarded([&] { read_host(bed, ind_row, n, ind_col, m, center, scale, 0, nullptr, out); });
 }
 
+// _bigsnpr_prod_and_rowSumsSq (6 args) src/bed-fun.cpp:103-133
+int bsn_bed_prod_and_rowsumssq(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                               int64_t m, const double *center, const double *scale, const double *V,
+                               int64_t K, double *XV, double *rowSumsSq) {
+  return guarded([&] {
+    if (K <= 0) fail("'V' must have at least one column.");
+    bsn_op op;
+    fill_op(&op, bed, ind_row, n, ind_col, m, center, scale);
+    op.slices = 7;
+    DevBuf<double> d_V, d_XV, d_r;
+    BSN_HIP(hipMemcpyAsync(d_V.ensure((size_t)m * K), V, (size_t)m * K * 8, hipMemcpyHostToDevice, bed->stream));
+    d_XV.ensure((size_t)n * K);
+    d_r.ensure((size_t)n);
+    op_prod(&op, d_V.p, m, (int)K, d_XV.p, n);
+    op_row_sums_sq(&op, d_r.p);
+    BSN_HIP(hipMemcpyAsync(XV, d_XV.p, (size_t)n * K * 8, hipMemcpyDeviceToHost, bed->stream));
+    BSN_HIP(hipMemcpyAsync(rowSumsSq, d_r.p, (size_t)n * 8, hipMemcpyDeviceToHost, bed->stream));
+    BSN_HIP(hipStreamSynchronize(bed->stream));
+  });
+}
+
 static void convert_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
                          int64_t m, uint8_t *out, bool packed) {
   if (n <= 0 || m <= 0) fail("'ind.row' and 'ind.col' can't be empty.");

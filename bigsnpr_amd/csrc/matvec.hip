@@ -86,6 +86,9 @@ __global__ void k_absmax(const double *X, int64_t ldx, int64_t len, const double
       a = a / s;
       double b = fabs(c * a);
       if (!(b <= 1.79e308)) bad++; else mx = fmax(mx, b);
+    } else if (mode == 2) {  // raw second plane: center[] is W2 (same shape as X)
+      double b = center ? fabs(center[k + v * ldx]) : 0.0;
+      if (!(b <= 1.79e308)) bad++; else mx = fmax(mx, b);
     }
     a = fabs(a);
     if (!(a <= 1.79e308)) bad++; else mx = fmax(mx, a);
@@ -131,7 +134,7 @@ __global__ void k_quant(const double *X, int64_t ldx, int64_t len, int64_t len_p
                         int permute, VecMeta *meta, int8_t *q) {
   int64_t kb = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // 16-block index
   int v = blockIdx.y;
-  int nplanes = mode == 1 ? 2 : 1;
+  int nplanes = mode >= 1 ? 2 : 1;
   long long shi = 0, slo = 0, shi2 = 0, slo2 = 0;
   if (kb * 16 < len_pad) {
     double qs = meta[v].qscale;
@@ -146,6 +149,8 @@ __global__ void k_quant(const double *X, int64_t ldx, int64_t len, int64_t len_p
           double s = scale ? scale[k] : 1.0, c = center ? center[k] : 0.0;
           a = a / s;
           b = c * a;
+        } else if (mode == 2) {
+          b = center ? center[k + v * ldx] : 0.0;
         }
       }
       if (!(fabs(a) <= 1.79e308)) a = 0;
@@ -157,7 +162,7 @@ __global__ void k_quant(const double *X, int64_t ldx, int64_t len, int64_t len_p
       int8_t d[8];
       digits_of(A, S, d);
       for (int s = 0; s < S; s++) dg[0][s][pos] = d[s];
-      if (mode == 1) {
+      if (mode >= 1) {
         digits_of(B, S, d);
         for (int s = 0; s < S; s++) dg[1][s][pos] = d[s];
       }
@@ -175,7 +180,7 @@ __global__ void k_quant(const double *X, int64_t ldx, int64_t len, int64_t len_p
   if ((threadIdx.x & 63) == 0) {
     atomicAdd((unsigned long long *)&meta[v].sum_hi, (unsigned long long)shi);
     atomicAdd((unsigned long long *)&meta[v].sum_lo, (unsigned long long)slo);
-    if (mode == 1) {
+    if (mode >= 1) {
       atomicAdd((unsigned long long *)&meta[v].sum2_hi, (unsigned long long)shi2);
       atomicAdd((unsigned long long *)&meta[v].sum2_lo, (unsigned long long)slo2);
     }
@@ -374,7 +379,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
                                               const int32_t *__restrict__ cols, int64_t col0,
                                               int64_t m_pad, int64_t mc,
                                               const int8_t *__restrict__ wq,
-                                              int32_t *__restrict__ acc_out, int64_t n_pad) {
+                                              int32_t *__restrict__ acc_out, int64_t n_pad,
+                                              uint32_t lutP, uint32_t lutQ) {
   constexpr int NCOL = 16 * NB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int sg = lane & 15, g = lane >> 4;
@@ -459,8 +465,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
 #pragma unroll
         for (int r4 = 0; r4 < 4; r4++) {
           const uint32_t sel = (T[q][r4] >> (2 * uu)) & 0x03030303u;
-          g0[r4] = (int)lut4(kLutG0, sel);
-          na[r4] = (int)lut4(kLutNA, sel);
+          g0[r4] = (int)lut4(lutP, sel);
+          na[r4] = (int)lut4(lutQ, sel);
         }
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) {
@@ -493,7 +499,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
 template <int NCOL>
 __global__ void k_prod_final(const int32_t *__restrict__ acc, int64_t n_pad, int ky, int S, int nv,
                              const VecMeta *meta, const int32_t *rows, int64_t n, double *Y,
-                             int64_t ldy) {
+                             int64_t ldy, int sub_const, double beta) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int64_t i2 = rows ? (int64_t)rows[i] : i;
@@ -519,11 +525,11 @@ __global__ void k_prod_final(const int32_t *__restrict__ acc, int64_t n_pad, int
       for (int c = 0; c < NCOL; c++) dv = (c == v * S + s) ? d[c] : dv;
       r = r * 256.0 + (double)dv;
     }
-    double C = (double)meta[v].sum2_hi * 16777216.0 + (double)meta[v].sum2_lo;
+    double C = sub_const ? (double)meta[v].sum2_hi * 16777216.0 + (double)meta[v].sum2_lo : 0.0;
     double qs = meta[v].qscale;
     double y = qs > 0 ? (r - C) / qs : 0.0;
     if (meta[v].nonfinite) y = __longlong_as_double(0x7ff8000000000000LL);
-    Y[i + v * ldy] = y;
+    Y[i + v * ldy] = beta != 0.0 ? beta * Y[i + v * ldy] + y : y;
   }
 }
 
@@ -563,22 +569,22 @@ static int pick_nb(int ncols_needed) { return ncols_needed <= 16 ? 1 : 2; }
 
 static void quantise(bsn_op *op, const double *d_X, int64_t ldx, int64_t len, int64_t len_pad,
                      int nvec, int mode, int S, int ncol, int permute, int exact_int,
-                     VecMeta *meta, int8_t *q) {
+                     VecMeta *meta, int8_t *q, const double *d_W2 = nullptr) {
   hipStream_t st = op->bed->stream;
   hipLaunchKernelGGL(k_meta_clear, dim3(1), dim3(64), 0, st, meta, nvec);
   if (!exact_int) {
     int gx = (int)((len + 255) / 256);
     if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL(k_absmax, dim3(gx, nvec), dim3(256), 0, st, d_X, ldx, len,
-                       mode == 1 ? op->d_center.p : nullptr, mode == 1 ? op->d_scale.p : nullptr,
-                       mode, meta);
+                       mode == 1 ? op->d_center.p : mode == 2 ? d_W2 : nullptr,
+                       mode == 1 ? op->d_scale.p : nullptr, mode, meta);
   }
   hipLaunchKernelGGL(k_set_qscale, dim3(1), dim3(64), 0, st, meta, nvec, S, exact_int);
-  int nplanes = mode == 1 ? 2 : 1;
+  int nplanes = mode >= 1 ? 2 : 1;
   BSN_HIP(hipMemsetAsync(q, 0, (size_t)(len_pad / 16) * nplanes * ncol * 16, st));
   int64_t nblk = len_pad / 16;
   hipLaunchKernelGGL(k_quant, dim3((unsigned)((nblk + 63) / 64), nvec), dim3(64), 0, st, d_X, ldx,
-                     len, len_pad, mode == 1 ? op->d_center.p : nullptr,
+                     len, len_pad, mode == 1 ? op->d_center.p : mode == 2 ? d_W2 : nullptr,
                      mode == 1 ? op->d_scale.p : nullptr, mode, S, ncol, permute, meta, q);
   BSN_HIP(hipGetLastError());
 }
@@ -661,9 +667,13 @@ void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z,
   }
 }
 
-void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy) {
+// Y (+)= sum_j lutP[code_ij] W1[j, v] + sum_j lutQ[code_ij] W2[j, v]  (- sum_j W2[j, v] if sub_const)
+// mode 1: W1 = X / scale, W2 = center * W1 derived from the operator's centre / scale (the
+// scaled product A~ X); mode 2: W1 = d_X, W2 = d_W2 given directly (raw plane weights).
+static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64_t ldx, int nvec,
+                        double *d_Y, int64_t ldy, int mode, uint32_t lutP, uint32_t lutQ, int sub_const,
+                        double beta, int S) {
   bsn_bed *b = op->bed;
-  const int S = op->slices;
   const int vmax = 32 / S;
   if (nvec <= 0) return;
   const int64_t npad = b->pitch * 4;
@@ -686,24 +696,25 @@ void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, 
     size_t acc_need = (size_t)ky * npad * ncol;
     if (acc_need < (size_t)2 * op->m * 32) acc_need = (size_t)2 * op->m * 32;
     int32_t *acc = op->d_acc.ensure(acc_need);
-    quantise(op, d_X + (int64_t)v0 * ldx, ldx, op->m, m_pad, nv, 1, S, ncol, 0, 0, meta, q);
+    quantise(op, d_X + (int64_t)v0 * ldx, ldx, op->m, m_pad, nv, mode, S, ncol, 0, 0, meta, q,
+             d_W2 ? d_W2 + (int64_t)v0 * ldx : nullptr);
     dim3 grid((unsigned)wgx, (unsigned)ky);
     const int32_t *cols = op->d_cols.p;
     prof_begin(op, 1);
     if (op->cols_contig) {
       if (NB == 1)
         hipLaunchKernelGGL((k_prod<1, true>), grid, dim3(256), 0, b->stream, b->d_img, b->pitch,
-                           cols, op->col0, m_pad, mc, q, acc, npad);
+                           cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
       else
         hipLaunchKernelGGL((k_prod<2, true>), grid, dim3(256), 0, b->stream, b->d_img, b->pitch,
-                           cols, op->col0, m_pad, mc, q, acc, npad);
+                           cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
     } else {
       if (NB == 1)
         hipLaunchKernelGGL((k_prod<1, false>), grid, dim3(256), 0, b->stream, b->d_img, b->pitch,
-                           cols, op->col0, m_pad, mc, q, acc, npad);
+                           cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
       else
         hipLaunchKernelGGL((k_prod<2, false>), grid, dim3(256), 0, b->stream, b->d_img, b->pitch,
-                           cols, op->col0, m_pad, mc, q, acc, npad);
+                           cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
     }
     BSN_HIP(hipGetLastError());
     prof_end(op);
@@ -711,13 +722,44 @@ void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, 
     if (NB == 1)
       hipLaunchKernelGGL((k_prod_final<16>), dim3((unsigned)((op->n + 255) / 256)), dim3(256), 0, b->stream,
                          acc, npad, ky, S, nv, meta, op->rows_identity ? nullptr : op->d_rows.p, op->n,
-                         d_Y + (int64_t)v0 * ldy, ldy);
+                         d_Y + (int64_t)v0 * ldy, ldy, sub_const, beta);
     else
       hipLaunchKernelGGL((k_prod_final<32>), dim3((unsigned)((op->n + 255) / 256)), dim3(256), 0, b->stream,
                          acc, npad, ky, S, nv, meta, op->rows_identity ? nullptr : op->d_rows.p, op->n,
-                         d_Y + (int64_t)v0 * ldy, ldy);
+                         d_Y + (int64_t)v0 * ldy, ldy, sub_const, beta);
     BSN_HIP(hipGetLastError());
   }
+}
+
+void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy) {
+  prod_planes(op, d_X, nullptr, ldx, nvec, d_Y, ldy, 1, kLutG0, kLutNA, 1, 0.0, op->slices);
+}
+
+// rowSumsSq[i] = sum_j A~[i, j]^2 over the non-missing genotypes (src/bed-fun.cpp:121-123):
+//   ((g - c) / s)^2 = g^2 a + g b + d,  a = 1/s^2, b = -2c/s^2, d = c^2/s^2
+// = X2 . a + X . b + M . d with the planes X2 = g^2, X = g, M = non-missing: two passes.
+__global__ void k_rowsq_weights(const double *center, const double *scale, int64_t m, double *a,
+                                double *b, double *d) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const double c = center[j], s = scale[j];
+  a[j] = 1.0 / (s * s);
+  b[j] = -2.0 * c / (s * s);
+  d[j] = c * c / (s * s);
+}
+
+void op_row_sums_sq(bsn_op *op, double *d_out) {
+  bsn_bed *bed = op->bed;
+  DevBuf<double> w;
+  double *a = w.ensure((size_t)3 * op->m), *b2 = a + op->m, *d = b2 + op->m;
+  hipLaunchKernelGGL(k_rowsq_weights, dim3((unsigned)((op->m + 255) / 256)), dim3(256), 0, bed->stream,
+                     op->d_center.p, op->d_scale.p, op->m, a, b2, d);
+  BSN_HIP(hipGetLastError());
+  constexpr uint32_t kLutX2 = 0x00010004u;  // code 0,1,2,3 -> 4, 0, 1, 0
+  constexpr uint32_t kLutM = 0x01010001u;   //               -> 1, 0, 1, 1
+  prod_planes(op, a, b2, op->m, 1, d_out, op->n, 2, kLutX2, kLutG0, 0, 0.0, 7);
+  prod_planes(op, d, nullptr, op->m, 1, d_out, op->n, 2, kLutM, 0u, 0, 1.0, 7);
+  BSN_HIP(hipStreamSynchronize(bed->stream));  // `w` is released on return
 }
 
 // counts of codes weighted by integer row multiplicities (general ind_row):

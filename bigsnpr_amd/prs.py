@@ -63,3 +63,34 @@ def bed_tcrossprodSelf(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_co
                                          ic.size, ptr(center, f64p), ptr(scale, f64p),
                                          int(block_size), K.ctypes.data_as(f64p)))
     return K, dict(center=center, scale=scale)
+
+
+def prod_and_rowSumsSq(obj_bed, ind_row, ind_col, center, scale, V):
+    """src/bed-fun.cpp:103-133: (X V, rowSums(X^2)) for the scaled sub-matrix X"""
+    ir, ic = _args(obj_bed, ind_row, ind_col)
+    center, scale = as_f64(np.ravel(center)), as_f64(np.ravel(scale))
+    V = np.asfortranarray(np.asarray(V, dtype=np.float64))
+    if V.ndim == 1:
+        V = V[:, None]
+    if V.shape[0] != ic.size:
+        raise ValueError("Incompatibility between dimensions.")     # myassert_size(m, V.rows())
+    assert_lengths(center, ic); assert_lengths(scale, ic)
+    XV = np.empty((ir.size, V.shape[1]), dtype=np.float64, order="F")
+    rs = np.empty(ir.size)
+    check(_lib.load().bsn_bed_prod_and_rowsumssq(obj_bed.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p),
+                                                 ic.size, ptr(center, f64p), ptr(scale, f64p),
+                                                 V.ctypes.data_as(f64p), V.shape[1],
+                                                 XV.ctypes.data_as(f64p), ptr(rs, f64p)))
+    return XV, rs
+
+
+def bed_projectSelfPCA(obj_svd, obj_bed, ind_row, ind_col=None, ncores=1):
+    """R/bed-projectPCA.R:196-227: simple projection X V of new rows on the PCs of `obj_svd`
+    plus the squared row norms that the OADP correction needs.  The OADP step itself
+    (bigutilsr::pca_OADP_proj2, external) is not restated: `OADP_proj` is None."""
+    ind_col = obj_svd["subset"] if ind_col is None and "subset" in obj_svd else ind_col
+    ir, ic = _args(obj_bed, ind_row, ind_col)
+    if np.asarray(obj_svd["v"]).shape[0] != ic.size:
+        raise ValueError("Incompatibility between dimensions.")
+    XV, X_norm = prod_and_rowSumsSq(obj_bed, ir, ic, obj_svd["center"], obj_svd["scale"], obj_svd["v"])
+    return dict(obj_svd_ref=obj_svd, simple_proj=XV, X_norm=X_norm, OADP_proj=None)

@@ -95,6 +95,13 @@ int bsn_bed_read(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t 
 int bsn_bed_read_scaled(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
                         int64_t m, const double *center, const double *scale, double *out);
 
+/* _bigsnpr_prod_and_rowSumsSq (6 args) src/bed-fun.cpp:103-133 (the kernel of
+ * bed_projectSelfPCA, R/bed-projectPCA.R:45-59): XV[n x K] = A~ V[m x K] and
+ * rowSumsSq[i] = sum_j A~[i, j]^2, column-major host buffers. */
+int bsn_bed_prod_and_rowsumssq(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                               int64_t m, const double *center, const double *scale, const double *V,
+                               int64_t K, double *XV, double *rowSumsSq);
+
 /* ---- .bed <-> FBM.code256 (the data formats either side of the path) ------
  * _bigsnpr_readbina2 (5 args) src/read-plink.cpp:61-80: decoded genotypes of the sub-matrix,
  * one byte each (0, 1, 2, 3 = missing), n x m column-major — the content of the .bk file that

@@ -528,3 +528,20 @@ def read_rds(path):
         return v
 
     return item()
+
+
+def prod_and_rowSumsSq(bed, ind_row, ind_col, center, scale, V):
+    """src/bed-fun.cpp:103-133"""
+    ir, ic = _sub(bed, ind_row, ind_col)
+    center, scale = _f64(center), _f64(scale)
+    V = np.asfortranarray(np.asarray(V, dtype=np.float64))
+    assert V.shape[0] == ic.size
+    K = V.shape[1]
+    XV = np.empty((ir.size, K), dtype=np.float64, order="F")
+    rs = np.empty(ir.size)
+    lib().orc_prod_and_rowSumsSq(_p(bed.payload, C.c_uint8), C.c_int64(bed.n_byte), _p(ir, C.c_int64),
+                                 C.c_int64(ir.size), _p(ic, C.c_int64), C.c_int64(ic.size),
+                                 _p(center, C.c_double), _p(scale, C.c_double),
+                                 V.ctypes.data_as(f64p), C.c_int64(K), XV.ctypes.data_as(f64p),
+                                 _p(rs, C.c_double))
+    return XV, rs

@@ -61,3 +61,25 @@ def test_tcrossprod_self(ba, orc, golden_dir, example_bed, missing_bed):
     K2, _ = ba.bed_tcrossprodSelf(gm, ind_row=ir, ind_col=icm)
     K2ref, _ = orc.bed_tcrossprodSelf(missing_bed, ir, icm)
     np.testing.assert_allclose(K2, K2ref, rtol=0, atol=1e-10 * np.abs(K2ref).max())
+
+
+def test_prod_and_rowsumssq_and_self_projection(ba, orc, golden_dir, missing_bed, example_bed):
+    """src/bed-fun.cpp:103-133 + tests/testthat/test-2-pca-project.R (simple projection):
+    projecting the SVD's own rows gives u d, and rowSumsSq == rowSums(X^2)"""
+    gm = ba.bed(os.path.join(golden_dir, "example-missing.bed"))
+    rng = np.random.default_rng(3)
+    ir = rng.choice(missing_bed.n, 120, replace=True)
+    sc = orc.bed_scaleBinom(missing_bed)
+    ic = np.nonzero(sc["scale"] > 0)[0][::2]
+    V = rng.normal(size=(ic.size, 5))
+    XV, rs = ba.prod_and_rowSumsSq(gm, ir, ic, sc["center"][ic], sc["scale"][ic], V)
+    XVr, rsr = orc.prod_and_rowSumsSq(missing_bed, ir, ic, sc["center"][ic], sc["scale"][ic], V)
+    np.testing.assert_allclose(XV, XVr, rtol=0, atol=1e-9 * np.abs(XVr).max())
+    np.testing.assert_allclose(rs, rsr, rtol=1e-9)
+    with pytest.raises(ValueError, match="Incompatibility between dimensions"):
+        ba.prod_and_rowSumsSq(gm, ir, ic, sc["center"][ic], sc["scale"][ic], V[:-1])
+    ge = ba.bed(os.path.join(golden_dir, "example.bed"))
+    svd = ba.bed_randomSVD(ge, k=5, tol=1e-10, slices=7)
+    svd["subset"] = np.arange(example_bed.m)
+    proj = ba.bed_projectSelfPCA(svd, ge, ind_row=np.arange(example_bed.n))
+    np.testing.assert_allclose(proj["simple_proj"], svd["u"] * svd["d"], rtol=0, atol=1e-6 * svd["d"][0])
