@@ -59,6 +59,7 @@ SIGNATURES = {
     "bsn_snp_colstats": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p]),
     "bsn_bed_read": (C.c_int, [vp, i64p, i64, i64p, i64, C.c_int32, i32p]),
     "bsn_bed_read_scaled": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, f64p]),
+    "bsn_bed_cprod_planes": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, i64, f64p, f64p]),
     "bsn_bed_prod_and_rowsumssq": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, f64p, i64, f64p, f64p]),
     "bsn_bed_to_fbm": (C.c_int, [vp, i64p, i64, i64p, i64, u8p]),
     "bsn_bed_subset_payload": (C.c_int, [vp, i64p, i64, i64p, i64, u8p]),

@@ -396,6 +396,25 @@ int bsn_bed_read_scaled(bsn_bed *bed, const int64_t *ind_row, int64_t n, const i
   return guarded([&] { read_host(bed, ind_row, n, ind_col, m, center, scale, 0, nullptr, out); });
 }
 
+// plane sums behind multLinReg (src/multLinReg.cpp:25-44)
+int bsn_bed_cprod_planes(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                         int64_t m, const double *X, int64_t K, double *P, double *Q) {
+  return guarded([&] {
+    if (K <= 0) fail("'U' must have at least one column.");
+    bsn_op op;
+    fill_op(&op, bed, ind_row, n, ind_col, m, nullptr, nullptr);
+    op.slices = 7;
+    DevBuf<double> d_X, d_P, d_Q;
+    BSN_HIP(hipMemcpyAsync(d_X.ensure((size_t)n * K), X, (size_t)n * K * 8, hipMemcpyHostToDevice, bed->stream));
+    d_P.ensure((size_t)m * K);
+    d_Q.ensure((size_t)m * K);
+    op_cprod_raw(&op, d_X.p, n, (int)K, d_P.p, d_Q.p, m);
+    BSN_HIP(hipMemcpyAsync(P, d_P.p, (size_t)m * K * 8, hipMemcpyDeviceToHost, bed->stream));
+    BSN_HIP(hipMemcpyAsync(Q, d_Q.p, (size_t)m * K * 8, hipMemcpyDeviceToHost, bed->stream));
+    BSN_HIP(hipStreamSynchronize(bed->stream));
+  });
+}
+
 // _bigsnpr_prod_and_rowSumsSq (6 args) src/bed-fun.cpp:103-133
 int bsn_bed_prod_and_rowsumssq(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
                                int64_t m, const double *center, const double *scale, const double *V,

@@ -731,6 +731,44 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
   }
 }
 
+// raw plane sums of the cprod kernel: P[j, v] = sum_i g0_ij x_iv, Q[j, v] = sum_i na_ij x_iv
+__global__ void k_cprod_raw_final(const int32_t *acc, int64_t m, int ncol, int S, const VecMeta *meta,
+                                  double *P, double *Q, int64_t ld) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int v = blockIdx.y;
+  if (j >= m) return;
+  const double qs = meta[v].qscale;
+  const double inv = qs > 0 ? 1.0 / qs : 0.0;
+  double p = horner(acc + j * ncol + v * S, S) * inv, q = horner(acc + (m + j) * ncol + v * S, S) * inv;
+  if (meta[v].nonfinite) p = q = __longlong_as_double(0x7ff8000000000000LL);
+  P[j + v * ld] = p;
+  Q[j + v * ld] = q;
+}
+
+void op_cprod_raw(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_P, double *d_Q,
+                  int64_t ld) {
+  bsn_bed *b = op->bed;
+  const int S = op->slices;
+  const int vmax = 32 / S;
+  if (nvec <= 0) return;
+  const double *xsrc = scatter_rows_if_needed(op, d_X, &ldx, nvec);
+  const int64_t npad = b->pitch * 4;
+  VecMeta *meta = (VecMeta *)op->d_meta.ensure(8 * 64);
+  for (int v0 = 0; v0 < nvec; v0 += vmax) {
+    int nv = nvec - v0 < vmax ? nvec - v0 : vmax;
+    int NB = pick_nb(nv * S), ncol = 16 * NB;
+    int8_t *q = op->d_q.ensure((size_t)npad * 32 * 2);
+    int32_t *acc = op->d_acc.ensure((size_t)2 * op->m * 32);
+    quantise(op, xsrc + (int64_t)v0 * ldx, ldx, b->n, npad, nv, 0, S, ncol, 1, 0, meta, q);
+    launch_cprod<2>(op, NB, q, acc, kLutG0, kLutNA, 0);
+    op->passes++;
+    hipLaunchKernelGGL(k_cprod_raw_final, dim3((unsigned)((op->m + 255) / 256), nv), dim3(256), 0,
+                       b->stream, acc, op->m, ncol, S, meta, d_P + (int64_t)v0 * ld,
+                       d_Q + (int64_t)v0 * ld, ld);
+    BSN_HIP(hipGetLastError());
+  }
+}
+
 void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy) {
   prod_planes(op, d_X, nullptr, ldx, nvec, d_Y, ldy, 1, kLutG0, kLutNA, 1, 0.0, op->slices);
 }

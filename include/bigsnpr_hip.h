@@ -95,6 +95,14 @@ int bsn_bed_read(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t 
 int bsn_bed_read_scaled(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
                         int64_t m, const double *center, const double *scale, double *out);
 
+/* The genotype-touching part of _bigsnpr_multLinReg (5 args, src/multLinReg.cpp:8-86; SURVEY.md
+ * §8f-2): for every variant j and column k of X (n x K, e.g. PC scores)
+ *   P[j, k] = sum_i g_ij X[i, k] over non-missing genotypes,  Q[j, k] = sum_{i: g_ij missing} X[i, k]
+ * (m x K column-major).  With the genotype counts these give xySum, ySum, yySum of the reference;
+ * the K t-scores per variant are then a few flops on the host (bigsnpr_amd/pcadapt.py). */
+int bsn_bed_cprod_planes(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                         int64_t m, const double *X, int64_t K, double *P, double *Q);
+
 /* _bigsnpr_prod_and_rowSumsSq (6 args) src/bed-fun.cpp:103-133 (the kernel of
  * bed_projectSelfPCA, R/bed-projectPCA.R:45-59): XV[n x K] = A~ V[m x K] and
  * rowSumsSq[i] = sum_j A~[i, j]^2, column-major host buffers. */

@@ -516,3 +516,41 @@ void orc_fake_bed(uint8_t *payload, int64_t n, int64_t m, int64_t n_byte, uint32
     }
   }
 }
+
+/* ------------------------------------------------------------------------- */
+/* f2: src/multLinReg.cpp:8-60 — t-scores of each variant regressed on K columns of U,
+ * pairwise-complete.  res is m x K column-major (the reference returns transpose(K x m)). */
+void orc_multLinReg(int kind, const uint8_t *data, int64_t ld, const double *code256,
+                    const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                    const double *U /* n x K */, int64_t K, double *res /* m x K */, int ncores) {
+  orc_acc a = {kind, data, ld, code256};
+#pragma omp parallel for num_threads(ncores)
+  for (int64_t j = 0; j < m; j++) {
+    double *xySum = (double *)calloc((size_t)(3 * K), sizeof(double));
+    double *ySum = xySum + K, *yySum = ySum + K;
+    int nona = (int)n;
+    double xSum = 0, xxSum = 0;
+    for (int64_t i = 0; i < n; i++) {
+      double x = orc_get(&a, ind_row[i], ind_col[j]);
+      if (x != 3) {
+        xSum += x;
+        xxSum += x * x;
+        for (int64_t k = 0; k < K; k++) {
+          double y = U[i + k * n];
+          xySum[k] += x * y;
+          ySum[k] += y;
+          yySum[k] += y * y;
+        }
+      } else
+        nona--;
+    }
+    double deno_x = xxSum - xSum * xSum / nona;
+    for (int64_t k = 0; k < K; k++) {
+      double num = xySum[k] - xSum * ySum[k] / nona;
+      double deno_y = yySum[k] - ySum[k] * ySum[k] / nona;
+      double deno = deno_x * deno_y - num * num;
+      res[j + k * m] = (deno == 0 || nona < 2) ? NAN : num * sqrt((nona - 2) / deno);
+    }
+    free(xySum);
+  }
+}

@@ -545,3 +545,21 @@ def prod_and_rowSumsSq(bed, ind_row, ind_col, center, scale, V):
                                  V.ctypes.data_as(f64p), C.c_int64(K), XV.ctypes.data_as(f64p),
                                  _p(rs, C.c_double))
     return XV, rs
+
+
+def multLinReg(obj, ind_row, ind_col, U, ncores=1):
+    """src/multLinReg.cpp:8-86: m x K t-scores"""
+    kind, data, ld, code, n_tot, m_tot = _acc_args(obj)
+    ir = np.arange(n_tot, dtype=np.int64) if ind_row is None else _i64(ind_row)
+    ic = np.arange(m_tot, dtype=np.int64) if ind_col is None else _i64(ind_col)
+    U = np.asfortranarray(np.asarray(U, dtype=np.float64))
+    if U.ndim == 1:
+        U = U[:, None]
+    assert U.shape[0] == ir.size
+    res = np.empty((ic.size, U.shape[1]), dtype=np.float64, order="F")
+    with np.errstate(all="ignore"):
+        lib().orc_multLinReg(C.c_int(kind), _p(data, C.c_uint8), C.c_int64(ld), _p(code, C.c_double),
+                             _p(ir, C.c_int64), C.c_int64(ir.size), _p(ic, C.c_int64),
+                             C.c_int64(ic.size), U.ctypes.data_as(f64p), C.c_int64(U.shape[1]),
+                             res.ctypes.data_as(f64p), C.c_int(ncores))
+    return res
