@@ -17,6 +17,7 @@ from .prs import (bed_projectSelfPCA, bed_tcrossprodSelf, prod_and_rowSumsSq, pr
 from .autosvd import bed_autoSVD, snp_autoSVD  # noqa: F401,E402
 from .plink_io import bed_to_bytes, snp_readBed, snp_writeBed  # noqa: F401,E402
 from .pcadapt import bed_pcadapt, multLinReg, snp_pcadapt  # noqa: F401,E402
+from .sct import seq_log, snp_grid_clumping, snp_grid_PRS  # noqa: F401,E402
 
 
 def selftest():

@@ -79,6 +79,10 @@ SIGNATURES = {
     "bsn_ld_scores": (C.c_int, [vp, i64p, i64, i64p, i64, C.c_double, f64p, f64p]),
     "bsn_clumping_chr": (C.c_int, [vp, i64p, i64, i64p, i64, C.c_int, f64p, f64p, i32p, i32p, f64p,
                                    C.c_double, C.c_double, i32p]),
+    "bsn_clumping_chr_cached": (C.c_int, [vp, i64p, i64, i64p, i64, C.c_int, f64p, f64p, i32p, i32p, f64p,
+                                          i64, f64p, f64p, i32p]),
+    "bsn_snp_grid_prs": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, i32p, C.POINTER(C.c_uint8), i64, i64,
+                                   C.c_int, f64p]),
     "bsn_malloc": (C.c_int, [C.POINTER(vp), i64]),
     "bsn_free": (C.c_int, [vp]),
     "bsn_memcpy_h2d": (C.c_int, [vp, vp, i64]),

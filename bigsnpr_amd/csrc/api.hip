@@ -436,6 +436,72 @@ int bsn_bed_prod_and_rowsumssq(bsn_bed *bed, const int64_t *ind_row, int64_t n, 
   });
 }
 
+// running sums of snp_grid_PRS: last[:, c] += Y[:, c]; out[:, c * T + t] = last[:, c]
+__global__ void k_prs_accum(const double *__restrict__ Y, int64_t n, int64_t C, double *__restrict__ last,
+                            double *__restrict__ out, int64_t T, int64_t t) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * C) return;
+  const int64_t i = idx % n, c = idx / n;
+  const double v = last[idx] + (Y ? Y[idx] : 0.0);
+  last[idx] = v;
+  out[(c * T + t) * n + i] = v;
+}
+
+int bsn_snp_grid_prs(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                     const double *betas, const int32_t *bin, const uint8_t *member, int64_t C, int64_t T,
+                     int slices, double *out) {
+  return guarded([&] {
+    if (n <= 0) fail("'ind.row' can't be empty.");
+    if (C <= 0 || T <= 0) fail("the grid is empty");
+    require_gpu();
+    BSN_HIP(hipSetDevice(bed->device));
+    // columns by bin, highest first (R/PRS.R:66-73 accumulates from the highest threshold down)
+    std::vector<std::vector<int64_t>> by_bin((size_t)T + 1);
+    for (int64_t j = 0; j < m; j++) {
+      if (bin[j] < 0 || bin[j] > T) fail("'bin' out of range");
+      bool any = false;
+      for (int64_t c = 0; c < C && !any; c++) any = member[c * m + j] != 0;
+      if (any && bin[j] > 0) by_bin[(size_t)bin[j]].push_back(j);
+    }
+    DevBuf<double> d_last, d_out, d_V, d_Y;
+    BSN_HIP(hipMemsetAsync(d_last.ensure((size_t)n * C), 0, (size_t)n * C * 8, bed->stream));
+    d_out.ensure((size_t)n * C * T);
+    d_Y.ensure((size_t)n * C);
+    std::vector<double> V;
+    std::vector<int64_t> cols;
+    const unsigned nblk = (unsigned)((n * C + 255) / 256);
+    for (int64_t b = T; b >= 1; b--) {
+      const std::vector<int64_t> &jj = by_bin[(size_t)b];
+      const int64_t mb = (int64_t)jj.size();
+      if (mb > 0) {
+        cols.resize((size_t)mb);
+        V.assign((size_t)mb * C, 0.0);
+        for (int64_t k = 0; k < mb; k++) {
+          cols[(size_t)k] = ind_col ? ind_col[jj[(size_t)k]] : jj[(size_t)k];
+          for (int64_t c = 0; c < C; c++)
+            if (member[c * m + jj[(size_t)k]]) V[(size_t)(c * mb + k)] = betas[jj[(size_t)k]];
+        }
+        bsn_op op;
+        fill_op(&op, bed, ind_row, n, cols.data(), mb, nullptr, nullptr);
+        op.slices = slices > 0 ? slices : 7;
+        BSN_HIP(hipMemcpyAsync(d_V.ensure((size_t)mb * C), V.data(), (size_t)mb * C * 8, hipMemcpyHostToDevice,
+                               bed->stream));
+        op_prod(&op, d_V.p, mb, (int)C, d_Y.p, n);
+        hipLaunchKernelGGL(k_prs_accum, dim3(nblk), dim3(256), 0, bed->stream, d_Y.p, n, C, d_last.p, d_out.p,
+                           T, b - 1);
+        BSN_HIP(hipGetLastError());
+        BSN_HIP(hipStreamSynchronize(bed->stream));  // `op` and V are reused by the next bin
+      } else {
+        hipLaunchKernelGGL(k_prs_accum, dim3(nblk), dim3(256), 0, bed->stream, (const double *)nullptr, n, C,
+                           d_last.p, d_out.p, T, b - 1);
+        BSN_HIP(hipGetLastError());
+      }
+    }
+    BSN_HIP(hipMemcpyAsync(out, d_out.p, (size_t)n * C * T * 8, hipMemcpyDeviceToHost, bed->stream));
+    BSN_HIP(hipStreamSynchronize(bed->stream));
+  });
+}
+
 static void convert_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
                          int64_t m, uint8_t *out, bool packed) {
   if (n <= 0 || m <= 0) fail("'ind.row' and 'ind.col' can't be empty.");

@@ -240,6 +240,21 @@ __global__ void k_ld_sum(const double *__restrict__ band, const int64_t *__restr
   ld[j] = s;
 }
 
+// bit w of the 64-bit word (j0 * Wq + w / 64) = band[j0 * W + w] > thr (NaN -> 0; slots outside
+// the window of j0 -> 0).  One workgroup per j0; this is what the host sweep of the
+// clumping functions reads (1/64 of the band's bytes per threshold).
+__global__ void k_band_gt(const double *__restrict__ band, const int64_t *__restrict__ lo, int64_t W,
+                          int64_t Wq, double thr, unsigned long long *__restrict__ bits) {
+  const int64_t j0 = blockIdx.x;
+  const int64_t width = j0 - lo[j0];
+  for (int64_t w0 = (int64_t)(threadIdx.x & ~63); w0 < Wq * 64; w0 += blockDim.x) {
+    const int64_t w = w0 + (threadIdx.x & 63);
+    const bool gt = (w < width) && (band[j0 * W + w] > thr);
+    const unsigned long long b = __ballot(gt);
+    if ((threadIdx.x & 63) == 0) bits[j0 * Wq + (w0 >> 6)] = b;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 struct BandJob {
   bsn_bed *bed = nullptr;
@@ -432,26 +447,58 @@ int bsn_ld_scores(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t
   });
 }
 
-// Greedy clumping inside one chromosome.  mode 0: FBM formula (aux1 = sumX, aux2 = denoX);
-// mode 1: bed formula (aux1 = center, aux2 = scale).  keep[] is written with 0 / 1.
-int bsn_clumping_chr(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
-                     int64_t m, int mode, const double *aux1, const double *aux2,
-                     const int32_t *ordInd, const int32_t *rankInd, const double *pos, double size,
-                     double thr, int32_t *keep) {
-  return guarded([&] {
-    BandJob J;
-    band_stats(J, bed, ind_row, n, ind_col, m, pos, size, true);
-    BSN_HIP(hipMemcpyAsync(J.d_v1.ensure((size_t)m), aux1, (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
-    BSN_HIP(hipMemcpyAsync(J.d_v2.ensure((size_t)m), aux2, (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
-    band_run(J, mode == 0 ? 2 : 3, nullptr, J.d_v1.p, J.d_v2.p, (double)n);
-    std::vector<double> band((size_t)m * (size_t)J.W);
-    BSN_HIP(hipMemcpyAsync(band.data(), J.d_band.p, band.size() * 8, hipMemcpyDeviceToHost, bed->stream));
+// Greedy clumping inside one chromosome for a grid of (size, thr) pairs that share one r2
+// band: the band is computed once at the largest window and thresholded on the device once
+// per distinct thr; this replaces the sparse r2 cache that clumping_chr_cached threads
+// through the grid loops of R/SCT.R:100-131.  mode 0: FBM formula (aux1 = sumX, aux2 = denoX);
+// mode 1: bed formula (aux1 = center, aux2 = scale).  keep[g * m + j] receives 0 / 1.
+static void clumping_grid(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                          int64_t m, int mode, const double *aux1, const double *aux2,
+                          const int32_t *ordInd, const int32_t *rankInd, const double *pos,
+                          int64_t n_grid, const double *sizes, const double *thrs, int32_t *keep_out) {
+  if (n_grid <= 0) return;
+  for (int64_t k = 0; k < m; k++)
+    if (ordInd[k] < 0 || ordInd[k] >= m || rankInd[k] < 0 || rankInd[k] >= m)
+      fail("'ordInd' / 'rankInd' out of bounds");
+  double size_max = sizes[0];
+  for (int64_t g = 1; g < n_grid; g++) size_max = std::max(size_max, sizes[g]);
+  BandJob J;
+  band_stats(J, bed, ind_row, n, ind_col, m, pos, size_max, true);
+  BSN_HIP(hipMemcpyAsync(J.d_v1.ensure((size_t)m), aux1, (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
+  BSN_HIP(hipMemcpyAsync(J.d_v2.ensure((size_t)m), aux2, (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
+  band_run(J, mode == 0 ? 2 : 3, nullptr, J.d_v1.p, J.d_v2.p, (double)n);
+  // distinct thresholds -> one bit image each
+  std::vector<double> uthr;
+  std::vector<int> thr_id((size_t)n_grid);
+  for (int64_t g = 0; g < n_grid; g++) {
+    size_t t = 0;
+    while (t < uthr.size() && !(uthr[t] == thrs[g])) t++;
+    if (t == uthr.size()) uthr.push_back(thrs[g]);
+    thr_id[(size_t)g] = (int)t;
+  }
+  const int64_t Wq = (J.W + 63) / 64;
+  std::vector<std::vector<unsigned long long>> bits(uthr.size());
+  DevBuf<unsigned long long> d_bits;
+  d_bits.ensure((size_t)m * (size_t)Wq);
+  for (size_t t = 0; t < uthr.size(); t++) {
+    hipLaunchKernelGGL(k_band_gt, dim3((unsigned)m), dim3(256), 0, bed->stream, J.d_band.p, J.d_lo.p, J.W,
+                       Wq, uthr[t], d_bits.p);
+    BSN_HIP(hipGetLastError());
+    bits[t].resize((size_t)m * (size_t)Wq);
+    BSN_HIP(hipMemcpyAsync(bits[t].data(), d_bits.p, bits[t].size() * 8, hipMemcpyDeviceToHost, bed->stream));
     BSN_HIP(hipStreamSynchronize(bed->stream));
-    // the rank-ordered sweep of src/clumping.cpp:33-88 (sequential order == the reference's
-    // result for any ncores, tests/testthat/test-7-OpenMP.R:104-115)
-    auto r2_of = [&](int64_t a, int64_t b) {  // a != b
-      int64_t hi = a > b ? a : b, lo_ = a > b ? b : a;
-      return band[(size_t)hi * (size_t)J.W + (size_t)(hi - lo_ - 1)];
+  }
+  J.d_band.release();
+  J.d_stats.release();
+  // the rank-ordered sweep of src/clumping.cpp:33-88 (sequential order == the reference's
+  // result for any ncores, tests/testthat/test-7-OpenMP.R:104-115)
+  for (int64_t g = 0; g < n_grid; g++) {
+    const unsigned long long *B = bits[(size_t)thr_id[(size_t)g]].data();
+    const double size = sizes[g];
+    int32_t *keep = keep_out + g * m;
+    auto r2_gt = [&](int64_t a, int64_t b) {  // a != b, inside the band by construction
+      const int64_t hi = a > b ? a : b, w = hi - (a > b ? b : a) - 1;
+      return (B[(size_t)hi * (size_t)Wq + (size_t)(w >> 6)] >> (w & 63)) & 1ull;
     };
     for (int64_t j = 0; j < m; j++) keep[j] = -1;
     for (int64_t k = 0; k < m; k++) {
@@ -461,11 +508,30 @@ int bsn_clumping_chr(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int6
       // which_to_check (src/clumping-utils.h:12-43): neighbours inside the window with a
       // better rank that are still kept
       for (int64_t j = j0 + 1; keep_j0 && j < m && pos[j] <= pos_max; j++)
-        if (rankInd[j0] > rankInd[j] && keep[j] != 0 && r2_of(j0, j) > thr) keep_j0 = false;
+        if (rankInd[j0] > rankInd[j] && keep[j] != 0 && r2_gt(j0, j)) keep_j0 = false;
       for (int64_t j = j0 - 1; keep_j0 && j >= 0 && pos[j] >= pos_min; j--)
-        if (rankInd[j0] > rankInd[j] && keep[j] != 0 && r2_of(j0, j) > thr) keep_j0 = false;
+        if (rankInd[j0] > rankInd[j] && keep[j] != 0 && r2_gt(j0, j)) keep_j0 = false;
       keep[j0] = keep_j0 ? 1 : 0;
     }
+  }
+}
+
+int bsn_clumping_chr(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                     int64_t m, int mode, const double *aux1, const double *aux2,
+                     const int32_t *ordInd, const int32_t *rankInd, const double *pos, double size,
+                     double thr, int32_t *keep) {
+  return guarded([&] {
+    clumping_grid(bed, ind_row, n, ind_col, m, mode, aux1, aux2, ordInd, rankInd, pos, 1, &size, &thr, keep);
+  });
+}
+
+int bsn_clumping_chr_cached(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                            int64_t m, int mode, const double *aux1, const double *aux2,
+                            const int32_t *ordInd, const int32_t *rankInd, const double *pos,
+                            int64_t n_grid, const double *sizes, const double *thrs, int32_t *keep) {
+  return guarded([&] {
+    clumping_grid(bed, ind_row, n, ind_col, m, mode, aux1, aux2, ordInd, rankInd, pos, n_grid, sizes, thrs,
+                  keep);
   });
 }
 

@@ -65,9 +65,9 @@ def _ind(obj, ind_row, ind_col):
     return im, ir, ic
 
 
-def assert_sorted(x):
+def assert_sorted(x, name="infos.pos"):
     if np.any(np.diff(x) < 0):
-        raise ValueError("'infos.pos' is not sorted.")
+        raise ValueError("'%s' is not sorted." % name)
 
 
 def _cor_thresholds(n, alpha, thr_r2):

@@ -110,6 +110,19 @@ int bsn_bed_prod_and_rowsumssq(bsn_bed *bed, const int64_t *ind_row, int64_t n, 
                                int64_t m, const double *center, const double *scale, const double *V,
                                int64_t K, double *XV, double *rowSumsSq);
 
+/* The genotype-touching part of snp_grid_PRS (R/SCT.R:201-262), which in the
+ * reference is one snp_PRS call (R/PRS.R:36-76 -> bigstatsr::big_prodVec) per clumping set:
+ * scores for C column sets x T thresholds in a single sweep, one n x C GEMM per threshold bin.
+ *   ind_col[m], betas[m]  the union of the C sets and its weights
+ *   bin[m]                number of (ascending-sorted) thresholds that lpS[j] exceeds, 0..T
+ *   member[m x C]         column-major 0/1: column j belongs to set c
+ *   out[n x (C*T)]        column c*T + t = sum over j in set c with bin[j] > t of G[, j] betas[j],
+ *                         accumulated from the highest threshold down as snp_PRS does
+ * slices: fixed-point width of the weight panel (0 -> 7 = 56 bits). */
+int bsn_snp_grid_prs(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                     const double *betas, const int32_t *bin, const uint8_t *member, int64_t C, int64_t T,
+                     int slices, double *out);
+
 /* ---- .bed <-> FBM.code256 (the data formats either side of the path) ------
  * _bigsnpr_readbina2 (5 args) src/read-plink.cpp:61-80: decoded genotypes of the sub-matrix,
  * one byte each (0, 1, 2, 3 = missing), n x m column-major — the content of the .bk file that
@@ -207,6 +220,15 @@ int bsn_clumping_chr(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int6
                      int64_t m, int mode, const double *aux1, const double *aux2,
                      const int32_t *ordInd, const int32_t *rankInd, const double *pos, double size,
                      double thr, int32_t *keep);
+/* _bigsnpr_clumping_chr_cached (14 args) src/clumping-cached.cpp:11-107 as driven by the grid
+ * loops of snp_grid_clumping (R/SCT.R:100-131): the same greedy clumping for
+ * n_grid (size, thr) pairs over one column set.  The reference threads a sparse r2 cache through
+ * the calls; here the r2 band is computed once at the largest window and every grid point sweeps
+ * it.  keep[g * m + j] receives 0 / 1 for grid point g. */
+int bsn_clumping_chr_cached(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                            int64_t m, int mode, const double *aux1, const double *aux2,
+                            const int32_t *ordInd, const int32_t *rankInd, const double *pos,
+                            int64_t n_grid, const double *sizes, const double *thrs, int32_t *keep);
 
 /* ---- device memory + timing helpers for hosts without a HIP binding -------- */
 int bsn_malloc(void **d_ptr, int64_t bytes);

@@ -441,6 +441,55 @@ void orc_clumping_chr(const uint8_t *fbm, int64_t n_total, const double *code256
   free(chk);
 }
 
+/* f4: src/clumping-cached.cpp:11-107.  Same sweep as orc_clumping_chr, but squared
+ * correlations are looked up in / added to a cache that the caller threads through the grid
+ * loops of R/SCT.R:100-131 (the reference uses an arma::sp_mat indexed by spInd; a stored value
+ * of exactly 0 means "not computed yet", src/clumping-cached.cpp:67-68).  Here the cache is an
+ * open-addressing table keyed by (spInd[j], spInd[j0]): keys[cap] (init -1), vals[cap]. */
+static inline uint64_t orc_hash64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return x;
+}
+int64_t orc_clumping_chr_cached(const uint8_t *fbm, int64_t n_total, const double *code256,
+                                int64_t *keys, double *vals, int64_t cap /* power of two */,
+                                const int32_t *spInd, const int64_t *ind_row, int64_t n,
+                                const int64_t *ind_col, int64_t m, const int32_t *ordInd,
+                                const int32_t *rankInd, const double *pos, const double *sumX,
+                                const double *denoX, double size, double thr,
+                                int32_t *keep /* m, init -1 */) {
+  orc_acc a = {1, fbm, n_total, code256};
+  int32_t *chk = (int32_t *)malloc(sizeof(int32_t) * (size_t)(m ? m : 1));
+  int64_t computed = 0;
+  for (int64_t k = 0; k < m; k++) {
+    int64_t j0 = ordInd[k];
+    int64_t j0_sp = spInd[j0];
+    int nb = which_to_check(j0, keep, rankInd, pos, m, size, chk);
+    int keep_j0 = 1;
+    for (int k2 = 0; k2 < nb; k2++) {
+      int64_t j = chk[k2];
+      if (keep[j] == 0) continue;
+      int64_t key = (int64_t)spInd[j] * 0x80000000LL + j0_sp;
+      uint64_t h = orc_hash64((uint64_t)key) & (uint64_t)(cap - 1);
+      while (keys[h] != -1 && keys[h] != key) h = (h + 1) & (uint64_t)(cap - 1);
+      double r2 = keys[h] == key ? vals[h] : 0.0;
+      if (r2 == 0) {
+        double xySum = 0;
+        for (int64_t i = 0; i < n; i++)
+          xySum += orc_get(&a, ind_row[i], ind_col[j]) * orc_get(&a, ind_row[i], ind_col[j0]);
+        double num = xySum - sumX[j] * sumX[j0] / n;
+        r2 = num * num / (denoX[j] * denoX[j0]);
+        keys[h] = key;
+        vals[h] = r2;
+        computed++;
+      }
+      if (r2 > thr) { keep_j0 = 0; break; }
+    }
+    keep[j0] = keep_j0;
+  }
+  free(chk);
+  return computed;
+}
+
 void orc_bed_clumping_chr(const uint8_t *payload, int64_t n_byte, const int64_t *ind_row,
                           int64_t n, const int64_t *ind_col, int64_t m,
                           const double *center, const double *scale,

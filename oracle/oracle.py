@@ -35,6 +35,7 @@ def lib():
         build()
         _lib = C.CDLL(_SO)
         _lib.orc_corMat.restype = C.c_int64
+        _lib.orc_clumping_chr_cached.restype = C.c_int64
     return _lib
 
 
@@ -563,3 +564,94 @@ def multLinReg(obj, ind_row, ind_col, U, ncores=1):
                              C.c_int64(ic.size), U.ctypes.data_as(f64p), C.c_int64(U.shape[1]),
                              res.ctypes.data_as(f64p), C.c_int(ncores))
     return res
+
+
+# ---- f4: Stacked C+T grids, R/SCT.R --------------------------------------------------------
+def seq_log(from_, to, length_out):
+    """R/SCT.R:150-154"""
+    if length_out < 0:
+        raise ValueError("'length.out' must be a non-negative number")
+    return np.exp(np.linspace(np.log(from_), np.log(to), int(length_out)))
+
+
+def snp_grid_clumping(G, infos_chr, infos_pos, lpS, ind_row=None,
+                      grid_thr_r2=(0.01, 0.05, 0.1, 0.2, 0.5, 0.8, 0.95),
+                      grid_base_size=(50, 100, 200, 500), infos_imp=None, grid_thr_imp=(1,),
+                      groups=None, exclude=None, stats=None):
+    """R/SCT.R:32-134 + src/clumping-cached.cpp:11-107, 0-based indices.  Returns
+    (all_keep: list per chromosome of list of index arrays, grid dict, n_computed)."""
+    infos_chr, infos_pos, lpS = np.asarray(infos_chr), _f64(infos_pos), _f64(lpS)
+    m_all = G.m
+    infos_imp = np.ones(m_all) if infos_imp is None else _f64(infos_imp)
+    groups = [np.arange(m_all)] if groups is None else groups
+    ir = np.arange(G.n, dtype=np.int64) if ind_row is None else _i64(ind_row)
+    THR_IMP = np.unique(np.asarray(grid_thr_imp, dtype=np.float64))
+    THR_CLMP = np.unique(np.asarray(grid_thr_r2, dtype=np.float64))
+    BASE = np.unique(np.asarray(grid_base_size, dtype=np.float64))
+    grid = dict(size=[], thr_r2=[], grp_num=[], thr_imp=[])
+    for ti in THR_IMP:
+        for g in range(len(groups)):
+            for tc in THR_CLMP:
+                for bs in BASE:
+                    grid["size"].append(int(bs / tc)); grid["thr_r2"].append(tc)
+                    grid["grp_num"].append(g); grid["thr_imp"].append(ti)
+    grid = {k: np.asarray(v) for k, v in grid.items()}
+    excl = np.zeros(m_all, dtype=bool)
+    if exclude is not None and len(exclude):
+        excl[np.asarray(exclude, dtype=np.int64)] = True
+    flat = G.flat()
+    all_keep, computed = [], 0
+    for chrom in np.unique(infos_chr[~excl]):
+        ind_chr = np.nonzero((infos_chr == chrom) & ~excl)[0].astype(np.int64)
+        info, S, pos = infos_imp[ind_chr], lpS[ind_chr], infos_pos[ind_chr]
+        st = snp_colstats(G, ir, ind_chr)
+        sumX, denoX = st["sumX"], st["denoX"]
+        sp_id = np.arange(ind_chr.size, dtype=np.int32)      # row / column in spcor.chr
+        if np.any(np.diff(pos) < 0):
+            raise ValueError("'pos.chr' is not sorted.")
+        cap = 1 << 22
+        keys, vals = np.full(cap, -1, dtype=np.int64), np.zeros(cap)
+        ind_keep = []
+        for ti in THR_IMP:
+            sel = np.nonzero(info >= ti)[0]
+            ind_chr, info, pos, S = ind_chr[sel], info[sel], pos[sel], S[sel]
+            sumX, denoX, sp_id = sumX[sel], denoX[sel], sp_id[sel]
+            for group in groups:
+                ind2 = np.nonzero(np.isin(ind_chr, np.asarray(group, dtype=np.int64)))[0]
+                if ind2.size == 0:
+                    ind_keep += [np.zeros(0, dtype=np.int64)] * (THR_CLMP.size * BASE.size)
+                    continue
+                cols = _i64(ind_chr[ind2])
+                ord_ = r_order_decreasing(S[ind2]).astype(np.int32)
+                rank = _rank_from_order(ord_)
+                pos_g, sum_g, den_g = _f64(pos[ind2]), _f64(sumX[ind2]), _f64(denoX[ind2])
+                sp_g = _i32(sp_id[ind2])
+                for tc in THR_CLMP:
+                    for bs in BASE:
+                        keep = np.full(cols.size, -1, dtype=np.int32)
+                        with np.errstate(all="ignore"):
+                            computed += lib().orc_clumping_chr_cached(
+                                _p(flat, C.c_uint8), C.c_int64(G.n), _p(G.code256, C.c_double),
+                                _p(keys, C.c_int64), _p(vals, C.c_double), C.c_int64(cap),
+                                _p(sp_g, C.c_int32), _p(ir, C.c_int64), C.c_int64(ir.size),
+                                _p(cols, C.c_int64), C.c_int64(cols.size), _p(ord_, C.c_int32),
+                                _p(rank, C.c_int32), _p(pos_g, C.c_double), _p(sum_g, C.c_double),
+                                _p(den_g, C.c_double), C.c_double(1000.0 * bs / tc), C.c_double(tc),
+                                _p(keep, C.c_int32))
+                        assert np.all((keep == 0) | (keep == 1))
+                        ind_keep.append(cols[keep == 1])
+        all_keep.append(ind_keep)
+    return all_keep, grid, computed
+
+
+def snp_grid_PRS(G, all_keep, betas, lpS, grid_lpS_thr, ind_row=None):
+    """R/SCT.R:201-262 (scores only): one snp_PRS per clumping set, n x (sets * thresholds)"""
+    betas, lpS = _f64(betas), _f64(lpS)
+    ir = np.arange(G.n, dtype=np.int64) if ind_row is None else _i64(ind_row)
+    sets = [k for chrom in all_keep for k in chrom]
+    thr = np.atleast_1d(np.asarray(grid_lpS_thr, dtype=np.float64))
+    out = np.empty((ir.size, len(sets) * thr.size))
+    for ic, ind_keep in enumerate(sets):
+        out[:, ic * thr.size:(ic + 1) * thr.size] = snp_PRS(
+            G, betas[ind_keep], ind_test=ir, ind_keep=ind_keep, lpS_keep=lpS[ind_keep], thr_list=thr)
+    return out
