@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "bsn_internal.hpp"
+#include <type_traits>
 
 namespace bsn {
 
@@ -195,8 +196,8 @@ __global__ void k_quant(const double *X, int64_t ldx, int64_t len, int64_t len_p
 //   A operand: lane l -> variant row (l&15), k-group (l>>4): 16 samples of that variant
 //   B operand: lane l -> digit column (l&15), same 16 samples (from LDS)
 //   D        : lane l -> column (l&15), rows 4*(l>>4)+r
-template <int NB, int NPLANE, int KC, int ABL = 0, int TILES = 2, int WAVES = 8>
-__global__ __launch_bounds__(64 * WAVES) void k_cprod(const uint8_t *__restrict__ img, int64_t pitch,
+template <int NB, int NPLANE, int KC, int ABL = 0, int TILES = 2, int WAVES = 8, int MINW = 1>
+__global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__restrict__ img, int64_t pitch,
                                                const int32_t *__restrict__ cols, int64_t col0,
                                                int64_t m, const int8_t *__restrict__ xq,
                                                int32_t *__restrict__ acc_out, int64_t m_out,
@@ -231,40 +232,71 @@ __global__ __launch_bounds__(64 * WAVES) void k_cprod(const uint8_t *__restrict_
   constexpr int NX = (XS + NT - 1) / NT;   // staged uint4 per thread per chunk
   static_assert(NX <= 4, "staging registers");
   constexpr bool XFULL = (XS % NT == 0);   // every thread stages NX entries
-  uint4 a_cur[TILES][LD], a_nxt[TILES][LD];
+  // Two genotype register sets, chunk ch lives in set ch & 1.  A register is reloaded with the
+  // chunk two ahead as soon as its four K-steps are consumed (rolling prefetch): every wave
+  // keeps 4 - 8 loads in flight at all times instead of draining to zero at each chunk edge.
+  uint4 ga[2][TILES][LD];
   uint4 xr0 = {0, 0, 0, 0}, xr1 = {0, 0, 0, 0}, xr2 = {0, 0, 0, 0}, xr3 = {0, 0, 0, 0};
   // prologue
 #pragma unroll
   for (int t = 0; t < TILES; t++)
 #pragma unroll
-    for (int it = 0; it < LD; it++) a_cur[t][it] = *(const uint4 *)(rowp[t] + it * 64);
+    for (int it = 0; it < LD; it++) ga[0][t][it] = *(const uint4 *)(rowp[t] + it * 64);
   if (XFULL || tid < XS) xs[0][tid] = xq4[tid];
   if constexpr (NX > 1) xs[0][tid + NT] = xq4[tid + NT];
   if constexpr (NX > 2) xs[0][tid + 2 * NT] = xq4[tid + 2 * NT];
   if constexpr (NX > 3) xs[0][tid + 3 * NT] = xq4[tid + 3 * NT];
+#pragma unroll
+  for (int t = 0; t < TILES; t++)
+#pragma unroll
+    for (int it = 0; it < LD; it++)
+      ga[1][t][it] = *(const uint4 *)(rowp[t] + (nchunks > 1 ? KC / 4 : 0) + it * 64);
   __syncthreads();
 
-  for (int ch = 0; ch < nchunks; ch++) {
-    const int cur = ch & 1;
-    const bool has_next = ch + 1 < nchunks;
-    if (has_next) {
-      // issue order matters: the digit panel first, so that waiting for it later does not
-      // also wait for the (younger) genotype loads of the next chunk
-      const uint4 *src = xq4 + (int64_t)(ch + 1) * XS;
+  auto chunk = [&](auto SETC, const int ch) {
+    constexpr int SET = decltype(SETC)::value;
+    // No branches around the loads: a conditional load makes the compiler's waitcnt insertion
+    // fall back to vmcnt(0) at the join, which drains the prefetch.  Past the end the last
+    // chunk is simply loaded again (into registers / an LDS buffer nobody reads).
+    const int ch1 = ch + 1 < nchunks ? ch + 1 : nchunks - 1;
+    const int ch2 = ch + 2 < nchunks ? ch + 2 : nchunks - 1;
+    {
+      // the digit panel of the next chunk: into registers now, into LDS after the compute
+      const uint4 *src = xq4 + (int64_t)ch1 * XS;
       if (XFULL || tid < XS) xr0 = src[tid];
       if constexpr (NX > 1) xr1 = src[tid + NT];
       if constexpr (NX > 2) xr2 = src[tid + 2 * NT];
       if constexpr (NX > 3) xr3 = src[tid + 3 * NT];
-      const int64_t off = (int64_t)(ch + 1) * (KC / 4);
-#pragma unroll
-      for (int t = 0; t < TILES; t++)
-#pragma unroll
-        for (int it = 0; it < LD; it++)
-          a_nxt[t][it] = *(const uint4 *)(rowp[t] + off + it * 64);
     }
+    __builtin_amdgcn_sched_barrier(0);  // keep the digit loads up here, a chunk ahead of their use
+    const int64_t off2 = (int64_t)ch2 * (KC / 4);
+    // one K-step of one tile: 16 samples x 16 variants per lane-quad, decode + MFMAs
+    auto kstep = [&](const int t, const uint32_t w, const uint4 (&bv)[NB]) {
+      uint32_t s0 = w & 0x03030303u, s1 = (w >> 2) & 0x03030303u,
+               s2 = (w >> 4) & 0x03030303u, s3 = (w >> 6) & 0x03030303u;
+#pragma unroll
+      for (int p = 0; p < NPLANE; p++) {
+        const uint32_t lut = p == 0 ? lutA : p == 1 ? lutB : lutC;
+        v4i a;
+        if (ABL & 2) {  // ablation: no decode, raw bits as operand
+          a = v4i{(int)w, (int)(w ^ lut), (int)s1, (int)s3};
+        } else {
+          a = v4i{(int)lut4(lut, s0), (int)lut4(lut, s1), (int)lut4(lut, s2), (int)lut4(lut, s3)};
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+          v4i b = {(int)bv[nb].x, (int)bv[nb].y, (int)bv[nb].z, (int)bv[nb].w};
+          if (ABL & 1) {  // ablation: no MFMA, keep the operands alive
+            asm volatile("" ::"v"(a), "v"(b));
+          } else {
+            acc[t][p][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[t][p][nb], 0, 0, 0);
+          }
+        }
+      }
+    };
     uint4 bv[NB], bn[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; nb++) bv[nb] = xs[cur][(g * 4) * NCOL + nb * 16 + c];
+    for (int nb = 0; nb < NB; nb++) bv[nb] = xs[SET][(g * 4) * NCOL + nb * 16 + c];
     if (ABL & 4) {  // ablation: digit operand read once per chunk instead of once per K-step
 #pragma unroll
       for (int nb = 0; nb < NB; nb++) bn[nb] = bv[nb];
@@ -275,52 +307,49 @@ __global__ __launch_bounds__(64 * WAVES) void k_cprod(const uint8_t *__restrict_
       for (int d = 0; d < 4; d++) {
         // prefetch the digit operand of the next K-step so that its LDS latency hides
         // under this step's decode + MFMA
-        if (!(ABL & 4) && it * 4 + d + 1 < LD * 4) {
+        if (ABL & 16) {  // ablation: no LDS read of the digit operand
+#pragma unroll
+          for (int nb = 0; nb < NB; nb++) { bn[nb] = bv[nb]; bn[nb].x += 1; }
+        } else if (!(ABL & 4) && it * 4 + d + 1 < LD * 4) {
           const int itn = (it * 4 + d + 1) / 4, dn = (it * 4 + d + 1) % 4;
 #pragma unroll
-          for (int nb = 0; nb < NB; nb++) bn[nb] = xs[cur][(itn * 16 + g * 4 + dn) * NCOL + nb * 16 + c];
+          for (int nb = 0; nb < NB; nb++) bn[nb] = xs[SET][(itn * 16 + g * 4 + dn) * NCOL + nb * 16 + c];
         }
 #pragma unroll
         for (int t = 0; t < TILES; t++) {
-          const uint32_t w = d == 0 ? a_cur[t][it].x : d == 1 ? a_cur[t][it].y
-                             : d == 2 ? a_cur[t][it].z : a_cur[t][it].w;
-          uint32_t s0 = w & 0x03030303u, s1 = (w >> 2) & 0x03030303u,
-                   s2 = (w >> 4) & 0x03030303u, s3 = (w >> 6) & 0x03030303u;
-#pragma unroll
-          for (int p = 0; p < NPLANE; p++) {
-            const uint32_t lut = p == 0 ? lutA : p == 1 ? lutB : lutC;
-            v4i a;
-            if (ABL & 2) {  // ablation: no decode, raw bits as operand
-              a = v4i{(int)w, (int)(w ^ lut), (int)s1, (int)s3};
-            } else {
-              a = v4i{(int)lut4(lut, s0), (int)lut4(lut, s1), (int)lut4(lut, s2), (int)lut4(lut, s3)};
-            }
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++) {
-              v4i b = {(int)bv[nb].x, (int)bv[nb].y, (int)bv[nb].z, (int)bv[nb].w};
-              if (ABL & 1) {  // ablation: no MFMA, keep the operands alive
-                asm volatile("" ::"v"(a), "v"(b));
-              } else {
-                acc[t][p][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[t][p][nb], 0, 0, 0);
-              }
-            }
-          }
+          const uint32_t w = d == 0 ? ga[SET][t][it].x : d == 1 ? ga[SET][t][it].y
+                             : d == 2 ? ga[SET][t][it].z : ga[SET][t][it].w;
+          kstep(t, w, bv);
         }
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) bv[nb] = bn[nb];
       }
     }
-    if (has_next) {
-      if (XFULL || tid < XS) xs[cur ^ 1][tid] = xr0;
-      if constexpr (NX > 1) xs[cur ^ 1][tid + NT] = xr1;
-      if constexpr (NX > 2) xs[cur ^ 1][tid + 2 * NT] = xr2;
-      if constexpr (NX > 3) xs[cur ^ 1][tid + 3 * NT] = xr3;
-    }
-    __syncthreads();
+    // This set is consumed: refill it with the chunk two ahead.  All loads of a tile go out
+    // back to back so that both 64-B halves of every 128-B line are requested together
+    // (refilling half-way through the chunk, one half at a time, costs 8 % of the bandwidth).
 #pragma unroll
     for (int t = 0; t < TILES; t++)
 #pragma unroll
-      for (int it = 0; it < LD; it++) a_cur[t][it] = a_nxt[t][it];
+      for (int it = 0; it < LD; it++) {
+        if (ABL & 32) {  // ablation: no genotype loads after the prologue
+          ga[SET][t][it].x ^= (uint32_t)off2;
+        } else {
+          ga[SET][t][it] = *(const uint4 *)(rowp[t] + off2 + it * 64);
+        }
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      if (XFULL || tid < XS) xs[SET ^ 1][tid] = xr0;
+      if constexpr (NX > 1) xs[SET ^ 1][tid + NT] = xr1;
+      if constexpr (NX > 2) xs[SET ^ 1][tid + 2 * NT] = xr2;
+      if constexpr (NX > 3) xs[SET ^ 1][tid + 3 * NT] = xr3;
+    }
+    if (!(ABL & 8)) __syncthreads();  // ablation 8: no barrier
+  };
+  for (int ch = 0; ch < nchunks; ch += 2) {
+    chunk(std::integral_constant<int, 0>{}, ch);
+    if (ch + 1 < nchunks) chunk(std::integral_constant<int, 1>{}, ch + 1);  // (odd only for KC = 1024)
   }
 
   // raw accumulators: acc_out[plane][variant][NCOL]
@@ -374,7 +403,7 @@ __global__ void k_cprod_final(const int32_t *acc, int64_t m, int ncol, int S, co
 //   A operand: lane l -> digit column (l&15), k-group (l>>4): 16 variants' digits
 //   B operand: lane l -> sample group (l&15), same 16 variants, sample u of the group
 //   D        : lane l -> sample group (l&15), digit columns 4*(l>>4)+r
-template <int NB, bool CONTIG, int WAVES = 4>
+template <int NB, bool CONTIG, int WAVES = 4, int ABL = 0, int UG = 1>
 __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__ img, int64_t pitch,
                                               const int32_t *__restrict__ cols, int64_t col0,
                                               int64_t m_pad, int64_t mc,
@@ -404,8 +433,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
   // contiguous in wq; shared by the 4 waves through LDS, double-buffered
   constexpr int WS = 8 * NCOL;
   __shared__ uint4 ws[2][WS];
-  uint32_t X[16], Xn[16];
+  static_assert((WS & (WS - 1)) == 0 && WS <= 64 * WAVES, "digit staging");
+  // Two genotype register sets, step s lives in set s & 1 (as in k_cprod): a set is free as
+  // soon as its 4x4 byte transposes are done, so it is refilled with the step two ahead
+  // right there.  No branches around loads (see k_cprod); past the end the last step is
+  // loaded again.
+  uint32_t X[2][16];
   uint4 wreg = {0, 0, 0, 0};
+  const int wtid = tid & (WS - 1);
   auto load = [&](int64_t jb, uint32_t *dst) {
     if (CONTIG) {
       const uint8_t *sbase = img + (col0 + jb) * pitch;
@@ -423,23 +458,24 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
       }
     }
   };
-  if (j0 < j1) {
-    if (tid < WS) ws[0][tid] = wq4[(j0 / 16) * 2 * NCOL + tid];
-    load(j0, X);
-  }
+  // j0 < j1 by the launch geometry of prod_planes (every K-slab has at least one step)
+  if (j0 >= j1) return;  // never taken; without it the compiler allocates 144 instead of 80 VGPRs
+  const int64_t jlast = j1 - 64;
+  ws[0][wtid] = wq4[(j0 / 16) * 2 * NCOL + wtid];
+  load(j0, X[0]);
+  load(j0 + 64 < j1 ? j0 + 64 : jlast, X[1]);
   __syncthreads();
-  int cur = 0;
-  for (int64_t jb = j0; jb < j1; jb += 64) {
-    const bool has_next = jb + 64 < j1;
-    if (has_next) {
-      if (tid < WS) wreg = wq4[((jb + 64) / 16) * 2 * NCOL + tid];  // first: see k_cprod
-      load(jb + 64, Xn);
-    }
+
+  auto step = [&](auto SETC, const int64_t jb) {
+    constexpr int SET = decltype(SETC)::value;
+    const int64_t jn1 = jb + 64 < j1 ? jb + 64 : jlast, jn2 = jb + 128 < j1 ? jb + 128 : jlast;
+    wreg = wq4[(jn1 / 16) * 2 * NCOL + wtid];  // next step's digits: registers now, LDS later
+    __builtin_amdgcn_sched_barrier(0);
     v4i aw[NB], awc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
-      uint4 t0 = ws[cur][(g * 2 + 0) * NCOL + nb * 16 + sg];
-      uint4 t1 = ws[cur][(g * 2 + 1) * NCOL + nb * 16 + sg];
+      uint4 t0 = ws[SET][(g * 2 + 0) * NCOL + nb * 16 + sg];
+      uint4 t1 = ws[SET][(g * 2 + 1) * NCOL + nb * 16 + sg];
       aw[nb] = v4i{(int)t0.x, (int)t0.y, (int)t0.z, (int)t0.w};
       awc[nb] = v4i{(int)t1.x, (int)t1.y, (int)t1.z, (int)t1.w};
     }
@@ -447,7 +483,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
     uint32_t T[4][4];
 #pragma unroll
     for (int r4 = 0; r4 < 4; r4++) {
-      const uint32_t x0 = X[4 * r4], x1 = X[4 * r4 + 1], x2 = X[4 * r4 + 2], x3 = X[4 * r4 + 3];
+      const uint32_t x0 = X[SET][4 * r4], x1 = X[SET][4 * r4 + 1], x2 = X[SET][4 * r4 + 2],
+                     x3 = X[SET][4 * r4 + 3];
       const uint32_t lo01 = perm8(x1, x0, 0x05010400u);  // x0.b0 x1.b0 x0.b1 x1.b1
       const uint32_t hi01 = perm8(x1, x0, 0x07030602u);  // x0.b2 x1.b2 x0.b3 x1.b3
       const uint32_t lo23 = perm8(x3, x2, 0x05010400u);
@@ -457,30 +494,58 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
       T[2][r4] = perm8(hi23, hi01, 0x05040100u);
       T[3][r4] = perm8(hi23, hi01, 0x07060302u);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ABL & 32) {  // ablation: no genotype loads after the prologue
+#pragma unroll
+      for (int r = 0; r < 16; r++) X[SET][r] += (uint32_t)jn2;
+    } else {
+      load(jn2, X[SET]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // G samples are decoded together and their MFMAs interleaved (g0 of all, then na of all);
+    // G = 1, 2, 4 time the same (profiles/r01_ablation.txt), so the smallest is used
+    constexpr int G = UG;
 #pragma unroll
     for (int q = 0; q < 4; q++)
 #pragma unroll
-      for (int uu = 0; uu < 4; uu++) {
-        v4i g0, na;
+      for (int u0 = 0; u0 < 4; u0 += G) {
+        v4i g0[G], na[G];
 #pragma unroll
-        for (int r4 = 0; r4 < 4; r4++) {
-          const uint32_t sel = (T[q][r4] >> (2 * uu)) & 0x03030303u;
-          g0[r4] = (int)lut4(lutP, sel);
-          na[r4] = (int)lut4(lutQ, sel);
-        }
+        for (int k = 0; k < G; k++)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; r4++) {
+            const uint32_t sel = (T[q][r4] >> (2 * (u0 + k))) & 0x03030303u;
+            if (ABL & 2) {  // ablation: no decode
+              g0[k][r4] = (int)T[q][r4];
+              na[k][r4] = (int)(T[q][r4] ^ lutQ);
+            } else {
+              g0[k][r4] = (int)lut4(lutP, sel);
+              na[k][r4] = (int)lut4(lutQ, sel);
+            }
+          }
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) {
-          acc[q * 4 + uu][nb] =
-              __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[nb], g0, acc[q * 4 + uu][nb], 0, 0, 0);
-          acc[q * 4 + uu][nb] =
-              __builtin_amdgcn_mfma_i32_16x16x64_i8(awc[nb], na, acc[q * 4 + uu][nb], 0, 0, 0);
+          if (ABL & 1) {  // ablation: no MFMA
+#pragma unroll
+            for (int k = 0; k < G; k++) asm volatile("" ::"v"(g0[k]), "v"(na[k]), "v"(aw[nb]), "v"(awc[nb]));
+          } else {
+#pragma unroll
+            for (int k = 0; k < G; k++)
+              acc[q * 4 + u0 + k][nb] =
+                  __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[nb], g0[k], acc[q * 4 + u0 + k][nb], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < G; k++)
+              acc[q * 4 + u0 + k][nb] =
+                  __builtin_amdgcn_mfma_i32_16x16x64_i8(awc[nb], na[k], acc[q * 4 + u0 + k][nb], 0, 0, 0);
+          }
         }
       }
-    if (has_next && tid < WS) ws[cur ^ 1][tid] = wreg;
+    ws[SET ^ 1][wtid] = wreg;
     __syncthreads();
-    cur ^= 1;
-#pragma unroll
-    for (int r = 0; r < 16; r++) X[r] = Xn[r];
+  };
+  for (int64_t jb = j0; jb < j1; jb += 128) {
+    step(std::integral_constant<int, 0>{}, jb);
+    if (jb + 64 < j1) step(std::integral_constant<int, 1>{}, jb + 64);
   }
   // raw accumulators: acc_out[ky][sample][NCOL], lane holds columns nb*16 + 4g .. +3
   if (active) {
@@ -619,17 +684,24 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
   constexpr int KC = 512;
   dim3 grid((unsigned)((op->m + 255) / 256));
   const int32_t *cols = op->cols_contig ? nullptr : op->d_cols.p;
-  // BSN_TUNE = 11 / 12 / 13 / 14 select the ablation builds (no MFMA / no decode / neither /
-  // digit operand read once per chunk) used
-  // for profiles/r01_ablation.txt; they produce wrong numbers by construction.
+  // BSN_TUNE = 11 / 12 / 13 / 14 / 15 / 16 / 17 / 18 / 19 select the ablation builds (no MFMA /
+  // no decode / neither / digit operand read once per chunk / no barrier / no LDS operand reads /
+  // no genotype loads / no LDS at all / compute only) used for profiles/r01_ablation.txt; they
+  // produce wrong numbers by construction.
   const int abl = tune_variant();
-#define BSN_LAUNCH_CPROD(NBV, ABLV)                                                              \
-  hipLaunchKernelGGL((k_cprod<NBV, NPLANE, KC, ABLV>), grid, dim3(512), 0, b->stream, b->d_img, \
-                     b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2)
+#define BSN_LAUNCH_CPROD_W(NBV, ABLV, MINWV)                                                        \
+  hipLaunchKernelGGL((k_cprod<NBV, NPLANE, KC, ABLV, 2, 8, MINWV>), grid, dim3(512), 0, b->stream, \
+                     b->d_img, b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2)
+#define BSN_LAUNCH_CPROD(NBV, ABLV) BSN_LAUNCH_CPROD_W(NBV, ABLV, 1)
   if (NB == 1) {
     if (abl == 11) BSN_LAUNCH_CPROD(1, 1);
     else if (abl == 12) BSN_LAUNCH_CPROD(1, 2);
     else if (abl == 13) BSN_LAUNCH_CPROD(1, 3);
+    else if (abl == 15) BSN_LAUNCH_CPROD(1, 8);
+    else if (abl == 16) BSN_LAUNCH_CPROD(1, 16);
+    else if (abl == 17) BSN_LAUNCH_CPROD(1, 32);
+    else if (abl == 18) BSN_LAUNCH_CPROD(1, 24);
+    else if (abl == 19) BSN_LAUNCH_CPROD(1, 56);
     else BSN_LAUNCH_CPROD(1, 0);
   } else {
     if (abl == 11) BSN_LAUNCH_CPROD(2, 1);
@@ -639,6 +711,7 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
     else BSN_LAUNCH_CPROD(2, 0);
   }
 #undef BSN_LAUNCH_CPROD
+#undef BSN_LAUNCH_CPROD_W
   BSN_HIP(hipGetLastError());
 }
 
@@ -701,6 +774,17 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
     dim3 grid((unsigned)wgx, (unsigned)ky);
     const int32_t *cols = op->d_cols.p;
     prof_begin(op, 1);
+    if (tune_variant() >= 61 && tune_variant() <= 64 && NB == 1 && op->cols_contig) {
+      const int tv = tune_variant();
+#define BSN_LAUNCH_PROD_ABL(A)                                                                        \
+  hipLaunchKernelGGL((k_prod<1, true, 4, A>), grid, dim3(256), 0, b->stream, b->d_img, b->pitch, cols, \
+                     op->col0, m_pad, mc, q, acc, npad, lutP, lutQ)
+      if (tv == 61) BSN_LAUNCH_PROD_ABL(1);        // no MFMA
+      else if (tv == 62) BSN_LAUNCH_PROD_ABL(2);   // no decode
+      else if (tv == 63) BSN_LAUNCH_PROD_ABL(3);   // memory skeleton
+      else BSN_LAUNCH_PROD_ABL(32);                // compute only
+#undef BSN_LAUNCH_PROD_ABL
+    } else
     if (op->cols_contig) {
       if (NB == 1)
         hipLaunchKernelGGL((k_prod<1, true>), grid, dim3(256), 0, b->stream, b->d_img, b->pitch,
