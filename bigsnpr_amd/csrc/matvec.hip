@@ -403,7 +403,7 @@ __global__ void k_cprod_final(const int32_t *acc, int64_t m, int ncol, int S, co
 //   A operand: lane l -> digit column (l&15), k-group (l>>4): 16 variants' digits
 //   B operand: lane l -> sample group (l&15), same 16 variants, sample u of the group
 //   D        : lane l -> sample group (l&15), digit columns 4*(l>>4)+r
-template <int NB, bool CONTIG, int WAVES = 4, int ABL = 0, int UG = 1>
+template <int NB, bool CONTIG, int WAVES = 4, int ABL = 0, int UG = 1, int SETS = 2>
 __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__ img, int64_t pitch,
                                               const int32_t *__restrict__ cols, int64_t col0,
                                               int64_t m_pad, int64_t mc,
@@ -438,14 +438,18 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
   // soon as its 4x4 byte transposes are done, so it is refilled with the step two ahead
   // right there.  No branches around loads (see k_cprod); past the end the last step is
   // loaded again.
-  uint32_t X[2][16];
+  uint32_t X[SETS][16];
   uint4 wreg = {0, 0, 0, 0};
   const int wtid = tid & (WS - 1);
   auto load = [&](int64_t jb, uint32_t *dst) {
     if (CONTIG) {
-      const uint8_t *sbase = img + (col0 + jb) * pitch;
+      // buffer loads: scalar descriptor (re-based per step) + scalar row offset + one 32-bit lane
+      // offset, so the 16 addresses of a step cost no VALU (global loads took a 64-bit add each)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void *)(img + (col0 + jb) * pitch), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-      for (int r = 0; r < 16; r++) dst[r] = *(const uint32_t *)(sbase + (int64_t)r * pitch + lane_off);
+      for (int r = 0; r < 16; r++)
+        dst[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)lane_off, r * (int)pitch, 0);
     } else {
       const int4 *ip = (const int4 *)(cols + jb + g * 16);
 #pragma unroll
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
   const int64_t jlast = j1 - 64;
   ws[0][wtid] = wq4[(j0 / 16) * 2 * NCOL + wtid];
   load(j0, X[0]);
-  load(j0 + 64 < j1 ? j0 + 64 : jlast, X[1]);
+  if constexpr (SETS == 2) load(j0 + 64 < j1 ? j0 + 64 : jlast, X[1]);
   __syncthreads();
 
   auto step = [&](auto SETC, const int64_t jb) {
@@ -483,8 +487,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
     uint32_t T[4][4];
 #pragma unroll
     for (int r4 = 0; r4 < 4; r4++) {
-      const uint32_t x0 = X[SET][4 * r4], x1 = X[SET][4 * r4 + 1], x2 = X[SET][4 * r4 + 2],
-                     x3 = X[SET][4 * r4 + 3];
+      constexpr int XS_ = SETS == 2 ? SET : 0;
+      const uint32_t x0 = X[XS_][4 * r4], x1 = X[XS_][4 * r4 + 1], x2 = X[XS_][4 * r4 + 2],
+                     x3 = X[XS_][4 * r4 + 3];
       const uint32_t lo01 = perm8(x1, x0, 0x05010400u);  // x0.b0 x1.b0 x0.b1 x1.b1
       const uint32_t hi01 = perm8(x1, x0, 0x07030602u);  // x0.b2 x1.b2 x0.b3 x1.b3
       const uint32_t lo23 = perm8(x3, x2, 0x05010400u);
@@ -497,9 +502,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
     __builtin_amdgcn_sched_barrier(0);
     if (ABL & 32) {  // ablation: no genotype loads after the prologue
 #pragma unroll
-      for (int r = 0; r < 16; r++) X[SET][r] += (uint32_t)jn2;
+      for (int r = 0; r < 16; r++) X[SETS == 2 ? SET : 0][r] += (uint32_t)jn2;
     } else {
-      load(jn2, X[SET]);
+      load(SETS == 2 ? jn2 : jn1, X[SETS == 2 ? SET : 0]);
     }
     __builtin_amdgcn_sched_barrier(0);
     // G samples are decoded together and their MFMAs interleaved (g0 of all, then na of all);
@@ -749,6 +754,8 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
   bsn_bed *b = op->bed;
   const int vmax = 32 / S;
   if (nvec <= 0) return;
+  // k_prod addresses a 64-variant step with 32-bit offsets from its first row
+  if (b->pitch >= ((int64_t)1 << 24)) fail("more than 6.7e7 samples are not supported by the product kernel");
   const int64_t npad = b->pitch * 4;
   const int64_t m_pad = round_up(op->m, 64);
   VecMeta *meta = (VecMeta *)op->d_meta.ensure(8 * 64);
