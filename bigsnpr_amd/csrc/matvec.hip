@@ -98,7 +98,20 @@ __global__ void k_absmax(const double *X, int64_t ldx, int64_t len, const double
     mx = fmax(mx, __shfl_down(mx, off));
     bad += __shfl_down(bad, off);
   }
+  // one atomic per workgroup: thousands of same-address 64-bit atomics cost ~20 ns each
+  __shared__ double smx[16];
+  __shared__ unsigned long long sbad[16];
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   if ((threadIdx.x & 63) == 0) {
+    smx[wave] = mx;
+    sbad[wave] = bad;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < nw; w++) {
+      mx = fmax(mx, smx[w]);
+      bad += sbad[w];
+    }
     atomicMax(&meta[v].absmax_bits, (unsigned long long)__double_as_longlong(mx));
     if (bad) atomicAdd(&meta[v].nonfinite, bad);
   }
@@ -126,59 +139,81 @@ __device__ __forceinline__ void digits_of(long long X, int S, int8_t *d) {
   }
 }
 
-// One thread quantises 16 consecutive k of one vector into S digit rows of 16 bytes.
+// One wave quantises 1024 consecutive k of one vector; a thread ends up with 16 of them as S
+// digit rows of 16 bytes.
 // Layout: q[(k/16) * (nplanes*ncol) + plane*ncol + col][16 B], col = v*S + s.
-// permute = 1 (cprod operand): sample e of the 16 is stored at byte (e%4)*4 + e/4, the
-// order in which k_cprod's decode emits them;  permute = 0 (prod operand): natural.
-__global__ void k_quant(const double *X, int64_t ldx, int64_t len, int64_t len_pad,
-                        const double *center, const double *scale, int mode, int S, int ncol,
-                        int permute, VecMeta *meta, int8_t *q) {
-  int64_t kb = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // 16-block index
-  int v = blockIdx.y;
-  int nplanes = mode >= 1 ? 2 : 1;
+// PERM = 1 (cprod operand): sample e of the 16 is stored at byte (e%4)*4 + e/4, the
+// order in which k_cprod's decode emits them;  PERM = 0 (prod operand): natural.
+// The values are read coalesced and handed over through LDS (row stride 17 against bank
+// conflicts); the digit bytes are packed in registers (S and PERM are compile-time).
+template <int S, int PERM>
+__global__ __launch_bounds__(64) void k_quant(const double *__restrict__ X, int64_t ldx, int64_t len,
+                                              int64_t len_pad, const double *__restrict__ center,
+                                              const double *__restrict__ scale, int mode, int ncol,
+                                              VecMeta *meta, int8_t *__restrict__ q) {
+  __shared__ double sa[64 * 17], sb[64 * 17];
+  const int tid = threadIdx.x, v = blockIdx.y;
+  const int64_t kb = (int64_t)blockIdx.x * 64 + tid;  // 16-block index of this thread
+  const int nplanes = mode >= 1 ? 2 : 1;
+  const double qs = meta[v].qscale;
+  for (int t = tid; t < 1024; t += 64) {
+    const int64_t k = (int64_t)blockIdx.x * 1024 + t;
+    double a = 0, b = 0;
+    if (k < len) {
+      a = X[k + v * ldx];
+      if (mode == 1) {
+        const double sc = scale ? scale[k] : 1.0, c = center ? center[k] : 0.0;
+        a = a / sc;
+        b = c * a;
+      } else if (mode == 2) {
+        b = center ? center[k + v * ldx] : 0.0;
+      }
+    }
+    if (!(fabs(a) <= 1.79e308)) a = 0;
+    if (!(fabs(b) <= 1.79e308)) b = 0;
+    sa[t + (t >> 4)] = a * qs;
+    sb[t + (t >> 4)] = b * qs;
+  }
+  __syncthreads();
   long long shi = 0, slo = 0, shi2 = 0, slo2 = 0;
   if (kb * 16 < len_pad) {
-    double qs = meta[v].qscale;
-    int8_t dg[2][8][16];
+    uint32_t pk[2][S][4];
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+      for (int s = 0; s < S; s++)
+#pragma unroll
+        for (int w = 0; w < 4; w++) pk[p][s][w] = 0;
 #pragma unroll
     for (int e = 0; e < 16; e++) {
-      int64_t k = kb * 16 + e;
-      double a = 0, b = 0;
-      if (k < len) {
-        a = X[k + v * ldx];
-        if (mode == 1) {
-          double s = scale ? scale[k] : 1.0, c = center ? center[k] : 0.0;
-          a = a / s;
-          b = c * a;
-        } else if (mode == 2) {
-          b = center ? center[k + v * ldx] : 0.0;
-        }
-      }
-      if (!(fabs(a) <= 1.79e308)) a = 0;
-      if (!(fabs(b) <= 1.79e308)) b = 0;
-      long long A = llrint(a * qs), B = llrint(b * qs);
+      long long A = llrint(sa[tid * 17 + e]), B = llrint(sb[tid * 17 + e]);
       shi += A >> 24; slo += A & 0xFFFFFF;
       shi2 += B >> 24; slo2 += B & 0xFFFFFF;
-      int pos = permute ? ((e & 3) * 4 + (e >> 2)) : e;
-      int8_t d[8];
-      digits_of(A, S, d);
-      for (int s = 0; s < S; s++) dg[0][s][pos] = d[s];
-      if (mode >= 1) {
-        digits_of(B, S, d);
-        for (int s = 0; s < S; s++) dg[1][s][pos] = d[s];
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int pos = PERM ? ((e & 3) * 4 + (e >> 2)) : e;
+#pragma unroll
+      for (int s = 0; s < S; s++) {
+        const int8_t da = (int8_t)(A & 0xFF), db = (int8_t)(B & 0xFF);
+        A = (A - da) >> 8;
+        B = (B - db) >> 8;
+        pk[0][s][pos >> 2] |= (uint32_t)(uint8_t)da << (8 * (pos & 3));
+        pk[1][s][pos >> 2] |= (uint32_t)(uint8_t)db << (8 * (pos & 3));
       }
     }
     for (int p = 0; p < nplanes; p++)
+#pragma unroll
       for (int s = 0; s < S; s++) {
         int8_t *dst = q + ((kb * nplanes + p) * ncol + (v * S + s)) * 16;
-        *(uint4 *)dst = *(const uint4 *)dg[p][s];
+        *(uint4 *)dst = p == 0 ? uint4{pk[0][s][0], pk[0][s][1], pk[0][s][2], pk[0][s][3]}
+                               : uint4{pk[1][s][0], pk[1][s][1], pk[1][s][2], pk[1][s][3]};
       }
   }
   for (int off = 32; off > 0; off >>= 1) {
     shi += __shfl_down(shi, off); slo += __shfl_down(slo, off);
     shi2 += __shfl_down(shi2, off); slo2 += __shfl_down(slo2, off);
   }
-  if ((threadIdx.x & 63) == 0) {
+  if (tid == 0) {
     atomicAdd((unsigned long long *)&meta[v].sum_hi, (unsigned long long)shi);
     atomicAdd((unsigned long long *)&meta[v].sum_lo, (unsigned long long)slo);
     if (mode >= 1) {
@@ -643,9 +678,9 @@ static void quantise(bsn_op *op, const double *d_X, int64_t ldx, int64_t len, in
   hipStream_t st = op->bed->stream;
   hipLaunchKernelGGL(k_meta_clear, dim3(1), dim3(64), 0, st, meta, nvec);
   if (!exact_int) {
-    int gx = (int)((len + 255) / 256);
-    if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(k_absmax, dim3(gx, nvec), dim3(256), 0, st, d_X, ldx, len,
+    int gx = (int)((len + 1023) / 1024);
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(k_absmax, dim3(gx, nvec), dim3(1024), 0, st, d_X, ldx, len,
                        mode == 1 ? op->d_center.p : mode == 2 ? d_W2 : nullptr,
                        mode == 1 ? op->d_scale.p : nullptr, mode, meta);
   }
@@ -653,9 +688,23 @@ static void quantise(bsn_op *op, const double *d_X, int64_t ldx, int64_t len, in
   int nplanes = mode >= 1 ? 2 : 1;
   BSN_HIP(hipMemsetAsync(q, 0, (size_t)(len_pad / 16) * nplanes * ncol * 16, st));
   int64_t nblk = len_pad / 16;
-  hipLaunchKernelGGL(k_quant, dim3((unsigned)((nblk + 63) / 64), nvec), dim3(64), 0, st, d_X, ldx,
-                     len, len_pad, mode == 1 ? op->d_center.p : mode == 2 ? d_W2 : nullptr,
-                     mode == 1 ? op->d_scale.p : nullptr, mode, S, ncol, permute, meta, q);
+  const double *qc = mode == 1 ? op->d_center.p : mode == 2 ? d_W2 : nullptr;
+  const double *qsc = mode == 1 ? op->d_scale.p : nullptr;
+  const dim3 qgrid((unsigned)((nblk + 63) / 64), nvec);
+#define BSN_QUANT(SV)                                                                                  \
+  case SV:                                                                                             \
+    if (permute)                                                                                       \
+      hipLaunchKernelGGL((k_quant<SV, 1>), qgrid, dim3(64), 0, st, d_X, ldx, len, len_pad, qc, qsc, mode, \
+                         ncol, meta, q);                                                               \
+    else                                                                                               \
+      hipLaunchKernelGGL((k_quant<SV, 0>), qgrid, dim3(64), 0, st, d_X, ldx, len, len_pad, qc, qsc, mode, \
+                         ncol, meta, q);                                                               \
+    break;
+  switch (S) {
+    BSN_QUANT(1) BSN_QUANT(2) BSN_QUANT(3) BSN_QUANT(4) BSN_QUANT(5) BSN_QUANT(6) BSN_QUANT(7) BSN_QUANT(8)
+    default: fail("slices must be in 1..8");
+  }
+#undef BSN_QUANT
   BSN_HIP(hipGetLastError());
 }
 

@@ -74,13 +74,17 @@ __global__ __launch_bounds__(256) void k_gemm_tn_part(const double *__restrict__
   }
 }
 
-__global__ void k_gemm_tn_reduce(const double *partial, int nrc, int p, int cb, double *C) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per output element, fixed summation order (lane-strided partial sums, then a
+// shuffle tree): the result is identical on every rank and in every run
+__global__ __launch_bounds__(256) void k_gemm_tn_reduce(const double *partial, int nrc, int p, int cb,
+                                                        double *C) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (t >= p * cb) return;
-  int a = t % p, j = t / p;
+  const int a = t % p, j = t / p;
   double s = 0;
-  for (int rc = 0; rc < nrc; rc++) s += partial[((int64_t)rc * p + a) * kMaxB + j];
-  C[a + (int64_t)j * p] = s;
+  for (int rc = lane; rc < nrc; rc += 64) s += partial[((int64_t)rc * p + a) * kMaxB + j];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if (lane == 0) C[a + (int64_t)j * p] = s;
 }
 
 // Out[i, j] = alpha * In[i, j] + beta * sum_a Q[i, a] S[a, j],  j < nc <= 8; S (p x nc) in global
@@ -143,12 +147,74 @@ __global__ void k_right_mult(double *W, int64_t ld, int64_t n, int cb, int r, co
     if (c < r) W[i + c * ld] = o[c];
 }
 
+// One normalisation pass of the block orthonormalisation on the device (single thread; b <= 12):
+// the arithmetic of chol_upper / inv_upper (dense_small.hpp) and of the rank tests of
+// svd_driver.hpp's orth().  G0 = W'W before the projections (scale of the deficiency test,
+// pass 0 only), G = W'W now.  Writes Ri = R^-1, Rout = R (pass 0) or R * Rout (pass 1), and
+// raises *flag when W is not numerically of full rank (the host then redoes the step on the
+// step-by-step path).
+__global__ void k_orth_small(const double *G0, const double *G, int b, int pass, double *Ri,
+                             double *Rout, double *flag) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double R[kMaxB * kMaxB], Rn[kMaxB * kMaxB];
+  for (int t = 0; t < b * b; t++) R[t] = 0.0, Ri[t] = 0.0;
+  bool bad = false;
+  if (pass == 0) {
+    double w0 = 0;
+    for (int i = 0; i < b; i++) w0 = fmax(w0, G0[i + i * b]);
+    for (int i = 0; i < b; i++)
+      if (!(G[i + i * b] > 1e-22 * w0 && w0 > 0)) bad = true;
+  }
+  double dmax = 0;
+  for (int i = 0; i < b; i++) dmax = fmax(dmax, G[i + i * b]);
+  for (int j = 0; j < b && !bad; j++) {
+    double s = G[j + j * b];
+    for (int k = 0; k < j; k++) s -= R[k + j * b] * R[k + j * b];
+    if (!(s > 1e-22 * dmax) || !(dmax > 0)) {
+      bad = true;
+      break;
+    }
+    const double rjj = sqrt(s);
+    R[j + j * b] = rjj;
+    for (int i = j + 1; i < b; i++) {
+      double t = G[j + i * b];
+      for (int k = 0; k < j; k++) t -= R[k + j * b] * R[k + i * b];
+      R[j + i * b] = t / rjj;
+    }
+  }
+  if (bad) {
+    *flag = 1.0;
+    for (int i = 0; i < b; i++) Ri[i + i * b] = 1.0;  // keep the following kernels finite
+    return;
+  }
+  for (int j = 0; j < b; j++) {
+    Ri[j + j * b] = 1.0 / R[j + j * b];
+    for (int i = j - 1; i >= 0; i--) {
+      double s = 0;
+      for (int k = i + 1; k <= j; k++) s += R[i + k * b] * Ri[k + j * b];
+      Ri[i + j * b] = -s / R[i + i * b];
+    }
+  }
+  if (pass == 0) {
+    for (int t = 0; t < b * b; t++) Rout[t] = R[t];
+  } else {
+    for (int j = 0; j < b; j++)
+      for (int i = 0; i < b; i++) {
+        double s = 0;
+        for (int t = i; t < b; t++) s += R[i + t * b] * Rout[t + j * b];
+        Rn[i + j * b] = s;
+      }
+    for (int t = 0; t < b * b; t++) Rout[t] = Rn[t];
+  }
+}
+
 struct HipSvdBackend : SvdBackend {
   bsn_op *op = nullptr;
   hipStream_t st = nullptr;
   bsn_allreduce_fn allreduce = nullptr;
   void *ctx = nullptr;
-  DevBuf<double> Q, Z, W, partial, dsmall, tmp;
+  DevBuf<double> Q, Z, W, partial, dsmall, tmp, Wsave, dorth;
+  std::vector<double> horth;
   int cap = 0, b = 0;
   int64_t rows_per = 0;
   int nrc = 0;
@@ -164,6 +230,8 @@ struct HipSvdBackend : SvdBackend {
     nrc = (int)((n + rows_per - 1) / rows_per);
     partial.ensure((size_t)nrc * (cap + 4) * kMaxB);
     dsmall.ensure((size_t)(cap + 4) * 64);
+    Wsave.ensure((size_t)n * kMaxB);
+    dorth.ensure((size_t)8 * kMaxB * kMaxB + (size_t)3 * (cap + 4) * kMaxB);
   }
   void random_W(int bb, uint32_t seed) override {
     hipLaunchKernelGGL(k_random, dim3((unsigned)((n + 255) / 256), bb), dim3(256), 0, st, W.p, n, n,
@@ -184,11 +252,61 @@ struct HipSvdBackend : SvdBackend {
     dim3 grid((unsigned)((p + 3) / 4), (unsigned)nrc);
     hipLaunchKernelGGL(k_gemm_tn_part, grid, dim3(256), 0, st, A, n, p, W.p, n, cb, n, rows_per,
                        partial.p);
-    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((p * cb + 255) / 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((p * cb + 3) / 4)), dim3(256), 0, st,
                        partial.p, nrc, p, cb, dsmall.p);
     BSN_HIP(hipGetLastError());
     BSN_HIP(hipMemcpyAsync(C_host, dsmall.p, (size_t)p * cb * 8, hipMemcpyDeviceToHost, st));
     BSN_HIP(hipStreamSynchronize(st));
+  }
+  void gemm_tn_dev(const double *A, int p, int cb, double *dC) {
+    dim3 grid((unsigned)((p + 3) / 4), (unsigned)nrc);
+    hipLaunchKernelGGL(k_gemm_tn_part, grid, dim3(256), 0, st, A, n, p, W.p, n, cb, n, rows_per,
+                       partial.p);
+    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((p * cb + 3) / 4)), dim3(256), 0, st,
+                       partial.p, nrc, p, cb, dC);
+  }
+  // The whole orth() of svd_driver.hpp queued on the stream with the small matrices kept on
+  // the device: one host synchronisation per block step instead of eleven.
+  int orth_fused(int p, int cb, std::vector<double> &Cacc, std::vector<double> &Rout) override {
+    if (cb <= 0 || cb > kMaxB) return -1;
+    constexpr int B2 = kMaxB * kMaxB;
+    // arena: [flag | Rout | C1 | C2] is downloaded in one piece; then G0, G, Ri, C3
+    double *flag = dorth.p, *dRout = flag + 1, *C1 = dRout + B2, *C2 = C1 + (size_t)p * cb,
+           *G0 = C2 + (size_t)p * cb, *G = G0 + B2, *Ri = G + B2, *C3 = Ri + B2;
+    const size_t nsmall = 1 + B2 + (size_t)2 * p * cb;
+    BSN_HIP(hipMemsetAsync(flag, 0, nsmall * 8, st));
+    BSN_HIP(hipMemcpyAsync(Wsave.p, W.p, (size_t)n * cb * 8, hipMemcpyDeviceToDevice, st));
+    const dim3 rows((unsigned)((n + 255) / 256));
+    auto project = [&](double *C) {
+      gemm_tn_dev(Q.p, p, cb, C);
+      hipLaunchKernelGGL(k_gemm_nn, rows, dim3(256), 512 * kMaxB * 8, st, Q.p, n, p, C, cb, W.p, n, 1.0, -1.0,
+                         W.p, n, n);
+    };
+    gemm_tn_dev(W.p, cb, cb, G0);
+    if (p > 0) {
+      project(C1);
+      project(C2);
+    }
+    for (int pass = 0; pass < 2; pass++) {
+      gemm_tn_dev(W.p, cb, cb, G);
+      hipLaunchKernelGGL(k_orth_small, dim3(1), dim3(64), 0, st, G0, G, cb, pass, Ri, dRout, flag);
+      hipLaunchKernelGGL(k_right_mult, rows, dim3(256), 0, st, W.p, n, n, cb, cb, Ri);
+      if (pass == 0 && p > 0) project(C3);
+    }
+    BSN_HIP(hipGetLastError());
+    horth.resize(nsmall);
+    BSN_HIP(hipMemcpyAsync(horth.data(), flag, nsmall * 8, hipMemcpyDeviceToHost, st));
+    BSN_HIP(hipStreamSynchronize(st));
+    if (horth[0] != 0.0) {  // rank deficient: undo and let the driver take the careful path
+      BSN_HIP(hipMemcpyAsync(W.p, Wsave.p, (size_t)n * cb * 8, hipMemcpyDeviceToDevice, st));
+      return -1;
+    }
+    Rout.assign((size_t)cb * cb, 0.0);
+    for (int t = 0; t < cb * cb; t++) Rout[(size_t)t] = horth[1 + (size_t)t];
+    Cacc.assign((size_t)p * cb, 0.0);
+    const double *h1 = horth.data() + 1 + B2, *h2 = h1 + (size_t)p * cb;
+    for (size_t t = 0; t < (size_t)p * cb; t++) Cacc[t] = h1[t] + h2[t];
+    return cb;
   }
   void QtW(int p, int cb, double *C) override { gemm_tn(Q.p, p, cb, C); }
   void WtW(int cb, double *G) override { gemm_tn(W.p, cb, cb, G); }

@@ -35,6 +35,14 @@ struct SvdBackend {
   virtual void WtW(int cb, double *G) = 0;                  // G (cb x cb) = W' W
   virtual void W_times(int cb, int r, const double *M) = 0; // W[:, :r] = W[:, :cb] M (cb x r)
   virtual void W_to_Q(int p0, int r) = 0;                   // Q[:, p0:p0+r] = W[:, :r]
+  // Optional fused form of the whole orthonormalisation step below (same arithmetic, same
+  // outputs) for backends that can run it without returning to the host between its parts.
+  // Returns the rank (== cb) on success; -1 if unsupported or if W turned out rank deficient,
+  // in which case W is left as on entry and the driver takes the step-by-step path.
+  virtual int orth_fused(int p, int cb, std::vector<double> &Cacc, std::vector<double> &Rout) {
+    (void)p; (void)cb; (void)Cacc; (void)Rout;
+    return -1;
+  }
   // u (n x k) = Q[:, :pp] S ; v (m_local x k) = Z[:, :pp] S diag(dinv); host outputs
   virtual void finalize(int pp, int k, const double *S, const double *dinv, double *u,
                         double *v) = 0;
@@ -82,6 +90,10 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
   // orthonormalise W (cb columns) against Q[:, :p] and itself; returns rank r and the
   // cb x cb upper factor Rt with W_in = Q C + W_out Rt  (first r rows of Rt meaningful)
   auto orth = [&](int p, int cb, std::vector<double> &Cacc, std::vector<double> &Rout) -> int {
+    {
+      const int rf = bk.orth_fused(p, cb, Cacc, Rout);
+      if (rf >= 0) return rf;
+    }
     Cacc.assign((size_t)p * cb, 0.0);
     G.assign((size_t)cb * cb, 0.0);
     bk.WtW(cb, G.data());
