@@ -1,5 +1,6 @@
 """Size-independent properties at BASELINE.json's full sizes (the oracle cannot run there):
-C2 = 50K x 200K through the FBM-style products, C3 = 400K x 1M bed_randomSVD k = 20.
+C2 = 50K x 200K through the FBM-style products, C3 = 400K x 1M bed_randomSVD k = 20, C5 = windowed LD on
+one chromosome of 400K x 100K.
 The matrix is generated in HBM; each test takes a few seconds on MI355X."""
 import numpy as np
 import pytest
@@ -58,3 +59,47 @@ def test_c3_randomsvd_full_size_properties(ba):
     # reproducible and insensitive to the panel precision at the 1e-6 level
     res2 = ba.bed_randomSVD(gb, k=k, block=8, slices=4, return_uv=False)
     np.testing.assert_allclose(res2["d"], d, rtol=1e-6)
+
+
+def test_c5_ld_window_full_size_spot_checks(ba):
+    """C5: one chromosome of 400K x 100K, window of ~2 000 variants.  The oracle cannot run at
+    this size; spot-check entries of the band against r computed on the host from the two
+    decoded columns (pairwise-complete Pearson, src/corr.cpp:54-80), and the LD scores of a few
+    columns against the sum of their r^2 (src/ld-scores.cpp:52-78)."""
+    n, m, W = 400000, 100000, 2000
+    gb = ba.bed.synthetic(n, m, seed=5)
+    pos = np.arange(m, dtype=np.float64)
+    rng = np.random.default_rng(5)
+    cols = np.sort(rng.choice(np.arange(W, m - W), 3, replace=False))
+    ic = np.unique(np.concatenate([np.arange(c - 40, c + 41) for c in cols]))
+    # a narrow band first (cheap): all pairs within 40 variants of the sampled columns
+    sub = ba.bed_cor(gb, ind_col=ic, size=40 / 1000.0, infos_pos=pos[ic], fill_diag=False)
+    G = ba.read_bed(gb, np.arange(n), ic, na_val=-1).astype(np.float64)
+    G[G < 0] = np.nan
+    jj = np.repeat(np.arange(ic.size), np.diff(sub.p))
+    pick = rng.choice(sub.i.size, 60, replace=False)
+    for t in pick:
+        x, y = G[:, jj[t]], G[:, sub.i[t]]
+        ok = ~(np.isnan(x) | np.isnan(y))
+        r = np.corrcoef(x[ok], y[ok])[0, 1]
+        assert abs(sub.x[t] - r) < 1e-10
+    # full-width LD scores: finite, >= 1, and not below the scores of a narrower window (which adds
+    # a subset of the same non-negative terms); the narrow scores are checked exactly for two columns
+    ld = ba.bed_ld_scores(gb, size=W / 1000.0, infos_pos=pos)
+    assert ld.shape == (m,) and np.all(ld >= 1.0) and np.all(np.isfinite(ld))
+    Wn = 150
+    ldn = ba.bed_ld_scores(gb, size=Wn / 1000.0, infos_pos=pos)
+    assert np.all(ld >= ldn * (1 - 1e-12)) and np.all(ldn >= 1.0)
+    for c in cols[:2]:
+        win = np.arange(c - Wn, c + Wn + 1)
+        Gw = ba.read_bed(gb, np.arange(n), win, na_val=-1)
+        x = Gw[:, Wn].astype(np.float64)
+        s = 1.0
+        for j in range(win.size):
+            if j == Wn:
+                continue
+            y = Gw[:, j].astype(np.float64)
+            ok = (x >= 0) & (y >= 0)
+            r = np.corrcoef(x[ok], y[ok])[0, 1]
+            s += r * r
+        assert abs(ldn[c] - s) < 1e-8 * s
