@@ -55,6 +55,7 @@ SIGNATURES = {
     "bsn_bed_prodvec": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, f64p, f64p]),
     "bsn_bed_cprodvec": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, f64p, f64p]),
     "bsn_bed_col_counts": (C.c_int, [vp, i64p, i64, i64p, i64, i32p]),
+    "bsn_bed_row_counts": (C.c_int, [vp, i64p, i64, i64p, i64, i32p]),
     "bsn_bed_colstats": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, i32p, i32p]),
     "bsn_snp_colstats": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p]),
     "bsn_bed_read": (C.c_int, [vp, i64p, i64, i64p, i64, C.c_int32, i32p]),

@@ -250,10 +250,13 @@ def bed_colstats(obj_bed, ind_row=None, ind_col=None, ncores=1):
 
 
 def bed_counts(obj_bed, ind_row=None, ind_col=None, byrow=False, ncores=1):
-    """R/binom-scaling.R:166-178; 4 x m, rows = counts of 0, 1, 2, NA."""
-    if byrow:
-        raise NotImplementedError("byrow = TRUE (bed_row_counts_cpp) is outside the hot path")
+    """R/binom-scaling.R:166-178; 4 x m (4 x n if byrow), rows = counts of 0, 1, 2, NA."""
     ir, ic = _args(obj_bed, ind_row, ind_col)
+    if byrow:  # src/bed-fun.cpp:72-99
+        res = np.empty((ir.size, 4), dtype=np.int32)
+        check(_lib.load().bsn_bed_row_counts(obj_bed.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p),
+                                             ic.size, ptr(res, i32p)))
+        return res.T
     res = np.empty((ic.size, 4), dtype=np.int32)
     check(_lib.load().bsn_bed_col_counts(obj_bed.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p),
                                          ic.size, ptr(res, i32p)))

@@ -322,6 +322,26 @@ int bsn_bed_col_counts(bsn_bed *bed, const int64_t *ind_row, int64_t n, const in
   return guarded([&] { counts_host(bed, ind_row, n, ind_col, m, res); });
 }
 
+int bsn_bed_row_counts(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                       int32_t *res) {
+  return guarded([&] {
+    bsn_op op;
+    fill_op(&op, bed, ind_row, n, ind_col, m, nullptr, nullptr);
+    DevBuf<double> d_c;
+    d_c.ensure((size_t)3 * n);
+    op_row_counts(&op, d_c.p);
+    std::vector<double> c((size_t)3 * n);
+    BSN_HIP(hipMemcpy(c.data(), d_c.p, (size_t)3 * n * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; i++) {
+      const int64_t n2 = (int64_t)c[(size_t)i], n1 = (int64_t)c[(size_t)(n + i)], na = (int64_t)c[(size_t)(2 * n + i)];
+      res[4 * i + 0] = (int32_t)(m - n1 - n2 - na);
+      res[4 * i + 1] = (int32_t)n1;
+      res[4 * i + 2] = (int32_t)n2;
+      res[4 * i + 3] = (int32_t)na;
+    }
+  });
+}
+
 int bsn_bed_colstats(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
                      int64_t m, double *sumX, double *denoX, int32_t *nb_nona_col,
                      int32_t *n_bad) {

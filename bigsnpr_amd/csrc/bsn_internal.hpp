@@ -140,7 +140,8 @@ void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, 
 void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z, int64_t ldz);
 void op_cprod_raw(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_P, double *d_Q,
                   int64_t ld);  // P = sum_i g0 x, Q = sum_i na x (m x nvec each)
-void op_row_sums_sq(bsn_op *op, double *d_out);  // n doubles: sum_j A~[i, j]^2
+void op_row_sums_sq(bsn_op *op, double *d_out);
+void op_row_counts(bsn_op *op, double *d_out);  // n doubles: sum_j A~[i, j]^2
 // weighted code counts: d_w = per-file-row integer weights (n_file doubles); out 4 x m
 void counts_weighted(bsn_op *op, const double *d_w, int64_t n_sub, int32_t *d_counts);
 void selftest();

@@ -940,6 +940,22 @@ void op_row_sums_sq(bsn_op *op, double *d_out) {
   BSN_HIP(hipStreamSynchronize(bed->stream));  // `w` is released on return
 }
 
+// per-sample counts of the codes over the selected variants (bed_row_counts_cpp,
+// src/bed-fun.cpp:72-99): three single-plane passes against a vector of ones — exact, the
+// fixed-point image of 1.0 is a power of two and the plane sums are integers < 2^31.
+// d_out: 3 x n doubles (n2, n1, nNA per selected row).
+void op_row_counts(bsn_op *op, double *d_out) {
+  bsn_bed *bed = op->bed;
+  std::vector<double> ones((size_t)op->m, 1.0);
+  DevBuf<double> w;
+  BSN_HIP(hipMemcpyAsync(w.ensure((size_t)op->m), ones.data(), (size_t)op->m * 8, hipMemcpyHostToDevice,
+                         bed->stream));
+  prod_planes(op, w.p, nullptr, op->m, 1, d_out, op->n, 2, kLutHom2, 0u, 0, 0.0, 7);
+  prod_planes(op, w.p, nullptr, op->m, 1, d_out + op->n, op->n, 2, kLutHet, 0u, 0, 0.0, 7);
+  prod_planes(op, w.p, nullptr, op->m, 1, d_out + 2 * op->n, op->n, 2, kLutNA, 0u, 0, 0.0, 7);
+  BSN_HIP(hipStreamSynchronize(bed->stream));  // `w` and `ones` are released on return
+}
+
 // counts of codes weighted by integer row multiplicities (general ind_row):
 // three planes (hom2, het, na) against the multiplicity vector, exact.
 __global__ void k_counts_final(const int32_t *acc, int64_t m, int ncol, int S, int64_t n_sub,

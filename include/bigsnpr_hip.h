@@ -80,6 +80,11 @@ int bsn_bed_cprodvec(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int6
  * (rows: counts of 0, 1, 2, NA) */
 int bsn_bed_col_counts(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
                        int64_t m, int32_t *res);
+/* _bigsnpr_bed_row_counts_cpp (4 args) src/bed-fun.cpp:72-99 (bed_counts(byrow = TRUE),
+ * R/binom-scaling.R:166-178): per SAMPLE counts of 0, 1, 2, NA over the selected variants,
+ * res[4 x n] column-major. */
+int bsn_bed_row_counts(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                       int32_t *res);
 /* _bigsnpr_bed_colstats (4 args) src/bed-fun.cpp:9-46; *n_bad = number of variants with
  * more than 50 % missing values (the reference warns "%d variants have >50%% missing values.") */
 int bsn_bed_colstats(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,

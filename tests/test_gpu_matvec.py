@@ -58,6 +58,10 @@ def test_counts_colstats_bit_exact(ba, orc, golden_dir, name):
         ir = rng.choice(ob.n, ob.n // 2, replace=replace)
         ic = rng.choice(ob.m, 300, replace=replace)
         np.testing.assert_array_equal(ba.bed_counts(gb, ir, ic), orc.bed_col_counts(ob, ir, ic))
+        # byrow = TRUE (src/bed-fun.cpp:72-99): counts per sample from the decoded sub-matrix
+        g = orc.read_bed(ob, ir, ic, na_val=3)
+        want = np.stack([(g == c).sum(1) for c in range(4)]).astype(np.int32)
+        np.testing.assert_array_equal(ba.bed_counts(gb, ir, ic, byrow=True), want)
         a, b = ba.bed_colstats(gb, ir, ic), orc.bed_colstats(ob, ir, ic)
         for k in ("sumX", "denoX", "nb_nona_col"):
             np.testing.assert_array_equal(a[k], b[k])
