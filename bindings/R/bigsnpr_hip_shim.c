@@ -165,6 +165,132 @@ SEXP _bigsnpr_bed_randomSVD_hip(SEXP obj_bed, SEXP ind_row, SEXP ind_col, SEXP c
   return res;
 }
 
+/* _bigsnpr_bed_row_counts_cpp(obj_bed, ind_row, ind_col, ncores) -> 4 x n integer matrix */
+SEXP _bigsnpr_bed_row_counts_cpp(SEXP obj_bed, SEXP ind_row, SEXP ind_col, SEXP ncores) {
+  R_xlen_t n = XLENGTH(ind_row), m = XLENGTH(ind_col);
+  SEXP res = PROTECT(Rf_allocMatrix(INTSXP, 4, (int) n));
+  CHECK(bsn_bed_row_counts(get_bed(obj_bed), ind0(ind_row), n, ind0(ind_col), m, INTEGER(res)));
+  UNPROTECT(1);
+  return res;
+}
+
+/* _bigsnpr_prod_and_rowSumsSq(obj_bed, ind_row, ind_col, center, scale, V) -> list(XV, rowSumsSq) */
+SEXP _bigsnpr_prod_and_rowSumsSq(SEXP obj_bed, SEXP ind_row, SEXP ind_col, SEXP center, SEXP scale,
+                                 SEXP V) {
+  R_xlen_t n = XLENGTH(ind_row), m = XLENGTH(ind_col);
+  assert_size(Rf_nrows(V), m);                                   /* src/bed-fun.cpp:114 */
+  int K = Rf_ncols(V);
+  SEXP XV = PROTECT(Rf_allocMatrix(REALSXP, (int) n, K)), rs = PROTECT(Rf_allocVector(REALSXP, n));
+  CHECK(bsn_bed_prod_and_rowsumssq(get_bed(obj_bed), ind0(ind_row), n, ind0(ind_col), m, REAL(center),
+                                   REAL(scale), REAL(V), K, REAL(XV), REAL(rs)));
+  const char *names[] = {"XV", "rowSumsSq", ""};
+  SEXP res = PROTECT(Rf_mkNamed(VECSXP, names));
+  SET_VECTOR_ELT(res, 0, XV); SET_VECTOR_ELT(res, 1, rs);
+  UNPROTECT(3);
+  return res;
+}
+
+/* ---- LD / clumping: the accessor is either a bed object or an FBM.code256 ---------------
+ * (type dispatch by the presence of the "code256" field, as src/corr.cpp:113-125 does).
+ * For an FBM the .bk file (one byte per genotype, column-major, R/bigSNP-class.R:7) is mapped
+ * here and repacked to the 2-bit device image once; the handle is cached per backing file. */
+#include <fcntl.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+typedef struct fbm_cache { char *path; bsn_bed *img; struct fbm_cache *next; } fbm_cache;
+static fbm_cache *g_fbm = NULL;
+
+static SEXP field(SEXP obj, const char *name) {
+  return Rf_eval(Rf_lang3(Rf_install("$"), obj, Rf_install(name)), R_GlobalEnv);
+}
+static int has_field(SEXP obj, const char *name) {
+  return Rf_findVarInFrame3(obj, Rf_install(name), FALSE) != R_UnboundValue;
+}
+static bsn_bed *get_image(SEXP obj) {
+  if (!has_field(obj, "code256")) return get_bed(obj);
+  const char *bk = CHAR(STRING_ELT(field(obj, "backingfile"), 0));
+  for (fbm_cache *c = g_fbm; c; c = c->next)
+    if (strcmp(c->path, bk) == 0) return c->img;
+  int64_t n = (int64_t) Rf_asReal(field(obj, "nrow")), m = (int64_t) Rf_asReal(field(obj, "ncol"));
+  int fd = open(bk, O_RDONLY);
+  if (fd < 0) Rf_error("cannot open backing file '%s'", bk);
+  void *map = mmap(NULL, (size_t) (n * m), PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (map == MAP_FAILED) Rf_error("cannot map backing file '%s'", bk);
+  bsn_bed *img = NULL;
+  int rc = bsn_bed_from_fbm((const uint8_t *) map, n, m, n, &img);
+  munmap(map, (size_t) (n * m));
+  if (rc != 0) Rf_error("%s", bsn_last_error());
+  fbm_cache *c = (fbm_cache *) malloc(sizeof(fbm_cache));
+  c->path = strdup(bk); c->img = img; c->next = g_fbm; g_fbm = c;
+  return img;
+}
+static int32_t *ind0_32(SEXP v) {
+  R_xlen_t n = XLENGTH(v);
+  int32_t *out = (int32_t *) R_alloc((size_t) n, sizeof(int32_t));
+  for (R_xlen_t i = 0; i < n; i++) out[i] = INTEGER(v)[i] - 1;
+  return out;
+}
+
+/* _bigsnpr_corMat(obj, rowInd, colInd, size, thr, pos, fill_diag, ncores) -> list(i, p, x)
+ * (the R wrapper of R/corr.R:43-47 builds the dsCMatrix from it, unchanged) */
+SEXP _bigsnpr_corMat(SEXP obj, SEXP rowInd, SEXP colInd, SEXP size, SEXP thr, SEXP pos,
+                     SEXP fill_diag, SEXP ncores) {
+  R_xlen_t n = XLENGTH(rowInd), m = XLENGTH(colInd);
+  assert_size(XLENGTH(thr), n); assert_size(XLENGTH(pos), m);
+  SEXP p = PROTECT(Rf_allocVector(INTSXP, m + 1));
+  int64_t nnz = 0; bsn_cor *cor = NULL;
+  CHECK(bsn_cormat(get_image(obj), ind0(rowInd), n, ind0(colInd), m, Rf_asReal(size), REAL(thr),
+                   REAL(pos), Rf_asLogical(fill_diag), INTEGER(p), &nnz, &cor));
+  SEXP i = PROTECT(Rf_allocVector(INTSXP, (R_xlen_t) nnz)), x = PROTECT(Rf_allocVector(REALSXP, (R_xlen_t) nnz));
+  int rc = bsn_cormat_fetch(cor, INTEGER(i), REAL(x));
+  bsn_cormat_free(cor);
+  if (rc != 0) Rf_error("%s", bsn_last_error());
+  const char *names[] = {"i", "p", "x", ""};
+  SEXP res = PROTECT(Rf_mkNamed(VECSXP, names));
+  SET_VECTOR_ELT(res, 0, i); SET_VECTOR_ELT(res, 1, p); SET_VECTOR_ELT(res, 2, x);
+  UNPROTECT(4);
+  return res;
+}
+
+/* _bigsnpr_ld_scores(obj, rowInd, colInd, size, pos, ncores) */
+SEXP _bigsnpr_ld_scores(SEXP obj, SEXP rowInd, SEXP colInd, SEXP size, SEXP pos, SEXP ncores) {
+  R_xlen_t n = XLENGTH(rowInd), m = XLENGTH(colInd);
+  assert_size(XLENGTH(pos), m);
+  SEXP res = PROTECT(Rf_allocVector(REALSXP, m));
+  CHECK(bsn_ld_scores(get_image(obj), ind0(rowInd), n, ind0(colInd), m, Rf_asReal(size), REAL(pos),
+                      REAL(res)));
+  UNPROTECT(1);
+  return res;
+}
+
+/* `keep` of the reference is a 1 x m integer FBM written in place (R/clumping.R:116,
+ * R/bed-clumping.R:53); its bytes are reached through the mapped address of BM2.  Here the
+ * result comes back as an integer vector and the two R callers do `keep[] <- .Call(...)`. */
+static SEXP clump(SEXP obj, int mode, SEXP rowInd, SEXP colInd, SEXP ordInd, SEXP rankInd, SEXP pos,
+                  SEXP aux1, SEXP aux2, SEXP size, SEXP thr) {
+  R_xlen_t n = XLENGTH(rowInd), m = XLENGTH(colInd);
+  assert_size(XLENGTH(pos), m); assert_size(XLENGTH(aux1), m); assert_size(XLENGTH(aux2), m);
+  SEXP keep = PROTECT(Rf_allocVector(INTSXP, m));
+  CHECK(bsn_clumping_chr(get_image(obj), ind0(rowInd), n, ind0(colInd), m, mode, REAL(aux1), REAL(aux2),
+                         ind0_32(ordInd), ind0_32(rankInd), REAL(pos), Rf_asReal(size), Rf_asReal(thr),
+                         INTEGER(keep)));
+  UNPROTECT(1);
+  return keep;
+}
+/* _bigsnpr_clumping_chr(BM, BM2, rowInd, colInd, ordInd, rankInd, pos, sumX, denoX, size, thr, ncores) */
+SEXP _bigsnpr_clumping_chr(SEXP BM, SEXP BM2, SEXP rowInd, SEXP colInd, SEXP ordInd, SEXP rankInd,
+                           SEXP pos, SEXP sumX, SEXP denoX, SEXP size, SEXP thr, SEXP ncores) {
+  return clump(BM, 0, rowInd, colInd, ordInd, rankInd, pos, sumX, denoX, size, thr);
+}
+/* _bigsnpr_bed_clumping_chr(obj_bed, BM2, ind_row, ind_col, center, scale, ordInd, rankInd, pos, size, thr, ncores) */
+SEXP _bigsnpr_bed_clumping_chr(SEXP obj_bed, SEXP BM2, SEXP ind_row, SEXP ind_col, SEXP center, SEXP scale,
+                               SEXP ordInd, SEXP rankInd, SEXP pos, SEXP size, SEXP thr, SEXP ncores) {
+  return clump(obj_bed, 1, ind_row, ind_col, ordInd, rankInd, pos, center, scale, size, thr);
+}
+
 static const R_CallMethodDef CallEntries[] = {
   {"_bigsnpr_bedXPtr", (DL_FUNC) &_bigsnpr_bedXPtr, 3},
   {"_bigsnpr_bed_colstats", (DL_FUNC) &_bigsnpr_bed_colstats, 4},
@@ -174,6 +300,12 @@ static const R_CallMethodDef CallEntries[] = {
   {"_bigsnpr_bed_pMatVec4", (DL_FUNC) &_bigsnpr_bed_pMatVec4, 7},
   {"_bigsnpr_bed_cpMatVec4", (DL_FUNC) &_bigsnpr_bed_cpMatVec4, 7},
   {"_bigsnpr_bed_randomSVD_hip", (DL_FUNC) &_bigsnpr_bed_randomSVD_hip, 8},
+  {"_bigsnpr_bed_row_counts_cpp", (DL_FUNC) &_bigsnpr_bed_row_counts_cpp, 4},
+  {"_bigsnpr_prod_and_rowSumsSq", (DL_FUNC) &_bigsnpr_prod_and_rowSumsSq, 6},
+  {"_bigsnpr_corMat", (DL_FUNC) &_bigsnpr_corMat, 8},
+  {"_bigsnpr_ld_scores", (DL_FUNC) &_bigsnpr_ld_scores, 6},
+  {"_bigsnpr_clumping_chr", (DL_FUNC) &_bigsnpr_clumping_chr, 12},
+  {"_bigsnpr_bed_clumping_chr", (DL_FUNC) &_bigsnpr_bed_clumping_chr, 12},
   {NULL, NULL, 0}
 };
 
