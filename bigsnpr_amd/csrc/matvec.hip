@@ -156,18 +156,31 @@ __global__ __launch_bounds__(64) void k_quant(const double *__restrict__ X, int6
   const int64_t kb = (int64_t)blockIdx.x * 64 + tid;  // 16-block index of this thread
   const int nplanes = mode >= 1 ? 2 : 1;
   const double qs = meta[v].qscale;
-  for (int t = tid; t < 1024; t += 64) {
-    const int64_t k = (int64_t)blockIdx.x * 1024 + t;
-    double a = 0, b = 0;
-    if (k < len) {
-      a = X[k + v * ldx];
-      if (mode == 1) {
-        const double sc = scale ? scale[k] : 1.0, c = center ? center[k] : 0.0;
-        a = a / sc;
-        b = c * a;
-      } else if (mode == 2) {
-        b = center ? center[k + v * ldx] : 0.0;
-      }
+  // all 16 x (1..3) loads of a thread are issued before the first use
+  double xa[16], xc[16], xs[16];
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const int64_t k = (int64_t)blockIdx.x * 1024 + it * 64 + tid;
+    const bool in = k < len;
+    xa[it] = in ? X[k + v * ldx] : 0.0;
+    xc[it] = 0.0;
+    xs[it] = 1.0;
+    if (mode == 1) {
+      if (in && scale) xs[it] = scale[k];
+      if (in && center) xc[it] = center[k];
+    } else if (mode == 2) {
+      if (in && center) xc[it] = center[k + v * ldx];
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const int t = it * 64 + tid;
+    double a = xa[it], b = 0;
+    if (mode == 1) {
+      a = a / xs[it];
+      b = xc[it] * a;
+    } else if (mode == 2) {
+      b = xc[it];
     }
     if (!(fabs(a) <= 1.79e308)) a = 0;
     if (!(fabs(b) <= 1.79e308)) b = 0;

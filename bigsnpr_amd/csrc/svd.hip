@@ -223,6 +223,7 @@ struct HipSvdBackend : SvdBackend {
     if (b_ > kMaxB) fail("block size must be <= %d", kMaxB);
     cap = cap_;
     b = b_;
+    auto t0 = std::chrono::steady_clock::now();
     Q.ensure((size_t)n * cap);
     Z.ensure((size_t)m_local * cap);
     W.ensure((size_t)n * kMaxB);
@@ -232,6 +233,10 @@ struct HipSvdBackend : SvdBackend {
     dsmall.ensure((size_t)(cap + 4) * 64);
     Wsave.ensure((size_t)n * kMaxB);
     dorth.ensure((size_t)8 * kMaxB * kMaxB + (size_t)3 * (cap + 4) * kMaxB);
+    if (getenv("BSN_TIMING"))
+      std::fprintf(stderr, "[bsn svd] workspace alloc %.2f ms (Q %.2f GB, Z %.2f GB)\n",
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+                   (double)n * cap * 8e-9, (double)m_local * cap * 8e-9);
   }
   void random_W(int bb, uint32_t seed) override {
     hipLaunchKernelGGL(k_random, dim3((unsigned)((n + 255) / 256), bb), dim3(256), 0, st, W.p, n, n,
