@@ -8,6 +8,8 @@
 #include <cstring>
 #include <memory>
 
+#include <cstdlib>
+
 #include "bsn_internal.hpp"
 
 namespace bsn {
@@ -90,6 +92,13 @@ static void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n,
                            hipMemcpyHostToDevice, bed->stream));
     BSN_HIP(hipStreamSynchronize(bed->stream));
   }
+  // missing-value knowledge (BSN_FORCE_NA_PLANE=1 keeps the general kernels, for A/B tests)
+  op->no_na = false;
+  if ((int64_t)bed->na_cnt.size() == bed->m && !getenv("BSN_FORCE_NA_PLANE")) {
+    bool all0 = true;
+    for (int64_t j = 0; all0 && j < m; j++) all0 = bed->na_cnt[(size_t)(ind_col ? ind_col[j] : j)] == 0;
+    op->no_na = all0;
+  }
   // centre / scale (defaults 0 / 1, R/bed-mult-vec.R:23-24)
   std::vector<double> tmp((size_t)m);
   for (int64_t j = 0; j < m; j++) tmp[(size_t)j] = center ? center[j] : 0.0;
@@ -122,6 +131,10 @@ static void counts_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const i
   }
   BSN_HIP(hipMemcpyAsync(res, d_counts.p, (size_t)4 * m * 4, hipMemcpyDeviceToHost, bed->stream));
   BSN_HIP(hipStreamSynchronize(bed->stream));
+  if (op.rows_identity) {  // remember which variants are complete
+    if ((int64_t)bed->na_cnt.size() != bed->m) bed->na_cnt.assign((size_t)bed->m, -1);
+    for (int64_t j = 0; j < m; j++) bed->na_cnt[(size_t)(ind_col ? ind_col[j] : j)] = res[4 * j + 3];
+  }
 }
 
 }  // namespace bsn
@@ -206,6 +219,10 @@ int bsn_bed_from_fbm(const uint8_t *bytes, int64_t n, int64_t m, int64_t ld, bsn
     std::unique_ptr<bsn_bed, void (*)(bsn_bed *)> b(new bsn_bed(), free_bed);
     image_alloc(b.get(), n, m);
     image_from_fbm(b.get(), bytes, ld);
+    {  // FBMs of imputed data have no missing value: one count pass settles it for every later operator
+      std::vector<int32_t> cnt((size_t)4 * m);
+      counts_host(b.get(), nullptr, n, nullptr, m, cnt.data());
+    }
     *out = b.release();
   });
 }
@@ -217,6 +234,7 @@ int bsn_bed_synthetic(int64_t n, int64_t m, uint32_t seed, uint32_t npop, uint32
     std::unique_ptr<bsn_bed, void (*)(bsn_bed *)> b(new bsn_bed(), free_bed);
     image_alloc(b.get(), n, m);
     image_generate(b.get(), seed, npop ? npop : 1, na16, j_begin);
+    if (na16 == 0) b->na_cnt.assign((size_t)m, 0);  // the generator draws no missing value then
     *out = b.release();
   });
 }

@@ -86,6 +86,10 @@ struct bsn_bed {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // number of missing genotypes per variant over ALL samples, -1 = not known yet; filled as a
+  // by-product of every full-row count (and at creation for FBM / NA-free synthetic images).
+  // An operator whose variants are all known to be complete skips the missing-value plane.
+  std::vector<int32_t> na_cnt;
 };
 
 struct bsn_op {
@@ -93,6 +97,7 @@ struct bsn_op {
   int64_t n = 0, m = 0;        // dimensions of the sub-view
   bool rows_identity = true;   // ind_row == 0..n_file-1
   bool cols_contig = true;     // ind_col == col0 .. col0+m-1
+  bool no_na = false;          // every selected variant is known to have no missing genotype
   int64_t col0 = 0;
   int slices = 4;
   int64_t passes = 0;         // streaming launches over the image issued so far

@@ -424,12 +424,13 @@ __device__ __forceinline__ double horner(const int32_t *a, int S) {
 
 // z[j, v] = (P - c_j (Sx - Q)) / (s_j qs)
 __global__ void k_cprod_final(const int32_t *acc, int64_t m, int ncol, int S, const VecMeta *meta,
-                              const double *center, const double *scale, double *Z, int64_t ldz) {
+                              const double *center, const double *scale, double *Z, int64_t ldz,
+                              int has_q) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int v = blockIdx.y;
   if (j >= m) return;
   double P = horner(acc + j * ncol + v * S, S);
-  double Q = horner(acc + (m + j) * ncol + v * S, S);
+  double Q = has_q ? horner(acc + (m + j) * ncol + v * S, S) : 0.0;  // no missing plane: Q == 0
   double Sx = (double)meta[v].sum_hi * 16777216.0 + (double)meta[v].sum_lo;
   double c = center ? center[j] : 0.0, s = scale ? scale[j] : 1.0;
   double qs = meta[v].qscale;
@@ -451,7 +452,7 @@ __global__ void k_cprod_final(const int32_t *acc, int64_t m, int ncol, int S, co
 //   A operand: lane l -> digit column (l&15), k-group (l>>4): 16 variants' digits
 //   B operand: lane l -> sample group (l&15), same 16 variants, sample u of the group
 //   D        : lane l -> sample group (l&15), digit columns 4*(l>>4)+r
-template <int NB, bool CONTIG, int WAVES = 4, int ABL = 0, int UG = 1, int SETS = 2>
+template <int NB, bool CONTIG, int WAVES = 4, int ABL = 0, int UG = 1, int SETS = 2, bool HASQ = true>
 __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__ img, int64_t pitch,
                                               const int32_t *__restrict__ cols, int64_t col0,
                                               int64_t m_pad, int64_t mc,
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
               na[k][r4] = (int)(T[q][r4] ^ lutQ);
             } else {
               g0[k][r4] = (int)lut4(lutP, sel);
-              na[k][r4] = (int)lut4(lutQ, sel);
+              if (HASQ) na[k][r4] = (int)lut4(lutQ, sel);
             }
           }
 #pragma unroll
@@ -586,10 +587,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
             for (int k = 0; k < G; k++)
               acc[q * 4 + u0 + k][nb] =
                   __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[nb], g0[k], acc[q * 4 + u0 + k][nb], 0, 0, 0);
+            if (HASQ) {
 #pragma unroll
-            for (int k = 0; k < G; k++)
-              acc[q * 4 + u0 + k][nb] =
-                  __builtin_amdgcn_mfma_i32_16x16x64_i8(awc[nb], na[k], acc[q * 4 + u0 + k][nb], 0, 0, 0);
+              for (int k = 0; k < G; k++)
+                acc[q * 4 + u0 + k][nb] =
+                    __builtin_amdgcn_mfma_i32_16x16x64_i8(awc[nb], na[k], acc[q * 4 + u0 + k][nb], 0, 0, 0);
+            }
           }
         }
       }
@@ -797,12 +800,15 @@ void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z,
     int32_t *acc = op->d_acc.ensure((size_t)2 * op->m * 32);
     quantise(op, xsrc + (int64_t)v0 * ldx, ldx, b->n, npad, nv, 0, S, ncol, 1, 0, meta, q);
     prof_begin(op, 0);
-    launch_cprod<2>(op, NB, q, acc, kLutG0, kLutNA, 0);
+    if (op->no_na)
+      launch_cprod<1>(op, NB, q, acc, kLutG0, 0, 0);  // complete variants: the na plane is all zero
+    else
+      launch_cprod<2>(op, NB, q, acc, kLutG0, kLutNA, 0);
     prof_end(op);
     op->passes++;
     hipLaunchKernelGGL(k_cprod_final, dim3((unsigned)((op->m + 255) / 256), nv), dim3(256), 0,
                        b->stream, acc, op->m, ncol, S, meta, op->d_center.p, op->d_scale.p,
-                       d_Z + (int64_t)v0 * ldz, ldz);
+                       d_Z + (int64_t)v0 * ldz, ldz, op->no_na ? 0 : 1);
     BSN_HIP(hipGetLastError());
   }
 }
@@ -853,6 +859,23 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
       else if (tv == 63) BSN_LAUNCH_PROD_ABL(3);   // memory skeleton
       else BSN_LAUNCH_PROD_ABL(32);                // compute only
 #undef BSN_LAUNCH_PROD_ABL
+    } else if (op->no_na && lutQ == kLutNA) {
+      // complete variants: the second plane (missing -> c w) is all zero, skip its look-ups and MFMAs
+      if (op->cols_contig) {
+        if (NB == 1)
+          hipLaunchKernelGGL((k_prod<1, true, 4, 0, 1, 2, false>), grid, dim3(256), 0, b->stream, b->d_img,
+                             b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
+        else
+          hipLaunchKernelGGL((k_prod<2, true, 4, 0, 1, 2, false>), grid, dim3(256), 0, b->stream, b->d_img,
+                             b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
+      } else {
+        if (NB == 1)
+          hipLaunchKernelGGL((k_prod<1, false, 4, 0, 1, 2, false>), grid, dim3(256), 0, b->stream, b->d_img,
+                             b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
+        else
+          hipLaunchKernelGGL((k_prod<2, false, 4, 0, 1, 2, false>), grid, dim3(256), 0, b->stream, b->d_img,
+                             b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
+      }
     } else
     if (op->cols_contig) {
       if (NB == 1)
