@@ -752,6 +752,8 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
                          uint32_t l1, uint32_t l2) {
   bsn_bed *b = op->bed;
   constexpr int KC = 512;
+  // int32 accumulators over the whole sample range: a plane adds at most 4 * 128 per sample
+  if (b->pitch * 4 > 4000000) fail("more than 4e6 samples are not supported by the crossproduct kernel");
   dim3 grid((unsigned)((op->m + 255) / 256));
   const int32_t *cols = op->cols_contig ? nullptr : op->d_cols.p;
   // BSN_TUNE = 11 / 12 / 13 / 14 / 15 / 16 / 17 / 18 / 19 select the ablation builds (no MFMA /
@@ -834,6 +836,9 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
   if (ky > steps) ky = (int)steps;
   if (ky > 64) ky = 64;
   if (ky < 1) ky = 1;
+  // int32 accumulators: a slab adds at most 768 per variant (planes up to 4, digits up to 128)
+  const int64_t ky_min = (m_pad + 2499999) / 2500000;
+  if (ky < ky_min) ky = (int)ky_min;
   int64_t mc = round_up((steps + ky - 1) / ky, 1) * 64;
   ky = (int)((m_pad + mc - 1) / mc);
   for (int v0 = 0; v0 < nvec; v0 += vmax) {
