@@ -127,3 +127,20 @@ def test_empty_selection_errors(ba, orc):
         ba.bed_counts(gb, ind_col=np.array([8]))
     with pytest.raises(IndexError):
         ba.bed_prodVec(gb, np.zeros(1), ind_col=np.array([-1]))
+
+
+def test_many_variants_use_several_accumulator_slabs(ba):
+    """m > 2.5e6: the variant range of the product is split so that the int32 partial sums cannot
+    overflow; checked through adjointness and linearity (the oracle would take minutes here)."""
+    n, m = 1000, 2600000
+    gb = ba.bed.synthetic(n, m, seed=9)
+    sc = ba.bed_scaleBinom(gb)
+    rng = np.random.default_rng(9)
+    x, y = rng.normal(size=m), rng.normal(size=n)
+    kw = dict(center=sc["center"], scale=sc["scale"])
+    a, z = ba.bed_prodVec(gb, x, **kw), ba.bed_cprodVec(gb, y, **kw)
+    assert abs(a @ y - x @ z) <= 1e-10 * np.linalg.norm(a) * np.linalg.norm(y)
+    # all-ones weights on unscaled genotypes: the row sums are integers that must be exact
+    rs = ba.bed_prodVec(gb, np.ones(m))
+    cnt = ba.bed_counts(gb, byrow=True)
+    np.testing.assert_array_equal(rs, cnt[1] + 2.0 * cnt[2])
