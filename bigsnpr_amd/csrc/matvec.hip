@@ -131,13 +131,6 @@ __global__ void k_set_qscale(VecMeta *meta, int nvec, int slices, int exact_int)
   meta[v].qscale = qs;
 }
 
-__device__ __forceinline__ void digits_of(long long X, int S, int8_t *d) {
-  for (int s = 0; s < S; s++) {
-    int8_t b = (int8_t)(X & 0xFF);
-    d[s] = b;
-    X = (X - b) >> 8;
-  }
-}
 
 // One wave quantises 1024 consecutive k of one vector; a thread ends up with 16 of them as S
 // digit rows of 16 bytes.
@@ -202,8 +195,6 @@ __global__ __launch_bounds__(64) void k_quant(const double *__restrict__ X, int6
       long long A = llrint(sa[tid * 17 + e]), B = llrint(sb[tid * 17 + e]);
       shi += A >> 24; slo += A & 0xFFFFFF;
       shi2 += B >> 24; slo2 += B & 0xFFFFFF;
-      constexpr int dummy = 0;
-      (void)dummy;
       const int pos = PERM ? ((e & 3) * 4 + (e >> 2)) : e;
 #pragma unroll
       for (int s = 0; s < S; s++) {

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const double *__restrict__ Q, i
 // in place W[:, :r] = W[:, :cb] * M (cb x r), one thread per row
 __global__ void k_right_mult(double *W, int64_t ld, int64_t n, int cb, int r, const double *M) {
   __shared__ double sM[kMaxB * kMaxB];
-  if (threadIdx.x < cb * r) sM[threadIdx.x] = M[threadIdx.x];
+  if ((int)threadIdx.x < cb * r) sM[threadIdx.x] = M[threadIdx.x];
   __syncthreads();
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
