@@ -12,8 +12,8 @@ from .svd import bed_randomSVD  # noqa: F401,E402
 from .ld import (FBM_code256, bed_clumping, bed_cor, bed_ld_scores, big_randomSVD,  # noqa: F401,E402
                  snp_clumping, snp_colstats, snp_cor, snp_ld_scores, snp_MAF, snp_scaleAlpha,
                  snp_scaleBinom)
-from .prs import (bed_projectSelfPCA, bed_tcrossprodSelf, prod_and_rowSumsSq, prodVecRev,  # noqa: F401,E402
-                  snp_PRS)
+from .prs import (bed_projectSelfPCA, bed_tcrossprodSelf, prod_and_rowSumsSq,  # noqa: F401,E402
+                  prod_and_rowSumsSq2, prodVecRev, snp_PRS, snp_projectSelfPCA)
 from .autosvd import bed_autoSVD, snp_autoSVD  # noqa: F401,E402
 from .plink_io import bed_to_bytes, snp_readBed, snp_writeBed  # noqa: F401,E402
 from .pcadapt import bed_pcadapt, multLinReg, snp_pcadapt  # noqa: F401,E402

@@ -89,8 +89,36 @@ def bed_projectSelfPCA(obj_svd, obj_bed, ind_row, ind_col=None, ncores=1):
     plus the squared row norms that the OADP correction needs.  The OADP step itself
     (bigutilsr::pca_OADP_proj2, external) is not restated: `OADP_proj` is None."""
     ind_col = obj_svd["subset"] if ind_col is None and "subset" in obj_svd else ind_col
+    if ind_col is None:
+        raise ValueError("'ind.col' can't be `NULL`.")     # check_args(), test-2-pca-project.R:16-17
     ir, ic = _args(obj_bed, ind_row, ind_col)
     if np.asarray(obj_svd["v"]).shape[0] != ic.size:
         raise ValueError("Incompatibility between dimensions.")
     XV, X_norm = prod_and_rowSumsSq(obj_bed, ir, ic, obj_svd["center"], obj_svd["scale"], obj_svd["v"])
     return dict(obj_svd_ref=obj_svd, simple_proj=XV, X_norm=X_norm, OADP_proj=None)
+
+
+def prod_and_rowSumsSq2(G, ind_row, ind_col, center, scale, V):
+    """src/project-utils.cpp:12-43, the FBM.code256 twin of prod_and_rowSumsSq.  The FBM accessor
+    has no missing-value handling: a missing code is NA_real and poisons its whole row of XV and
+    its rowSumsSq entry (src/project-utils.cpp:33-38), which is reproduced here (NaN)."""
+    im, ir, ic = _ind(G, ind_row, ind_col)
+    XV, rs = prod_and_rowSumsSq(im, ir, ic, center, scale, V)
+    from .bed import bed_counts
+    has_na = bed_counts(im, ir, ic, byrow=True)[3] > 0
+    if has_na.any():
+        XV[has_na, :] = np.nan
+        rs[has_na] = np.nan
+    return XV, rs
+
+
+def snp_projectSelfPCA(obj_svd, G, ind_row, ind_col=None, ncores=1):
+    """R/bed-projectPCA.R:252-281; `OADP_proj` is None for the same reason as in
+    bed_projectSelfPCA (bigutilsr::pca_OADP_proj2 is external)."""
+    ind_col = obj_svd["subset"] if ind_col is None and "subset" in obj_svd else ind_col
+    if ind_col is None:
+        raise ValueError("'ind.col' can't be `NULL`.")
+    im, ir, ic = _ind(G, ind_row, ind_col)
+    assert_lengths(np.arange(np.asarray(obj_svd["v"]).shape[0]), ic)
+    XV, _ = prod_and_rowSumsSq2(im, ir, ic, obj_svd["center"], obj_svd["scale"], obj_svd["v"])
+    return dict(obj_svd_ref=obj_svd, simple_proj=XV, OADP_proj=None)

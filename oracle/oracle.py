@@ -655,3 +655,12 @@ def snp_grid_PRS(G, all_keep, betas, lpS, grid_lpS_thr, ind_row=None):
         out[:, ic * thr.size:(ic + 1) * thr.size] = snp_PRS(
             G, betas[ind_keep], ind_test=ir, ind_keep=ind_keep, lpS_keep=lpS[ind_keep], thr_list=thr)
     return out
+
+
+def prod_and_rowSumsSq2(G, ind_row, ind_col, center, scale, V):
+    """src/project-utils.cpp:12-43 (FBM.code256: decoded value through code256, NA propagates)"""
+    ir = np.arange(G.n) if ind_row is None else np.asarray(ind_row)
+    ic = np.arange(G.m) if ind_col is None else np.asarray(ind_col)
+    X = G.code256[G.bytes[np.ix_(ir, ic)]]
+    X = (X - _f64(center)[None, :]) / _f64(scale)[None, :]
+    return X @ np.asarray(V, dtype=np.float64), (X * X).sum(1)

@@ -83,3 +83,37 @@ def test_prod_and_rowsumssq_and_self_projection(ba, orc, golden_dir, missing_bed
     svd["subset"] = np.arange(example_bed.m)
     proj = ba.bed_projectSelfPCA(svd, ge, ind_row=np.arange(example_bed.n))
     np.testing.assert_allclose(proj["simple_proj"], svd["u"] * svd["d"], rtol=0, atol=1e-6 * svd["d"][0])
+
+
+def test_fbm_twin_of_the_projection(ba, orc, golden_dir, example_bed, missing_bed):
+    """src/project-utils.cpp:12-43 + test-2-pca-project.R:65-70: the FBM path gives the same
+    simple projection as the bed path; on an FBM with missing codes the affected rows are NA."""
+    ge = ba.bed(os.path.join(golden_dir, "example.bed"))
+    Go = orc.fbm_from_bed(example_bed)
+    G = ba.FBM_code256(Go.bytes)
+    rng = np.random.default_rng(8)
+    ir = np.sort(rng.choice(example_bed.n, 400, replace=False))
+    svd = ba.bed_randomSVD(ge, ind_row=ir, k=5, tol=1e-8)
+    test = np.setdiff1d(np.arange(example_bed.n), ir)
+    with pytest.raises(ValueError, match="'ind.col' can't be `NULL`."):
+        ba.snp_projectSelfPCA(svd, G, ind_row=test)
+    with pytest.raises(ValueError, match="Incompatibility between dimensions"):
+        ba.snp_projectSelfPCA(svd, G, ind_row=test, ind_col=np.arange(5))
+    p_bed = ba.bed_projectSelfPCA(svd, ge, ind_row=np.arange(example_bed.n), ind_col=np.arange(example_bed.m))
+    p_fbm = ba.snp_projectSelfPCA(svd, G, ind_row=test, ind_col=np.arange(example_bed.m))
+    np.testing.assert_array_equal(p_fbm["simple_proj"], p_bed["simple_proj"][test])
+    ref, ref_rs = orc.prod_and_rowSumsSq2(Go, test, None, svd["center"], svd["scale"], svd["v"])
+    np.testing.assert_allclose(p_fbm["simple_proj"], ref, rtol=0, atol=1e-9 * np.abs(ref).max())
+    # missing codes: NA rows exactly where the reference's accessor would produce them
+    Gm_o = orc.fbm_from_bed(missing_bed)
+    Gm = ba.FBM_code256(Gm_o.bytes)
+    sc = orc.bed_scaleBinom(missing_bed)
+    ic = np.nonzero(sc["scale"] > 0)[0][:60]
+    V = rng.normal(size=(ic.size, 3))
+    XV, rs = ba.prod_and_rowSumsSq2(Gm, None, ic, sc["center"][ic], sc["scale"][ic], V)
+    XVr, rsr = orc.prod_and_rowSumsSq2(Gm_o, None, ic, sc["center"][ic], sc["scale"][ic], V)
+    assert np.array_equal(np.isnan(rs), np.isnan(rsr)) and np.isnan(rsr).any() and not np.isnan(rsr).all()
+    ok = ~np.isnan(rsr)
+    np.testing.assert_allclose(XV[ok], XVr[ok], rtol=0, atol=1e-9 * np.abs(XVr[ok]).max())
+    np.testing.assert_allclose(rs[ok], rsr[ok], rtol=1e-9)
+    assert np.isnan(XV[~ok]).all()
