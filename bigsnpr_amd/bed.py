@@ -31,6 +31,15 @@ def _count_lines(path):
         return sum(1 for _ in f)
 
 
+def sub_bed(path, replacement="", stop_if_not_ext=True):
+    """R/bed-class.R:20-32: replace the extension '.bed'"""
+    if not str(path).endswith(".bed"):
+        raise ValueError("Path '%s' must have 'bed' extension." % path)
+    if stop_if_not_ext and len(replacement) > 0 and replacement[0] != ".":
+        raise ValueError("Replacement must be an extension starting with '.' if provided.")
+    return str(path)[:-4] + replacement
+
+
 class bed:
     """RC class ``bed`` (R/bed-class.R:65-134): a PLINK .bed file attached to the GPU.
 
@@ -116,6 +125,25 @@ class bed:
                              genetic_dist=np.array(gd), physical_pos=np.array(pos),
                              allele1=np.array(a1), allele2=np.array(a2))
         return self._map
+
+    @property
+    def fam(self):
+        """columns of the .fam file (NAMES.FAM, R/utils.R:47-48)"""
+        if self._fam is None:
+            cols = [[] for _ in range(6)]
+            with open(self.famfile) as f:
+                for line in f:
+                    t = line.split()
+                    for c in range(6):
+                        cols[c].append(t[c])
+            names = ("family_ID", "sample_ID", "paternal_ID", "maternal_ID", "sex", "affection")
+            self._fam = {k: np.array(v) for k, v in zip(names, cols)}
+            for k in ("sex", "affection"):
+                try:
+                    self._fam[k] = self._fam[k].astype(np.int64)
+                except ValueError:
+                    pass
+        return self._fam
 
     @property
     def light(self):

@@ -83,3 +83,10 @@ def test_host_api_argument_checks(lib):
         ba.bed_prodVec(object(), np.zeros(3))
     with pytest.raises(ValueError, match="must have 'bed' extension"):
         ba.bed("foo.txt")
+    # sub_bed (R/bed-class.R:20-32, examples in its documentation)
+    assert ba.sub_bed("toto.bed") == "toto" and ba.sub_bed("toto.bed", ".bim") == "toto.bim"
+    assert ba.sub_bed("toto.bed", "_QC", stop_if_not_ext=False) == "toto_QC"
+    with pytest.raises(ValueError, match="must have 'bed' extension"):
+        ba.sub_bed("toto.txt")
+    with pytest.raises(ValueError, match="Replacement must be an extension starting with '.'"):
+        ba.sub_bed("toto.bed", "_QC")
