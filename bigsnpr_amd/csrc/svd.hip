@@ -30,48 +30,67 @@ __global__ void k_random(double *W, int64_t ld, int64_t n, int b, uint32_t seed)
   W[i + j * ld] = 2.0 * x - 1.0;
 }
 
-// partial[rc][pt*4 + a][j] = sum over the row chunk of Q[i, pt*4+a] * W[i, j]
+// partial[rc][pt*4 + a][j] = sum over the row chunk of Q[i, pt*4+a] * W[i, j]; CB = number of
+// columns of W (compile-time, so that no register or FMA is spent on absent columns)
+template <int CB>
 __global__ __launch_bounds__(256) void k_gemm_tn_part(const double *__restrict__ Q, int64_t ldq,
                                                       int p, const double *__restrict__ W,
-                                                      int64_t ldw, int cb, int64_t n,
-                                                      int64_t rows_per, double *partial) {
+                                                      int64_t ldw, int64_t n, int64_t rows_per,
+                                                      double *partial) {
   const int pt = blockIdx.x, rc = blockIdx.y, tid = threadIdx.x;
   const int64_t r0 = (int64_t)rc * rows_per;
   int64_t r1 = r0 + rows_per;
   if (r1 > n) r1 = n;
-  double acc[4][kMaxB];
+  double acc[4][CB];
 #pragma unroll
   for (int a = 0; a < 4; a++)
 #pragma unroll
-    for (int j = 0; j < kMaxB; j++) acc[a][j] = 0;
+    for (int j = 0; j < CB; j++) acc[a][j] = 0;
   const int pc = pt * 4;
+  // columns past p are read from the last valid one and discarded at the end (no branch in the loop)
+  const double *q0 = Q + (int64_t)(pc + 0 < p ? pc + 0 : p - 1) * ldq, *q1 = Q + (int64_t)(pc + 1 < p ? pc + 1 : p - 1) * ldq,
+               *q2 = Q + (int64_t)(pc + 2 < p ? pc + 2 : p - 1) * ldq, *q3 = Q + (int64_t)(pc + 3 < p ? pc + 3 : p - 1) * ldq;
+#pragma unroll 2
   for (int64_t i = r0 + tid; i < r1; i += 256) {
-    double w[kMaxB];
+    double w[CB];
 #pragma unroll
-    for (int j = 0; j < kMaxB; j++) w[j] = j < cb ? W[i + j * ldw] : 0.0;
+    for (int j = 0; j < CB; j++) w[j] = W[i + j * ldw];
+    const double q[4] = {q0[i], q1[i], q2[i], q3[i]};
 #pragma unroll
-    for (int a = 0; a < 4; a++) {
-      double q = (pc + a) < p ? Q[i + (int64_t)(pc + a) * ldq] : 0.0;
+    for (int a = 0; a < 4; a++)
 #pragma unroll
-      for (int j = 0; j < kMaxB; j++) acc[a][j] += q * w[j];
-    }
+      for (int j = 0; j < CB; j++) acc[a][j] += q[a] * w[j];
   }
-  __shared__ double red[4][4 * kMaxB];
+  __shared__ double red[4][4 * CB];
   const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int a = 0; a < 4; a++)
 #pragma unroll
-    for (int j = 0; j < kMaxB; j++) {
+    for (int j = 0; j < CB; j++) {
       double v = acc[a][j];
       for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-      if (lane == 0) red[wave][a * kMaxB + j] = v;
+      if (lane == 0) red[wave][a * CB + j] = v;
     }
   __syncthreads();
-  if (tid < 4 * kMaxB) {
+  if (tid < 4 * CB) {
     double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-    int a = tid / kMaxB, j = tid % kMaxB;
-    if (pc + a < p && j < cb) partial[((int64_t)rc * p + pc + a) * kMaxB + j] = v;
+    int a = tid / CB, j = tid % CB;
+    if (pc + a < p) partial[((int64_t)rc * p + pc + a) * kMaxB + j] = v;
   }
+}
+
+static void launch_gemm_tn_part(dim3 grid, hipStream_t st, const double *A, int64_t n, int p, const double *W,
+                                int cb, int64_t rows_per, double *partial) {
+#define BSN_TN(CBV)                                                                                     \
+  case CBV:                                                                                             \
+    hipLaunchKernelGGL((k_gemm_tn_part<CBV>), grid, dim3(256), 0, st, A, n, p, W, n, n, rows_per, partial); \
+    break;
+  switch (cb) {
+    BSN_TN(1) BSN_TN(2) BSN_TN(3) BSN_TN(4) BSN_TN(5) BSN_TN(6) BSN_TN(7) BSN_TN(8) BSN_TN(9) BSN_TN(10)
+    BSN_TN(11) BSN_TN(12)
+    default: fail("block size must be <= %d", kMaxB);
+  }
+#undef BSN_TN
 }
 
 // one wave per output element, fixed summation order (lane-strided partial sums, then a
@@ -153,59 +172,78 @@ __global__ void k_right_mult(double *W, int64_t ld, int64_t n, int cb, int r, co
 // pass 0 only), G = W'W now.  Writes Ri = R^-1, Rout = R (pass 0) or R * Rout (pass 1), and
 // raises *flag when W is not numerically of full rank (the host then redoes the step on the
 // step-by-step path).
-__global__ void k_orth_small(const double *G0, const double *G, int b, int pass, double *Ri,
-                             double *Rout, double *flag) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double R[kMaxB * kMaxB], Rn[kMaxB * kMaxB];
-  for (int t = 0; t < b * b; t++) R[t] = 0.0, Ri[t] = 0.0;
-  bool bad = false;
-  if (pass == 0) {
-    double w0 = 0;
-    for (int i = 0; i < b; i++) w0 = fmax(w0, G0[i + i * b]);
-    for (int i = 0; i < b; i++)
-      if (!(G[i + i * b] > 1e-22 * w0 && w0 > 0)) bad = true;
+__global__ __launch_bounds__(64) void k_orth_small(const double *G0, const double *G, int b, int pass,
+                                                    double *Ri, double *Rout, double *flag) {
+  // inputs are staged in LDS by the whole wave; thread 0 then works on LDS only (a chain of
+  // dependent global loads cost 30 us for a 5 x 5 block)
+  __shared__ double sG[kMaxB * kMaxB], sG0d[kMaxB], sR[kMaxB * kMaxB], sRi[kMaxB * kMaxB],
+      sRo[kMaxB * kMaxB], sRn[kMaxB * kMaxB];
+  __shared__ int sbad;
+  const int tid = threadIdx.x, bb = b * b;
+  for (int t = tid; t < bb; t += 64) {
+    sG[t] = G[t];
+    sR[t] = 0.0;
+    sRi[t] = 0.0;
+    sRo[t] = pass == 0 ? 0.0 : Rout[t];
   }
-  double dmax = 0;
-  for (int i = 0; i < b; i++) dmax = fmax(dmax, G[i + i * b]);
-  for (int j = 0; j < b && !bad; j++) {
-    double s = G[j + j * b];
-    for (int k = 0; k < j; k++) s -= R[k + j * b] * R[k + j * b];
-    if (!(s > 1e-22 * dmax) || !(dmax > 0)) {
-      bad = true;
-      break;
+  if (tid < b) sG0d[tid] = G0[tid + tid * b];
+  __syncthreads();
+  if (tid == 0) {
+    bool bad = false;
+    if (pass == 0) {
+      double w0 = 0;
+      for (int i = 0; i < b; i++) w0 = fmax(w0, sG0d[i]);
+      for (int i = 0; i < b; i++)
+        if (!(sG[i + i * b] > 1e-22 * w0 && w0 > 0)) bad = true;
     }
-    const double rjj = sqrt(s);
-    R[j + j * b] = rjj;
-    for (int i = j + 1; i < b; i++) {
-      double t = G[j + i * b];
-      for (int k = 0; k < j; k++) t -= R[k + j * b] * R[k + i * b];
-      R[j + i * b] = t / rjj;
-    }
-  }
-  if (bad) {
-    *flag = 1.0;
-    for (int i = 0; i < b; i++) Ri[i + i * b] = 1.0;  // keep the following kernels finite
-    return;
-  }
-  for (int j = 0; j < b; j++) {
-    Ri[j + j * b] = 1.0 / R[j + j * b];
-    for (int i = j - 1; i >= 0; i--) {
-      double s = 0;
-      for (int k = i + 1; k <= j; k++) s += R[i + k * b] * Ri[k + j * b];
-      Ri[i + j * b] = -s / R[i + i * b];
-    }
-  }
-  if (pass == 0) {
-    for (int t = 0; t < b * b; t++) Rout[t] = R[t];
-  } else {
-    for (int j = 0; j < b; j++)
-      for (int i = 0; i < b; i++) {
-        double s = 0;
-        for (int t = i; t < b; t++) s += R[i + t * b] * Rout[t + j * b];
-        Rn[i + j * b] = s;
+    double dmax = 0;
+    for (int i = 0; i < b; i++) dmax = fmax(dmax, sG[i + i * b]);
+    for (int j = 0; j < b && !bad; j++) {
+      double s = sG[j + j * b];
+      for (int k = 0; k < j; k++) s -= sR[k + j * b] * sR[k + j * b];
+      if (!(s > 1e-22 * dmax) || !(dmax > 0)) {
+        bad = true;
+        break;
       }
-    for (int t = 0; t < b * b; t++) Rout[t] = Rn[t];
+      const double rjj = sqrt(s);
+      sR[j + j * b] = rjj;
+      for (int i = j + 1; i < b; i++) {
+        double t = sG[j + i * b];
+        for (int k = 0; k < j; k++) t -= sR[k + j * b] * sR[k + i * b];
+        sR[j + i * b] = t / rjj;
+      }
+    }
+    if (bad) {
+      for (int t = 0; t < bb; t++) sRi[t] = 0.0;
+      for (int i = 0; i < b; i++) sRi[i + i * b] = 1.0;  // keep the following kernels finite
+    } else {
+      for (int j = 0; j < b; j++) {
+        sRi[j + j * b] = 1.0 / sR[j + j * b];
+        for (int i = j - 1; i >= 0; i--) {
+          double s = 0;
+          for (int k = i + 1; k <= j; k++) s += sR[i + k * b] * sRi[k + j * b];
+          sRi[i + j * b] = -s / sR[i + i * b];
+        }
+      }
+      if (pass == 0) {
+        for (int t = 0; t < bb; t++) sRn[t] = sR[t];
+      } else {
+        for (int j = 0; j < b; j++)
+          for (int i = 0; i < b; i++) {
+            double s = 0;
+            for (int t = i; t < b; t++) s += sR[i + t * b] * sRo[t + j * b];
+            sRn[i + j * b] = s;
+          }
+      }
+    }
+    sbad = bad ? 1 : 0;
   }
+  __syncthreads();
+  for (int t = tid; t < bb; t += 64) {
+    Ri[t] = sRi[t];
+    if (!sbad) Rout[t] = sRn[t];
+  }
+  if (tid == 0 && sbad) *flag = 1.0;
 }
 
 struct HipSvdBackend : SvdBackend {
@@ -255,8 +293,7 @@ struct HipSvdBackend : SvdBackend {
   }
   void gemm_tn(const double *A, int p, int cb, double *C_host) {
     dim3 grid((unsigned)((p + 3) / 4), (unsigned)nrc);
-    hipLaunchKernelGGL(k_gemm_tn_part, grid, dim3(256), 0, st, A, n, p, W.p, n, cb, n, rows_per,
-                       partial.p);
+    launch_gemm_tn_part(grid, st, A, n, p, W.p, cb, rows_per, partial.p);
     hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((p * cb + 3) / 4)), dim3(256), 0, st,
                        partial.p, nrc, p, cb, dsmall.p);
     BSN_HIP(hipGetLastError());
@@ -265,8 +302,7 @@ struct HipSvdBackend : SvdBackend {
   }
   void gemm_tn_dev(const double *A, int p, int cb, double *dC) {
     dim3 grid((unsigned)((p + 3) / 4), (unsigned)nrc);
-    hipLaunchKernelGGL(k_gemm_tn_part, grid, dim3(256), 0, st, A, n, p, W.p, n, cb, n, rows_per,
-                       partial.p);
+    launch_gemm_tn_part(grid, st, A, n, p, W.p, cb, rows_per, partial.p);
     hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((p * cb + 3) / 4)), dim3(256), 0, st,
                        partial.p, nrc, p, cb, dC);
   }
