@@ -70,13 +70,18 @@ def assert_sorted(x, name="infos.pos"):
         raise ValueError("'%s' is not sorted." % name)
 
 
-def _cor_thresholds(n, alpha, thr_r2):
-    """R/corr.R:18-23,29: |r| threshold per number of non-missing pairs"""
-    from scipy import stats
-    df = np.arange(1, n + 1, dtype=np.float64) - 2
+def _cor_thresholds(n, alpha, thr_r2, n_min=1):
+    """R/corr.R:18-23,29: |r| threshold per number of non-missing pairs, thr[nona - 1].
+    qt() costs 1 us per value in scipy, so only the entries a pair can actually reach
+    (nona >= n_min, from the missing counts of the selected variants) are evaluated; the
+    others are never read by the kernel and are left NaN."""
+    from scipy import special
+    THR = np.full(n, np.nan)
+    lo = max(int(n_min), 1)
+    df = np.arange(lo, n + 1, dtype=np.float64) - 2
     with np.errstate(all="ignore"):
-        q = stats.t.isf(alpha / 2, df=np.where(df > 0, df, np.nan))
-        THR = q / np.sqrt(df + q * q)
+        q = -special.stdtrit(np.where(df > 0, df, np.nan), alpha / 2)   # == stats.t.isf(alpha / 2, df)
+        THR[lo - 1:] = q / np.sqrt(df + q * q)
     return np.maximum(THR, np.sqrt(thr_r2))
 
 
@@ -97,7 +102,11 @@ def _cor0(obj, ind_row, ind_col, size, alpha, thr_r2, fill_diag, infos_pos):
     pos = 1000.0 * np.arange(1, ic.size + 1) if infos_pos is None else as_f64(np.ravel(infos_pos))
     assert_lengths(pos, ic)
     assert_sorted(pos)
-    thr = as_f64(_cor_thresholds(ir.size, alpha, thr_r2))
+    # a pair of variants shares at least n - na_x - na_y samples
+    from .bed import bed_counts
+    na = bed_counts(im, ir, ic)[3].astype(np.int64)
+    top2 = np.sort(na)[-2:].sum() if na.size > 1 else int(na.sum())
+    thr = as_f64(_cor_thresholds(ir.size, alpha, thr_r2, n_min=ir.size - int(top2)))
     p = np.empty(ic.size + 1, dtype=np.int32)
     nnz = C.c_int64(0)
     h = vp()
