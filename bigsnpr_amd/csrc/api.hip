@@ -181,24 +181,21 @@ int bsn_bed_from_host(const uint8_t *payload, int64_t n, int64_t m, int64_t n_by
 
 int bsn_bed_open(const char *path, int64_t n, int64_t m, bsn_bed **out) {
   return guarded([&] {
-    // validation order and messages of src/bed-acc-xptr.cpp:14-35
+    // validation order and messages of src/bed-acc-xptr.cpp:14-35 (the reference maps the file;
+    // here it is read once into the device image, so the header is checked with a 3-byte read)
     int fd = open(path, O_RDONLY);
     if (fd < 0) fail("Error when mapping file:\n  %s.\n", strerror(errno));
+    struct Close {
+      int fd;
+      ~Close() { close(fd); }
+    } closer{fd};
     struct stat st;
-    if (fstat(fd, &st) != 0) {
-      close(fd);
-      fail("Error when mapping file:\n  %s.\n", strerror(errno));
-    }
-    size_t size = (size_t)st.st_size;
-    void *map = size ? mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
-    close(fd);
-    if (map == MAP_FAILED) fail("Error when mapping file:\n  %s.\n", strerror(errno));
-    struct Unmap {
-      void *p;
-      size_t s;
-      ~Unmap() { munmap(p, s); }
-    } unmap{map, size};
-    const uint8_t *f = (const uint8_t *)map;
+    if (fstat(fd, &st) != 0) fail("Error when mapping file:\n  %s.\n", strerror(errno));
+    const size_t size = (size_t)st.st_size;
+    uint8_t f[3] = {0, 0, 0};
+    if (size == 0) fail("Error when mapping file:\n  %s.\n", strerror(EINVAL));  // mmap of an empty file
+    const ssize_t got = pread(fd, f, 3, 0);
+    if (got < 0) fail("Error when mapping file:\n  %s.\n", strerror(errno));
     if (size < 3 || !(f[0] == 0x6C && f[1] == 0x1B)) fail("File is not a binary PED file.");
     if (f[2] != 0x01) fail("Variant-major is the only mode supported.");
     int64_t n_byte = (n + 3) / 4;
@@ -207,7 +204,7 @@ int bsn_bed_open(const char *path, int64_t n, int64_t m, bsn_bed **out) {
     require_gpu();
     std::unique_ptr<bsn_bed, void (*)(bsn_bed *)> b(new bsn_bed(), free_bed);
     image_alloc(b.get(), n, m);
-    image_from_host(b.get(), f + 3, n_byte);
+    image_from_file(b.get(), fd, 3, n_byte);
     *out = b.release();
   });
 }

@@ -125,6 +125,7 @@ namespace bsn {
 // image.hip
 void image_alloc(bsn_bed *b, int64_t n, int64_t m);
 void image_from_host(bsn_bed *b, const uint8_t *payload, int64_t n_byte_src);
+void image_from_file(bsn_bed *b, int fd, int64_t offset, int64_t n_byte_src);
 void image_from_fbm(bsn_bed *b, const uint8_t *bytes, int64_t ld);
 void image_generate(bsn_bed *b, uint32_t seed, uint32_t npop, uint32_t na16, int64_t j_begin);
 void image_download(bsn_bed *b, uint8_t *payload_out);
