@@ -756,6 +756,9 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
   hipLaunchKernelGGL((k_cprod<NBV, NPLANE, KC, ABLV, 2, 8, MINWV>), grid, dim3(512), 0, b->stream, \
                      b->d_img, b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2)
 #define BSN_LAUNCH_CPROD(NBV, ABLV) BSN_LAUNCH_CPROD_W(NBV, ABLV, 1)
+#define BSN_LAUNCH_CPROD_16(NBV)                                                                      \
+  hipLaunchKernelGGL((k_cprod<NBV, NPLANE, KC, 0, 2, 16, 1>), dim3((unsigned)((op->m + 511) / 512)), \
+                     dim3(1024), 0, b->stream, b->d_img, b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2)
   if (NB == 1) {
     if (abl == 11) BSN_LAUNCH_CPROD(1, 1);
     else if (abl == 12) BSN_LAUNCH_CPROD(1, 2);
@@ -771,10 +774,12 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
     else if (abl == 12) BSN_LAUNCH_CPROD(2, 2);
     else if (abl == 13) BSN_LAUNCH_CPROD(2, 3);
     else if (abl == 14) BSN_LAUNCH_CPROD(2, 4);
-    else BSN_LAUNCH_CPROD(2, 0);
+    else if (abl == 29) BSN_LAUNCH_CPROD(2, 0);  // 8-wave workgroups (12.8 ms vs 12.4 on a 50 GB shard)
+    else BSN_LAUNCH_CPROD_16(2);               // 16 waves share one digit panel: half the L2 reads of it
   }
 #undef BSN_LAUNCH_CPROD
 #undef BSN_LAUNCH_CPROD_W
+#undef BSN_LAUNCH_CPROD_16
   BSN_HIP(hipGetLastError());
 }
 
