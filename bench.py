@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--n", type=int, default=400000)
     ap.add_argument("--m", type=int, default=1000000, help="total SNP columns over all ranks")
     ap.add_argument("--k", type=int, default=20)
-    ap.add_argument("--block", type=int, default=5)
+    ap.add_argument("--block", type=int, default=0, help="vectors per pass (0 = library default: 8 at tol 1e-4)")
     ap.add_argument("--tol", type=float, default=1e-4)
     ap.add_argument("--slices", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -93,7 +93,7 @@ def main():
     gen_s = time.time() - t0
 
     allreduce = None
-    ar_stats = {"calls": 0, "seconds": 0.0}
+    ar_stats = {"calls": 0, "seconds": 0.0, "bytes": 0}
     if use_dist:
         views = {}
 
@@ -105,6 +105,7 @@ def main():
             dist.all_reduce(t)
             torch.cuda.current_stream().synchronize()
             ar_stats["calls"] += 1
+            ar_stats["bytes"] += 8 * count
             ar_stats["seconds"] += time.perf_counter() - t0
 
     def sync():
@@ -146,7 +147,8 @@ def main():
     traffic = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if pm["workload"] == {"n": n, "m_per_gpu": m_local} and a.block == 5:
+        # the counters were collected on the one-column-block kernels (block x slices <= 16)
+        if pm["workload"] == {"n": n, "m_per_gpu": m_local} and infos[-1]["block"] * infos[-1]["slices"] <= 16:
             traffic = pm["kernels"][dom_key]["hbm_read_bytes"]
     except Exception:
         traffic = None
@@ -158,8 +160,9 @@ def main():
         "vs_baseline": None, "dtype": "i8 MFMA products / f64 panels", "data": "synthetic",
         "config": {"workload": "bed_randomSVD k=%d on synthetic %dx%d 2-bit .bed image resident in HBM"
                                % (a.k, n, m_total),
-                   "n": n, "m_total": m_total, "m_per_gpu": m_local, "block": a.block, "tol": a.tol,
-                   "parallelism": "columns sharded x%d, n x %d panel all-reduce" % (world, a.block)},
+                   "n": n, "m_total": m_total, "m_per_gpu": m_local, "block": infos[-1]["block"],
+                   "slices": infos[-1]["slices"], "tol": a.tol,
+                   "parallelism": "columns sharded x%d, n x %d panel all-reduce" % (world, infos[-1]["block"])},
         "passes_per_solve": passes / a.steps,
         "niter": infos[-1]["niter"], "converged": infos[-1]["converged"],
         "end_to_end_cols_per_s": m_total * a.steps / wall,
@@ -167,7 +170,8 @@ def main():
         "sigma": [float(x) for x in infos[-1]["d"][:5]],
         "generate_s": gen_s,
         "allreduce": {"calls": ar_stats["calls"], "ms_per_call": 1e3 * ar_stats["seconds"] / max(ar_stats["calls"], 1),
-                      "bytes_per_call": 8 * n * a.block} if use_dist else None,
+                      "bytes_per_solve": ar_stats["bytes"] / max(a.steps + a.warmup, 1),
+                      "note": "per block step: one n x block panel + one small Gram block"} if use_dist else None,
         "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2, bytes per launch)" if traffic else None,

@@ -4,6 +4,7 @@
 // (matvec.hip); the tall-skinny fp64 panel algebra below is memory-bound on the basis Q
 // (n x p doubles) and is a few percent of a step.
 #include <chrono>
+#include <cmath>
 #include <memory>
 
 #include "bsn_internal.hpp"
@@ -12,7 +13,6 @@
 namespace bsn {
 
 constexpr int kMaxB = 12;
-constexpr int kDefaultB = 5;
 
 __device__ __forceinline__ uint32_t hmix(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
@@ -246,6 +246,36 @@ __global__ __launch_bounds__(64) void k_orth_small(const double *G0, const doubl
   if (tid == 0 && sbad) *flag = 1.0;
 }
 
+// ---- rounding of a finished basis block to the fixed-point grid of the streaming products ----
+// (svd_driver.hpp: the products are then exact for the stored vectors).  The scale is the largest
+// power of two with absmax * qs <= 0.98 * 2^(8S-1): one notch below the 0.99 the product's own
+// quantiser uses, so that re-quantising the rounded vector can only pick the same or a finer grid.
+__global__ void k_col_absmax(const double *W, int64_t ld, int64_t n, unsigned long long *mx) {
+  const int v = blockIdx.y;
+  double m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmax(m, fabs(W[i + v * ld]));
+  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off));
+  __shared__ double sm[16];
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) sm[wave] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < nw; w++) m = fmax(m, sm[w]);
+    atomicMax(&mx[v], (unsigned long long)__double_as_longlong(m));
+  }
+}
+__global__ void k_round_cols(double *W, int64_t ld, int64_t n, const unsigned long long *mx, int slices) {
+  const int v = blockIdx.y;
+  const double m = __longlong_as_double((long long)mx[v]);
+  if (!(m > 0)) return;
+  int e;
+  frexp(ldexp(0.98, 8 * slices - 1) / m, &e);
+  const double qs = ldexp(1.0, e - 1), iq = ldexp(1.0, 1 - e);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) W[i + v * ld] = (double)llrint(W[i + v * ld] * qs) * iq;
+}
+
 struct HipSvdBackend : SvdBackend {
   bsn_op *op = nullptr;
   hipStream_t st = nullptr;
@@ -267,7 +297,10 @@ struct HipSvdBackend : SvdBackend {
     W.ensure((size_t)n * kMaxB);
     rows_per = 4096;
     nrc = (int)((n + rows_per - 1) / rows_per);
-    partial.ensure((size_t)nrc * (cap + 4) * kMaxB);
+    {
+      const int64_t rows_max = n > m_local ? n : m_local;
+      partial.ensure((size_t)((rows_max + rows_per - 1) / rows_per) * (cap + 4) * kMaxB);
+    }
     dsmall.ensure((size_t)(cap + 4) * 64);
     Wsave.ensure((size_t)n * kMaxB);
     dorth.ensure((size_t)8 * kMaxB * kMaxB + (size_t)3 * (cap + 4) * kMaxB);
@@ -300,11 +333,40 @@ struct HipSvdBackend : SvdBackend {
     BSN_HIP(hipMemcpyAsync(C_host, dsmall.p, (size_t)p * cb * 8, hipMemcpyDeviceToHost, st));
     BSN_HIP(hipStreamSynchronize(st));
   }
-  void gemm_tn_dev(const double *A, int p, int cb, double *dC) {
-    dim3 grid((unsigned)((p + 3) / 4), (unsigned)nrc);
-    launch_gemm_tn_part(grid, st, A, n, p, W.p, cb, rows_per, partial.p);
+  void gemm_tn_dev(const double *A, int p, int cb, double *dC) { gemm_tn_any(A, W.p, n, p, cb, dC); }
+  // dC (p x cb) = A[:, :p]' B[:, :cb] for operands with `rows` rows (leading dimension = rows)
+  void gemm_tn_any(const double *A, const double *B, int64_t rows, int p, int cb, double *dC) {
+    const int nrc_ = (int)((rows + rows_per - 1) / rows_per);
+    dim3 grid((unsigned)((p + 3) / 4), (unsigned)nrc_);
+    launch_gemm_tn_part(grid, st, A, rows, p, B, cb, rows_per, partial.p);
     hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((p * cb + 3) / 4)), dim3(256), 0, st,
-                       partial.p, nrc, p, cb, dC);
+                       partial.p, nrc_, p, cb, dC);
+  }
+  void round_W(int cb) override {
+    if (cb <= 0) return;
+    unsigned long long *mx = (unsigned long long *)dorth.p;
+    BSN_HIP(hipMemsetAsync(mx, 0, (size_t)cb * 8, st));
+    hipLaunchKernelGGL(k_col_absmax, dim3(256, cb), dim3(1024), 0, st, W.p, n, n, mx);
+    hipLaunchKernelGGL(k_round_cols, dim3((unsigned)((n + 255) / 256), cb), dim3(256), 0, st, W.p, n, n, mx,
+                       op->slices);
+    BSN_HIP(hipGetLastError());
+  }
+  void gram_to_host(const double *A, const double *B, int64_t rows, int p, int cb, bool reduce_ranks,
+                    double *out) {
+    gemm_tn_any(A, B, rows, p, cb, dsmall.p);
+    BSN_HIP(hipGetLastError());
+    if (reduce_ranks && allreduce) {
+      BSN_HIP(hipStreamSynchronize(st));
+      allreduce(dsmall.p, (int64_t)p * cb, ctx);
+    }
+    BSN_HIP(hipMemcpyAsync(out, dsmall.p, (size_t)p * cb * 8, hipMemcpyDeviceToHost, st));
+    BSN_HIP(hipStreamSynchronize(st));
+  }
+  void ZtZ(int p, int p0, int cb, double *G) override {
+    gram_to_host(Z.p, Z.p + (int64_t)p0 * m_local, m_local, p, cb, true, G);
+  }
+  void QtQ(int p, int p0, int cb, double *M) override {
+    gram_to_host(Q.p, Q.p + (int64_t)p0 * n, n, p, cb, false, M);
   }
   // The whole orth() of svd_driver.hpp queued on the stream with the small matrices kept on
   // the device: one host synchronisation per block step instead of eleven.
@@ -434,15 +496,25 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     SvdOptions so;
     so.k = o->k;
     so.tol = o->tol > 0 ? o->tol : 1e-4;
-    so.block = o->block > 0 ? (o->block > kMaxB ? kMaxB : o->block) : kDefaultB;
-    // digit slices per fp64 value: as many as fit the MFMA column blocks the block size
-    // needs anyway (16 columns per block): b <= 4 -> 4 slices, b = 5 -> 3 (15 columns),
-    // 6..8 -> 4 (two blocks), 9..10 -> 3
+    // Digit slices per fp64 value and vectors per pass.  Rounding a basis block to 8 S bits leaves a
+    // relative residual of about 1.2 * 2^(-8 S) on a converged pair (the Ritz VALUES are not
+    // affected, svd_driver.hpp), so S is the smallest width whose floor is below tol / 4; the
+    // block then fills the 16 MFMA columns of one column block (8 x 2, 5 x 3, 4 x 4, 3 x 5, 2 x 7).
+    // A block chosen by the caller gets as many slices as its column blocks hold anyway.
     {
-      int bb = so.block;
-      int autos = bb * 4 <= 16 ? 4 : bb * 3 <= 16 ? 3 : bb * 4 <= 32 ? 4 : bb * 3 <= 32 ? 3 : 2;
-      op->slices = o->slices > 0 ? o->slices : autos;
+      int s_tol = 2;
+      while (s_tol < 7 && 1.2 * std::ldexp(1.0, -8 * s_tol) > so.tol / 4) s_tol++;
+      if (o->slices > 0) s_tol = o->slices;
+      int bb = o->block > 0 ? (o->block > kMaxB ? kMaxB : o->block) : std::max(1, std::min(8, 16 / s_tol));
+      int ss = s_tol;
+      if (o->slices <= 0) {
+        const int nb = (bb * s_tol + 15) / 16;
+        ss = std::max(s_tol, std::min(7, 16 * nb / bb));
+      }
+      so.block = bb;
+      op->slices = ss;
     }
+    so.resid_floor = 1.2 * std::ldexp(1.0, -8 * op->slices);
     so.max_basis = o->max_basis;
     so.seed = o->seed ? o->seed : 1;
     so.verbose = o->verbose;
@@ -469,6 +541,8 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       info->prod_ms = pms[1];
       info->n_cprod = pc[0];
       info->n_prod = pc[1];
+      info->block = so.block;
+      info->slices = op->slices;
     }
   });
 }

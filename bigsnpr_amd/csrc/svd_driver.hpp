@@ -8,6 +8,15 @@
 // pass over the 2-bit image costs the same for 1 or 8 vectors (the i8 MFMA pipe is idle
 // otherwise), so a block method divides the number of HBM passes by ~b.
 //
+// Accuracy of the Ritz values does not depend on the precision of the products: a finished
+// basis block is rounded to the fixed-point grid of the backend (round_W), so Z = A' Q is the
+// EXACT product for the stored Q, and the projected problem is the generalised pair
+//   (Z'Z) s = theta (Q'Q) s
+// — the Galerkin condition on span(Q) in exact arithmetic, whatever rounding the expansion
+// W = A Z went through.  The expansion direction and the residual estimate (from the coupling
+// block of the orthonormalisation) see first-order rounding effects only, which perturb the
+// subspace, not the Ritz values computed on it.
+//
 // Columns (variants) may be sharded over ranks: Z = A' Q is local to the shard,
 // W = A Z is summed over ranks by the backend (one all-reduce of n x b doubles per
 // step); everything else is replicated and deterministic, so all ranks take identical
@@ -35,6 +44,12 @@ struct SvdBackend {
   virtual void WtW(int cb, double *G) = 0;                  // G (cb x cb) = W' W
   virtual void W_times(int cb, int r, const double *M) = 0; // W[:, :r] = W[:, :cb] M (cb x r)
   virtual void W_to_Q(int p0, int r) = 0;                   // Q[:, p0:p0+r] = W[:, :r]
+  // Exact-product Rayleigh-Ritz (see block_lanczos_svd): the backend rounds a finished block
+  // to the grid on which its products are exact, and supplies the Gram blocks of the stored
+  // Z = A' Q and of the stored (rounded) Q.
+  virtual void round_W(int cb) = 0;                          // W[:, :cb] <- nearest grid point
+  virtual void ZtZ(int p, int p0, int cb, double *G) = 0;    // G (p x cb) = sum_ranks Z[:, :p]' Z[:, p0:p0+cb]
+  virtual void QtQ(int p, int p0, int cb, double *M) = 0;    // M (p x cb) = Q[:, :p]' Q[:, p0:p0+cb]
   // Optional fused form of the whole orthonormalisation step below (same arithmetic, same
   // outputs) for backends that can run it without returning to the host between its parts.
   // Returns the rank (== cb) on success; -1 if unsupported or if W turned out rank deficient,
@@ -55,6 +70,9 @@ struct SvdOptions {
   int max_basis = 0;  // 0 -> chosen from k and block
   uint32_t seed = 1;
   int verbose = 0;
+  // relative residual that the rounding of the basis blocks leaves on a converged pair (about
+  // 1.2 * 2^(-8 slices), measured); added to the estimate before it is compared with tol
+  double resid_floor = 0.0;
 };
 
 struct SvdResult {
@@ -82,9 +100,11 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
   if (cap < k) cap = k;
   bk.alloc(cap + b, b);
 
-  std::vector<double> T((size_t)cap * cap, 0.0);
-  auto Tat = [&](int i, int j) -> double & { return T[(size_t)i + (size_t)j * cap]; };
-  std::vector<double> C, C2, G, R, Ri, R2, Rt, evec, eval, M;
+  // projected pair: Gz = Z'Z, Mq = Q'Q (both cap x cap, symmetric, filled block column by block column)
+  std::vector<double> Gz((size_t)cap * cap, 0.0), Mq((size_t)cap * cap, 0.0);
+  auto Gat = [&](int i, int j) -> double & { return Gz[(size_t)i + (size_t)j * cap]; };
+  auto Mat = [&](int i, int j) -> double & { return Mq[(size_t)i + (size_t)j * cap]; };
+  std::vector<double> C, C2, G, R, Ri, R2, Rt, evec, eval, M, blk;
   SvdResult res;
 
   // orthonormalise W (cb columns) against Q[:, :p] and itself; returns rank r and the
@@ -158,6 +178,7 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
   bk.random_W(b, opt.seed);
   int r = orth(0, b, C2, Rt);
   if (r == 0) r = 0;
+  bk.round_W(r);
   bk.W_to_Q(0, r);
   int p = r;      // basis size (columns of Q filled)
   int cb = r;     // size of the newest block
@@ -171,19 +192,22 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
     bk.A_Zblock(p0, cb);
     res.nops += 2;
     res.niter++;
-    int rn = orth(p, cb, C2, Rt);  // C2: p x cb, Rt: cb x cb (rn rows used)
-    // T[:, p0:p] = C2 (and mirror)
+    // Gram blocks of the new columns p0 .. p-1 (Z of this step is complete now, Q was stored rounded)
+    blk.assign((size_t)p * cb, 0.0);
+    bk.ZtZ(p, p0, cb, blk.data());
     for (int j = 0; j < cb; j++)
-      for (int i = 0; i < p; i++) {
-        Tat(i, p0 + j) = C2[(size_t)i + (size_t)j * p];
-        Tat(p0 + j, i) = C2[(size_t)i + (size_t)j * p];
-      }
-    for (int j = 0; j < cb; j++)  // symmetrise the diagonal block
+      for (int i = 0; i < p; i++) Gat(i, p0 + j) = Gat(p0 + j, i) = blk[(size_t)i + (size_t)j * p];
+    bk.QtQ(p, p0, cb, blk.data());
+    for (int j = 0; j < cb; j++)
+      for (int i = 0; i < p; i++) Mat(i, p0 + j) = Mat(p0 + j, i) = blk[(size_t)i + (size_t)j * p];
+    for (int j = 0; j < cb; j++)  // symmetrise the diagonal blocks
       for (int i = 0; i < j; i++) {
-        double a = 0.5 * (C2[(size_t)(p0 + i) + (size_t)j * p] + C2[(size_t)(p0 + j) + (size_t)i * p]);
-        Tat(p0 + i, p0 + j) = a;
-        Tat(p0 + j, p0 + i) = a;
+        double a = 0.5 * (Gat(p0 + i, p0 + j) + Gat(p0 + j, p0 + i));
+        Gat(p0 + i, p0 + j) = Gat(p0 + j, p0 + i) = a;
+        a = 0.5 * (Mat(p0 + i, p0 + j) + Mat(p0 + j, p0 + i));
+        Mat(p0 + i, p0 + j) = Mat(p0 + j, p0 + i) = a;
       }
+    int rn = orth(p, cb, C2, Rt);  // Rt: cb x cb (rn rows used): W_in = Q C2 + W_out Rt
     pp = p;
     const bool exhausted = (rn == 0) || (p >= dim);  // Krylov space is invariant: Ritz pairs exact
     if (rn > cap - p) rn = cap - p;
@@ -194,11 +218,36 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
     rl_rows = rn;
     rl_cols = cb;
 
-    // Rayleigh-Ritz on the complete part
-    evec.assign((size_t)pp * pp, 0.0);
-    for (int j = 0; j < pp; j++)
-      for (int i = 0; i < pp; i++) evec[(size_t)i + (size_t)j * pp] = Tat(i, j);
-    eig_sym(pp, evec, eval);
+    // Rayleigh-Ritz on span(Q[:, :pp]): (Gz) s = theta (Mq) s with Mq = R'R,
+    // i.e. the standard problem for R^-T Gz R^-1, s = R^-1 y
+    {
+      std::vector<double> Mp((size_t)pp * pp), Gp((size_t)pp * pp), Rm, Rmi, tmp((size_t)pp * pp);
+      for (int j = 0; j < pp; j++)
+        for (int i = 0; i < pp; i++) {
+          Mp[(size_t)i + (size_t)j * pp] = Mat(i, j);
+          Gp[(size_t)i + (size_t)j * pp] = Gat(i, j);
+        }
+      int rk = chol_upper(pp, Mp, Rm, 1e-14);
+      if (rk < pp) {  // cannot happen for an orthonormalised, then rounded, basis; be safe
+        Rm.assign((size_t)pp * pp, 0.0);
+        for (int i = 0; i < pp; i++) Rm[(size_t)i + (size_t)i * pp] = 1.0;
+      }
+      inv_upper(pp, Rm, Rmi);
+      // tmp = Gp * Rmi ; evec = Rmi' * tmp
+      small_mm(pp, pp, pp, Gp.data(), Rmi.data(), tmp.data());
+      evec.assign((size_t)pp * pp, 0.0);
+      for (int j = 0; j < pp; j++)
+        for (int i = 0; i <= j; i++) {
+          double a = 0;
+          for (int t = 0; t <= i; t++) a += Rmi[(size_t)t + (size_t)i * pp] * tmp[(size_t)t + (size_t)j * pp];
+          evec[(size_t)i + (size_t)j * pp] = a;
+          evec[(size_t)j + (size_t)i * pp] = a;
+        }
+      eig_sym(pp, evec, eval);
+      // back-transform: s = Rmi * y (upper triangular)
+      small_mm(pp, pp, pp, Rmi.data(), evec.data(), tmp.data());
+      evec.swap(tmp);
+    }
     bool done = false;
     if (pp >= k) {
       double worst = 0;
@@ -219,7 +268,7 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
       if (opt.verbose)
         std::fprintf(stderr, "[bsn svd] step %d basis %d max rel resid %.3e sigma1 %.6g\n", res.niter,
                      pp, worst, std::sqrt(std::max(eval[pp - 1], 0.0)));
-      if (worst <= opt.tol) {
+      if (worst + opt.resid_floor <= opt.tol) {
         done = true;
         res.converged = 1;
       }
@@ -228,13 +277,8 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
       if (exhausted) res.converged = 1;
       break;
     }
+    bk.round_W(rn);
     bk.W_to_Q(p, rn);
-    // T[p:p+rn, p0:p] = Rlast
-    for (int j = 0; j < cb; j++)
-      for (int i = 0; i < rn; i++) {
-        Tat(p + i, p0 + j) = Rlast[(size_t)i + (size_t)j * rn];
-        Tat(p0 + j, p + i) = Rlast[(size_t)i + (size_t)j * rn];
-      }
     p += rn;
     cb = rn;
   }

@@ -47,4 +47,4 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
                 basis=info.basis, converged=bool(info.converged),
                 max_rel_resid=info.max_rel_resid, gpu_ms=info.gpu_ms,
                 cprod_ms=info.cprod_ms, prod_ms=info.prod_ms, n_cprod=info.n_cprod,
-                n_prod=info.n_prod)
+                n_prod=info.n_prod, block=info.block, slices=info.slices)

@@ -166,8 +166,9 @@ typedef void (*bsn_allreduce_fn)(void *d_buf, int64_t count, void *ctx);
 typedef struct bsn_svd_options {
   int32_t k;          /* number of singular triplets (R default 10) */
   double tol;         /* relative residual on eigenvalues of A~A~' (R default 1e-4) */
-  int32_t block;      /* vectors per pass, 1..12 (0 -> 5) */
-  int32_t slices;     /* int8 slices of the fp64 panels, 1..7 (0 -> chosen from block: 5 -> 3) */
+  int32_t block;      /* vectors per pass, 1..12 (0 -> 16 / slices, at most 8: 8 at the default tol) */
+  int32_t slices;     /* int8 slices of the fp64 panels, 1..7 (0 -> from tol and block: 2 at tol 1e-4
+                         with block 8, 3 with block 5; the Ritz values do not depend on it) */
   int32_t max_basis;  /* cap on the Krylov basis (0 -> automatic) */
   uint32_t seed;      /* start block seed (0 -> 1) */
   int32_t verbose;
@@ -186,6 +187,7 @@ typedef struct bsn_svd_info {
   double cprod_ms;    /* total over n_cprod launches of k_cprod (A~' panel) */
   double prod_ms;     /* total over n_prod launches of k_prod (A~ panel) */
   int32_t n_cprod, n_prod;
+  int32_t block, slices; /* vectors per pass and int8 slices actually used */
 } bsn_svd_info;
 int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
                       int64_t m, const double *center, const double *scale,

@@ -2,6 +2,7 @@
 // (bigsnpr_amd/csrc/svd_driver.hpp, dense_small.hpp) on CPU with a dense host backend so
 // that the driver logic — including the column-sharded multi-rank path with an all-reduce
 // hook — can be tested without a GPU (gloo, world_size 2).  Not part of the product.
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -30,21 +31,58 @@ struct HostBackend : SvdBackend {
     }
   }
   void At_Qblock(int p0, int cb) override {
+    std::vector<double> q(Q.begin() + (size_t)p0 * n, Q.begin() + (size_t)(p0 + cb) * n);
+    round_cols(q.data(), n, cb, 0.99);  // what the product's own quantiser does (exact for a rounded block)
     for (int c = 0; c < cb; c++)
       for (int64_t j = 0; j < m_local; j++) {
         double s = 0;
-        for (int64_t i = 0; i < n; i++) s += A[i + j * n] * Q[i + (size_t)(p0 + c) * n];
+        for (int64_t i = 0; i < n; i++) s += A[i + j * n] * q[i + (size_t)c * n];
         Z[j + (size_t)(p0 + c) * m_local] = s;
       }
   }
   void A_Zblock(int p0, int cb) override {
+    std::vector<double> z(Z.begin() + (size_t)p0 * m_local, Z.begin() + (size_t)(p0 + cb) * m_local);
+    round_cols(z.data(), m_local, cb, 0.99);
     std::fill(W.begin(), W.begin() + (size_t)n * cb, 0.0);
     for (int c = 0; c < cb; c++)
       for (int64_t j = 0; j < m_local; j++) {
-        double z = Z[j + (size_t)(p0 + c) * m_local];
-        for (int64_t i = 0; i < n; i++) W[i + (size_t)c * n] += A[i + j * n] * z;
+        double zz = z[j + (size_t)c * m_local];
+        for (int64_t i = 0; i < n; i++) W[i + (size_t)c * n] += A[i + j * n] * zz;
       }
     if (ar) ar(W.data(), n * cb, ctx);
+  }
+  // slices > 0 emulates the product backend: vectors entering a product are rounded to a fixed-point
+  // grid of 8 * slices bits (per-vector power-of-two scale); 0 = exact fp64 products
+  int slices = 0;
+  void round_cols(double *X, int64_t rows, int cols, double headroom) const {
+    if (slices <= 0) return;
+    for (int c = 0; c < cols; c++) {
+      double mx = 0;
+      for (int64_t i = 0; i < rows; i++) mx = std::fmax(mx, std::fabs(X[i + (size_t)c * rows]));
+      if (!(mx > 0)) continue;
+      int e;
+      std::frexp(std::ldexp(headroom, 8 * slices - 1) / mx, &e);
+      const double qs = std::ldexp(1.0, e - 1);
+      for (int64_t i = 0; i < rows; i++) X[i + (size_t)c * rows] = std::nearbyint(X[i + (size_t)c * rows] * qs) / qs;
+    }
+  }
+  void round_W(int cb) override { round_cols(W.data(), n, cb, 0.98); }
+  void ZtZ(int p, int p0, int cb, double *G) override {
+    for (int c = 0; c < cb; c++)
+      for (int a = 0; a < p; a++) {
+        double s = 0;
+        for (int64_t j = 0; j < m_local; j++) s += Z[j + (size_t)a * m_local] * Z[j + (size_t)(p0 + c) * m_local];
+        G[a + (size_t)c * p] = s;
+      }
+    if (ar) ar(G, (int64_t)p * cb, ctx);
+  }
+  void QtQ(int p, int p0, int cb, double *M) override {
+    for (int c = 0; c < cb; c++)
+      for (int a = 0; a < p; a++) {
+        double s = 0;
+        for (int64_t i = 0; i < n; i++) s += Q[i + (size_t)a * n] * Q[i + (size_t)(p0 + c) * n];
+        M[a + (size_t)c * p] = s;
+      }
   }
   void QtW(int p, int cb, double *C) override {
     for (int c = 0; c < cb; c++)
@@ -100,7 +138,12 @@ struct HostBackend : SvdBackend {
   }
 };
 
+static int g_slices = 0;
+
 extern "C" {
+
+// emulate the product's fixed-point products in the host backend (0 = exact)
+void nt_set_slices(int slices) { g_slices = slices; }
 
 void nt_eig_sym(int n, double *A, double *d) {
   std::vector<double> V(A, A + (size_t)n * n), w;
@@ -131,12 +174,14 @@ void nt_svd_host(const double *A, int64_t n, int64_t m_local, int64_t m_total, i
   bk.m_total = m_total;
   bk.ar = ar;
   bk.ctx = ctx;
+  bk.slices = g_slices;
   SvdOptions o;
   o.k = k;
   o.tol = tol;
   o.block = block;
   o.max_basis = max_basis;
   o.seed = seed;
+  o.resid_floor = g_slices > 0 ? 1.2 * std::ldexp(1.0, -8 * g_slices) : 0.0;
   SvdResult r = block_lanczos_svd(bk, o, d, u, v);
   info[0] = r.niter;
   info[1] = r.nops;

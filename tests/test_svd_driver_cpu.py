@@ -143,3 +143,32 @@ def test_sharded_two_ranks_gloo(tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_ritz_values_do_not_see_the_product_precision(nt):
+    """The driver rounds finished basis blocks to the backend's grid and solves (Z'Z) s = theta (Q'Q) s,
+    so 16-bit fixed-point products (slices = 2) give the same singular values as exact ones up to
+    the convergence level — the old projected matrix built from the rounded expansion was off by
+    ~1e-6 (numpy prototype of both variants in the round's notes)."""
+    rng = np.random.default_rng(42)
+    n, m, k = 600, 450, 8
+    A = rng.normal(size=(n, 60)) @ np.diag(np.linspace(1, 40, 60) ** 1.3) @ rng.normal(size=(60, m)) / 8 \
+        + 0.3 * rng.normal(size=(n, m))
+    d_true = np.linalg.svd(A, compute_uv=False)[:k]
+    try:
+        errs = {}
+        for S, tol in ((0, 1e-4), (2, 1e-4), (3, 1e-6), (0, 1e-6)):
+            nt.nt_set_slices(S)
+            res = host_svd(nt, A, k, tol=tol, block=8)
+            assert res["converged"]
+            errs[(S, tol)] = np.abs(res["d"] / d_true - 1).max()
+            # u and v stay consistent with the returned d:  A' u = d v  exactly for the stored basis
+            np.testing.assert_allclose(A.T @ res["u"], res["v"] * res["d"], atol=1e-9 * d_true[0])
+        # an unattainable tolerance (below the rounding floor of 16-bit products) is reported, not faked
+        nt.nt_set_slices(2)
+        assert not host_svd(nt, A, k, tol=1e-7, block=8, max_basis=64)["converged"]
+    finally:
+        nt.nt_set_slices(0)
+    # the error of d is the convergence level (~tol^2) with or without rounded products
+    assert errs[(2, 1e-4)] < 5e-8 and errs[(0, 1e-4)] < 5e-8, errs
+    assert errs[(3, 1e-6)] < 1e-10 and errs[(0, 1e-6)] < 1e-10, errs
