@@ -156,7 +156,9 @@ int bsn_op_sync(bsn_op *op);
 
 /* ---- partial SVD (replaces bed_randomSVD -> bigstatsr::big_randomSVD -> RSpectra::svds,
  *      R/autoSVD.R:205-219; result fields of class "big_SVD": d, u, v, niter, nops) --------
- * Block Lanczos with full re-orthogonalisation on A~ A~' driven entirely on the device.
+ * Block Lanczos with full re-orthogonalisation on A~ A~' driven entirely on the device; basis
+ * blocks are rounded to the fixed-point grid of the streaming products, which makes the products
+ * exact, and the Ritz values come from the pair (Z'Z, Q'Q): d does not depend on `slices`.
  * `center`/`scale` are what fun.scaling returned (bed_scaleBinom, R/binom-scaling.R:133-142).
  * Multi-GPU: every rank calls this on its own column shard (ind_col local to its image),
  * passes m_total and an all-reduce hook that sums a device buffer of `count` doubles over
