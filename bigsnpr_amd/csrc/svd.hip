@@ -12,7 +12,8 @@
 
 namespace bsn {
 
-constexpr int kMaxB = 12;
+constexpr int kMaxB = 16;
+constexpr int kTP = 256;  // basis columns per LDS tile of k_gemm_nn
 
 __device__ __forceinline__ uint32_t hmix(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
@@ -87,7 +88,7 @@ static void launch_gemm_tn_part(dim3 grid, hipStream_t st, const double *A, int6
     break;
   switch (cb) {
     BSN_TN(1) BSN_TN(2) BSN_TN(3) BSN_TN(4) BSN_TN(5) BSN_TN(6) BSN_TN(7) BSN_TN(8) BSN_TN(9) BSN_TN(10)
-    BSN_TN(11) BSN_TN(12)
+    BSN_TN(11) BSN_TN(12) BSN_TN(13) BSN_TN(14) BSN_TN(15) BSN_TN(16)
     default: fail("block size must be <= %d", kMaxB);
   }
 #undef BSN_TN
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const double *__restrict__ Q, i
                                                  const double *In, int64_t ldi, double alpha,
                                                  double beta, double *Out, int64_t ldo, int64_t n) {
   extern __shared__ __attribute__((aligned(16))) double sS[];  // tile of S: TP x kMaxB
-  constexpr int TP = 512;
+  constexpr int TP = kTP;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   double acc[kMaxB];
 #pragma unroll
@@ -382,7 +383,7 @@ struct HipSvdBackend : SvdBackend {
     const dim3 rows((unsigned)((n + 255) / 256));
     auto project = [&](double *C) {
       gemm_tn_dev(Q.p, p, cb, C);
-      hipLaunchKernelGGL(k_gemm_nn, rows, dim3(256), 512 * kMaxB * 8, st, Q.p, n, p, C, cb, W.p, n, 1.0, -1.0,
+      hipLaunchKernelGGL(k_gemm_nn, rows, dim3(256), kTP * kMaxB * 8, st, Q.p, n, p, C, cb, W.p, n, 1.0, -1.0,
                          W.p, n, n);
     };
     gemm_tn_dev(W.p, cb, cb, G0);
@@ -415,7 +416,7 @@ struct HipSvdBackend : SvdBackend {
   void WtW(int cb, double *G) override { gemm_tn(W.p, cb, cb, G); }
   void W_minus_QC(int p, int cb, const double *C) override {
     BSN_HIP(hipMemcpyAsync(dsmall.p, C, (size_t)p * cb * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((n + 255) / 256)), dim3(256), 512 * kMaxB * 8, st,
+    hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((n + 255) / 256)), dim3(256), kTP * kMaxB * 8, st,
                        Q.p, n, p, dsmall.p, cb, W.p, n, 1.0, -1.0, W.p, n, n);
     BSN_HIP(hipGetLastError());
     BSN_HIP(hipStreamSynchronize(st));  // C is a host vector that may be reused
@@ -442,11 +443,11 @@ struct HipSvdBackend : SvdBackend {
     BSN_HIP(hipMemcpyAsync(dS.p + (size_t)pp * k, Sv.data(), (size_t)pp * k * 8, hipMemcpyHostToDevice, st));
     for (int c0 = 0; c0 < k && pp > 0; c0 += kMaxB) {
       int nc = k - c0 < kMaxB ? k - c0 : kMaxB;
-      hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((n + 255) / 256)), dim3(256), 512 * kMaxB * 8, st,
+      hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((n + 255) / 256)), dim3(256), kTP * kMaxB * 8, st,
                          Q.p, n, pp, dS.p + (size_t)c0 * pp, nc, (const double *)nullptr, (int64_t)0,
                          0.0, 1.0, dU.p + (int64_t)c0 * n, n, n);
       hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((m_local + 255) / 256)), dim3(256),
-                         512 * kMaxB * 8, st, Z.p, m_local, pp, dS.p + (size_t)pp * k + (size_t)c0 * pp,
+                         kTP * kMaxB * 8, st, Z.p, m_local, pp, dS.p + (size_t)pp * k + (size_t)c0 * pp,
                          nc, (const double *)nullptr, (int64_t)0, 0.0, 1.0,
                          dV.p + (int64_t)c0 * m_local, m_local, m_local);
     }

@@ -168,7 +168,7 @@ typedef void (*bsn_allreduce_fn)(void *d_buf, int64_t count, void *ctx);
 typedef struct bsn_svd_options {
   int32_t k;          /* number of singular triplets (R default 10) */
   double tol;         /* relative residual on eigenvalues of A~A~' (R default 1e-4) */
-  int32_t block;      /* vectors per pass, 1..12 (0 -> 16 / slices, at most 8: 8 at the default tol) */
+  int32_t block;      /* vectors per pass, 1..16 (0 -> 16 / slices, at most 8: 8 at the default tol) */
   int32_t slices;     /* int8 slices of the fp64 panels, 1..7 (0 -> from tol and block: 2 at tol 1e-4
                          with block 8, 3 with block 5; the Ritz values do not depend on it) */
   int32_t max_basis;  /* cap on the Krylov basis (0 -> automatic) */

@@ -130,12 +130,20 @@ print("rank", rank, "ok", res["niter"])
 '''
 
 
-def test_sharded_two_ranks_gloo(tmp_path):
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
+def test_sharded_two_ranks_gloo(tmp_path, nt):
     """N>1 path: columns sharded over 2 ranks, W all-reduced (gloo on CPU); both ranks must
-    converge to the global SVD and hold identical u."""
+    converge to the global SVD and hold identical u.  (`nt` builds the test library once in this
+    process so that the two workers only load it.)"""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    port = str(29500 + os.getpid() % 2000)
+    port = _free_port()
     env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "tests", "native"))
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
