@@ -19,9 +19,13 @@ def test_two_shards_equal_one(tmp_path):
     import bigsnpr_amd as ba
     n, m, k = 1500, 2200, 6
     out = str(tmp_path / "sharded.json")
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533",
+           "--master-addr", "127.0.0.1", "--master-port", port,
            os.path.join(ROOT, "tests", "helpers", "sharded_svd_worker.py"), str(n), str(m), str(k), out]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
