@@ -112,8 +112,8 @@ static void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n,
 }
 
 // counts for an arbitrary sub-view into a host 4 x m int32 array
-static void counts_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
-                        int64_t m, int32_t *res) {
+void counts_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                 int64_t m, int32_t *res) {
   bsn_op op;
   fill_op(&op, bed, ind_row, n, ind_col, m, nullptr, nullptr);
   DevBuf<int32_t> d_counts;

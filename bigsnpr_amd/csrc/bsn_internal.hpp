@@ -132,6 +132,9 @@ void image_download(bsn_bed *b, uint8_t *payload_out);
 // counts for variants cols[0..m) (device list or contiguous from col0) over all file rows;
 // d_counts: 4 x m int32 column-major (0,1,2,NA)
 void counts_all_rows(bsn_bed *b, const int32_t *d_cols, int64_t col0, int64_t m, int32_t *d_counts);
+// host result, 4 x m (counts of 0, 1, 2, NA) for arbitrary row / column selections (api.hip)
+void counts_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                 int32_t *res);
 void read_dense(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t m,
                 const double *d_center, const double *d_scale, int32_t na_val, int32_t *d_out_i,
                 double *d_out_d);

@@ -16,6 +16,8 @@
 #include <cmath>
 #include <memory>
 
+#include <cstdlib>
+
 #include "bsn_internal.hpp"
 
 namespace bsn {
@@ -47,6 +49,9 @@ __device__ __forceinline__ Planes decode3(uint32_t w) {
 // row = variant of tile I (the "x" / j0 side), col = variant of tile J (the "y" / j side).
 // rowmask (optional): 2 bits per sample, 11 = keep; dropped samples are turned into code 01
 // (missing) so that they vanish from all six sums.
+// ALL = false: only product 0 (xy) is computed and stored — the case of variants without missing
+// values among the selected samples, where the other five sums are per-variant constants.
+template <bool ALL>
 __global__ __launch_bounds__(256) void k_pair_stats(const uint8_t *__restrict__ img, int64_t pitch,
                                                     const int32_t *__restrict__ cols,
                                                     const int2 *__restrict__ pairs,
@@ -66,13 +71,14 @@ __global__ __launch_bounds__(256) void k_pair_stats(const uint8_t *__restrict__ 
   int64_t b0 = (int64_t)blockIdx.y * kbytes_per_split, b1 = b0 + kbytes_per_split;
   if (b1 > pitch) b1 = pitch;
 
-  v4i acc[2][2][6];
+  constexpr int NP = ALL ? 6 : 1;
+  v4i acc[2][2][NP];
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
-      for (int p = 0; p < 6; p++) acc[i][j][p] = v4i{0, 0, 0, 0};
+      for (int p = 0; p < NP; p++) acc[i][j][p] = v4i{0, 0, 0, 0};
 
   for (int64_t kb = b0; kb < b1; kb += 64) {  // 64 B per row = 256 samples per iteration
     uint4 a[2], b[2];
@@ -101,11 +107,13 @@ __global__ __launch_bounds__(256) void k_pair_stats(const uint8_t *__restrict__ 
 #pragma unroll
         for (int j = 0; j < 2; j++) {
           acc[i][j][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].x, B[j].x, acc[i][j][0], 0, 0, 0);
-          acc[i][j][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].x, B[j].m, acc[i][j][1], 0, 0, 0);
-          acc[i][j][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].x2, B[j].m, acc[i][j][2], 0, 0, 0);
-          acc[i][j][3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].m, B[j].x, acc[i][j][3], 0, 0, 0);
-          acc[i][j][4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].m, B[j].x2, acc[i][j][4], 0, 0, 0);
-          acc[i][j][5] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].m, B[j].m, acc[i][j][5], 0, 0, 0);
+          if constexpr (ALL) {
+            acc[i][j][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].x, B[j].m, acc[i][j][1], 0, 0, 0);
+            acc[i][j][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].x2, B[j].m, acc[i][j][2], 0, 0, 0);
+            acc[i][j][3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].m, B[j].x, acc[i][j][3], 0, 0, 0);
+            acc[i][j][4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].m, B[j].x2, acc[i][j][4], 0, 0, 0);
+            acc[i][j][5] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].m, B[j].m, acc[i][j][5], 0, 0, 0);
+          }
         }
     }
   }
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(256) void k_pair_stats(const uint8_t *__restrict__ 
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
-      for (int p = 0; p < 6; p++)
+      for (int p = 0; p < NP; p++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int row = wr * 32 + i * 16 + 4 * g + r, col = wc * 32 + j * 16 + r16;
@@ -134,7 +142,8 @@ __global__ __launch_bounds__(256) void k_pair_stats(const uint8_t *__restrict__ 
 __global__ void k_band_fill(const int32_t *__restrict__ stats, const int2 *__restrict__ pairs,
                             int npairs, int64_t m, const int64_t *__restrict__ lo, int64_t W,
                             const double *__restrict__ thr, int mode, const double *__restrict__ v1,
-                            const double *__restrict__ v2, double nrows, double *__restrict__ band) {
+                            const double *__restrict__ v2, double nrows, double *__restrict__ band,
+                            const double *__restrict__ cx, const double *__restrict__ cxx) {
   const int pi = blockIdx.x;
   if (pi >= npairs) return;
   const int2 pr = pairs[pi];
@@ -143,10 +152,14 @@ __global__ void k_band_fill(const int32_t *__restrict__ stats, const int2 *__res
     const int row = e / TB, col = e % TB;
     const int64_t j0 = (int64_t)pr.x * TB + row, j = (int64_t)pr.y * TB + col;
     if (j0 >= m || j >= j0 || j < lo[j0]) continue;
-    const double xySum = st[(0 * TB + row) * TB + col], xSum = st[(1 * TB + row) * TB + col],
-                 xxSum = st[(2 * TB + row) * TB + col], ySum = st[(3 * TB + row) * TB + col],
-                 yySum = st[(4 * TB + row) * TB + col];
-    const int nona = st[(5 * TB + row) * TB + col];
+    // cx != NULL: no missing value among the selected samples of any variant, the five
+    // one-sided sums are the per-variant totals (same integers the six-product path would produce)
+    const double xySum = st[(0 * TB + row) * TB + col];
+    const double xSum = cx ? cx[j0] : (double)st[(1 * TB + row) * TB + col],
+                 xxSum = cx ? cxx[j0] : (double)st[(2 * TB + row) * TB + col],
+                 ySum = cx ? cx[j] : (double)st[(3 * TB + row) * TB + col],
+                 yySum = cx ? cxx[j] : (double)st[(4 * TB + row) * TB + col];
+    const int nona = cx ? (int)nrows : st[(5 * TB + row) * TB + col];
     double val;
     if (mode == 0 || mode == 1) {
       const double num = xySum - xSum * ySum / nona;
@@ -264,7 +277,8 @@ struct BandJob {
   DevBuf<int2> d_pairs;
   DevBuf<int64_t> d_lo;
   DevBuf<uint32_t> d_mask;
-  DevBuf<double> d_band, d_thr, d_v1, d_v2;
+  DevBuf<double> d_band, d_thr, d_v1, d_v2, d_cx, d_cxx;
+  bool complete = false;  // no missing value among the selected samples of the selected variants
   bool use_mask = false;
   int64_t npairs = 0;
 };
@@ -326,6 +340,26 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
     BSN_HIP(hipMemcpyAsync(J.d_mask.ensure(mask.size()), mask.data(), mask.size() * 4, hipMemcpyHostToDevice, bed->stream));
     BSN_HIP(hipStreamSynchronize(bed->stream));
   }
+  // per-variant totals over the selected samples; when nothing is missing there, Sum x, Sum x^2 and
+  // the pair count of every pair are these totals and only the cross product needs the GEMM
+  {
+    std::vector<int32_t> cnt((size_t)4 * m);
+    counts_host(bed, ind_row, n, ind_col, m, cnt.data());
+    int64_t na = 0;
+    std::vector<double> cx((size_t)m), cxx((size_t)m);
+    for (int64_t j = 0; j < m; j++) {
+      const int32_t *c = &cnt[(size_t)4 * j];
+      na += c[3];
+      cx[(size_t)j] = (double)c[1] + 2.0 * c[2];
+      cxx[(size_t)j] = (double)c[1] + 4.0 * c[2];
+    }
+    J.complete = (na == 0) && !getenv("BSN_FORCE_NA_PLANE");
+    if (J.complete) {
+      BSN_HIP(hipMemcpyAsync(J.d_cx.ensure((size_t)m), cx.data(), (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
+      BSN_HIP(hipMemcpyAsync(J.d_cxx.ensure((size_t)m), cxx.data(), (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
+      BSN_HIP(hipStreamSynchronize(bed->stream));
+    }
+  }
   // tile pairs of the band
   std::vector<int2> pairs;
   for (int64_t I = 0; I < mt; I++) {
@@ -354,13 +388,20 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
     int64_t kbytes = round_up((bed->pitch + ksplit - 1) / ksplit, 64);
     ksplit = (int)((bed->pitch + kbytes - 1) / kbytes);
     if (ksplit > 1) BSN_HIP(hipMemsetAsync(J.d_stats.p, 0, (size_t)np * 6 * TB * TB * 4, bed->stream));
-    hipLaunchKernelGGL(k_pair_stats, dim3((unsigned)np, (unsigned)ksplit), dim3(256), 0, bed->stream,
-                       bed->d_img, bed->pitch, J.d_cols.p, J.d_pairs.p + p0,
-                       J.use_mask ? J.d_mask.p : nullptr, kbytes, J.d_stats.p, ksplit > 1 ? 1 : 0);
+    // FBM clumping (mode 2) reads the cross product only (src/clumping.cpp:66-73)
+    if (J.complete || mode == 2)
+      hipLaunchKernelGGL((k_pair_stats<false>), dim3((unsigned)np, (unsigned)ksplit), dim3(256), 0, bed->stream,
+                         bed->d_img, bed->pitch, J.d_cols.p, J.d_pairs.p + p0,
+                         J.use_mask ? J.d_mask.p : nullptr, kbytes, J.d_stats.p, ksplit > 1 ? 1 : 0);
+    else
+      hipLaunchKernelGGL((k_pair_stats<true>), dim3((unsigned)np, (unsigned)ksplit), dim3(256), 0, bed->stream,
+                         bed->d_img, bed->pitch, J.d_cols.p, J.d_pairs.p + p0,
+                         J.use_mask ? J.d_mask.p : nullptr, kbytes, J.d_stats.p, ksplit > 1 ? 1 : 0);
     BSN_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_band_fill, dim3((unsigned)np), dim3(256), 0, bed->stream, J.d_stats.p,
                        J.d_pairs.p + p0, (int)np, J.m, J.d_lo.p, J.W, d_thr, mode, d_v1, d_v2, nrows,
-                       J.d_band.p);
+                       J.d_band.p, J.complete ? J.d_cx.p : (const double *)nullptr,
+                       J.complete ? J.d_cxx.p : (const double *)nullptr);
     BSN_HIP(hipGetLastError());
   }
 }

@@ -90,3 +90,35 @@ def test_svd_and_fbm_on_complete_data(ba, orc):
     beta = np.random.default_rng(5).normal(size=m)
     f, g = _both_paths(lambda: ba.snp_PRS(G, beta))
     np.testing.assert_array_equal(f, g)
+
+
+def test_ld_on_complete_data_uses_one_product_and_is_identical(ba, orc):
+    """Without missing values among the selected samples only the cross-product GEMM is run (the other
+    five pairwise sums are per-variant totals); r, LD scores and clumping must be bit-identical to
+    the six-product path and match the oracle."""
+    n, m = 700, 320
+    ob = orc.fake_bed(n, m, na16=0, seed=21)
+    gb = ba.bed.synthetic(n, m, na16=0, seed=21)
+    rng = np.random.default_rng(21)
+    ir = np.sort(rng.choice(n, 500, replace=False))
+    ic = np.sort(rng.choice(m, 250, replace=False))
+    pos = np.cumsum(rng.uniform(0.5, 3.0, ic.size))
+    for rows in (None, ir):
+        f, g = _both_paths(lambda: ba.bed_cor(gb, rows, ic, size=0.03, infos_pos=pos, thr_r2=0.001))
+        for a, b in ((f.p, g.p), (f.i, g.i), (f.x, g.x)):
+            np.testing.assert_array_equal(a, b)
+        ref = orc.snp_cor(ob, rows, ic, size=0.03, infos_pos=pos, thr_r2=0.001)
+        np.testing.assert_array_equal(f.i, ref[0]); np.testing.assert_array_equal(f.p, ref[1])
+        np.testing.assert_allclose(f.x, ref[2], rtol=0, atol=1e-12)
+        f, g = _both_paths(lambda: ba.bed_ld_scores(gb, rows, ic, size=0.03, infos_pos=pos))
+        np.testing.assert_array_equal(f, g)
+        np.testing.assert_allclose(f, orc.ld_scores(ob, rows, ic, size=0.03, infos_pos=pos), rtol=1e-12)
+    chr_ = np.repeat([1, 2], [m // 2, m - m // 2])
+    bp = 1000.0 * np.arange(m)
+    f, g = _both_paths(lambda: ba.bed_clumping(gb, thr_r2=0.05, size=40, infos_chr=chr_, infos_pos=bp))
+    np.testing.assert_array_equal(f, g)
+    np.testing.assert_array_equal(f, orc.bed_clumping(ob, chr_, bp, thr_r2=0.05, size=40))
+    G = ba.FBM_code256(orc.fbm_from_bed(ob).bytes)
+    f, g = _both_paths(lambda: ba.snp_clumping(G, chr_, thr_r2=0.05, size=40, infos_pos=bp))
+    np.testing.assert_array_equal(f, g)
+    np.testing.assert_array_equal(f, orc.snp_clumping(orc.fbm_from_bed(ob), chr_, thr_r2=0.05, size=40, infos_pos=bp))
