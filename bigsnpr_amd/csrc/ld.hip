@@ -135,6 +135,90 @@ __global__ __launch_bounds__(256) void k_pair_stats(const uint8_t *__restrict__ 
         }
 }
 
+// Cross product only (variants without missing values, FBM clumping): one wave owns the whole
+// 64 x 64 tile pair for its share of the samples (4 x 4 MFMA sub-tiles, so each decoded operand
+// feeds four MFMAs instead of two) and adds its int32 partial with atomics (K is split over
+// blockIdx.y; integer sums are order-independent).  stats plane 0 must be zeroed by the caller.
+__global__ __launch_bounds__(64) void k_pair_xy64(const uint8_t *__restrict__ img, int64_t pitch,
+                                                  const int32_t *__restrict__ cols,
+                                                  const int2 *__restrict__ pairs,
+                                                  const uint32_t *__restrict__ rowmask,
+                                                  int64_t kbytes_per_split, int32_t *__restrict__ stats) {
+  const int lane = threadIdx.x;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int2 pr = pairs[blockIdx.x];
+  const uint8_t *pa[4], *pb[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    pa[s] = img + (int64_t)cols[pr.x * TB + s * 16 + r16] * pitch + g * 16;
+    pb[s] = img + (int64_t)cols[pr.y * TB + s * 16 + r16] * pitch + g * 16;
+  }
+  int64_t b0 = (int64_t)blockIdx.y * kbytes_per_split, b1 = b0 + kbytes_per_split;
+  if (b1 > pitch) b1 = pitch;
+  if (b0 >= b1) return;
+  v4i acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = v4i{0, 0, 0, 0};
+  auto decode_x = [](uint32_t w) {
+    const uint32_t s0 = w & 0x03030303u, s1 = (w >> 2) & 0x03030303u, s2 = (w >> 4) & 0x03030303u,
+                   s3 = (w >> 6) & 0x03030303u;
+    return v4i{(int)lut4b(kLX, s0), (int)lut4b(kLX, s1), (int)lut4b(kLX, s2), (int)lut4b(kLX, s3)};
+  };
+  uint4 a[4], b[4], an[4], bn[4], mk, mkn;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    a[s] = *(const uint4 *)(pa[s] + b0);
+    b[s] = *(const uint4 *)(pb[s] + b0);
+  }
+  mk = *(const uint4 *)((const uint8_t *)rowmask + b0 + g * 16);
+  for (int64_t kb = b0; kb < b1; kb += 64) {
+    const int64_t kn = kb + 64 < b1 ? kb + 64 : kb;  // branch-free prefetch of the next step
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      an[s] = *(const uint4 *)(pa[s] + kn);
+      bn[s] = *(const uint4 *)(pb[s] + kn);
+    }
+    mkn = *(const uint4 *)((const uint8_t *)rowmask + kn + g * 16);
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const uint32_t mw = d == 0 ? mk.x : d == 1 ? mk.y : d == 2 ? mk.z : mk.w;
+      v4i A[4], B[4];
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        uint32_t wa = d == 0 ? a[s].x : d == 1 ? a[s].y : d == 2 ? a[s].z : a[s].w;
+        uint32_t wb = d == 0 ? b[s].x : d == 1 ? b[s].y : d == 2 ? b[s].z : b[s].w;
+        wa = (wa & mw) | (0x55555555u & ~mw);  // dropped samples become missing (plane value 0)
+        wb = (wb & mw) | (0x55555555u & ~mw);
+        A[s] = decode_x(wa);
+        B[s] = decode_x(wb);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i], B[j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      a[s] = an[s];
+      b[s] = bn[s];
+    }
+    mk = mkn;
+  }
+  int32_t *out = stats + (int64_t)blockIdx.x * 6 * TB * TB;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = i * 16 + 4 * g + r, col = j * 16 + r16;
+        atomicAdd(out + row * TB + col, acc[i][j][r]);
+      }
+}
+
 // mode 0: r of corMat0 with threshold (dropped -> 2.0);  mode 1: r2 of ld_scores0;
 // mode 2: r2 of clumping_chr (raw formula with cached sumX/denoX, n rows);
 // mode 3: r2 of bed_clumping_chr (mean-imputed scaled values)
@@ -389,11 +473,16 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
     ksplit = (int)((bed->pitch + kbytes - 1) / kbytes);
     if (ksplit > 1) BSN_HIP(hipMemsetAsync(J.d_stats.p, 0, (size_t)np * 6 * TB * TB * 4, bed->stream));
     // FBM clumping (mode 2) reads the cross product only (src/clumping.cpp:66-73)
-    if (J.complete || mode == 2)
-      hipLaunchKernelGGL((k_pair_stats<false>), dim3((unsigned)np, (unsigned)ksplit), dim3(256), 0, bed->stream,
-                         bed->d_img, bed->pitch, J.d_cols.p, J.d_pairs.p + p0,
-                         J.use_mask ? J.d_mask.p : nullptr, kbytes, J.d_stats.p, ksplit > 1 ? 1 : 0);
-    else
+    if (J.complete || mode == 2) {
+      // one wave per workgroup here: four times the K splits of the 4-wave kernel
+      int ks4 = (int)std::min<int64_t>(std::max<int64_t>(4, 8192 / np), bed->pitch / 256);
+      if (ks4 < 1) ks4 = 1;
+      int64_t kb4 = round_up((bed->pitch + ks4 - 1) / ks4, 64);
+      ks4 = (int)((bed->pitch + kb4 - 1) / kb4);
+      if (ksplit <= 1) BSN_HIP(hipMemsetAsync(J.d_stats.p, 0, (size_t)np * 6 * TB * TB * 4, bed->stream));
+      hipLaunchKernelGGL(k_pair_xy64, dim3((unsigned)np, (unsigned)ks4), dim3(64), 0, bed->stream, bed->d_img,
+                         bed->pitch, J.d_cols.p, J.d_pairs.p + p0, J.d_mask.p, kb4, J.d_stats.p);
+    } else
       hipLaunchKernelGGL((k_pair_stats<true>), dim3((unsigned)np, (unsigned)ksplit), dim3(256), 0, bed->stream,
                          bed->d_img, bed->pitch, J.d_cols.p, J.d_pairs.p + p0,
                          J.use_mask ? J.d_mask.p : nullptr, kbytes, J.d_stats.p, ksplit > 1 ? 1 : 0);
