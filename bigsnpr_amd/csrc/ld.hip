@@ -352,6 +352,20 @@ __global__ void k_band_gt(const double *__restrict__ band, const int64_t *__rest
   }
 }
 
+// same for the LATER neighbours of j0: bit w <-> j' = j0 + 1 + w, i.e. band[j' * W + w] > thr when
+// j' exists and j0 is inside its window.  With both images the host sweep of the clumping
+// functions is two word-wise ANDs against the bit set of kept variants per variant.
+__global__ void k_band_gt_upper(const double *__restrict__ band, const int64_t *__restrict__ lo, int64_t W,
+                                int64_t Wq, int64_t m, double thr, unsigned long long *__restrict__ bits) {
+  const int64_t j0 = blockIdx.x;
+  for (int64_t w0 = (int64_t)(threadIdx.x & ~63); w0 < Wq * 64; w0 += blockDim.x) {
+    const int64_t w = w0 + (threadIdx.x & 63), j = j0 + 1 + w;
+    const bool gt = (w < W) && (j < m) && (lo[j] <= j0) && (band[j * W + w] > thr);
+    const unsigned long long b = __ballot(gt);
+    if ((threadIdx.x & 63) == 0) bits[j0 * Wq + (w0 >> 6)] = b;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 struct BandJob {
   bsn_bed *bed = nullptr;
@@ -607,41 +621,79 @@ static void clumping_grid(bsn_bed *bed, const int64_t *ind_row, int64_t n, const
     thr_id[(size_t)g] = (int)t;
   }
   const int64_t Wq = (J.W + 63) / 64;
-  std::vector<std::vector<unsigned long long>> bits(uthr.size());
+  std::vector<std::vector<unsigned long long>> bitsL(uthr.size()), bitsU(uthr.size());
   DevBuf<unsigned long long> d_bits;
   d_bits.ensure((size_t)m * (size_t)Wq);
   for (size_t t = 0; t < uthr.size(); t++) {
-    hipLaunchKernelGGL(k_band_gt, dim3((unsigned)m), dim3(256), 0, bed->stream, J.d_band.p, J.d_lo.p, J.W,
-                       Wq, uthr[t], d_bits.p);
-    BSN_HIP(hipGetLastError());
-    bits[t].resize((size_t)m * (size_t)Wq);
-    BSN_HIP(hipMemcpyAsync(bits[t].data(), d_bits.p, bits[t].size() * 8, hipMemcpyDeviceToHost, bed->stream));
-    BSN_HIP(hipStreamSynchronize(bed->stream));
+    for (int side = 0; side < 2; side++) {
+      if (side == 0)
+        hipLaunchKernelGGL(k_band_gt, dim3((unsigned)m), dim3(256), 0, bed->stream, J.d_band.p, J.d_lo.p, J.W,
+                           Wq, uthr[t], d_bits.p);
+      else
+        hipLaunchKernelGGL(k_band_gt_upper, dim3((unsigned)m), dim3(256), 0, bed->stream, J.d_band.p, J.d_lo.p,
+                           J.W, Wq, m, uthr[t], d_bits.p);
+      BSN_HIP(hipGetLastError());
+      std::vector<unsigned long long> &dst = side == 0 ? bitsL[t] : bitsU[t];
+      dst.resize((size_t)m * (size_t)Wq);
+      BSN_HIP(hipMemcpyAsync(dst.data(), d_bits.p, dst.size() * 8, hipMemcpyDeviceToHost, bed->stream));
+      BSN_HIP(hipStreamSynchronize(bed->stream));
+    }
   }
   J.d_band.release();
   J.d_stats.release();
-  // the rank-ordered sweep of src/clumping.cpp:33-88 (sequential order == the reference's
-  // result for any ncores, tests/testthat/test-7-OpenMP.R:104-115)
+  // The rank-ordered sweep of src/clumping.cpp:33-88 (sequential order == the reference's result for
+  // any ncores, tests/testthat/test-7-OpenMP.R:104-115).  When j0 is visited, the neighbours that
+  // which_to_check (src/clumping-utils.h:12-43) would return and that are still kept are exactly the
+  // KEPT variants visited before it, so "is there one with r2 > thr" is
+  //   (bitsL[j0] AND kept[j0-1 .. j0-nL]) OR (bitsU[j0] AND kept[j0+1 .. j0+nU])  !=  0,
+  // evaluated 64 neighbours per word on two bit sets of the kept variants (ascending, and
+  // reversed for the earlier neighbours).
+  const size_t kw = (size_t)(m + 63) / 64 + 2;
+  std::vector<unsigned long long> kept(kw), kept_rev(kw);
+  std::vector<int64_t> nL((size_t)m), nU((size_t)m);
+  auto any_and = [](const unsigned long long *A, const unsigned long long *K, int64_t kbase, int64_t len) {
+    for (int64_t q = 0; q * 64 < len; q++) {
+      unsigned long long a = A[q];
+      const int64_t rem = len - q * 64;
+      if (rem < 64) a &= (1ull << rem) - 1ull;
+      if (!a) continue;
+      const int64_t bpos = kbase + q * 64;
+      const int sh = (int)(bpos & 63);
+      unsigned long long kwd = K[bpos >> 6] >> sh;
+      if (sh) kwd |= K[(bpos >> 6) + 1] << (64 - sh);
+      if (a & kwd) return true;
+    }
+    return false;
+  };
   for (int64_t g = 0; g < n_grid; g++) {
-    const unsigned long long *B = bits[(size_t)thr_id[(size_t)g]].data();
+    const unsigned long long *BL = bitsL[(size_t)thr_id[(size_t)g]].data();
+    const unsigned long long *BU = bitsU[(size_t)thr_id[(size_t)g]].data();
     const double size = sizes[g];
     int32_t *keep = keep_out + g * m;
-    auto r2_gt = [&](int64_t a, int64_t b) {  // a != b, inside the band by construction
-      const int64_t hi = a > b ? a : b, w = hi - (a > b ? b : a) - 1;
-      return (B[(size_t)hi * (size_t)Wq + (size_t)(w >> 6)] >> (w & 63)) & 1ull;
-    };
-    for (int64_t j = 0; j < m; j++) keep[j] = -1;
+    // window of this grid point in index units (positions are sorted)
+    {
+      int64_t l = 0, u = 0;
+      for (int64_t j0 = 0; j0 < m; j0++) {
+        const double pos_min = pos[j0] - size, pos_max = pos[j0] + size;
+        while (l < j0 && !(pos[l] >= pos_min)) l++;
+        if (u < j0) u = j0;
+        while (u + 1 < m && pos[u + 1] <= pos_max) u++;
+        nL[(size_t)j0] = j0 - l;
+        nU[(size_t)j0] = u - j0;
+      }
+    }
+    std::fill(kept.begin(), kept.end(), 0ull);
+    std::fill(kept_rev.begin(), kept_rev.end(), 0ull);
     for (int64_t k = 0; k < m; k++) {
       const int64_t j0 = ordInd[k];
-      const double pos_min = pos[j0] - size, pos_max = pos[j0] + size;
-      bool keep_j0 = true;
-      // which_to_check (src/clumping-utils.h:12-43): neighbours inside the window with a
-      // better rank that are still kept
-      for (int64_t j = j0 + 1; keep_j0 && j < m && pos[j] <= pos_max; j++)
-        if (rankInd[j0] > rankInd[j] && keep[j] != 0 && r2_gt(j0, j)) keep_j0 = false;
-      for (int64_t j = j0 - 1; keep_j0 && j >= 0 && pos[j] >= pos_min; j--)
-        if (rankInd[j0] > rankInd[j] && keep[j] != 0 && r2_gt(j0, j)) keep_j0 = false;
-      keep[j0] = keep_j0 ? 1 : 0;
+      const bool pruned = any_and(BL + (size_t)j0 * (size_t)Wq, kept_rev.data(), m - j0, nL[(size_t)j0]) ||
+                          any_and(BU + (size_t)j0 * (size_t)Wq, kept.data(), j0 + 1, nU[(size_t)j0]);
+      keep[j0] = pruned ? 0 : 1;
+      if (!pruned) {
+        kept[(size_t)(j0 >> 6)] |= 1ull << (j0 & 63);
+        const int64_t r = m - 1 - j0;
+        kept_rev[(size_t)(r >> 6)] |= 1ull << (r & 63);
+      }
     }
   }
 }
