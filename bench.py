@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="exercise the RCCL all-reduce hook even with one rank (self-test)")
     ap.add_argument("--cpu-sample-cols", type=int, default=0)
+    ap.add_argument("--verbose", type=int, default=0, help="1: residual trajectory of every solve on stderr")
     return ap.parse_args()
 
 
@@ -117,7 +118,7 @@ def main():
 
     def step():
         return ba.bed_randomSVD(gb, k=a.k, tol=a.tol, block=a.block, slices=a.slices, allreduce=allreduce,
-                                m_total=m_total, return_uv=False)
+                                m_total=m_total, return_uv=False, verbose=a.verbose)
 
     for _ in range(a.warmup):
         step()

@@ -25,14 +25,16 @@ class SvdOptions(C.Structure):
     _fields_ = [("k", C.c_int32), ("tol", C.c_double), ("block", C.c_int32),
                 ("slices", C.c_int32), ("max_basis", C.c_int32), ("seed", C.c_uint32),
                 ("verbose", C.c_int32), ("m_total", C.c_int64), ("allreduce", ALLREDUCE_FN),
-                ("allreduce_ctx", C.c_void_p)]
+                ("allreduce_ctx", C.c_void_p), ("comm", C.c_void_p), ("binom_scaling", C.c_int32),
+                ("center_out", C.POINTER(C.c_double)), ("scale_out", C.POINTER(C.c_double))]
 
 
 class SvdInfo(C.Structure):
     _fields_ = [("niter", C.c_int32), ("nops", C.c_int32), ("basis", C.c_int32),
                 ("converged", C.c_int32), ("max_rel_resid", C.c_double), ("gpu_ms", C.c_double),
                 ("cprod_ms", C.c_double), ("prod_ms", C.c_double), ("n_cprod", C.c_int32),
-                ("n_prod", C.c_int32), ("block", C.c_int32), ("slices", C.c_int32)]
+                ("n_prod", C.c_int32), ("block", C.c_int32), ("slices", C.c_int32),
+                ("n_bad", C.c_int32), ("fused_stats", C.c_int32)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check that every symbol
@@ -103,6 +105,8 @@ class BsnError(RuntimeError):
 def load():
     global _lib
     if _lib is None:
+        # BSN_LIB_PATH: another build of the same ABI (the -DBSN_ABLATION profiling build, tools/)
+        LIB_PATH = os.environ.get("BSN_LIB_PATH") or globals()["LIB_PATH"]
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 "%s not found: build it with `python -m bigsnpr_amd.build` "

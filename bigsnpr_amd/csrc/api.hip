@@ -54,8 +54,8 @@ static void free_bed(bsn_bed *b) {
   delete b;
 }
 
-static void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n,
-                    const int64_t *ind_col, int64_t m, const double *center, const double *scale) {
+void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+             int64_t m, const double *center, const double *scale, bool defer_scale) {
   if (n <= 0 || m <= 0) fail("'ind.row' and 'ind.col' can't be empty.");
   if (bed->n >= (int64_t)1 << 31 || bed->m >= (int64_t)1 << 31) fail("dimension too large");
   BSN_HIP(hipSetDevice(bed->device));
@@ -98,6 +98,11 @@ static void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n,
     bool all0 = true;
     for (int64_t j = 0; all0 && j < m; j++) all0 = bed->na_cnt[(size_t)(ind_col ? ind_col[j] : j)] == 0;
     op->no_na = all0;
+  }
+  if (defer_scale) {  // written on the device by the first crossproduct pass (matvec.hip)
+    op->d_center.ensure((size_t)m);
+    op->d_scale.ensure((size_t)m);
+    return;
   }
   // centre / scale (defaults 0 / 1, R/bed-mult-vec.R:23-24)
   std::vector<double> tmp((size_t)m);

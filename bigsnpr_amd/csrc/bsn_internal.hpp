@@ -72,14 +72,31 @@ constexpr int64_t kPitchAlign = 256;  // bytes; one SNP row = pitch bytes, 1024 
 
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
+// ---- device coding of a genotype -----------------------------------------------
+// The .bed file codes a genotype as 00 = 2 copies of A1, 01 = missing, 10 = 1, 11 = 0
+// (src/bed-acc.h:22-37).  The HBM image holds the same 2 bits per genotype at the same
+// position, RECODED once at upload to   0, 1, 2 = allele count, 3 = missing,
+// so that the masked 2-bit field IS the int8 MFMA operand of the genotype plane (no look-up;
+// the 3 of a missing value is subtracted through the missing-value plane, matvec.hip) and
+// pad samples / pad variants are plain zero bytes.  Every path that hands bytes back to the
+// caller (bsn_bed_download, bsn_bed_subset_payload) applies the inverse.
+//   high' = ~high, low' = high ^ low   (and back: high = ~high', low = ~high' ^ low')
+__host__ __device__ inline uint32_t dev_from_plink(uint32_t w) {
+  return (~w & 0xAAAAAAAAu) | ((w ^ (w >> 1)) & 0x55555555u);
+}
+__host__ __device__ inline uint32_t plink_from_dev(uint32_t w) {
+  return (~w & 0xAAAAAAAAu) | (~(w ^ (w >> 1)) & 0x55555555u);
+}
+
 }  // namespace bsn
 
 // ---- the handle -------------------------------------------------------------
 // HBM layout: variant-major like the file (src/bed-acc.h:71-75): variant j occupies
-// bytes [j*pitch, j*pitch + n_byte); sample i sits in bits 2*(i%4) of byte i/4.
-// pitch = n_byte rounded up to 256 B.  Pad samples (pad bits of the last real byte and
-// all pad bytes) are coded 0b11 (genotype 0, not missing) so that they contribute
-// nothing to any plane product; kernels may therefore run over [0, 4*pitch) samples.
+// bytes [j*pitch, j*pitch + n_byte); sample i sits in bits 2*(i%4) of byte i/4, in the
+// device coding above (0/1/2 = allele count, 3 = missing).  pitch = n_byte rounded up to
+// 256 B.  Pad samples (pad bits of the last real byte and all pad bytes) are 0 (genotype 0,
+// not missing) so that they contribute nothing to any plane product; kernels may therefore
+// run over [0, 4*pitch) samples.
 struct bsn_bed {
   int64_t n = 0, m = 0, n_byte = 0, pitch = 0;
   uint8_t *d_img = nullptr;
@@ -98,6 +115,15 @@ struct bsn_op {
   bool rows_identity = true;   // ind_row == 0..n_file-1
   bool cols_contig = true;     // ind_col == col0 .. col0+m-1
   bool no_na = false;          // every selected variant is known to have no missing genotype
+  // centre / scale are not set yet: the next crossproduct pass counts the codes of every selected
+  // variant on the side and derives the binomial scaling from them (bsn_bed_randomsvd)
+  bool stats_pending = false;
+  bsn::DevBuf<int32_t> d_counts;  // 4 x m code counts of that pass
+  // total number of missing genotypes of that pass, copied to pinned host memory behind the pass
+  // (-1 until it has arrived): lets the solve switch to the complete-data kernels at its next
+  // synchronisation point without one of its own
+  long long *h_na_total = nullptr;
+  bool na_poll = false;
   int64_t col0 = 0;
   int slices = 4;
   int64_t passes = 0;         // streaming launches over the image issued so far
@@ -108,6 +134,7 @@ struct bsn_op {
   ~bsn_op() {
     for (auto e : ev_begin) (void)hipEventDestroy(e);
     for (auto e : ev_end) (void)hipEventDestroy(e);
+    if (h_na_total) (void)hipHostFree(h_na_total);
   }
   bsn::DevBuf<int32_t> d_rows;   // n (gather list) when !rows_identity
   bsn::DevBuf<int32_t> d_cols;   // m_pad (padded by repeating a valid column)
@@ -144,7 +171,12 @@ void to_bytes(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_col
 void subset_pack(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t m,
                  uint8_t *d_out);
 
+// api.hip: operator over a sub-view; defer_scale leaves centre / scale unset (stats_pending path)
+void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+             int64_t m, const double *center, const double *scale, bool defer_scale = false);
+
 // matvec.hip
+void op_poll_stats(bsn_op *op);  // after a stream synchronisation: pick up the missing-value total
 void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy);
 void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z, int64_t ldz);
 void op_cprod_raw(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_P, double *d_Q,

@@ -16,22 +16,38 @@
 namespace bsn {
 
 // ---------------------------------------------------------------------------
-// pad bits of the last real byte and all pad bytes -> 0b11 (genotype 0, non-missing)
-__global__ void k_tailfix(uint8_t *img, int64_t pitch, int64_t n, int64_t n_byte, int64_t m_rows,
-                          int64_t m_real) {
-  int64_t j = blockIdx.x;
-  uint8_t *row = img + j * pitch;
-  if (j >= m_real) {  // pad rows (read by the K-tail of k_prod): all genotype 0
-    for (int64_t b = threadIdx.x; b < pitch; b += blockDim.x) row[b] = 0xFF;
-    return;
+// In-place finish of an uploaded payload: .bed codes -> device codes (bsn_internal.hpp), pad
+// bits of the last real byte and all pad bytes -> 0 (genotype 0, non-missing).  One thread
+// per 16 B.
+__global__ void k_recode_fix(uint8_t *img, int64_t pitch, int64_t n, int64_t n_byte, int recode) {
+  const int64_t j = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (b >= pitch) return;
+  uint4 *p = (uint4 *)(img + j * pitch + b);
+  uint4 v = {0, 0, 0, 0};
+  if (b < n_byte) {
+    v = *p;
+    if (recode) {
+      v.x = dev_from_plink(v.x); v.y = dev_from_plink(v.y);
+      v.z = dev_from_plink(v.z); v.w = dev_from_plink(v.w);
+    }
+    // genotypes at or beyond sample n in this 16-B group (64 samples) -> 0
+    const int64_t left = n - b * 4;  // real samples from the start of the group
+    if (left < 64) {
+      uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int64_t l = left - 16 * q;
+        if (l <= 0) w[q] = 0;
+        else if (l < 16) w[q] &= (1u << (2 * (int)l)) - 1u;
+      }
+      v = uint4{w[0], w[1], w[2], w[3]};
+    }
   }
-  for (int64_t b = n_byte + threadIdx.x; b < pitch; b += blockDim.x) row[b] = 0xFF;
-  int rem = (int)(n & 3);
-  if (rem && threadIdx.x == 0) row[n_byte - 1] |= (uint8_t)(0xFF << (2 * rem));
-  (void)m_rows;
+  *p = v;
 }
 
-constexpr int64_t kPadRows = 64;  // extra all-0xFF rows after the last variant
+constexpr int64_t kPadRows = 64;  // extra all-zero rows after the last variant
 
 void image_alloc(bsn_bed *b, int64_t n, int64_t m) {
   if (n <= 0 || m <= 0) fail("n and p must be positive.");
@@ -47,10 +63,13 @@ void image_alloc(bsn_bed *b, int64_t n, int64_t m) {
   BSN_HIP(hipMalloc((void **)&b->d_img, bytes));
 }
 
-static void tailfix(bsn_bed *b) {
-  hipLaunchKernelGGL(k_tailfix, dim3((unsigned)(b->m + kPadRows)), dim3(256), 0, b->stream,
-                     b->d_img, b->pitch, b->n, b->n_byte, b->m + kPadRows, b->m);
+// recode = 1: the rows hold .bed codes (uploads); 0: device codes already (FBM repack)
+static void finish_image(bsn_bed *b, int recode) {
+  const int64_t gy = b->m < 65535 ? b->m : 65535, gz = (b->m + 65534) / 65535;
+  hipLaunchKernelGGL(k_recode_fix, dim3((unsigned)((b->pitch / 16 + 255) / 256), (unsigned)gy, (unsigned)gz),
+                     dim3(256), 0, b->stream, b->d_img, b->pitch, b->n, b->n_byte, recode);
   BSN_HIP(hipGetLastError());
+  BSN_HIP(hipMemsetAsync(b->d_img + b->m * b->pitch, 0, (size_t)(kPadRows * b->pitch), b->stream));
 }
 
 void image_from_host(bsn_bed *b, const uint8_t *payload, int64_t n_byte_src) {
@@ -64,7 +83,7 @@ void image_from_host(bsn_bed *b, const uint8_t *payload, int64_t n_byte_src) {
                              (size_t)n_byte_src, (size_t)b->n_byte, (size_t)cnt,
                              hipMemcpyHostToDevice, b->stream));
   }
-  tailfix(b);
+  finish_image(b, 1);
   BSN_HIP(hipStreamSynchronize(b->stream));
 }
 
@@ -125,13 +144,12 @@ void image_from_file(bsn_bed *b, int fd, int64_t offset, int64_t n_byte_src) {
                              (size_t)b->n_byte, (size_t)cnt, hipMemcpyHostToDevice, b->stream));
     BSN_HIP(hipEventRecord(done[k & 1], b->stream));
   }
-  tailfix(b);
+  finish_image(b, 1);
   BSN_HIP(hipStreamSynchronize(b->stream));
 }
 
 // ---------------------------------------------------------------------------
-// FBM.code256 bytes (CODE_012: 0,1,2, else NA) -> 2-bit PLINK codes.
-// genotype 0 -> 0b11, 1 -> 0b10, 2 -> 0b00, NA -> 0b01   (inverse of src/bed-acc.h:22-37)
+// FBM.code256 bytes (CODE_012: 0,1,2, else NA) -> 2-bit device codes (0, 1, 2, 3 = NA)
 __global__ void k_pack_fbm(const uint8_t *src, int64_t ld, int64_t n, int64_t n_byte, uint8_t *img,
                            int64_t pitch, int64_t ncols) {
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -141,10 +159,10 @@ __global__ void k_pack_fbm(const uint8_t *src, int64_t ld, int64_t n, int64_t n_
   uint32_t out = 0;
   for (int e = 0; e < 4; e++) {
     int64_t i = b * 4 + e;
-    uint32_t code = 3;
+    uint32_t code = 0;
     if (i < n) {
       uint8_t v = col[i];
-      code = (v == 0) ? 3u : (v == 1) ? 2u : (v == 2) ? 0u : 1u;
+      code = v < 3 ? v : 3u;
     }
     out |= code << (2 * e);
   }
@@ -167,7 +185,7 @@ void image_from_fbm(bsn_bed *b, const uint8_t *bytes, int64_t ld) {
     BSN_HIP(hipGetLastError());
     BSN_HIP(hipStreamSynchronize(b->stream));
   }
-  tailfix(b);
+  finish_image(b, 0);
   BSN_HIP(hipStreamSynchronize(b->stream));
 }
 
@@ -197,9 +215,8 @@ __device__ __forceinline__ uint32_t gen_code(uint32_t seed, uint32_t i, uint32_t
                                              uint32_t na16) {
   uint32_t r = mix32(i * 0x9E3779B1U + mix32(j * 0x85EBCA6BU + seed));
   uint32_t r2 = mix32(r ^ 0x68E31DA4U);
-  if ((r2 & 0xFFFF) < na16) return 1;
-  uint32_t g = ((r & 0xFFFF) < p16) + ((r >> 16) < p16);
-  return g == 2 ? 0u : (g == 1 ? 2u : 3u);
+  if ((r2 & 0xFFFF) < na16) return 3;  // device code of a missing value
+  return ((r & 0xFFFF) < p16) + ((r >> 16) < p16);
 }
 
 // one thread = one dword (16 samples) of one variant
@@ -212,7 +229,7 @@ __global__ void k_generate(uint8_t *img, int64_t pitch, int64_t n, int64_t m, ui
   uint32_t out = 0;
   for (int e = 0; e < 16; e++) {
     int64_t i = d * 16 + e;
-    uint32_t code = 3;
+    uint32_t code = 0;
     if (i < n) {
       uint32_t k = gen_pop(seed, (uint32_t)i, npop);
       code = gen_code(seed, (uint32_t)i, jj, gen_freq16(seed, jj, k), na16);
@@ -230,10 +247,8 @@ void image_generate(bsn_bed *b, uint32_t seed, uint32_t npop, uint32_t na16, int
   hipLaunchKernelGGL(k_generate, grid, dim3(256), 0, b->stream, b->d_img, b->pitch, b->n, b->m,
                      seed, npop, na16, j_begin);
   BSN_HIP(hipGetLastError());
-  // pad rows only (pad samples were already written as 0b11 above)
-  hipLaunchKernelGGL(k_tailfix, dim3((unsigned)kPadRows), dim3(256), 0, b->stream,
-                     b->d_img + b->m * b->pitch, b->pitch, b->n, b->n_byte, kPadRows, (int64_t)0);
-  BSN_HIP(hipGetLastError());
+  // pad rows only (pad samples were already written as 0 above)
+  BSN_HIP(hipMemsetAsync(b->d_img + b->m * b->pitch, 0, (size_t)(kPadRows * b->pitch), b->stream));
   BSN_HIP(hipStreamSynchronize(b->stream));
 }
 
@@ -243,7 +258,7 @@ __global__ void k_unpad(const uint8_t *img, int64_t pitch, int64_t n, int64_t n_
   int64_t j = blockIdx.y + (int64_t)blockIdx.z * 65535;
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n_byte) return;
-  uint8_t v = img[j * pitch + b];
+  uint8_t v = (uint8_t)plink_from_dev(img[j * pitch + b]);
   int rem = (int)(n & 3);
   if (rem && b == n_byte - 1) v &= (uint8_t)((1u << (2 * rem)) - 1);
   out[j * n_byte + b] = v;
@@ -287,9 +302,9 @@ __global__ __launch_bounds__(256) void k_counts(const uint8_t *img, int64_t pitc
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       uint32_t lo = w[q] & 0x55555555u, hi = (w[q] >> 1) & 0x55555555u;
-      c3 += __popc(lo & hi);   // 0b11 -> genotype 0
-      c1 += __popc(lo & ~hi);  // 0b01 -> missing
-      c2 += __popc(hi & ~lo);  // 0b10 -> genotype 1
+      c3 += __popc(lo & hi);   // 0b11 -> missing
+      c1 += __popc(lo & ~hi);  // 0b01 -> genotype 1
+      c2 += __popc(hi & ~lo);  // 0b10 -> genotype 2
     }
   }
 #pragma unroll
@@ -300,12 +315,10 @@ __global__ __launch_bounds__(256) void k_counts(const uint8_t *img, int64_t pitc
   }
   if (lane == 0) {
     int64_t total = pitch * 4;
-    int32_t n0 = (int32_t)(c3 - n_pad_samples);
-    int32_t n2 = (int32_t)(total - c1 - c2 - c3);
-    counts[4 * j + 0] = n0;
-    counts[4 * j + 1] = (int32_t)c2;
-    counts[4 * j + 2] = n2;
-    counts[4 * j + 3] = (int32_t)c1;
+    counts[4 * j + 0] = (int32_t)(total - c1 - c2 - c3 - n_pad_samples);  // pad samples are code 0
+    counts[4 * j + 1] = (int32_t)c1;
+    counts[4 * j + 2] = (int32_t)c2;
+    counts[4 * j + 3] = (int32_t)c3;
   }
 }
 
@@ -327,7 +340,7 @@ __global__ void k_read_dense(const uint8_t *img, int64_t pitch, const int32_t *r
   if (i >= n || j >= m) return;
   int64_t i2 = rows ? rows[i] : i, j2 = cols ? cols[j] : j;
   uint32_t code = (img[j2 * pitch + (i2 >> 2)] >> (2 * (i2 & 3))) & 3;
-  int g = code == 0 ? 2 : code == 2 ? 1 : code == 3 ? 0 : -1;
+  int g = code == 3 ? -1 : (int)code;
   if (out_i) out_i[i + j * n] = g < 0 ? na_val : g;
   if (out_d) out_d[i + j * n] = g < 0 ? 0.0 : ((double)g - center[j]) / scale[j];
 }
@@ -353,7 +366,7 @@ __global__ void k_to_bytes(const uint8_t *img, int64_t pitch, const int32_t *row
   if (i >= n || j >= m) return;
   int64_t i2 = rows ? rows[i] : i, j2 = cols ? cols[j] : j;
   uint32_t code = (img[j2 * pitch + (i2 >> 2)] >> (2 * (i2 & 3))) & 3;
-  out[i + j * n] = (uint8_t)(code == 0 ? 2 : code == 2 ? 1 : code == 3 ? 0 : 3);
+  out[i + j * n] = (uint8_t)code;  // the device code is the CODE_012 byte
 }
 
 // packed .bed payload of the sub-matrix [rows, cols]: ceil(n/4) bytes per variant, pad bits 0
@@ -363,15 +376,16 @@ __global__ void k_subset_pack(const uint8_t *img, int64_t pitch, const int32_t *
   int64_t j = blockIdx.y + (int64_t)blockIdx.z * 65535;
   if (b >= n_byte_out || j >= m) return;
   int64_t j2 = cols ? cols[j] : j;
-  uint32_t v = 0;
+  uint32_t v = 0, keep = 0;
   for (int e = 0; e < 4; e++) {
     int64_t i = b * 4 + e;
     if (i < n) {
       int64_t i2 = rows ? rows[i] : i;
       v |= ((img[j2 * pitch + (i2 >> 2)] >> (2 * (i2 & 3))) & 3u) << (2 * e);
+      keep |= 3u << (2 * e);
     }
   }
-  out[j * n_byte_out + b] = (uint8_t)v;
+  out[j * n_byte_out + b] = (uint8_t)(plink_from_dev(v) & keep);
 }
 
 void to_bytes(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t m,

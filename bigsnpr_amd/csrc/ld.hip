@@ -27,9 +27,10 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t lut4b(uint32_t lut, uint32_t sel) {
   return __builtin_amdgcn_perm(lut, lut, sel);
 }
-constexpr uint32_t kLX = 0x00010002u;   // code 0,1,2,3 -> 2, 0(NA), 1, 0
-constexpr uint32_t kLX2 = 0x00010004u;  //               -> 4, 0,     1, 0
-constexpr uint32_t kLM = 0x01010001u;   //               -> 1, 0,     1, 1
+// device code (bsn_internal.hpp: 0, 1, 2 = allele count, 3 = missing) -> plane value
+constexpr uint32_t kLX = 0x00020100u;   // code 0,1,2,3 -> 0, 1, 2, 0
+constexpr uint32_t kLX2 = 0x00040100u;  //               -> 0, 1, 4, 0
+constexpr uint32_t kLM = 0x00010101u;   //               -> 1, 1, 1, 0
 constexpr int TB = 64;                  // variants per tile side
 
 struct Planes {
@@ -47,7 +48,7 @@ __device__ __forceinline__ Planes decode3(uint32_t w) {
 
 // stats[pair][prod][row][col], prod: 0 xy, 1 x(both), 2 xx(both), 3 y(both), 4 yy(both), 5 nona
 // row = variant of tile I (the "x" / j0 side), col = variant of tile J (the "y" / j side).
-// rowmask (optional): 2 bits per sample, 11 = keep; dropped samples are turned into code 01
+// rowmask (optional): 2 bits per sample, 11 = keep; dropped samples are turned into code 11
 // (missing) so that they vanish from all six sums.
 // ALL = false: only product 0 (xy) is computed and stored — the case of variants without missing
 // values among the selected samples, where the other five sums are per-variant constants.
@@ -97,8 +98,8 @@ __global__ __launch_bounds__(256) void k_pair_stats(const uint8_t *__restrict__ 
       for (int s = 0; s < 2; s++) {
         uint32_t wa = d == 0 ? a[s].x : d == 1 ? a[s].y : d == 2 ? a[s].z : a[s].w;
         uint32_t wb = d == 0 ? b[s].x : d == 1 ? b[s].y : d == 2 ? b[s].z : b[s].w;
-        wa = (wa & mw) | (0x55555555u & ~mw);
-        wb = (wb & mw) | (0x55555555u & ~mw);
+        wa |= ~mw;
+        wb |= ~mw;
         A[s] = decode3(wa);
         B[s] = decode3(wb);
       }
@@ -189,8 +190,8 @@ __global__ __launch_bounds__(64) void k_pair_xy64(const uint8_t *__restrict__ im
       for (int s = 0; s < 4; s++) {
         uint32_t wa = d == 0 ? a[s].x : d == 1 ? a[s].y : d == 2 ? a[s].z : a[s].w;
         uint32_t wb = d == 0 ? b[s].x : d == 1 ? b[s].y : d == 2 ? b[s].z : b[s].w;
-        wa = (wa & mw) | (0x55555555u & ~mw);  // dropped samples become missing (plane value 0)
-        wb = (wb & mw) | (0x55555555u & ~mw);
+        wa |= ~mw;  // dropped samples become missing (plane value 0)
+        wb |= ~mw;
         A[s] = decode_x(wa);
         B[s] = decode_x(wb);
       }

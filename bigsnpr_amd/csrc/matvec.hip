@@ -9,13 +9,15 @@
 // 6 TB/s.  So the multiply-accumulate is moved to the i8 MFMA pipe, exactly:
 //   - the fp64 panel is scaled per vector to a fixed-point integer of 8*S bits and split
 //     into S balanced base-256 digits (int8 "slices");
-//   - each 2-bit code is expanded with v_perm_b32 byte look-ups into int8 planes
-//     g0 in {0,1,2} (missing -> 0) and na in {0,1};
-//   - v_mfma_i32_16x16x64_i8 accumulates  sum g0*digit  and  sum na*digit  in int32,
-//     which is exact; the digits are recombined in fp64 in a finalize kernel together
-//     with the centre/scale algebra
-//         A~' x = (P - c (Sx - Q)) / s,      P = sum g0 x, Q = sum na x, Sx = sum x
-//         A~ x  = sum_j g0 w_j + sum_j na (c w)_j - sum_j (c w)_j,   w = x / s.
+//   - the image holds device codes (bsn_internal.hpp: 0, 1, 2 = allele count, 3 = missing), so
+//     the masked 2-bit field IS the int8 operand of the genotype plane `code` in {0,1,2,3}
+//     (7 shift/and per 16 genotypes, no look-up); one v_perm_b32 byte look-up per register
+//     gives the plane na in {0,1};
+//   - v_mfma_i32_16x16x64_i8 accumulates  P' = sum code*digit  and  Q = sum na*digit  in int32,
+//     which is exact; the 3 of a missing value leaves through Q (g0 = code - 3 na) and the
+//     digits are recombined in fp64 in a finalize kernel together with the centre/scale algebra
+//         A~' x = (P - c (Sx - Q)) / s,      P = P' - 3 Q = sum g0 x, Q = sum na x, Sx = sum x
+//         A~ x  = sum_j code w_j + sum_j na (c w - 3 w)_j - sum_j (c w)_j,   w = x / s.
 //   Results are bit-reproducible (integer sums are order-independent).
 #include <cmath>
 #include <cstdlib>
@@ -38,11 +40,12 @@ __device__ __forceinline__ uint32_t perm8(uint32_t hi, uint32_t lo, uint32_t sel
   return __builtin_amdgcn_perm(hi, lo, sel);
 }
 
-// PLINK 2-bit code -> plane value.  code 0 = two copies, 1 = missing, 2 = one copy, 3 = none
-constexpr uint32_t kLutG0 = 0x00010002u;   // {2,0,1,0}
-constexpr uint32_t kLutNA = 0x00000100u;   // {0,1,0,0}
-constexpr uint32_t kLutHom2 = 0x00000001u; // {1,0,0,0}
-constexpr uint32_t kLutHet = 0x00010000u;  // {0,0,1,0}
+// device code -> plane value (byte k of the constant = value of code k)
+constexpr uint32_t kLutG0 = 0x00020100u;   // {0,1,2,0}
+constexpr uint32_t kLutNA = 0x01000000u;   // {0,0,0,1}
+constexpr uint32_t kLutHom2 = 0x00010000u; // {0,0,1,0}
+constexpr uint32_t kLutHet = 0x00000100u;  // {0,1,0,0}
+constexpr uint32_t kLutRaw = 0xFFFFFFFFu;  // marker: the plane is the code itself (no look-up)
 
 // ---- per-vector metadata -------------------------------------------------------
 struct VecMeta {
@@ -73,7 +76,8 @@ __global__ void k_scatter_rows(const double *X, int64_t ldx, const int32_t *rows
 }
 
 // mode 0 (cprod): value = X[k, v]                       for k < len
-// mode 1 (prod) : value = X[k, v]/scale[k] and c*value  for k < len
+// mode 1 (prod) : value a = X[k, v]/scale[k], b = c*a; the digit planes hold a and b - 3a
+// mode 2 (prod, raw plane weights): a = X[k, v], b = center[k, v] (a second panel)
 __global__ void k_absmax(const double *X, int64_t ldx, int64_t len, const double *center,
                          const double *scale, int mode, VecMeta *meta) {
   int v = blockIdx.y;
@@ -85,8 +89,10 @@ __global__ void k_absmax(const double *X, int64_t ldx, int64_t len, const double
     if (mode == 1) {
       double s = scale ? scale[k] : 1.0, c = center ? center[k] : 0.0;
       a = a / s;
-      double b = fabs(c * a);
-      if (!(b <= 1.79e308)) bad++; else mx = fmax(mx, b);
+      const double b = c * a;
+      const double b3 = fabs(b - 3.0 * a);  // the second digit plane (missing-value plane weights)
+      if (!(fabs(b) <= 1.79e308)) bad++; else mx = fmax(mx, fabs(b));
+      if (b3 <= 1.79e308) mx = fmax(mx, b3);
     } else if (mode == 2) {  // raw second plane: center[] is W2 (same shape as X)
       double b = center ? fabs(center[k + v * ldx]) : 0.0;
       if (!(b <= 1.79e308)) bad++; else mx = fmax(mx, b);
@@ -195,6 +201,9 @@ __global__ __launch_bounds__(64) void k_quant(const double *__restrict__ X, int6
       long long A = llrint(sa[tid * 17 + e]), B = llrint(sb[tid * 17 + e]);
       shi += A >> 24; slo += A & 0xFFFFFF;
       shi2 += B >> 24; slo2 += B & 0xFFFFFF;
+      // scaled product: the genotype plane is the raw code (3 for a missing value), so the
+      // missing-value plane carries c w - 3 w, in exact integers: 3 A + (B - 3 A) - B == 0
+      if (mode == 1) B -= 3 * A;
       const int pos = PERM ? ((e & 3) * 4 + (e >> 2)) : e;
 #pragma unroll
       for (int s = 0; s < S; s++) {
@@ -235,12 +244,21 @@ __global__ __launch_bounds__(64) void k_quant(const double *__restrict__ X, int6
 //   A operand: lane l -> variant row (l&15), k-group (l>>4): 16 samples of that variant
 //   B operand: lane l -> digit column (l&15), same 16 samples (from LDS)
 //   D        : lane l -> column (l&15), rows 4*(l>>4)+r
-template <int NB, int NPLANE, int KC, int ABL = 0, int TILES = 2, int WAVES = 8, int MINW = 1>
+// RAW0: plane 0 is the device code itself (no look-up).  STATS: the per-variant counts of the
+// codes 1, 2 and missing over all samples ride along (popcounts on the raw dwords; the first
+// crossproduct pass of a solve, which thereby replaces the separate statistics pass).
+// ABL != 0 only exists in -DBSN_ABLATION builds (profiling variants that compute wrong numbers).
+// CONTIG: the variants are col0 .. col0+m-1; the genotype loads are then buffer loads with a
+// scalar descriptor based at the workgroup's first row, one 32-bit lane offset per tile and a scalar
+// chunk offset, so that addressing costs no VALU (global loads spend a 64-bit add on each).
+template <int NB, int NPLANE, int KC, bool RAW0, bool STATS, bool CONTIG, int ABL = 0, int TILES = 2,
+          int WAVES = 8, int MINW = 1>
 __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__restrict__ img, int64_t pitch,
                                                const int32_t *__restrict__ cols, int64_t col0,
                                                int64_t m, const int8_t *__restrict__ xq,
                                                int32_t *__restrict__ acc_out, int64_t m_out,
-                                               uint32_t lutA, uint32_t lutB, uint32_t lutC) {
+                                               uint32_t lutA, uint32_t lutB, uint32_t lutC,
+                                               int32_t *__restrict__ counts, int32_t n_pad_samples) {
   constexpr int NCOL = 16 * NB;
   constexpr int LD = KC / 256;             // 16-B loads per variant row per chunk per lane
   constexpr int XS = KC / 16 * NCOL;       // uint4 entries per LDS buffer
@@ -248,15 +266,30 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int c = lane & 15, g = lane >> 4;
   constexpr int NT = 64 * WAVES;
-  const int64_t snp_base = ((int64_t)blockIdx.x * WAVES + wave) * (16 * TILES);
+  const int64_t wg_base = (int64_t)blockIdx.x * (WAVES * 16 * TILES);
+  const int64_t snp_base = wg_base + wave * (16 * TILES);
   const uint8_t *rowp[TILES];
+  uint32_t voff[TILES];
 #pragma unroll
   for (int t = 0; t < TILES; t++) {
     int64_t j = snp_base + t * 16 + c;
     if (j > m - 1) j = m - 1;
-    int64_t col = cols ? (int64_t)cols[j] : col0 + j;
+    int64_t col = CONTIG ? col0 + j : (int64_t)cols[j];
     rowp[t] = img + col * pitch + g * 16;
+    voff[t] = (uint32_t)((j - wg_base) * pitch + g * 16);
   }
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(img + (col0 + (CONTIG ? wg_base : 0)) * pitch), 0, 0x7fffffff, 0x00020000);
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  // 16 B of tile t at byte `off` (uniform) of the variant row
+  auto gload = [&](const int t, const int off) -> uint4 {
+    if constexpr (CONTIG) {
+      const v4u r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[t], off, 0);
+      return uint4{r.x, r.y, r.z, r.w};
+    } else {
+      return *(const uint4 *)(rowp[t] + off);
+    }
+  };
   const int nchunks = (int)(pitch * 4 / KC);
   const uint4 *xq4 = (const uint4 *)xq;
 
@@ -267,6 +300,9 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
     for (int p = 0; p < NPLANE; p++)
 #pragma unroll
       for (int nb = 0; nb < NB; nb++) acc[t][p][nb] = v4i{0, 0, 0, 0};
+  uint32_t st_lo[TILES], st_hi[TILES], st_na[TILES];  // popcounts of the low / high / both bits
+#pragma unroll
+  for (int t = 0; t < TILES; t++) st_lo[t] = st_hi[t] = st_na[t] = 0;
 
   constexpr int NX = (XS + NT - 1) / NT;   // staged uint4 per thread per chunk
   static_assert(NX <= 4, "staging registers");
@@ -280,7 +316,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
 #pragma unroll
   for (int t = 0; t < TILES; t++)
 #pragma unroll
-    for (int it = 0; it < LD; it++) ga[0][t][it] = *(const uint4 *)(rowp[t] + it * 64);
+    for (int it = 0; it < LD; it++) ga[0][t][it] = gload(t, it * 64);
   if (XFULL || tid < XS) xs[0][tid] = xq4[tid];
   if constexpr (NX > 1) xs[0][tid + NT] = xq4[tid + NT];
   if constexpr (NX > 2) xs[0][tid + 2 * NT] = xq4[tid + 2 * NT];
@@ -289,7 +325,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
   for (int t = 0; t < TILES; t++)
 #pragma unroll
     for (int it = 0; it < LD; it++)
-      ga[1][t][it] = *(const uint4 *)(rowp[t] + (nchunks > 1 ? KC / 4 : 0) + it * 64);
+      ga[1][t][it] = gload(t, (nchunks > 1 ? KC / 4 : 0) + it * 64);
   __syncthreads();
 
   auto chunk = [&](auto SETC, const int ch) {
@@ -308,17 +344,25 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
       if constexpr (NX > 3) xr3 = src[tid + 3 * NT];
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the digit loads up here, a chunk ahead of their use
-    const int64_t off2 = (int64_t)ch2 * (KC / 4);
+    const int off2 = ch2 * (KC / 4);
     // one K-step of one tile: 16 samples x 16 variants per lane-quad, decode + MFMAs
     auto kstep = [&](const int t, const uint32_t w, const uint4 (&bv)[NB]) {
       uint32_t s0 = w & 0x03030303u, s1 = (w >> 2) & 0x03030303u,
                s2 = (w >> 4) & 0x03030303u, s3 = (w >> 6) & 0x03030303u;
+      if constexpr (STATS) {
+        const uint32_t lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;
+        st_lo[t] += __popc(lo);
+        st_hi[t] += __popc(hi);
+        st_na[t] += __popc(lo & hi);
+      }
 #pragma unroll
       for (int p = 0; p < NPLANE; p++) {
         const uint32_t lut = p == 0 ? lutA : p == 1 ? lutB : lutC;
         v4i a;
         if (ABL & 2) {  // ablation: no decode, raw bits as operand
           a = v4i{(int)w, (int)(w ^ lut), (int)s1, (int)s3};
+        } else if (RAW0 && p == 0) {
+          a = v4i{(int)s0, (int)s1, (int)s2, (int)s3};
         } else {
           a = v4i{(int)lut4(lut, s0), (int)lut4(lut, s1), (int)lut4(lut, s2), (int)lut4(lut, s3)};
         }
@@ -374,7 +418,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
         if (ABL & 32) {  // ablation: no genotype loads after the prologue
           ga[SET][t][it].x ^= (uint32_t)off2;
         } else {
-          ga[SET][t][it] = *(const uint4 *)(rowp[t] + off2 + it * 64);
+          ga[SET][t][it] = gload(t, off2 + it * 64);
         }
       }
     __builtin_amdgcn_sched_barrier(0);
@@ -405,6 +449,21 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
             acc_out[((int64_t)p * m_out + j) * NCOL + nb * 16 + c] = acc[t][p][nb][r];
       }
     }
+  if constexpr (STATS) {
+    // a variant row is spread over the 4 k-groups of the wave (lanes c, c+16, c+32, c+48)
+#pragma unroll
+    for (int t = 0; t < TILES; t++) {
+      uint32_t lo = st_lo[t], hi = st_hi[t], na = st_na[t];
+      lo += __shfl_xor(lo, 16); hi += __shfl_xor(hi, 16); na += __shfl_xor(na, 16);
+      lo += __shfl_xor(lo, 32); hi += __shfl_xor(hi, 32); na += __shfl_xor(na, 32);
+      const int64_t j = snp_base + t * 16 + c;
+      if (g == 0 && j < m) {
+        const int32_t n1 = (int32_t)(lo - na), n2 = (int32_t)(hi - na);
+        *(int4 *)(counts + 4 * j) =
+            int4{(int32_t)(pitch * 4) - n1 - n2 - (int32_t)na - n_pad_samples, n1, n2, (int32_t)na};
+      }
+    }
+  }
 }
 
 __device__ __forceinline__ double horner(const int32_t *a, int S) {
@@ -412,16 +471,25 @@ __device__ __forceinline__ double horner(const int32_t *a, int S) {
   for (int s = S - 1; s >= 0; s--) r = r * 256.0 + (double)a[s];
   return r;
 }
+// sum over the slices of a[s] - k q[s] (the genotype plane sum from the raw-code plane sum:
+// g0 = code - 3 na, per slice in exact integers)
+__device__ __forceinline__ double horner_sub(const int32_t *a, const int32_t *q, int k, int S) {
+  double r = 0;
+  for (int s = S - 1; s >= 0; s--) r = r * 256.0 + (double)((long long)a[s] - (long long)k * q[s]);
+  return r;
+}
 
-// z[j, v] = (P - c_j (Sx - Q)) / (s_j qs)
+// z[j, v] = (P - c_j (Sx - Q)) / (s_j qs),  P = P' - 3 Q  (P' = plane sum of the raw codes)
 __global__ void k_cprod_final(const int32_t *acc, int64_t m, int ncol, int S, const VecMeta *meta,
                               const double *center, const double *scale, double *Z, int64_t ldz,
                               int has_q) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int v = blockIdx.y;
   if (j >= m) return;
-  double P = horner(acc + j * ncol + v * S, S);
-  double Q = has_q ? horner(acc + (m + j) * ncol + v * S, S) : 0.0;  // no missing plane: Q == 0
+  // no missing plane: Q == 0 and P' == P
+  double P = has_q ? horner_sub(acc + j * ncol + v * S, acc + (m + j) * ncol + v * S, 3, S)
+                   : horner(acc + j * ncol + v * S, S);
+  double Q = has_q ? horner(acc + (m + j) * ncol + v * S, S) : 0.0;
   double Sx = (double)meta[v].sum_hi * 16777216.0 + (double)meta[v].sum_lo;
   double c = center ? center[j] : 0.0, s = scale ? scale[j] : 1.0;
   double qs = meta[v].qscale;
@@ -443,7 +511,8 @@ __global__ void k_cprod_final(const int32_t *acc, int64_t m, int ncol, int S, co
 //   A operand: lane l -> digit column (l&15), k-group (l>>4): 16 variants' digits
 //   B operand: lane l -> sample group (l&15), same 16 variants, sample u of the group
 //   D        : lane l -> sample group (l&15), digit columns 4*(l>>4)+r
-template <int NB, bool CONTIG, int WAVES = 4, int ABL = 0, int UG = 1, int SETS = 2, bool HASQ = true>
+// RAWP: the P plane is the device code itself (no look-up).
+template <int NB, bool CONTIG, bool RAWP, bool HASQ = true, int WAVES = 4, int ABL = 0, int UG = 1, int SETS = 2>
 __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__ img, int64_t pitch,
                                               const int32_t *__restrict__ cols, int64_t col0,
                                               int64_t m_pad, int64_t mc,
@@ -564,7 +633,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
               g0[k][r4] = (int)T[q][r4];
               na[k][r4] = (int)(T[q][r4] ^ lutQ);
             } else {
-              g0[k][r4] = (int)lut4(lutP, sel);
+              g0[k][r4] = RAWP ? (int)sel : (int)lut4(lutP, sel);
               if (HASQ) na[k][r4] = (int)lut4(lutQ, sel);
             }
           }
@@ -728,7 +797,10 @@ static const double *scatter_rows_if_needed(bsn_op *op, const double *d_X, int64
   return xf;
 }
 
-// BSN_TUNE selects profiling builds of k_cprod (see launch_cprod); default 0 = the product
+// Ablation builds only (-DBSN_ABLATION, tools/build_ablation.py): BSN_TUNE selects profiling
+// variants of the two streaming kernels that compute wrong numbers by construction.  The product
+// library contains none of them.
+#ifdef BSN_ABLATION
 static int tune_variant() {
   static int v = -1;
   if (v < 0) {
@@ -737,50 +809,116 @@ static int tune_variant() {
   }
   return v;
 }
+#endif
 
-template <int NPLANE>
+// binomial scaling from the code counts (R/binom-scaling.R:133-142 on the sums of
+// src/bed-fun.cpp:22-38: sumX = n1 + 2 n2, nb_nona = n - nNA), same operations in the same order
+#pragma clang fp contract(off)
+__global__ void k_binom_scale(const int32_t *counts, int64_t m, double *center, double *scale) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const int4 c = *(const int4 *)(counts + 4 * j);
+  const double sumX = (double)(c.y + 2 * c.z);
+  const double nona = (double)(c.x + c.y + c.z);
+  const double af = sumX / (2.0 * nona);
+  center[j] = 2.0 * af;
+  scale[j] = sqrt(2.0 * af * (1.0 - af));
+}
+#pragma clang fp contract(on)
+
+// total number of missing genotypes over the counted variants (one workgroup; exact)
+__global__ __launch_bounds__(1024) void k_na_total(const int32_t *counts, int64_t m, long long *out) {
+  long long s = 0;
+  for (int64_t j = threadIdx.x; j < m; j += 1024) s += counts[4 * j + 3];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  __shared__ long long sw[16];
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; w++) s += sw[w];
+    *out = s;
+  }
+}
+
+template <int NPLANE, bool RAW0, bool STATS>
 static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint32_t l0,
-                         uint32_t l1, uint32_t l2) {
+                         uint32_t l1, uint32_t l2, int32_t *counts = nullptr) {
   bsn_bed *b = op->bed;
   constexpr int KC = 512;
   // int32 accumulators over the whole sample range: a plane adds at most 4 * 128 per sample
   if (b->pitch * 4 > 4000000) fail("more than 4e6 samples are not supported by the crossproduct kernel");
   dim3 grid((unsigned)((op->m + 255) / 256));
   const int32_t *cols = op->cols_contig ? nullptr : op->d_cols.p;
-  // BSN_TUNE = 11 / 12 / 13 / 14 / 15 / 16 / 17 / 18 / 19 select the ablation builds (no MFMA /
-  // no decode / neither / digit operand read once per chunk / no barrier / no LDS operand reads /
-  // no genotype loads / no LDS at all / compute only) used for profiles/r01_ablation.txt; they
-  // produce wrong numbers by construction.
-  const int abl = tune_variant();
-#define BSN_LAUNCH_CPROD_W(NBV, ABLV, MINWV)                                                        \
-  hipLaunchKernelGGL((k_cprod<NBV, NPLANE, KC, ABLV, 2, 8, MINWV>), grid, dim3(512), 0, b->stream, \
-                     b->d_img, b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2)
-#define BSN_LAUNCH_CPROD(NBV, ABLV) BSN_LAUNCH_CPROD_W(NBV, ABLV, 1)
-#define BSN_LAUNCH_CPROD_16(NBV)                                                                      \
-  hipLaunchKernelGGL((k_cprod<NBV, NPLANE, KC, 0, 2, 16, 1>), dim3((unsigned)((op->m + 511) / 512)), \
-                     dim3(1024), 0, b->stream, b->d_img, b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2)
+  const int32_t npad = (int32_t)(b->pitch * 4 - b->n);
+#define BSN_LAUNCH_CPROD_C(NBV, ABLV, CONTIGV)                                                          \
+  hipLaunchKernelGGL((k_cprod<NBV, NPLANE, KC, RAW0, STATS, CONTIGV, ABLV, 2, 8, 1>), grid, dim3(512), 0, \
+                     b->stream, b->d_img, b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad)
+#define BSN_LAUNCH_CPROD(NBV, ABLV)                     \
+  do {                                                  \
+    if (op->cols_contig) BSN_LAUNCH_CPROD_C(NBV, ABLV, true); \
+    else BSN_LAUNCH_CPROD_C(NBV, 0, false);             \
+  } while (0)
+#ifdef BSN_ABLATION
+  // BSN_TUNE = 11 / 12 / 13 / 15 / 16 / 17 / 18 / 19: no MFMA / no decode / neither / no barrier /
+  // no LDS operand reads / no genotype loads / no LDS at all / compute only
+  if constexpr (NPLANE == 2 && RAW0 && !STATS) {
+    const int abl = tune_variant();
+    if (NB == 1 && abl >= 11 && abl <= 19) {
+      if (abl == 11) BSN_LAUNCH_CPROD(1, 1);
+      else if (abl == 12) BSN_LAUNCH_CPROD(1, 2);
+      else if (abl == 13) BSN_LAUNCH_CPROD(1, 3);
+      else if (abl == 15) BSN_LAUNCH_CPROD(1, 8);
+      else if (abl == 16) BSN_LAUNCH_CPROD(1, 16);
+      else if (abl == 17) BSN_LAUNCH_CPROD(1, 32);
+      else if (abl == 18) BSN_LAUNCH_CPROD(1, 24);
+      else BSN_LAUNCH_CPROD(1, 56);
+      BSN_HIP(hipGetLastError());
+      return;
+    }
+  }
+#endif
   if (NB == 1) {
-    if (abl == 11) BSN_LAUNCH_CPROD(1, 1);
-    else if (abl == 12) BSN_LAUNCH_CPROD(1, 2);
-    else if (abl == 13) BSN_LAUNCH_CPROD(1, 3);
-    else if (abl == 15) BSN_LAUNCH_CPROD(1, 8);
-    else if (abl == 16) BSN_LAUNCH_CPROD(1, 16);
-    else if (abl == 17) BSN_LAUNCH_CPROD(1, 32);
-    else if (abl == 18) BSN_LAUNCH_CPROD(1, 24);
-    else if (abl == 19) BSN_LAUNCH_CPROD(1, 56);
-    else BSN_LAUNCH_CPROD(1, 0);
+    BSN_LAUNCH_CPROD(1, 0);
   } else {
-    if (abl == 11) BSN_LAUNCH_CPROD(2, 1);
-    else if (abl == 12) BSN_LAUNCH_CPROD(2, 2);
-    else if (abl == 13) BSN_LAUNCH_CPROD(2, 3);
-    else if (abl == 14) BSN_LAUNCH_CPROD(2, 4);
-    else if (abl == 29) BSN_LAUNCH_CPROD(2, 0);  // 8-wave workgroups (12.8 ms vs 12.4 on a 50 GB shard)
-    else BSN_LAUNCH_CPROD_16(2);               // 16 waves share one digit panel: half the L2 reads of it
+    // 16 waves share one digit panel: half the L2 reads of it (12.4 vs 12.8 ms on a 50 GB shard)
+    if (op->cols_contig)
+      hipLaunchKernelGGL((k_cprod<2, NPLANE, KC, RAW0, STATS, true, 0, 2, 16, 1>),
+                         dim3((unsigned)((op->m + 511) / 512)), dim3(1024), 0, b->stream, b->d_img, b->pitch, cols,
+                         op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad);
+    else
+      hipLaunchKernelGGL((k_cprod<2, NPLANE, KC, RAW0, STATS, false, 0, 2, 16, 1>),
+                         dim3((unsigned)((op->m + 511) / 512)), dim3(1024), 0, b->stream, b->d_img, b->pitch, cols,
+                         op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad);
   }
 #undef BSN_LAUNCH_CPROD
-#undef BSN_LAUNCH_CPROD_W
-#undef BSN_LAUNCH_CPROD_16
+#undef BSN_LAUNCH_CPROD_C
   BSN_HIP(hipGetLastError());
+}
+
+// The scaling statistics of a solve ride along its first crossproduct pass: counts of the codes
+// -> centre / scale on the device, before the finalize kernel needs them.
+static void finish_fused_stats(bsn_op *op) {
+  bsn_bed *b = op->bed;
+  hipLaunchKernelGGL(k_binom_scale, dim3((unsigned)((op->m + 255) / 256)), dim3(256), 0, b->stream,
+                     op->d_counts.p, op->m, op->d_center.p, op->d_scale.p);
+  BSN_HIP(hipGetLastError());
+  op->stats_pending = false;
+  // missing-value total -> pinned host word, picked up by op_poll_stats at the caller's next sync
+  if (!op->h_na_total) BSN_HIP(hipHostMalloc((void **)&op->h_na_total, sizeof(long long), hipHostMallocDefault));
+  *op->h_na_total = -1;
+  long long *d_tot = (long long *)(op->d_counts.p + 4 * op->m);  // two spare words behind the counts
+  hipLaunchKernelGGL(k_na_total, dim3(1), dim3(1024), 0, b->stream, op->d_counts.p, op->m, d_tot);
+  BSN_HIP(hipGetLastError());
+  BSN_HIP(hipMemcpyAsync(op->h_na_total, d_tot, sizeof(long long), hipMemcpyDeviceToHost, b->stream));
+  op->na_poll = true;
+}
+
+void op_poll_stats(bsn_op *op) {
+  if (!op->na_poll || !op->h_na_total) return;
+  const long long t = *(volatile long long *)op->h_na_total;
+  if (t < 0) return;
+  op->na_poll = false;
+  if (t == 0 && !getenv("BSN_FORCE_NA_PLANE")) op->no_na = true;  // complete data: skip the missing-value plane from now on
 }
 
 void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z, int64_t ldz) {
@@ -798,22 +936,62 @@ void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z,
     int32_t *acc = op->d_acc.ensure((size_t)2 * op->m * 32);
     quantise(op, xsrc + (int64_t)v0 * ldx, ldx, b->n, npad, nv, 0, S, ncol, 1, 0, meta, q);
     prof_begin(op, 0);
-    if (op->no_na)
-      launch_cprod<1>(op, NB, q, acc, kLutG0, 0, 0);  // complete variants: the na plane is all zero
-    else
-      launch_cprod<2>(op, NB, q, acc, kLutG0, kLutNA, 0);
+    if (op->stats_pending) {
+      if (!op->rows_identity) fail("internal: fused scaling statistics need all samples");
+      launch_cprod<2, true, true>(op, NB, q, acc, kLutRaw, kLutNA, 0, op->d_counts.ensure((size_t)4 * op->m + 4));
+    } else if (op->no_na) {
+      launch_cprod<1, true, false>(op, NB, q, acc, kLutRaw, 0, 0);  // complete variants: code == genotype
+    } else {
+      launch_cprod<2, true, false>(op, NB, q, acc, kLutRaw, kLutNA, 0);
+    }
     prof_end(op);
     op->passes++;
+    const bool has_q = op->stats_pending || !op->no_na;
+    if (op->stats_pending) finish_fused_stats(op);
     hipLaunchKernelGGL(k_cprod_final, dim3((unsigned)((op->m + 255) / 256), nv), dim3(256), 0,
                        b->stream, acc, op->m, ncol, S, meta, op->d_center.p, op->d_scale.p,
-                       d_Z + (int64_t)v0 * ldz, ldz, op->no_na ? 0 : 1);
+                       d_Z + (int64_t)v0 * ldz, ldz, has_q ? 1 : 0);
     BSN_HIP(hipGetLastError());
   }
 }
 
-// Y (+)= sum_j lutP[code_ij] W1[j, v] + sum_j lutQ[code_ij] W2[j, v]  (- sum_j W2[j, v] if sub_const)
+template <int NB, bool CONTIG>
+static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const int8_t *q, int32_t *acc,
+                        int64_t npad, uint32_t lutP, uint32_t lutQ, bool has_q) {
+  bsn_bed *b = op->bed;
+  const int32_t *cols = op->d_cols.p;
+#define BSN_LAUNCH_PROD(RAWP, HASQ, ABLV)                                                               \
+  hipLaunchKernelGGL((k_prod<NB, CONTIG, RAWP, HASQ, 4, ABLV>), grid, dim3(256), 0, b->stream, b->d_img, \
+                     b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ)
+#ifdef BSN_ABLATION
+  if constexpr (NB == 1 && CONTIG) {  // BSN_TUNE = 61 .. 64: no MFMA / no decode / memory skeleton / compute only
+    const int tv = tune_variant();
+    if (tv >= 61 && tv <= 64 && lutP == kLutRaw && has_q) {
+      if (tv == 61) BSN_LAUNCH_PROD(true, true, 1);
+      else if (tv == 62) BSN_LAUNCH_PROD(true, true, 2);
+      else if (tv == 63) BSN_LAUNCH_PROD(true, true, 3);
+      else BSN_LAUNCH_PROD(true, true, 32);
+      BSN_HIP(hipGetLastError());
+      return;
+    }
+  }
+#endif
+  if (lutP == kLutRaw) {
+    if (has_q) BSN_LAUNCH_PROD(true, true, 0);
+    else BSN_LAUNCH_PROD(true, false, 0);
+  } else {
+    if (has_q) BSN_LAUNCH_PROD(false, true, 0);
+    else BSN_LAUNCH_PROD(false, false, 0);
+  }
+#undef BSN_LAUNCH_PROD
+  BSN_HIP(hipGetLastError());
+}
+
+// Y (+)= sum_j P[code_ij] W1[j, v] + sum_j lutQ[code_ij] W2[j, v]  (- sum_j W2[j, v] if sub_const)
+// P = lutP look-up, or the code itself when lutP == kLutRaw.
 // mode 1: W1 = X / scale, W2 = center * W1 derived from the operator's centre / scale (the
-// scaled product A~ X); mode 2: W1 = d_X, W2 = d_W2 given directly (raw plane weights).
+// scaled product A~ X; lutP must be kLutRaw and lutQ kLutNA: the quantiser then stores W2 - 3 W1
+// in the second plane, see k_quant); mode 2: W1 = d_X, W2 = d_W2 given directly (raw plane weights).
 static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64_t ldx, int nvec,
                         double *d_Y, int64_t ldy, int mode, uint32_t lutP, uint32_t lutQ, int sub_const,
                         double beta, int S) {
@@ -837,6 +1015,8 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
   if (ky < ky_min) ky = (int)ky_min;
   int64_t mc = round_up((steps + ky - 1) / ky, 1) * 64;
   ky = (int)((m_pad + mc - 1) / mc);
+  // complete variants: the missing-value plane is all zero, skip its look-ups and MFMAs
+  const bool has_q = lutQ != 0u && !(op->no_na && lutQ == kLutNA);
   for (int v0 = 0; v0 < nvec; v0 += vmax) {
     int nv = nvec - v0 < vmax ? nvec - v0 : vmax;
     int NB = pick_nb(nv * S), ncol = 16 * NB;
@@ -848,52 +1028,14 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
     quantise(op, d_X + (int64_t)v0 * ldx, ldx, op->m, m_pad, nv, mode, S, ncol, 0, 0, meta, q,
              d_W2 ? d_W2 + (int64_t)v0 * ldx : nullptr);
     dim3 grid((unsigned)wgx, (unsigned)ky);
-    const int32_t *cols = op->d_cols.p;
     prof_begin(op, 1);
-    if (tune_variant() >= 61 && tune_variant() <= 64 && NB == 1 && op->cols_contig) {
-      const int tv = tune_variant();
-#define BSN_LAUNCH_PROD_ABL(A)                                                                        \
-  hipLaunchKernelGGL((k_prod<1, true, 4, A>), grid, dim3(256), 0, b->stream, b->d_img, b->pitch, cols, \
-                     op->col0, m_pad, mc, q, acc, npad, lutP, lutQ)
-      if (tv == 61) BSN_LAUNCH_PROD_ABL(1);        // no MFMA
-      else if (tv == 62) BSN_LAUNCH_PROD_ABL(2);   // no decode
-      else if (tv == 63) BSN_LAUNCH_PROD_ABL(3);   // memory skeleton
-      else BSN_LAUNCH_PROD_ABL(32);                // compute only
-#undef BSN_LAUNCH_PROD_ABL
-    } else if (op->no_na && lutQ == kLutNA) {
-      // complete variants: the second plane (missing -> c w) is all zero, skip its look-ups and MFMAs
-      if (op->cols_contig) {
-        if (NB == 1)
-          hipLaunchKernelGGL((k_prod<1, true, 4, 0, 1, 2, false>), grid, dim3(256), 0, b->stream, b->d_img,
-                             b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
-        else
-          hipLaunchKernelGGL((k_prod<2, true, 4, 0, 1, 2, false>), grid, dim3(256), 0, b->stream, b->d_img,
-                             b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
-      } else {
-        if (NB == 1)
-          hipLaunchKernelGGL((k_prod<1, false, 4, 0, 1, 2, false>), grid, dim3(256), 0, b->stream, b->d_img,
-                             b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
-        else
-          hipLaunchKernelGGL((k_prod<2, false, 4, 0, 1, 2, false>), grid, dim3(256), 0, b->stream, b->d_img,
-                             b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
-      }
-    } else
     if (op->cols_contig) {
-      if (NB == 1)
-        hipLaunchKernelGGL((k_prod<1, true>), grid, dim3(256), 0, b->stream, b->d_img, b->pitch,
-                           cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
-      else
-        hipLaunchKernelGGL((k_prod<2, true>), grid, dim3(256), 0, b->stream, b->d_img, b->pitch,
-                           cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
+      if (NB == 1) launch_prod<1, true>(op, grid, m_pad, mc, q, acc, npad, lutP, lutQ, has_q);
+      else launch_prod<2, true>(op, grid, m_pad, mc, q, acc, npad, lutP, lutQ, has_q);
     } else {
-      if (NB == 1)
-        hipLaunchKernelGGL((k_prod<1, false>), grid, dim3(256), 0, b->stream, b->d_img, b->pitch,
-                           cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
-      else
-        hipLaunchKernelGGL((k_prod<2, false>), grid, dim3(256), 0, b->stream, b->d_img, b->pitch,
-                           cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
+      if (NB == 1) launch_prod<1, false>(op, grid, m_pad, mc, q, acc, npad, lutP, lutQ, has_q);
+      else launch_prod<2, false>(op, grid, m_pad, mc, q, acc, npad, lutP, lutQ, has_q);
     }
-    BSN_HIP(hipGetLastError());
     prof_end(op);
     op->passes++;
     if (NB == 1)
@@ -916,7 +1058,8 @@ __global__ void k_cprod_raw_final(const int32_t *acc, int64_t m, int ncol, int S
   if (j >= m) return;
   const double qs = meta[v].qscale;
   const double inv = qs > 0 ? 1.0 / qs : 0.0;
-  double p = horner(acc + j * ncol + v * S, S) * inv, q = horner(acc + (m + j) * ncol + v * S, S) * inv;
+  double p = horner_sub(acc + j * ncol + v * S, acc + (m + j) * ncol + v * S, 3, S) * inv,
+         q = horner(acc + (m + j) * ncol + v * S, S) * inv;
   if (meta[v].nonfinite) p = q = __longlong_as_double(0x7ff8000000000000LL);
   P[j + v * ld] = p;
   Q[j + v * ld] = q;
@@ -937,7 +1080,7 @@ void op_cprod_raw(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *
     int8_t *q = op->d_q.ensure((size_t)npad * 32 * 2);
     int32_t *acc = op->d_acc.ensure((size_t)2 * op->m * 32);
     quantise(op, xsrc + (int64_t)v0 * ldx, ldx, b->n, npad, nv, 0, S, ncol, 1, 0, meta, q);
-    launch_cprod<2>(op, NB, q, acc, kLutG0, kLutNA, 0);
+    launch_cprod<2, true, false>(op, NB, q, acc, kLutRaw, kLutNA, 0);
     op->passes++;
     hipLaunchKernelGGL(k_cprod_raw_final, dim3((unsigned)((op->m + 255) / 256), nv), dim3(256), 0,
                        b->stream, acc, op->m, ncol, S, meta, d_P + (int64_t)v0 * ld,
@@ -947,7 +1090,7 @@ void op_cprod_raw(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *
 }
 
 void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy) {
-  prod_planes(op, d_X, nullptr, ldx, nvec, d_Y, ldy, 1, kLutG0, kLutNA, 1, 0.0, op->slices);
+  prod_planes(op, d_X, nullptr, ldx, nvec, d_Y, ldy, 1, kLutRaw, kLutNA, 1, 0.0, op->slices);
 }
 
 // rowSumsSq[i] = sum_j A~[i, j]^2 over the non-missing genotypes (src/bed-fun.cpp:121-123):
@@ -970,8 +1113,8 @@ void op_row_sums_sq(bsn_op *op, double *d_out) {
   hipLaunchKernelGGL(k_rowsq_weights, dim3((unsigned)((op->m + 255) / 256)), dim3(256), 0, bed->stream,
                      op->d_center.p, op->d_scale.p, op->m, a, b2, d);
   BSN_HIP(hipGetLastError());
-  constexpr uint32_t kLutX2 = 0x00010004u;  // code 0,1,2,3 -> 4, 0, 1, 0
-  constexpr uint32_t kLutM = 0x01010001u;   //               -> 1, 0, 1, 1
+  constexpr uint32_t kLutX2 = 0x00040100u;  // code 0,1,2,3 -> 0, 1, 4, 0
+  constexpr uint32_t kLutM = 0x00010101u;   //               -> 1, 1, 1, 0
   prod_planes(op, a, b2, op->m, 1, d_out, op->n, 2, kLutX2, kLutG0, 0, 0.0, 7);
   prod_planes(op, d, nullptr, op->m, 1, d_out, op->n, 2, kLutM, 0u, 0, 1.0, 7);
   BSN_HIP(hipStreamSynchronize(bed->stream));  // `w` is released on return
@@ -1016,7 +1159,7 @@ void counts_weighted(bsn_op *op, const double *d_w, int64_t n_sub, int32_t *d_co
   int8_t *q = op->d_q.ensure((size_t)npad * 64);
   int32_t *acc = op->d_acc.ensure((size_t)3 * op->m * 16);
   quantise(op, d_w, b->n, b->n, npad, 1, 0, S, 16, 1, 1, meta, q);
-  launch_cprod<3>(op, 1, q, acc, kLutHom2, kLutHet, kLutNA);
+  launch_cprod<3, false, false>(op, 1, q, acc, kLutHom2, kLutHet, kLutNA);
   hipLaunchKernelGGL(k_counts_final, dim3((unsigned)((op->m + 255) / 256)), dim3(256), 0, b->stream,
                      acc, op->m, 16, S, n_sub, d_counts);
   BSN_HIP(hipGetLastError());

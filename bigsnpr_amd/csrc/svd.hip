@@ -362,6 +362,7 @@ struct HipSvdBackend : SvdBackend {
     }
     BSN_HIP(hipMemcpyAsync(out, dsmall.p, (size_t)p * cb * 8, hipMemcpyDeviceToHost, st));
     BSN_HIP(hipStreamSynchronize(st));
+    op_poll_stats(op);
   }
   void ZtZ(int p, int p0, int cb, double *G) override {
     gram_to_host(Z.p, Z.p + (int64_t)p0 * m_local, m_local, p, cb, true, G);
@@ -401,6 +402,7 @@ struct HipSvdBackend : SvdBackend {
     horth.resize(nsmall);
     BSN_HIP(hipMemcpyAsync(horth.data(), flag, nsmall * 8, hipMemcpyDeviceToHost, st));
     BSN_HIP(hipStreamSynchronize(st));
+    op_poll_stats(op);
     if (horth[0] != 0.0) {  // rank deficient: undo and let the driver take the careful path
       BSN_HIP(hipMemcpyAsync(W.p, Wsave.p, (size_t)n * cb * 8, hipMemcpyDeviceToDevice, st));
       return -1;
@@ -466,22 +468,62 @@ struct HipSvdBackend : SvdBackend {
 
 using namespace bsn;
 
+// bed_scaleBinom from host code counts (the path of row subsets, where the statistics cannot ride
+// along a crossproduct pass over all samples): R/binom-scaling.R:133-142
+static void binom_scale_host(const std::vector<int32_t> &cnt, int64_t n, int64_t m, std::vector<double> &center,
+                             std::vector<double> &scale, int32_t *n_bad) {
+  center.resize((size_t)m);
+  scale.resize((size_t)m);
+  int32_t bad = 0;
+  for (int64_t j = 0; j < m; j++) {
+    const int32_t *c = &cnt[(size_t)4 * j];
+    const double sumX = (double)(c[1] + 2 * c[2]), nona = (double)(c[0] + c[1] + c[2]);
+    const double af = sumX / (2.0 * nona);
+    center[(size_t)j] = 2.0 * af;
+    scale[(size_t)j] = std::sqrt(2.0 * af * (1.0 - af));
+    if (2 * (int64_t)(c[0] + c[1] + c[2]) < n) bad++;
+  }
+  *n_bad = bad;
+}
+
 extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n,
                                  const int64_t *ind_col, int64_t m, const double *center,
                                  const double *scale, const bsn_svd_options *o, double *d, double *u,
                                  double *v, bsn_svd_info *info) {
-  return guarded([&] {
+  bool unconverged = false;
+  int rc = guarded([&] {
     if (!o) fail("options must not be NULL");
     if (o->k < 1) fail("'k' must be at least 1.");
     auto t_begin = std::chrono::steady_clock::now();
     auto since = [&]() {
       return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     };
-    bsn_op *op = nullptr;
-    if (bsn_op_create(bed, ind_row, n, ind_col, m, center, scale, &op) != 0)
-      throw Error(bsn_last_error());
+    std::unique_ptr<bsn_op> guard(new bsn_op());
+    bsn_op *op = guard.get();
+    int32_t n_bad = 0;
+    bool fused = false;
+    if (o->binom_scaling) {
+      fill_op(op, bed, ind_row, n, ind_col, m, nullptr, nullptr, true);
+      if (op->rows_identity) {
+        // the counts ride along the first crossproduct pass; until they are known the general kernels run
+        op->stats_pending = true;
+        op->no_na = false;
+        fused = true;
+      } else {
+        std::vector<int32_t> cnt((size_t)4 * m);
+        counts_host(bed, ind_row, n, ind_col, m, cnt.data());
+        std::vector<double> ce, sc;
+        binom_scale_host(cnt, n, m, ce, sc, &n_bad);
+        BSN_HIP(hipMemcpyAsync(op->d_center.p, ce.data(), (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
+        BSN_HIP(hipMemcpyAsync(op->d_scale.p, sc.data(), (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
+        BSN_HIP(hipStreamSynchronize(bed->stream));
+        if (o->center_out) std::copy(ce.begin(), ce.end(), o->center_out);
+        if (o->scale_out) std::copy(sc.begin(), sc.end(), o->scale_out);
+      }
+    } else {
+      fill_op(op, bed, ind_row, n, ind_col, m, center, scale);
+    }
     const double t_create = since();
-    std::unique_ptr<bsn_op> guard(op);
     op->profile = true;
     if (o->slices > 7) fail("slices must be in 1..7");
     HipSvdBackend bk;
@@ -528,7 +570,32 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     BSN_HIP(hipEventSynchronize(bed->ev1));
     float ms = 0;
     BSN_HIP(hipEventElapsedTime(&ms, bed->ev0, bed->ev1));
+    if (fused) {
+      // by-products of the counting pass: the scaling actually used, the > 50 % missing count of
+      // bed_colstats (src/bed-fun.cpp:40-41) and the per-variant completeness of the handle
+      std::vector<int32_t> cnt((size_t)4 * m);
+      BSN_HIP(hipMemcpy(cnt.data(), op->d_counts.p, (size_t)4 * m * 4, hipMemcpyDeviceToHost));
+      if ((int64_t)bed->na_cnt.size() != bed->m) bed->na_cnt.assign((size_t)bed->m, -1);
+      for (int64_t j = 0; j < m; j++) {
+        const int32_t *c = &cnt[(size_t)4 * j];
+        bed->na_cnt[(size_t)(ind_col ? ind_col[j] : j)] = c[3];
+        if (2 * (int64_t)(c[0] + c[1] + c[2]) < n) n_bad++;
+      }
+      if (o->center_out) BSN_HIP(hipMemcpy(o->center_out, op->d_center.p, (size_t)m * 8, hipMemcpyDeviceToHost));
+      if (o->scale_out) BSN_HIP(hipMemcpy(o->scale_out, op->d_scale.p, (size_t)m * 8, hipMemcpyDeviceToHost));
+    }
+    if (!r.converged) {
+      unconverged = true;
+      char buf[256];
+      std::snprintf(buf, sizeof(buf),
+                    "the Krylov basis is full (%d vectors) but only a relative residual of %.3g (tol %.3g) was "
+                    "reached for the %d requested singular triplets; increase max_basis or tol",
+                    r.basis, r.max_rel_resid, so.tol, so.k);
+      set_error(buf);
+    }
     if (info) {
+      info->n_bad = n_bad;
+      info->fused_stats = fused ? 1 : 0;
       info->niter = r.niter;
       info->nops = (int32_t)op->passes;
       info->basis = r.basis;
@@ -546,6 +613,7 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       info->slices = op->slices;
     }
   });
+  return rc != 0 ? rc : (unconverged ? 2 : 0);
 }
 
 

@@ -7,6 +7,7 @@ algebra all stay on the GPU.  The result mirrors class "big_SVD": d, u, v, niter
 center, scale.
 """
 import ctypes as C
+import warnings
 
 import numpy as np
 
@@ -24,10 +25,17 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
     ``m_total`` (columns over all ranks)."""
     assert_bed(obj_bed)
     ir, ic = _args(obj_bed, ind_row, ind_col)
-    ms = fun_scaling(obj_bed, ind_row=ir, ind_col=ic, ncores=ncores)
-    center = np.ascontiguousarray(ms["center"], dtype=np.float64)
-    scale = np.ascontiguousarray(ms["scale"], dtype=np.float64)
     opts = _lib.SvdOptions()
+    if fun_scaling is bed_scaleBinom:
+        # the default scaling is evaluated inside the solve: its code counts ride along the first
+        # crossproduct pass (same values as bed_scaleBinom(obj_bed, ind_row, ind_col), bit for bit)
+        center, scale = np.empty(ic.size), np.empty(ic.size)
+        opts.binom_scaling = 1
+        opts.center_out, opts.scale_out = ptr(center, f64p), ptr(scale, f64p)
+    else:
+        ms = fun_scaling(obj_bed, ind_row=ir, ind_col=ic, ncores=ncores)
+        center = np.ascontiguousarray(ms["center"], dtype=np.float64)
+        scale = np.ascontiguousarray(ms["scale"], dtype=np.float64)
     opts.k, opts.tol, opts.block, opts.slices = int(k), float(tol), int(block), int(slices)
     opts.max_basis, opts.seed, opts.verbose, opts.m_total = int(max_basis), int(seed), int(verbose), int(m_total)
     cb = None
@@ -38,13 +46,20 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
     d = np.empty(k)
     u = np.empty((k, ir.size)) if return_uv else None
     v = np.empty((k, ic.size)) if return_uv else None
-    check(_lib.load().bsn_bed_randomsvd(obj_bed.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p),
-                                        ic.size, ptr(center, f64p), ptr(scale, f64p),
-                                        C.byref(opts), ptr(d, f64p), ptr(u, f64p), ptr(v, f64p),
-                                        C.byref(info)))
+    L = _lib.load()
+    rc = L.bsn_bed_randomsvd(obj_bed.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p), ic.size,
+                             ptr(center, f64p), ptr(scale, f64p), C.byref(opts), ptr(d, f64p),
+                             ptr(u, f64p), ptr(v, f64p), C.byref(info))
+    if rc == 2:  # RSpectra::svds warns likewise when fewer than k triplets converged
+        warnings.warn("bed_randomSVD did not converge: " + L.bsn_last_error().decode(), RuntimeWarning)
+    else:
+        check(rc)
+    if info.n_bad > 0:  # src/bed-fun.cpp:40-41 (bed_colstats, called by bed_scaleBinom)
+        warnings.warn("%d variants have >50%% missing values." % info.n_bad)
     return dict(d=d, u=None if u is None else u.T, v=None if v is None else v.T,
                 niter=info.niter, nops=info.nops, center=center, scale=scale,
                 basis=info.basis, converged=bool(info.converged),
                 max_rel_resid=info.max_rel_resid, gpu_ms=info.gpu_ms,
                 cprod_ms=info.cprod_ms, prod_ms=info.prod_ms, n_cprod=info.n_cprod,
-                n_prod=info.n_prod, block=info.block, slices=info.slices)
+                n_prod=info.n_prod, block=info.block, slices=info.slices,
+                fused_stats=bool(info.fused_stats))

@@ -175,8 +175,16 @@ typedef struct bsn_svd_options {
   uint32_t seed;      /* start block seed (0 -> 1) */
   int32_t verbose;
   int64_t m_total;    /* total number of columns over all ranks (0 -> m) */
-  bsn_allreduce_fn allreduce;
+  bsn_allreduce_fn allreduce; /* host-side hook summing a device buffer over ranks (tests); NULL otherwise */
   void *allreduce_ctx;
+  struct bsn_comm *comm; /* RCCL communicator of bsn_comm_init: the panel exchange then runs inside the
+                            library on its own stream (NULL: one GPU, or the hook above) */
+  /* binom_scaling = 1: fun.scaling is bed_scaleBinom (R/binom-scaling.R:133-142) evaluated INSIDE the
+   * solve: the code counts ride along the first crossproduct pass (no separate statistics pass);
+   * the `center` / `scale` arguments are ignored and the values used are written to center_out /
+   * scale_out (length m each, may be NULL). */
+  int32_t binom_scaling;
+  double *center_out, *scale_out;
 } bsn_svd_options;
 typedef struct bsn_svd_info {
   int32_t niter;      /* block steps */
@@ -190,7 +198,12 @@ typedef struct bsn_svd_info {
   double prod_ms;     /* total over n_prod launches of k_prod (A~ panel) */
   int32_t n_cprod, n_prod;
   int32_t block, slices; /* vectors per pass and int8 slices actually used */
+  int32_t n_bad;      /* binom_scaling: variants with > 50 % missing values (src/bed-fun.cpp:40-41) */
+  int32_t fused_stats;/* 1 if the scaling statistics rode along the first crossproduct pass */
 } bsn_svd_info;
+/* Returns 0 on success, 1 on error, and 2 when the solve ran to the end of its basis without all
+ * k residuals meeting tol (outputs are filled with the best available triplets, bsn_last_error()
+ * says how far they are; RSpectra warns in that case, so should the caller). */
 int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
                       int64_t m, const double *center, const double *scale,
                       const bsn_svd_options *options, double *d, double *u, double *v,
