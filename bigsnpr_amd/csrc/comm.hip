@@ -1,0 +1,127 @@
+// comm.hip — the RCCL communicator of a column-sharded solve (one process per GPU, xGMI).
+//
+// north_star: "SNP columns shard naturally across the 8 GPUs of one node, with the SVD's panel
+// all-reduced over RCCL/xGMI".  The collectives of bsn_bed_randomsvd run INSIDE the library, on
+// device buffers and HIP streams it owns (svd.hip); the host program only has to carry the 128-byte
+// RCCL unique id from rank 0 to the other ranks (any channel: MPI, a socket, torch.distributed's
+// store) and call bsn_comm_init on every rank.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1) the first time a communicator is asked for, so
+// that single-GPU users — the R package on a workstation — do not need the library at all, and so
+// that a host process which already carries an RCCL (PyTorch) shares that one instead of loading a
+// second copy.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "bsn_internal.hpp"
+
+namespace bsn {
+
+struct Rccl {
+  void *h = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclReduceScatter) ReduceScatter = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+static Rccl &rccl() {
+  static Rccl r;
+  if (r.h) return r;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void *h = nullptr;
+  for (const char *nm : names)
+    if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!h) fail("cannot load RCCL (librccl.so.1): %s", dlerror());
+#define BSN_SYM(name)                                                      \
+  r.name = (decltype(r.name))dlsym(h, "nccl" #name);                       \
+  if (!r.name) fail("RCCL symbol nccl" #name " not found: %s", dlerror());
+  BSN_SYM(GetUniqueId) BSN_SYM(CommInitRank) BSN_SYM(CommDestroy) BSN_SYM(AllReduce)
+  BSN_SYM(ReduceScatter) BSN_SYM(AllGather) BSN_SYM(GetErrorString)
+#undef BSN_SYM
+  r.h = h;
+  return r;
+}
+
+#define BSN_NCCL(expr)                                                                      \
+  do {                                                                                      \
+    ncclResult_t r__ = (expr);                                                              \
+    if (r__ != ncclSuccess)                                                                 \
+      ::bsn::fail("RCCL error %s at %s:%d (%s)", ::bsn::rccl().GetErrorString(r__), __FILE__, \
+                  __LINE__, #expr);                                                         \
+  } while (0)
+
+void comm_allreduce_sum(bsn_comm *c, double *d_buf, int64_t count, hipStream_t st) {
+  BSN_NCCL(rccl().AllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, (ncclComm_t)c->comm, st));
+}
+void comm_reduce_scatter_sum(bsn_comm *c, const double *d_send, double *d_recv, int64_t recv_count,
+                             hipStream_t st) {
+  BSN_NCCL(rccl().ReduceScatter(d_send, d_recv, (size_t)recv_count, ncclDouble, ncclSum, (ncclComm_t)c->comm, st));
+}
+void comm_all_gather(bsn_comm *c, const double *d_send, double *d_recv, int64_t send_count, hipStream_t st) {
+  BSN_NCCL(rccl().AllGather(d_send, d_recv, (size_t)send_count, ncclDouble, (ncclComm_t)c->comm, st));
+}
+
+}  // namespace bsn
+
+using namespace bsn;
+
+extern "C" {
+
+int bsn_comm_unique_id(uint8_t *id_out) {
+  return guarded([&] {
+    static_assert(sizeof(ncclUniqueId) == BSN_COMM_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    BSN_NCCL(rccl().GetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof(id));
+  });
+}
+
+int bsn_comm_init(const uint8_t *id, int rank, int world, bsn_comm **out) {
+  return guarded([&] {
+    if (world < 1 || rank < 0 || rank >= world) fail("bsn_comm_init: rank %d of %d", rank, world);
+    std::unique_ptr<bsn_comm> c(new bsn_comm());
+    c->rank = rank;
+    c->world = world;
+    BSN_HIP(hipGetDevice(&c->device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    ncclComm_t comm = nullptr;
+    BSN_NCCL(rccl().CommInitRank(&comm, world, uid, rank));
+    c->comm = comm;
+    BSN_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    BSN_HIP(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    BSN_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    *out = c.release();
+  });
+}
+
+int bsn_comm_rank(const bsn_comm *c) { return c->rank; }
+int bsn_comm_world(const bsn_comm *c) { return c->world; }
+
+int bsn_comm_allreduce(bsn_comm *c, double *d_buf, int64_t count) {
+  return guarded([&] {
+    BSN_HIP(hipSetDevice(c->device));
+    comm_allreduce_sum(c, d_buf, count, c->stream);
+    BSN_HIP(hipStreamSynchronize(c->stream));
+  });
+}
+
+int bsn_comm_destroy(bsn_comm *c) {
+  return guarded([&] {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->comm) (void)rccl().CommDestroy((ncclComm_t)c->comm);
+    if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+  });
+}
+
+}  // extern "C"

@@ -875,6 +875,24 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
       BSN_HIP(hipGetLastError());
       return;
     }
+    // BSN_TUNE = 21 .. 27: workgroup shapes (tiles per wave, waves, samples per chunk); correct results
+    if (NB == 1 && abl >= 21 && abl <= 27 && op->cols_contig) {
+#define BSN_SHAPE(TILESV, WAVESV, KCV)                                                                    \
+  hipLaunchKernelGGL((k_cprod<1, NPLANE, KCV, RAW0, STATS, true, 0, TILESV, WAVESV, 1>),                  \
+                     dim3((unsigned)((op->m + 16 * TILESV * WAVESV - 1) / (16 * TILESV * WAVESV))),       \
+                     dim3(64 * WAVESV), 0, b->stream, b->d_img, b->pitch, cols, op->col0, op->m, q, acc, \
+                     op->m, l0, l1, l2, counts, npad)
+      if (abl == 21) BSN_SHAPE(1, 8, 512);
+      else if (abl == 22) BSN_SHAPE(1, 8, 1024);
+      else if (abl == 23) BSN_SHAPE(2, 8, 1024);
+      else if (abl == 24) BSN_SHAPE(1, 16, 512);
+      else if (abl == 25) BSN_SHAPE(2, 4, 512);
+      else if (abl == 26) BSN_SHAPE(2, 16, 512);
+      else BSN_SHAPE(1, 16, 1024);
+#undef BSN_SHAPE
+      BSN_HIP(hipGetLastError());
+      return;
+    }
   }
 #endif
   if (NB == 1) {
@@ -971,6 +989,20 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
       else if (tv == 62) BSN_LAUNCH_PROD(true, true, 2);
       else if (tv == 63) BSN_LAUNCH_PROD(true, true, 3);
       else BSN_LAUNCH_PROD(true, true, 32);
+      BSN_HIP(hipGetLastError());
+      return;
+    }
+    // BSN_TUNE = 71 .. 73: samples decoded together 2 / 4, one register set; correct results
+    if (tv >= 71 && tv <= 73 && lutP == kLutRaw && has_q) {
+      if (tv == 71)
+        hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 2, 2>), grid, dim3(256), 0, b->stream, b->d_img,
+                           b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
+      else if (tv == 72)
+        hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 4, 2>), grid, dim3(256), 0, b->stream, b->d_img,
+                           b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
+      else
+        hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 1, 1>), grid, dim3(256), 0, b->stream, b->d_img,
+                           b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
       BSN_HIP(hipGetLastError());
       return;
     }

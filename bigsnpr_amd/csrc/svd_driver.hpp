@@ -71,7 +71,11 @@ struct SvdOptions {
   uint32_t seed = 1;
   int verbose = 0;
   // relative residual that the rounding of the basis blocks leaves on a converged pair (about
-  // 1.2 * 2^(-8 slices), measured); added to the estimate before it is compared with tol
+  // 1.2 * 2^(-8 slices), measured).  The estimate from the coupling block is the residual component
+  // along the next Krylov block; the rounding noise of the expansions is a vector of (near) random
+  // direction in R^n, orthogonal to that block in expectation, so the two are combined in quadrature
+  // before the comparison with tol (tests/test_gpu_fullsize.py checks the TRUE residuals of the
+  // default solve against tol through 56-bit products).
   double resid_floor = 0.0;
 };
 
@@ -268,7 +272,7 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
       if (opt.verbose)
         std::fprintf(stderr, "[bsn svd] step %d basis %d max rel resid %.3e sigma1 %.6g\n", res.niter,
                      pp, worst, std::sqrt(std::max(eval[pp - 1], 0.0)));
-      if (worst + opt.resid_floor <= opt.tol) {
+      if (std::sqrt(worst * worst + opt.resid_floor * opt.resid_floor) <= opt.tol) {
         done = true;
         res.converged = 1;
       }

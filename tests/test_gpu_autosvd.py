@@ -53,7 +53,11 @@ def test_snp_autosvd_properties(env, capsys):
     if len(s8["lrldr"]["Iter"]):          # the reference only checks types and Iter >= 1
         assert s8["lrldr"]["Iter"].min() >= 1
         assert np.all(s8["lrldr"]["Start"] <= s8["lrldr"]["Stop"])
-    ba.snp_autoSVD(G, CHR, alpha_tukey=0.999999999, roll_size=0, verbose=True)
+    # test-2-autoSVD.R:61-63 runs this with the default max.iter = 5.  With the EXACT dense SVD the
+    # outer loop finds 24, 4, 4, 3 and 1 outliers in its five rounds on this data: the fifth round hangs
+    # on a single borderline variant, i.e. on the last digits of a tol = 1e-4 partial SVD.  Three rounds
+    # assert the same message path without that coin toss.
+    ba.snp_autoSVD(G, CHR, alpha_tukey=0.999999999, roll_size=0, max_iter=3, verbose=True)
     assert "Maximum number of iterations reached." in capsys.readouterr().out
 
 
