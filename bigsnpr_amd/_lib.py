@@ -25,7 +25,8 @@ class SvdOptions(C.Structure):
     _fields_ = [("k", C.c_int32), ("tol", C.c_double), ("block", C.c_int32),
                 ("slices", C.c_int32), ("max_basis", C.c_int32), ("seed", C.c_uint32),
                 ("verbose", C.c_int32), ("m_total", C.c_int64), ("allreduce", ALLREDUCE_FN),
-                ("allreduce_ctx", C.c_void_p), ("comm", C.c_void_p), ("binom_scaling", C.c_int32),
+                ("allreduce_ctx", C.c_void_p), ("hook_rank", C.c_int32), ("hook_world", C.c_int32),
+                ("comm", C.c_void_p), ("binom_scaling", C.c_int32),
                 ("center_out", C.POINTER(C.c_double)), ("scale_out", C.POINTER(C.c_double))]
 
 
@@ -45,6 +46,12 @@ SIGNATURES = {
     "bsn_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "bsn_set_device": (C.c_int, [C.c_int]),
     "bsn_selftest": (C.c_int, []),
+    "bsn_comm_unique_id": (C.c_int, [u8p]),
+    "bsn_comm_init": (C.c_int, [u8p, C.c_int, C.c_int, C.POINTER(vp)]),
+    "bsn_comm_rank": (C.c_int, [vp]),
+    "bsn_comm_world": (C.c_int, [vp]),
+    "bsn_comm_allreduce": (C.c_int, [vp, vp, i64]),
+    "bsn_comm_destroy": (C.c_int, [vp]),
     "bsn_bed_open": (C.c_int, [C.c_char_p, i64, i64, C.POINTER(vp)]),
     "bsn_bed_from_host": (C.c_int, [u8p, i64, i64, i64, C.POINTER(vp)]),
     "bsn_bed_from_fbm": (C.c_int, [u8p, i64, i64, i64, C.POINTER(vp)]),

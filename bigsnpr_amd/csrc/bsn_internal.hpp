@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -109,6 +110,14 @@ struct bsn_bed {
   std::vector<int32_t> na_cnt;
 };
 
+// RCCL communicator of a column-sharded solve (comm.hip); `comm` is an ncclComm_t
+struct bsn_comm {
+  void *comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  hipStream_t stream = nullptr;           // collectives that overlap compute of the solve's stream
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+};
+
 struct bsn_op {
   bsn_bed *bed = nullptr;
   int64_t n = 0, m = 0;        // dimensions of the sub-view
@@ -174,6 +183,12 @@ void subset_pack(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_
 // api.hip: operator over a sub-view; defer_scale leaves centre / scale unset (stats_pending path)
 void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
              int64_t m, const double *center, const double *scale, bool defer_scale = false);
+
+// comm.hip: RCCL collectives on device buffers of doubles, enqueued on `st`
+void comm_allreduce_sum(bsn_comm *c, double *d_buf, int64_t count, hipStream_t st);
+void comm_reduce_scatter_sum(bsn_comm *c, const double *d_send, double *d_recv, int64_t recv_count,
+                             hipStream_t st);
+void comm_all_gather(bsn_comm *c, const double *d_send, double *d_recv, int64_t send_count, hipStream_t st);
 
 // matvec.hip
 void op_poll_stats(bsn_op *op);  // after a stream synchronisation: pick up the missing-value total

@@ -20,15 +20,22 @@ __device__ __forceinline__ uint32_t hmix(uint32_t x) {
   return x;
 }
 
-__global__ void k_random(double *W, int64_t ld, int64_t n, int b, uint32_t seed) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// rows [row0, row0 + n) of the n_total x b start block (a function of the global row index, so that
+// sample blocks of different ranks are pieces of the same matrix); rows past n_total are zero
+__global__ void k_random(double *W, int64_t ld, int64_t n, int b, uint32_t seed, int64_t row0, int64_t n_total) {
+  int64_t il = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int j = blockIdx.y;
-  if (i >= n || j >= b) return;
+  if (il >= n || j >= b) return;
+  const int64_t i = il + row0;
+  if (i >= n_total) {
+    W[il + j * ld] = 0.0;
+    return;
+  }
   uint32_t h = hmix((uint32_t)i * 0x9E3779B1U + hmix(seed * 0x85EBCA6BU + (uint32_t)j + 0x1234567U));
   uint32_t h2 = hmix(h ^ 0xDEADBEEFU);
   // uniform in (-1, 1) with 53 random bits
   double x = ((double)(((uint64_t)h << 21) ^ (uint64_t)h2) + 0.5) * (1.0 / 9007199254740992.0);
-  W[i + j * ld] = 2.0 * x - 1.0;
+  W[il + j * ld] = 2.0 * x - 1.0;
 }
 
 // partial[rc][pt*4 + a][j] = sum over the row chunk of Q[i, pt*4+a] * W[i, j]; CB = number of
@@ -277,64 +284,183 @@ __global__ void k_round_cols(double *W, int64_t ld, int64_t n, const unsigned lo
   if (i < n) W[i + v * ld] = (double)llrint(W[i + v * ld] * qs) * iq;
 }
 
+// ---- sample-block layout of a panel for the collectives ------------------------------------
+// full: n x cb column-major (ld n).  blk: [rank][column][row of the rank's block], blocks of nr
+// rows (the last one zero-padded) — the chunk of rank r is contiguous, which is what
+// reduce-scatter / all-gather exchange.
+__global__ void k_block(const double *__restrict__ full, int64_t n, int cb, int64_t nr, int world,
+                        double *__restrict__ blk) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)world * cb * nr) return;
+  const int64_t i = t % nr, j = (t / nr) % cb, r = t / (nr * cb);
+  const int64_t gi = r * nr + i;
+  blk[t] = gi < n ? full[gi + j * n] : 0.0;
+}
+__global__ void k_unblock(const double *__restrict__ blk, int64_t n, int cb, int64_t nr,
+                          double *__restrict__ full) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * cb) return;
+  const int64_t gi = t % n, j = t / n;
+  full[t] = blk[((gi / nr) * cb + j) * nr + gi % nr];
+}
+// W (nr x cb, ld nr) = rows [row0, row0 + nr) of full (n x cb, ld n), zero past n
+__global__ void k_take_rows(const double *__restrict__ full, int64_t n, int cb, int64_t nr, int64_t row0,
+                            double *__restrict__ W) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nr * cb) return;
+  const int64_t i = t % nr, j = t / nr;
+  W[t] = row0 + i < n ? full[row0 + i + j * n] : 0.0;
+}
+
+// Panels of length n (samples) are held by SAMPLE BLOCKS when the solve is distributed: rank r owns
+// rows [r nr, (r+1) nr) of the basis Q and of the working panel W, orthogonalises them locally and
+// shares only the small coefficient matrices (p x b, b x b) — the n-side algebra is divided by the
+// number of ranks instead of being replicated.  The variants (columns of G, rows of Z) are sharded
+// as before.  Per block step:
+//   Z_g = A_g' Qfull           local crossproduct pass; Qfull = newest basis block, all n rows
+//   Wfull = A_g Z_g            local product pass, partial sums over this rank's variants
+//   W_r = reduce-scatter(Wfull) by sample blocks (own stream: overlaps the local Z'Z Gram kernels)
+//   orthonormalise W_r against Q_r (Gram blocks all-reduced, b x p doubles each)
+//   Qfull = round(all-gather(W_r)); Q_r gets its rows
+// Without a communicator (and without the test hook) nr = n and every collective is skipped: the
+// single-GPU path is the same code.
 struct HipSvdBackend : SvdBackend {
   bsn_op *op = nullptr;
   hipStream_t st = nullptr;
-  bsn_allreduce_fn allreduce = nullptr;
+  bsn_allreduce_fn hook = nullptr;
   void *ctx = nullptr;
-  DevBuf<double> Q, Z, W, partial, dsmall, tmp, Wsave, dorth;
+  bsn_comm *comm = nullptr;
+  int rank = 0, world = 1;
+  bool dist = false;
+  int64_t nr = 0, row0 = 0;  // rows of a sample block, first row of this rank's block
+  DevBuf<double> Q, Z, W, partial, dsmall, tmp, Wsave, dorth, Wfull, Wblk, Qfull;
   std::vector<double> horth;
   int cap = 0, b = 0;
   int64_t rows_per = 0;
   int nrc = 0;
+  bool rs_pending = false;
+  int kmax = 0;
 
+  void setup_ranks() {
+    if (comm) {
+      rank = comm->rank;
+      world = comm->world;
+    }
+    dist = comm != nullptr || hook != nullptr;
+    if (!dist) world = 1, rank = 0;
+    nr = dist ? (n + world - 1) / world : n;
+    row0 = (int64_t)rank * nr;
+  }
   void alloc(int cap_, int b_) override {
     if (b_ > kMaxB) fail("block size must be <= %d", kMaxB);
     cap = cap_;
     b = b_;
     auto t0 = std::chrono::steady_clock::now();
-    Q.ensure((size_t)n * cap);
+    Q.ensure((size_t)nr * cap);
     Z.ensure((size_t)m_local * cap);
-    W.ensure((size_t)n * kMaxB);
+    W.ensure((size_t)nr * kMaxB);
     rows_per = 4096;
-    nrc = (int)((n + rows_per - 1) / rows_per);
+    nrc = (int)((nr + rows_per - 1) / rows_per);
     {
-      const int64_t rows_max = n > m_local ? n : m_local;
+      const int64_t rows_max = nr > m_local ? nr : m_local;
       partial.ensure((size_t)((rows_max + rows_per - 1) / rows_per) * (cap + 4) * kMaxB);
     }
     dsmall.ensure((size_t)(cap + 4) * 64);
-    Wsave.ensure((size_t)n * kMaxB);
+    Wsave.ensure((size_t)nr * kMaxB);
     dorth.ensure((size_t)8 * kMaxB * kMaxB + (size_t)3 * (cap + 4) * kMaxB);
+    if (dist) {
+      const int wide = kmax > kMaxB ? kmax : kMaxB;
+      Wfull.ensure((size_t)n * wide);
+      Wblk.ensure((size_t)world * nr * wide);
+      Qfull.ensure((size_t)n * kMaxB);
+    }
     if (getenv("BSN_TIMING"))
       std::fprintf(stderr, "[bsn svd] workspace alloc %.2f ms (Q %.2f GB, Z %.2f GB)\n",
                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
-                   (double)n * cap * 8e-9, (double)m_local * cap * 8e-9);
+                   (double)nr * cap * 8e-9, (double)m_local * cap * 8e-9);
   }
-  void random_W(int bb, uint32_t seed) override {
-    hipLaunchKernelGGL(k_random, dim3((unsigned)((n + 255) / 256), bb), dim3(256), 0, st, W.p, n, n,
-                       bb, seed);
-    BSN_HIP(hipGetLastError());
-  }
-  void At_Qblock(int p0, int cb) override {
-    op_cprod(op, Q.p + (int64_t)p0 * n, n, cb, Z.p + (int64_t)p0 * m_local, m_local);
-  }
-  void A_Zblock(int p0, int cb) override {
-    op_prod(op, Z.p + (int64_t)p0 * m_local, m_local, cb, W.p, n);
-    if (allreduce) {
+
+  // ---- collectives ------------------------------------------------------------------------
+  // sum of a small device matrix over the ranks, in place, ordered on the solve's stream
+  void ar_small(double *d, int64_t count) {
+    if (!dist) return;
+    wait_rs();
+    if (comm) {
+      comm_allreduce_sum(comm, d, count, st);
+    } else {
       BSN_HIP(hipStreamSynchronize(st));
-      allreduce(W.p, n * cb, ctx);
+      hook(d, count, ctx);
     }
   }
-  void gemm_tn(const double *A, int p, int cb, double *C_host) {
-    dim3 grid((unsigned)((p + 3) / 4), (unsigned)nrc);
-    launch_gemm_tn_part(grid, st, A, n, p, W.p, cb, rows_per, partial.p);
-    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((p * cb + 3) / 4)), dim3(256), 0, st,
-                       partial.p, nrc, p, cb, dsmall.p);
+  // the reduce-scatter of the working panel runs on the communicator's stream; everything that
+  // reads W, and every later collective, waits for it here
+  void wait_rs() {
+    if (!rs_pending) return;
+    rs_pending = false;
+    if (comm) BSN_HIP(hipStreamWaitEvent(st, comm->ev_done, 0));
+  }
+  void reduce_scatter_W(int cb) {  // Wfull (n x cb partial sums) -> W (nr x cb, summed over ranks)
+    const int64_t tot = (int64_t)world * cb * nr;
+    hipLaunchKernelGGL(k_block, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Wfull.p, n, cb, nr, world,
+                       Wblk.p);
     BSN_HIP(hipGetLastError());
+    if (comm) {
+      BSN_HIP(hipEventRecord(comm->ev_ready, st));
+      BSN_HIP(hipStreamWaitEvent(comm->stream, comm->ev_ready, 0));
+      comm_reduce_scatter_sum(comm, Wblk.p, W.p, nr * cb, comm->stream);
+      BSN_HIP(hipEventRecord(comm->ev_done, comm->stream));
+      rs_pending = true;
+    } else {
+      BSN_HIP(hipStreamSynchronize(st));
+      hook(Wblk.p, tot, ctx);
+      BSN_HIP(hipMemcpyAsync(W.p, Wblk.p + (int64_t)rank * cb * nr, (size_t)nr * cb * 8,
+                             hipMemcpyDeviceToDevice, st));
+    }
+  }
+  // src (nr x cb local rows) -> dst (n x cb, all rows, column-major)
+  void all_gather_rows(const double *src, int cb, double *dst) {
+    wait_rs();
+    const int64_t tot = (int64_t)world * cb * nr;
+    if (comm) {
+      comm_all_gather(comm, src, Wblk.p, nr * cb, st);
+    } else {
+      BSN_HIP(hipMemsetAsync(Wblk.p, 0, (size_t)tot * 8, st));
+      BSN_HIP(hipMemcpyAsync(Wblk.p + (int64_t)rank * cb * nr, src, (size_t)nr * cb * 8, hipMemcpyDeviceToDevice, st));
+      BSN_HIP(hipStreamSynchronize(st));
+      hook(Wblk.p, tot, ctx);
+    }
+    hipLaunchKernelGGL(k_unblock, dim3((unsigned)((n * cb + 255) / 256)), dim3(256), 0, st, Wblk.p, n, cb, nr, dst);
+    BSN_HIP(hipGetLastError());
+  }
+
+  // ---- backend interface ------------------------------------------------------------------
+  void random_W(int bb, uint32_t seed) override {
+    hipLaunchKernelGGL(k_random, dim3((unsigned)((nr + 255) / 256), bb), dim3(256), 0, st, W.p, nr, nr, bb, seed,
+                       row0, n);
+    BSN_HIP(hipGetLastError());
+  }
+  // the newest basis block with all n rows: Q itself on one GPU, the gathered copy otherwise
+  const double *newest_block(int p0) const { return dist ? Qfull.p : Q.p + (int64_t)p0 * nr; }
+  void At_Qblock(int p0, int cb) override {
+    op_cprod(op, newest_block(p0), n, cb, Z.p + (int64_t)p0 * m_local, m_local);
+  }
+  void A_Zblock(int p0, int cb) override {
+    op_prod(op, Z.p + (int64_t)p0 * m_local, m_local, cb, dist ? Wfull.p : W.p, n);
+    if (dist) reduce_scatter_W(cb);
+  }
+  void gemm_tn(const double *A, int p, int cb, double *C_host) {
+    wait_rs();
+    gemm_tn_any(A, W.p, nr, p, cb, dsmall.p);
+    BSN_HIP(hipGetLastError());
+    ar_small(dsmall.p, (int64_t)p * cb);
     BSN_HIP(hipMemcpyAsync(C_host, dsmall.p, (size_t)p * cb * 8, hipMemcpyDeviceToHost, st));
     BSN_HIP(hipStreamSynchronize(st));
   }
-  void gemm_tn_dev(const double *A, int p, int cb, double *dC) { gemm_tn_any(A, W.p, n, p, cb, dC); }
+  // dC (p x cb) = sum over ranks of A[:, :p]' W[:, :cb] on the local sample block
+  void gemm_tn_dev(const double *A, int p, int cb, double *dC) {
+    gemm_tn_any(A, W.p, nr, p, cb, dC);
+    ar_small(dC, (int64_t)p * cb);
+  }
   // dC (p x cb) = A[:, :p]' B[:, :cb] for operands with `rows` rows (leading dimension = rows)
   void gemm_tn_any(const double *A, const double *B, int64_t rows, int p, int cb, double *dC) {
     const int nrc_ = (int)((rows + rows_per - 1) / rows_per);
@@ -343,49 +469,58 @@ struct HipSvdBackend : SvdBackend {
     hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((p * cb + 3) / 4)), dim3(256), 0, st,
                        partial.p, nrc_, p, cb, dC);
   }
-  void round_W(int cb) override {
-    if (cb <= 0) return;
+  void round_cols(double *X, int64_t rows, int cb) {
     unsigned long long *mx = (unsigned long long *)dorth.p;
     BSN_HIP(hipMemsetAsync(mx, 0, (size_t)cb * 8, st));
-    hipLaunchKernelGGL(k_col_absmax, dim3(256, cb), dim3(1024), 0, st, W.p, n, n, mx);
-    hipLaunchKernelGGL(k_round_cols, dim3((unsigned)((n + 255) / 256), cb), dim3(256), 0, st, W.p, n, n, mx,
+    hipLaunchKernelGGL(k_col_absmax, dim3(256, cb), dim3(1024), 0, st, X, rows, rows, mx);
+    hipLaunchKernelGGL(k_round_cols, dim3((unsigned)((rows + 255) / 256), cb), dim3(256), 0, st, X, rows, rows, mx,
                        op->slices);
     BSN_HIP(hipGetLastError());
   }
-  void gram_to_host(const double *A, const double *B, int64_t rows, int p, int cb, bool reduce_ranks,
-                    double *out) {
-    gemm_tn_any(A, B, rows, p, cb, dsmall.p);
-    BSN_HIP(hipGetLastError());
-    if (reduce_ranks && allreduce) {
-      BSN_HIP(hipStreamSynchronize(st));
-      allreduce(dsmall.p, (int64_t)p * cb, ctx);
+  void round_W(int cb) override {
+    if (cb <= 0) return;
+    if (!dist) {
+      round_cols(W.p, n, cb);
+      return;
     }
+    // every rank rounds the same gathered block (column maxima over all n rows), then keeps its rows
+    all_gather_rows(W.p, cb, Qfull.p);
+    round_cols(Qfull.p, n, cb);
+    hipLaunchKernelGGL(k_take_rows, dim3((unsigned)((nr * cb + 255) / 256)), dim3(256), 0, st, Qfull.p, n, cb, nr,
+                       row0, W.p);
+    BSN_HIP(hipGetLastError());
+  }
+  void gram_to_host(const double *A, const double *B, int64_t rows, int p, int cb, double *out) {
+    gemm_tn_any(A, B, rows, p, cb, dsmall.p);  // local part first: it overlaps the reduce-scatter of W
+    BSN_HIP(hipGetLastError());
+    ar_small(dsmall.p, (int64_t)p * cb);
     BSN_HIP(hipMemcpyAsync(out, dsmall.p, (size_t)p * cb * 8, hipMemcpyDeviceToHost, st));
     BSN_HIP(hipStreamSynchronize(st));
     op_poll_stats(op);
   }
   void ZtZ(int p, int p0, int cb, double *G) override {
-    gram_to_host(Z.p, Z.p + (int64_t)p0 * m_local, m_local, p, cb, true, G);
+    gram_to_host(Z.p, Z.p + (int64_t)p0 * m_local, m_local, p, cb, G);
   }
   void QtQ(int p, int p0, int cb, double *M) override {
-    gram_to_host(Q.p, Q.p + (int64_t)p0 * n, n, p, cb, false, M);
+    gram_to_host(Q.p, Q.p + (int64_t)p0 * nr, nr, p, cb, M);
   }
   // The whole orth() of svd_driver.hpp queued on the stream with the small matrices kept on
   // the device: one host synchronisation per block step instead of eleven.
   int orth_fused(int p, int cb, std::vector<double> &Cacc, std::vector<double> &Rout) override {
     if (cb <= 0 || cb > kMaxB) return -1;
+    wait_rs();
     constexpr int B2 = kMaxB * kMaxB;
     // arena: [flag | Rout | C1 | C2] is downloaded in one piece; then G0, G, Ri, C3
     double *flag = dorth.p, *dRout = flag + 1, *C1 = dRout + B2, *C2 = C1 + (size_t)p * cb,
            *G0 = C2 + (size_t)p * cb, *G = G0 + B2, *Ri = G + B2, *C3 = Ri + B2;
     const size_t nsmall = 1 + B2 + (size_t)2 * p * cb;
     BSN_HIP(hipMemsetAsync(flag, 0, nsmall * 8, st));
-    BSN_HIP(hipMemcpyAsync(Wsave.p, W.p, (size_t)n * cb * 8, hipMemcpyDeviceToDevice, st));
-    const dim3 rows((unsigned)((n + 255) / 256));
+    BSN_HIP(hipMemcpyAsync(Wsave.p, W.p, (size_t)nr * cb * 8, hipMemcpyDeviceToDevice, st));
+    const dim3 rows((unsigned)((nr + 255) / 256));
     auto project = [&](double *C) {
       gemm_tn_dev(Q.p, p, cb, C);
-      hipLaunchKernelGGL(k_gemm_nn, rows, dim3(256), kTP * kMaxB * 8, st, Q.p, n, p, C, cb, W.p, n, 1.0, -1.0,
-                         W.p, n, n);
+      hipLaunchKernelGGL(k_gemm_nn, rows, dim3(256), kTP * kMaxB * 8, st, Q.p, nr, p, C, cb, W.p, nr, 1.0, -1.0,
+                         W.p, nr, nr);
     };
     gemm_tn_dev(W.p, cb, cb, G0);
     if (p > 0) {
@@ -395,7 +530,7 @@ struct HipSvdBackend : SvdBackend {
     for (int pass = 0; pass < 2; pass++) {
       gemm_tn_dev(W.p, cb, cb, G);
       hipLaunchKernelGGL(k_orth_small, dim3(1), dim3(64), 0, st, G0, G, cb, pass, Ri, dRout, flag);
-      hipLaunchKernelGGL(k_right_mult, rows, dim3(256), 0, st, W.p, n, n, cb, cb, Ri);
+      hipLaunchKernelGGL(k_right_mult, rows, dim3(256), 0, st, W.p, nr, nr, cb, cb, Ri);
       if (pass == 0 && p > 0) project(C3);
     }
     BSN_HIP(hipGetLastError());
@@ -404,7 +539,7 @@ struct HipSvdBackend : SvdBackend {
     BSN_HIP(hipStreamSynchronize(st));
     op_poll_stats(op);
     if (horth[0] != 0.0) {  // rank deficient: undo and let the driver take the careful path
-      BSN_HIP(hipMemcpyAsync(W.p, Wsave.p, (size_t)n * cb * 8, hipMemcpyDeviceToDevice, st));
+      BSN_HIP(hipMemcpyAsync(W.p, Wsave.p, (size_t)nr * cb * 8, hipMemcpyDeviceToDevice, st));
       return -1;
     }
     Rout.assign((size_t)cb * cb, 0.0);
@@ -417,37 +552,40 @@ struct HipSvdBackend : SvdBackend {
   void QtW(int p, int cb, double *C) override { gemm_tn(Q.p, p, cb, C); }
   void WtW(int cb, double *G) override { gemm_tn(W.p, cb, cb, G); }
   void W_minus_QC(int p, int cb, const double *C) override {
+    wait_rs();
     BSN_HIP(hipMemcpyAsync(dsmall.p, C, (size_t)p * cb * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((n + 255) / 256)), dim3(256), kTP * kMaxB * 8, st,
-                       Q.p, n, p, dsmall.p, cb, W.p, n, 1.0, -1.0, W.p, n, n);
+    hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((nr + 255) / 256)), dim3(256), kTP * kMaxB * 8, st,
+                       Q.p, nr, p, dsmall.p, cb, W.p, nr, 1.0, -1.0, W.p, nr, nr);
     BSN_HIP(hipGetLastError());
     BSN_HIP(hipStreamSynchronize(st));  // C is a host vector that may be reused
   }
   void W_times(int cb, int r, const double *M) override {
+    wait_rs();
     BSN_HIP(hipMemcpyAsync(dsmall.p, M, (size_t)cb * r * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_right_mult, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W.p, n, n,
+    hipLaunchKernelGGL(k_right_mult, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, W.p, nr, nr,
                        cb, r, dsmall.p);
     BSN_HIP(hipGetLastError());
     BSN_HIP(hipStreamSynchronize(st));
   }
   void W_to_Q(int p0, int r) override {
-    BSN_HIP(hipMemcpyAsync(Q.p + (int64_t)p0 * n, W.p, (size_t)n * r * 8, hipMemcpyDeviceToDevice, st));
+    BSN_HIP(hipMemcpyAsync(Q.p + (int64_t)p0 * nr, W.p, (size_t)nr * r * 8, hipMemcpyDeviceToDevice, st));
   }
   void finalize(int pp, int k, const double *S, const double *dinv, double *u, double *v) override {
+    wait_rs();
     std::vector<double> Sv((size_t)pp * k);
     for (int t = 0; t < k; t++)
       for (int i = 0; i < pp; i++) Sv[(size_t)i + (size_t)t * pp] = S[(size_t)i + (size_t)t * pp] * dinv[t];
-    DevBuf<double> dS, dU, dV;
+    DevBuf<double> dS, dU, dV, dUfull;
     dS.ensure((size_t)pp * k * 2 + 16);
-    dU.ensure((size_t)n * k);
+    dU.ensure((size_t)nr * k);
     dV.ensure((size_t)m_local * k);
     BSN_HIP(hipMemcpyAsync(dS.p, S, (size_t)pp * k * 8, hipMemcpyHostToDevice, st));
     BSN_HIP(hipMemcpyAsync(dS.p + (size_t)pp * k, Sv.data(), (size_t)pp * k * 8, hipMemcpyHostToDevice, st));
     for (int c0 = 0; c0 < k && pp > 0; c0 += kMaxB) {
       int nc = k - c0 < kMaxB ? k - c0 : kMaxB;
-      hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((n + 255) / 256)), dim3(256), kTP * kMaxB * 8, st,
-                         Q.p, n, pp, dS.p + (size_t)c0 * pp, nc, (const double *)nullptr, (int64_t)0,
-                         0.0, 1.0, dU.p + (int64_t)c0 * n, n, n);
+      hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((nr + 255) / 256)), dim3(256), kTP * kMaxB * 8, st,
+                         Q.p, nr, pp, dS.p + (size_t)c0 * pp, nc, (const double *)nullptr, (int64_t)0,
+                         0.0, 1.0, dU.p + (int64_t)c0 * nr, nr, nr);
       hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((m_local + 255) / 256)), dim3(256),
                          kTP * kMaxB * 8, st, Z.p, m_local, pp, dS.p + (size_t)pp * k + (size_t)c0 * pp,
                          nc, (const double *)nullptr, (int64_t)0, 0.0, 1.0,
@@ -455,10 +593,16 @@ struct HipSvdBackend : SvdBackend {
     }
     BSN_HIP(hipGetLastError());
     if (pp == 0) {
-      BSN_HIP(hipMemsetAsync(dU.p, 0, (size_t)n * k * 8, st));
+      BSN_HIP(hipMemsetAsync(dU.p, 0, (size_t)nr * k * 8, st));
       BSN_HIP(hipMemsetAsync(dV.p, 0, (size_t)m_local * k * 8, st));
     }
-    if (u) BSN_HIP(hipMemcpyAsync(u, dU.p, (size_t)n * k * 8, hipMemcpyDeviceToHost, st));
+    const double *ufull = dU.p;
+    if (dist) {  // every rank returns all n rows of u
+      dUfull.ensure((size_t)n * k);
+      all_gather_rows(dU.p, k, dUfull.p);
+      ufull = dUfull.p;
+    }
+    if (u) BSN_HIP(hipMemcpyAsync(u, ufull, (size_t)n * k * 8, hipMemcpyDeviceToHost, st));
     if (v) BSN_HIP(hipMemcpyAsync(v, dV.p, (size_t)m_local * k * 8, hipMemcpyDeviceToHost, st));
     BSN_HIP(hipStreamSynchronize(st));
   }
@@ -532,8 +676,15 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     bk.n = n;
     bk.m_local = m;
     bk.m_total = o->m_total > 0 ? o->m_total : m;
-    bk.allreduce = o->allreduce;
+    bk.hook = o->comm ? nullptr : o->allreduce;
     bk.ctx = o->allreduce_ctx;
+    bk.comm = o->comm;
+    bk.rank = o->hook_rank;
+    bk.world = o->hook_world > 0 ? o->hook_world : 1;
+    bk.kmax = o->k;
+    if (bk.comm && bk.comm->device != bed->device) fail("the communicator was created on another device");
+    if (bk.hook && (bk.rank < 0 || bk.rank >= bk.world)) fail("hook_rank %d of %d", bk.rank, bk.world);
+    bk.setup_ranks();
     int64_t dim = bk.n < bk.m_total ? bk.n : bk.m_total;
     if (o->k > dim) fail("'k' is larger than the dimensions of the matrix.");
     SvdOptions so;

@@ -18,11 +18,12 @@ from .bed import _args, assert_bed, bed_scaleBinom
 
 def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=None, k=10,
                   tol=1e-4, verbose=False, ncores=1, block=0, slices=0, max_basis=0, seed=1,
-                  allreduce=None, m_total=0, return_uv=True):
+                  comm=None, allreduce=None, rank=0, world=1, m_total=0, return_uv=True):
     """Partial SVD of the scaled matrix.  Extra (non-reference) arguments: ``block``
-    (vectors per streaming pass), ``slices`` (int8 slices per fp64 value), ``allreduce``
-    (callable(ptr, count) summing a device buffer over ranks; column-sharded multi-GPU),
-    ``m_total`` (columns over all ranks)."""
+    (vectors per streaming pass), ``slices`` (int8 slices per fp64 value); column-sharded
+    multi-GPU: ``comm`` (a bigsnpr_amd.Comm: the exchange runs inside the library over RCCL),
+    ``m_total`` (columns over all ranks); tests: ``allreduce`` (callable(ptr, count) summing a
+    device buffer of doubles over ranks) with ``rank`` / ``world``."""
     assert_bed(obj_bed)
     ir, ic = _args(obj_bed, ind_row, ind_col)
     opts = _lib.SvdOptions()
@@ -39,9 +40,12 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
     opts.k, opts.tol, opts.block, opts.slices = int(k), float(tol), int(block), int(slices)
     opts.max_basis, opts.seed, opts.verbose, opts.m_total = int(max_basis), int(seed), int(verbose), int(m_total)
     cb = None
-    if allreduce is not None:
+    if comm is not None:
+        opts.comm = comm.handle
+    elif allreduce is not None:
         cb = _lib.ALLREDUCE_FN(lambda p, count, ctx: allreduce(p, count))
         opts.allreduce = cb
+        opts.hook_rank, opts.hook_world = int(rank), int(world)
     info = _lib.SvdInfo()
     d = np.empty(k)
     u = np.empty((k, ir.size)) if return_uv else None

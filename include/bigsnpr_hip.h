@@ -165,6 +165,28 @@ int bsn_op_sync(bsn_op *op);
  * ranks in place (RCCL); u (n x k) is then identical on all ranks and v (m x k) is the
  * rank's own shard.  u / v may be NULL. */
 typedef void (*bsn_allreduce_fn)(void *d_buf, int64_t count, void *ctx);
+
+/* ---- multi-GPU: one process per GPU, variants (columns) sharded over the ranks -------------
+ * north_star: "SNP columns shard naturally across the 8 GPUs of one node, with the SVD's panel
+ * all-reduced over RCCL/xGMI".  A communicator wraps an RCCL (ncclComm_t) communicator created
+ * on the CURRENT device; RCCL is loaded on first use (dlopen), single-GPU callers never need it.
+ * Rank 0 calls bsn_comm_unique_id and hands the BSN_COMM_ID_BYTES bytes to the other ranks by
+ * whatever means the host program has (MPI, a socket, a file); every rank then calls
+ * bsn_comm_init (collective).  With `comm` set in bsn_svd_options, bsn_bed_randomsvd runs its
+ * exchange inside the library: the n x b partial panel is reduce-scattered by sample blocks,
+ * each rank orthogonalises its block of rows (small b x p coefficient all-reduces), and the
+ * finished basis block is all-gathered for the next crossproduct pass — all on HIP streams the
+ * library owns, the reduce-scatter overlapping the local Gram kernels.  There is no reference
+ * counterpart: bigsnpr parallelises over OpenMP threads of one process (src/bed-prod-vec.cpp:29). */
+#define BSN_COMM_ID_BYTES 128
+typedef struct bsn_comm bsn_comm;
+int bsn_comm_unique_id(uint8_t *id_out /* BSN_COMM_ID_BYTES */);
+int bsn_comm_init(const uint8_t *id, int rank, int world, bsn_comm **out);
+int bsn_comm_rank(const bsn_comm *comm);
+int bsn_comm_world(const bsn_comm *comm);
+/* sum of a device buffer of doubles over the ranks, in place, blocking (tests, host-side reductions) */
+int bsn_comm_allreduce(bsn_comm *comm, double *d_buf, int64_t count);
+int bsn_comm_destroy(bsn_comm *comm);
 typedef struct bsn_svd_options {
   int32_t k;          /* number of singular triplets (R default 10) */
   double tol;         /* relative residual on eigenvalues of A~A~' (R default 1e-4) */
@@ -177,6 +199,7 @@ typedef struct bsn_svd_options {
   int64_t m_total;    /* total number of columns over all ranks (0 -> m) */
   bsn_allreduce_fn allreduce; /* host-side hook summing a device buffer over ranks (tests); NULL otherwise */
   void *allreduce_ctx;
+  int32_t hook_rank, hook_world; /* rank / number of ranks behind the hook (ignored with `comm`) */
   struct bsn_comm *comm; /* RCCL communicator of bsn_comm_init: the panel exchange then runs inside the
                             library on its own stream (NULL: one GPU, or the hook above) */
   /* binom_scaling = 1: fun.scaling is bed_scaleBinom (R/binom-scaling.R:133-142) evaluated INSIDE the

@@ -552,6 +552,14 @@ static inline uint32_t gen_code(uint32_t seed, uint32_t i, uint32_t j, uint32_t 
   return g == 2 ? 0u : (g == 1 ? 2u : 3u); /* PLINK 2-bit: 00 = 2 copies, 10 = 1, 11 = 0 */
 }
 
+/* bench.py only: copy of a payload whose pages are first touched by the thread that will later
+ * read them (static column partition, like the column loops above) — on a multi-socket host a
+ * payload filled by one thread sits on one NUMA node and the other sockets' threads crawl. */
+void orc_parallel_copy(uint8_t *dst, const uint8_t *src, int64_t n_byte, int64_t m, int ncores) {
+#pragma omp parallel for schedule(static) num_threads(ncores)
+  for (int64_t j = 0; j < m; j++) memcpy(dst + j * n_byte, src + j * n_byte, (size_t)n_byte);
+}
+
 void orc_fake_bed(uint8_t *payload, int64_t n, int64_t m, int64_t n_byte, uint32_t seed,
                   uint32_t npop, uint32_t na16, int64_t j_begin) {
   for (int64_t j = 0; j < m; j++) {

@@ -1,7 +1,9 @@
 """Worker of tests/test_gpu_sharded_svd.py: one rank of a column-sharded bed_randomSVD.
-All ranks share GPU 0 (the test box has one GPU); the panel is summed over ranks through the
-library's `allreduce` hook with a gloo all-reduce on a host copy — the same hook bench.py fills
-with RCCL on the device buffer.  Usage (via torch.distributed.run): worker.py n m k out.json"""
+All ranks share GPU 0 (the test box has one GPU, and RCCL refuses two ranks on one device), so the
+collectives of the sample-block layout (reduce-scatter of the panel, small Gram all-reduces, all-gather
+of the finished basis block) go through the library's `allreduce` hook with a gloo all-reduce on a host
+copy; with >= 2 GPUs the same code path runs on RCCL inside the library (bench.py --gpus N,
+tests/test_gpu_comm.py).  Usage (via torch.distributed.run): worker.py n m k out.json"""
 import ctypes as C
 import json
 import os
@@ -30,7 +32,7 @@ def main():
         dist.all_reduce(t)
         _lib.check(L.bsn_memcpy_h2d(C.c_void_p(ptr), host.ctypes.data_as(C.c_void_p), count * 8))
 
-    res = ba.bed_randomSVD(gb, k=k, tol=1e-9, allreduce=allreduce, m_total=m)
+    res = ba.bed_randomSVD(gb, k=k, tol=1e-9, allreduce=allreduce, rank=rank, world=world, m_total=m)
     # every rank must have taken the same decisions and hold the same d and u
     d_all = [None] * world
     dist.all_gather_object(d_all, (res["d"].tolist(), res["niter"], float(np.abs(res["u"]).sum())))

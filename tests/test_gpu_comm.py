@@ -1,0 +1,64 @@
+"""The in-library RCCL path of the column-sharded solve (include/bigsnpr_hip.h, bsn_comm_*).
+
+A single-rank communicator exercises the real thing on the one-GPU test box: RCCL is dlopen'ed,
+ncclCommInitRank / ncclReduceScatter / ncclAllReduce / ncclAllGather run on the library's streams over
+the sample-block layout, and the solve must reproduce the plain single-GPU solve bit for bit (one rank:
+every collective is the identity).  With two or more GPUs visible the two-rank run checks the sharded
+solve against the unsharded one (skipped otherwise — RCCL refuses two ranks on one device; the two-rank
+logic on one GPU is covered through the hook by tests/test_gpu_sharded_svd.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ba():
+    import bigsnpr_amd
+    return bigsnpr_amd
+
+
+def test_single_rank_communicator_is_the_identity(ba):
+    comm = ba.Comm(ba.Comm.unique_id(), 0, 1)
+    try:
+        x = np.arange(1000, dtype=np.float64) * 0.5
+        d = ba.DeviceArray.from_numpy(x)
+        comm.allreduce(d)
+        np.testing.assert_array_equal(d.to_numpy().ravel(), x)
+        n, m, k = 2501, 3000, 6
+        gb = ba.bed.synthetic(n, m, seed=12)
+        plain = ba.bed_randomSVD(gb, k=k)
+        viacomm = ba.bed_randomSVD(gb, k=k, comm=comm, m_total=m)
+        assert viacomm["niter"] == plain["niter"]
+        for key in ("d", "u", "v"):
+            np.testing.assert_array_equal(viacomm[key], plain[key])
+    finally:
+        comm.close()
+
+
+def test_two_ranks_over_rccl(tmp_path, ba):
+    if ba.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    n, m, k = 3000, 4400, 6
+    out = str(tmp_path / "rccl.json")
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(ROOT, "tests", "helpers", "rccl_svd_worker.py"), str(n), str(m), str(k), out]
+    r = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.load(open(out))
+    assert got["same"], "ranks diverged"
+    gb = ba.bed.synthetic(n, m, seed=31)
+    ref = ba.bed_randomSVD(gb, k=k, tol=1e-9)
+    np.testing.assert_allclose(got["d"], ref["d"], rtol=1e-7)

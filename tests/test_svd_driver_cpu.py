@@ -180,3 +180,17 @@ def test_ritz_values_do_not_see_the_product_precision(nt):
     # the error of d is the convergence level (~tol^2) with or without rounded products
     assert errs[(2, 1e-4)] < 5e-8 and errs[(0, 1e-4)] < 5e-8, errs
     assert errs[(3, 1e-6)] < 1e-10 and errs[(0, 1e-6)] < 1e-10, errs
+
+
+def test_full_basis_is_not_mistaken_for_convergence(nt):
+    """a cap on the Krylov basis that is reached before the residuals meet tol: the driver must say
+    'not converged' (RSpectra warns in that case); the clipped next block must not zero the estimate"""
+    rng = np.random.default_rng(5)
+    A = rng.normal(size=(400, 300))
+    res = host_svd(nt, A, 10, tol=1e-12, block=4, max_basis=16)
+    assert not res["converged"] and res["basis"] == 16
+    assert res["resid"] > 1e-6
+    assert np.all(np.isfinite(res["d"])) and np.all(np.diff(res["d"]) <= 0)
+    # with room for the whole space the same call converges
+    res = host_svd(nt, A, 10, tol=1e-12, block=4, max_basis=0)
+    assert res["converged"]
