@@ -84,6 +84,14 @@ def host_threads():
     return dict(affinity=n, cpu_count=os.cpu_count(), cgroup_quota=quota, effective=eff, model=model)
 
 
+def log(msg):
+    sys.stderr.write("[bench %.1fs] %s\n" % (time.time() - T_START, msg))
+    sys.stderr.flush()
+
+
+T_START = time.time()
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -104,11 +112,12 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29511"
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    else:
+    elif not os.environ.get("BSN_BENCH_NO_TORCH"):
         try:
             import torch
         except Exception:
             torch = None
+    log("torch %s" % ("imported" if torch is not None else "not imported"))
     import bigsnpr_amd as ba
     from bigsnpr_amd import _lib
     L = _lib.load()
@@ -116,6 +125,7 @@ def main():
     if torch is not None and torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
     ba.selftest()
+    log("selftest ok")
     if a.workload == "ld":
         out = ld_bench(a, ba, L)
         real_stdout.write(json.dumps(out) + "\n")
@@ -137,6 +147,7 @@ def main():
     gb = ba.bed.synthetic(n, m_local, seed=20250905, j_begin=j0)
     L.bsn_device_sync()
     gen_s = time.time() - t0
+    log("image generated (%.2f s)" % gen_s)
 
     def sync():
         L.bsn_device_sync()
@@ -153,10 +164,12 @@ def main():
     for _ in range(a.warmup):
         step()
     sync()
+    log("warmup done")
     t0 = time.perf_counter()
     infos = [step() for _ in range(a.steps)]
     sync()
     wall = time.perf_counter() - t0
+    log("timed solves done (%.1f ms per solve)" % (1e3 * wall / a.steps))
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -222,8 +235,10 @@ def main():
     if rank == 0 and world == 1:
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ba, gb, n, a.cpu_sample_cols)
+            log("cpu baseline done")
         if not a.no_ingest:
             out["ingest"] = ingest(ba, L, n, a.ingest_gb)
+            log("ingest done")
     if comm is not None:
         sync()
         comm.close()
@@ -357,7 +372,7 @@ def ld_bench(a, ba, L):
     gb = ba.bed.synthetic(n, m, seed=5)
     pos = np.arange(m, dtype=np.float64)
     L.bsn_device_sync()
-    res = {}
+    res, stats = {}, {}
     for name, fn in (("bed_ld_scores", lambda: ba.bed_ld_scores(gb, size=W / 1000.0, infos_pos=pos)),
                      ("bed_cor", lambda: ba.bed_cor(gb, size=W / 1000.0, infos_pos=pos))):
         for _ in range(a.warmup):
@@ -365,13 +380,15 @@ def ld_bench(a, ba, L):
         L.bsn_device_sync()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            r = fn()
+            fn()
         L.bsn_device_sync()
         res[name] = (time.perf_counter() - t0) / a.steps
-    st = ba.ld.last_stats()
+        stats[name] = ba.ld.last_stats()
+    st = stats["bed_ld_scores"]
     pairs = st["pairs"]
-    # six exact integer products of 2 * n ops per variant pair (src/corr.cpp:54-75 restated as GEMMs)
-    ops = 6 * 2.0 * n * st["tile_pairs"] * 64 * 64
+    # exact integer products of 2 * n ops per variant pair of every 64 x 64 tile pair the band touches
+    # (src/corr.cpp:54-75 restated as six GEMMs over the samples; one when no value is missing)
+    ops = st["products"] * 2.0 * n * st["tile_pairs"] * 64 * 64
     achieved = ops / (st["stats_ms"] * 1e-3) / 1e12
     return {"metric": "variant pairs/sec for bed_ld_scores, window %d variants" % W, "value": pairs / res["bed_ld_scores"],
             "unit": "pairs/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
@@ -382,7 +399,10 @@ def ld_bench(a, ba, L):
             "pairs": pairs, "bed_cor_ms": 1e3 * res["bed_cor"],
             "roofline": {"bound": "mfma", "kernel": st["kernel"], "achieved": achieved, "peak": I8_PEAK_TOPS,
                          "unit": "TOP/s", "frac": achieved / I8_PEAK_TOPS, "traffic": None,
-                         "ops_per_launch": ops, "avg_launch_ms": st["stats_ms"], "tile_pairs": st["tile_pairs"]}}
+                         "ops_all_launches": ops, "ms_all_launches": st["stats_ms"], "launches": st["launches"],
+                         "tile_pairs": st["tile_pairs"], "products": st["products"],
+                         "note": "achieved = useful int8 ops of the %d launches of one call / their summed HIP-event time"
+                                 % st["launches"]}}
 
 
 if __name__ == "__main__":

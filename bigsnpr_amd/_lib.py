@@ -52,6 +52,7 @@ SIGNATURES = {
     "bsn_comm_world": (C.c_int, [vp]),
     "bsn_comm_allreduce": (C.c_int, [vp, vp, i64]),
     "bsn_comm_destroy": (C.c_int, [vp]),
+    "bsn_ld_last_stats": (C.c_int, [f64p]),
     "bsn_bed_open": (C.c_int, [C.c_char_p, i64, i64, C.POINTER(vp)]),
     "bsn_bed_from_host": (C.c_int, [u8p, i64, i64, i64, C.POINTER(vp)]),
     "bsn_bed_from_fbm": (C.c_int, [u8p, i64, i64, i64, C.POINTER(vp)]),

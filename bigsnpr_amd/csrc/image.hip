@@ -19,10 +19,10 @@ namespace bsn {
 // In-place finish of an uploaded payload: .bed codes -> device codes (bsn_internal.hpp), pad
 // bits of the last real byte and all pad bytes -> 0 (genotype 0, non-missing).  One thread
 // per 16 B.
-__global__ void k_recode_fix(uint8_t *img, int64_t pitch, int64_t n, int64_t n_byte, int recode) {
+__global__ void k_recode_fix(uint8_t *img, int64_t pitch, int64_t n, int64_t n_byte, int64_t m, int recode) {
   const int64_t j = blockIdx.y + (int64_t)blockIdx.z * 65535;
   const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
-  if (b >= pitch) return;
+  if (b >= pitch || j >= m) return;
   uint4 *p = (uint4 *)(img + j * pitch + b);
   uint4 v = {0, 0, 0, 0};
   if (b < n_byte) {
@@ -67,7 +67,7 @@ void image_alloc(bsn_bed *b, int64_t n, int64_t m) {
 static void finish_image(bsn_bed *b, int recode) {
   const int64_t gy = b->m < 65535 ? b->m : 65535, gz = (b->m + 65534) / 65535;
   hipLaunchKernelGGL(k_recode_fix, dim3((unsigned)((b->pitch / 16 + 255) / 256), (unsigned)gy, (unsigned)gz),
-                     dim3(256), 0, b->stream, b->d_img, b->pitch, b->n, b->n_byte, recode);
+                     dim3(256), 0, b->stream, b->d_img, b->pitch, b->n, b->n_byte, b->m, recode);
   BSN_HIP(hipGetLastError());
   BSN_HIP(hipMemsetAsync(b->d_img + b->m * b->pitch, 0, (size_t)(kPadRows * b->pitch), b->stream));
 }

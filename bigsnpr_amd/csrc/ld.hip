@@ -46,19 +46,69 @@ __device__ __forceinline__ Planes decode3(uint32_t w) {
   return p;
 }
 
+// The fp64 epilogue of one variant pair, in the reference's operation order (no contraction):
+// mode 0: r of corMat0 with threshold (dropped -> 2.0), src/corr.cpp:76-86;  mode 1: r2 of
+// ld_scores0, src/ld-scores.cpp:52-78;  mode 2: r2 of clumping_chr (raw formula with cached
+// sumX / denoX, n rows), src/clumping.cpp:72-73;  mode 3: r2 of bed_clumping_chr on mean-imputed
+// scaled values, src/clumping-bed.cpp:69-73 (v1 = center, v2 = scale).
+#pragma clang fp contract(off)
+__device__ __forceinline__ double pair_value(int mode, double xySum, double xSum, double xxSum, double ySum,
+                                             double yySum, int nona, const double *__restrict__ thr,
+                                             const double *__restrict__ v1, const double *__restrict__ v2,
+                                             int64_t j0, int64_t j, double nrows) {
+  if (mode == 0 || mode == 1) {
+    const double num = xySum - xSum * ySum / nona;
+    const double deno_x = xxSum - xSum * xSum / nona;
+    const double deno_y = yySum - ySum * ySum / nona;
+    if (mode == 0) {
+      double r = num / sqrt(deno_x * deno_y);
+      // src/corr.cpp:82-86; thr[nona - 1] is only read when r is not NaN (nona >= 1 then)
+      if (isnan(r) || fabs(r) > thr[nona > 0 ? nona - 1 : 0]) {
+        if (r > 1) r = 1; else if (r < -1) r = -1;
+        return r;
+      }
+      return 2.0;
+    }
+    return num * num / (deno_x * deno_y);
+  } else if (mode == 2) {
+    // v1 = sumX, v2 = denoX (per position in ind_col)
+    const double num = xySum - v1[j] * v1[j0] / nrows;
+    return num * num / (v2[j] * v2[j0]);
+  }
+  // sum_i x~ y~ over rows where both are present (missing -> 0)
+  const double cx = v1[j0], cy = v1[j], sx = v2[j0], sy = v2[j];
+  const double s = xySum - cx * ySum - cy * xSum + cx * cy * (double)nona;
+  const double r = s / (sx * sy);
+  return r * r;
+}
+#pragma clang fp contract(on)
+
+// what the fused epilogue of k_pair_stats needs to turn its sums into band entries
+struct BandOut {
+  int64_t m, W;
+  const int64_t *lo;
+  const double *thr, *v1, *v2;
+  double nrows;
+  double *band;
+  int mode;
+};
+
 // stats[pair][prod][row][col], prod: 0 xy, 1 x(both), 2 xx(both), 3 y(both), 4 yy(both), 5 nona
 // row = variant of tile I (the "x" / j0 side), col = variant of tile J (the "y" / j side).
 // rowmask (optional): 2 bits per sample, 11 = keep; dropped samples are turned into code 11
 // (missing) so that they vanish from all six sums.
 // ALL = false: only product 0 (xy) is computed and stored — the case of variants without missing
 // values among the selected samples, where the other five sums are per-variant constants.
-template <bool ALL>
+// FUSE: the whole sample range is in this workgroup (no K split), so the six sums of a pair sit in
+// one lane's accumulators and the fp64 epilogue runs right here: the band entry is written, the
+// int32 statistics never leave the registers.
+template <bool ALL, bool FUSE>
 __global__ __launch_bounds__(256) void k_pair_stats(const uint8_t *__restrict__ img, int64_t pitch,
                                                     const int32_t *__restrict__ cols,
                                                     const int2 *__restrict__ pairs,
                                                     const uint32_t *__restrict__ rowmask,
                                                     int64_t kbytes_per_split,
-                                                    int32_t *__restrict__ stats, int use_atomic) {
+                                                    int32_t *__restrict__ stats, int use_atomic, BandOut bo) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r16 = lane & 15, g = lane >> 4;
   const int wr = wave >> 1, wc = wave & 1;
@@ -117,6 +167,23 @@ __global__ __launch_bounds__(256) void k_pair_stats(const uint8_t *__restrict__ 
           }
         }
     }
+  }
+  if constexpr (FUSE && ALL) {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = wr * 32 + i * 16 + 4 * g + r, col = wc * 32 + j * 16 + r16;
+          const int64_t j0 = (int64_t)pr.x * TB + row, jj = (int64_t)pr.y * TB + col;
+          if (j0 >= bo.m || jj >= j0 || jj < bo.lo[j0]) continue;
+          bo.band[j0 * bo.W + (j0 - jj - 1)] =
+              pair_value(bo.mode, (double)acc[i][j][0][r], (double)acc[i][j][1][r], (double)acc[i][j][2][r],
+                         (double)acc[i][j][3][r], (double)acc[i][j][4][r], acc[i][j][5][r], bo.thr, bo.v1, bo.v2,
+                         j0, jj, bo.nrows);
+        }
+    return;
   }
   int32_t *out = stats + (int64_t)blockIdx.x * 6 * TB * TB;
 #pragma unroll
@@ -220,10 +287,7 @@ __global__ __launch_bounds__(64) void k_pair_xy64(const uint8_t *__restrict__ im
       }
 }
 
-// mode 0: r of corMat0 with threshold (dropped -> 2.0);  mode 1: r2 of ld_scores0;
-// mode 2: r2 of clumping_chr (raw formula with cached sumX/denoX, n rows);
-// mode 3: r2 of bed_clumping_chr (mean-imputed scaled values)
-#pragma clang fp contract(off)
+// second stage of the K-split / cross-product-only paths: statistics buffer -> band entries
 __global__ void k_band_fill(const int32_t *__restrict__ stats, const int2 *__restrict__ pairs,
                             int npairs, int64_t m, const int64_t *__restrict__ lo, int64_t W,
                             const double *__restrict__ thr, int mode, const double *__restrict__ v1,
@@ -245,36 +309,7 @@ __global__ void k_band_fill(const int32_t *__restrict__ stats, const int2 *__res
                  ySum = cx ? cx[j] : (double)st[(3 * TB + row) * TB + col],
                  yySum = cx ? cxx[j] : (double)st[(4 * TB + row) * TB + col];
     const int nona = cx ? (int)nrows : st[(5 * TB + row) * TB + col];
-    double val;
-    if (mode == 0 || mode == 1) {
-      const double num = xySum - xSum * ySum / nona;
-      const double deno_x = xxSum - xSum * xSum / nona;
-      const double deno_y = yySum - ySum * ySum / nona;
-      if (mode == 0) {
-        double r = num / sqrt(deno_x * deno_y);
-        // src/corr.cpp:82-86; thr[nona - 1] is only read when r is not NaN (nona >= 1 then)
-        if (isnan(r) || fabs(r) > thr[nona > 0 ? nona - 1 : 0]) {
-          if (r > 1) r = 1; else if (r < -1) r = -1;
-          val = r;
-        } else {
-          val = 2.0;
-        }
-      } else {
-        val = num * num / (deno_x * deno_y);
-      }
-    } else if (mode == 2) {
-      // src/clumping.cpp:72-73 ; v1 = sumX, v2 = denoX (per position in ind_col)
-      const double num = xySum - v1[j] * v1[j0] / nrows;
-      val = num * num / (v2[j] * v2[j0]);
-    } else {
-      // src/clumping-bed.cpp:69-73 on mean-imputed scaled values: v1 = center, v2 = scale.
-      // sum_i x~ y~ over rows where both are present (missing -> 0)
-      const double cx = v1[j0], cy = v1[j], sx = v2[j0], sy = v2[j];
-      const double s = xySum - cx * ySum - cy * xSum + cx * cy * (double)nona;
-      const double r = s / (sx * sy);
-      val = r * r;
-    }
-    band[j0 * W + (j0 - j - 1)] = val;
+    band[j0 * W + (j0 - j - 1)] = pair_value(mode, xySum, xSum, xxSum, ySum, yySum, nona, thr, v1, v2, j0, j, nrows);
   }
 }
 
@@ -368,6 +403,13 @@ __global__ void k_band_gt_upper(const double *__restrict__ band, const int64_t *
 }
 
 // ---------------------------------------------------------------------------------------
+// what bench.py --workload ld reports: set by every band_run
+struct LdStats {
+  double pairs = 0, tile_pairs = 0, stats_ms = 0, launches = 0;
+  int kernel = 0;  // 0: six-product kernel with fused epilogue, 1: six-product + K split, 2: cross product only
+};
+static LdStats g_ld_stats;
+
 struct BandJob {
   bsn_bed *bed = nullptr;
   int64_t n = 0, m = 0, W = 1;
@@ -473,41 +515,72 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
   J.d_band.ensure((size_t)m * (size_t)W);
 }
 
-// runs the statistics + band fill in batches; fill_mode / aux as in k_band_fill
+// runs the statistics + band fill in batches; mode / aux as in pair_value
 static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_v1, const double *d_v2,
                      double nrows) {
   bsn_bed *bed = J.bed;
-  const int64_t batch = 4096;  // 4096 x 6 x 64 x 64 x 4 B = 403 MB of int32 statistics
-  J.d_stats.ensure((size_t)std::min(batch, J.npairs) * 6 * TB * TB);
-  // K split: enough workgroups to fill the chip when there are few tile pairs
+  const int64_t batch = 4096;  // 4096 x 6 x 64 x 64 x 4 B = 403 MB of int32 statistics (two-stage paths only)
+  const bool xy_only = J.complete || mode == 2;  // FBM clumping (mode 2) reads the cross product only (src/clumping.cpp:66-73)
+  LdStats ls;
+  ls.tile_pairs = (double)J.npairs;
+  for (int64_t j0 = 0; j0 < J.m; j0++) ls.pairs += (double)(j0 - J.lo[(size_t)j0]);
+  hipEvent_t e0, e1;
+  BSN_HIP(hipEventCreate(&e0));
+  BSN_HIP(hipEventCreate(&e1));
+  float ms_total = 0;
+  BandOut bo{J.m, J.W, J.d_lo.p, d_thr, d_v1, d_v2, nrows, J.d_band.p, mode};
   for (int64_t p0 = 0; p0 < J.npairs; p0 += batch) {
     const int64_t np = std::min(batch, J.npairs - p0);
+    // K split: enough workgroups to fill the chip when there are few tile pairs
     int ksplit = (int)std::min<int64_t>(std::max<int64_t>(1, 2048 / np), bed->pitch / 256);
     if (ksplit < 1) ksplit = 1;
     int64_t kbytes = round_up((bed->pitch + ksplit - 1) / ksplit, 64);
     ksplit = (int)((bed->pitch + kbytes - 1) / kbytes);
-    if (ksplit > 1) BSN_HIP(hipMemsetAsync(J.d_stats.p, 0, (size_t)np * 6 * TB * TB * 4, bed->stream));
-    // FBM clumping (mode 2) reads the cross product only (src/clumping.cpp:66-73)
-    if (J.complete || mode == 2) {
+    const bool fused = !xy_only && ksplit == 1;
+    if (!fused) {
+      J.d_stats.ensure((size_t)std::min(batch, J.npairs) * 6 * TB * TB);
+      if (ksplit > 1 || xy_only) BSN_HIP(hipMemsetAsync(J.d_stats.p, 0, (size_t)np * 6 * TB * TB * 4, bed->stream));
+    }
+    BSN_HIP(hipEventRecord(e0, bed->stream));
+    if (xy_only) {
       // one wave per workgroup here: four times the K splits of the 4-wave kernel
       int ks4 = (int)std::min<int64_t>(std::max<int64_t>(4, 8192 / np), bed->pitch / 256);
       if (ks4 < 1) ks4 = 1;
       int64_t kb4 = round_up((bed->pitch + ks4 - 1) / ks4, 64);
       ks4 = (int)((bed->pitch + kb4 - 1) / kb4);
-      if (ksplit <= 1) BSN_HIP(hipMemsetAsync(J.d_stats.p, 0, (size_t)np * 6 * TB * TB * 4, bed->stream));
       hipLaunchKernelGGL(k_pair_xy64, dim3((unsigned)np, (unsigned)ks4), dim3(64), 0, bed->stream, bed->d_img,
                          bed->pitch, J.d_cols.p, J.d_pairs.p + p0, J.d_mask.p, kb4, J.d_stats.p);
-    } else
-      hipLaunchKernelGGL((k_pair_stats<true>), dim3((unsigned)np, (unsigned)ksplit), dim3(256), 0, bed->stream,
+      ls.kernel = 2;
+    } else if (fused) {
+      hipLaunchKernelGGL((k_pair_stats<true, true>), dim3((unsigned)np, 1), dim3(256), 0, bed->stream,
                          bed->d_img, bed->pitch, J.d_cols.p, J.d_pairs.p + p0,
-                         J.use_mask ? J.d_mask.p : nullptr, kbytes, J.d_stats.p, ksplit > 1 ? 1 : 0);
+                         J.use_mask ? J.d_mask.p : nullptr, kbytes, (int32_t *)nullptr, 0, bo);
+      ls.kernel = 0;
+    } else {
+      hipLaunchKernelGGL((k_pair_stats<true, false>), dim3((unsigned)np, (unsigned)ksplit), dim3(256), 0, bed->stream,
+                         bed->d_img, bed->pitch, J.d_cols.p, J.d_pairs.p + p0,
+                         J.use_mask ? J.d_mask.p : nullptr, kbytes, J.d_stats.p, ksplit > 1 ? 1 : 0, bo);
+      ls.kernel = 1;
+    }
     BSN_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_band_fill, dim3((unsigned)np), dim3(256), 0, bed->stream, J.d_stats.p,
-                       J.d_pairs.p + p0, (int)np, J.m, J.d_lo.p, J.W, d_thr, mode, d_v1, d_v2, nrows,
-                       J.d_band.p, J.complete ? J.d_cx.p : (const double *)nullptr,
-                       J.complete ? J.d_cxx.p : (const double *)nullptr);
-    BSN_HIP(hipGetLastError());
+    BSN_HIP(hipEventRecord(e1, bed->stream));
+    if (!fused) {
+      hipLaunchKernelGGL(k_band_fill, dim3((unsigned)np), dim3(256), 0, bed->stream, J.d_stats.p,
+                         J.d_pairs.p + p0, (int)np, J.m, J.d_lo.p, J.W, d_thr, mode, d_v1, d_v2, nrows,
+                         J.d_band.p, J.complete ? J.d_cx.p : (const double *)nullptr,
+                         J.complete ? J.d_cxx.p : (const double *)nullptr);
+      BSN_HIP(hipGetLastError());
+    }
+    BSN_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    BSN_HIP(hipEventElapsedTime(&ms, e0, e1));
+    ms_total += ms;
+    ls.launches += 1;
   }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  ls.stats_ms = ms_total;
+  g_ld_stats = ls;
 }
 
 }  // namespace bsn
@@ -559,6 +632,16 @@ int bsn_cormat(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *i
     J.d_stats.release();
     *nnz_out = nnz;
     *out = C.release();
+  });
+}
+
+int bsn_ld_last_stats(double *out) {
+  return guarded([&] {
+    out[0] = g_ld_stats.pairs;
+    out[1] = g_ld_stats.tile_pairs;
+    out[2] = g_ld_stats.stats_ms;
+    out[3] = g_ld_stats.launches;
+    out[4] = (double)g_ld_stats.kernel;
   });
 }
 

@@ -285,3 +285,13 @@ def big_randomSVD(X, fun_scaling=None, ind_row=None, ind_col=None, k=10, tol=1e-
     fs = snp_scaleBinom() if fun_scaling is None else fun_scaling
     return bed_randomSVD(im, fun_scaling=lambda obj, ind_row, ind_col, ncores=1: fs(X, ind_row, ind_col, ncores),
                          ind_row=ir, ind_col=ic, k=k, tol=tol, verbose=verbose, ncores=ncores, **kw)
+
+
+def last_stats():
+    """figures of the last LD call of this process (bsn_ld_last_stats): bench.py --workload ld"""
+    out = np.zeros(5)
+    check(_lib.load().bsn_ld_last_stats(ptr(out, f64p)))
+    names = ("k_pair_stats<6 products, fused fp64 epilogue>", "k_pair_stats<6 products, K split> + k_band_fill",
+             "k_pair_xy64 (cross product only: no missing values) + k_band_fill")
+    return dict(pairs=out[0], tile_pairs=out[1], stats_ms=out[2], launches=int(out[3]), kernel=names[int(out[4])],
+                products=1 if int(out[4]) == 2 else 6)

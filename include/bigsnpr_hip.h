@@ -254,6 +254,11 @@ int bsn_cormat(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *i
                int64_t *nnz_out, bsn_cor **out);
 int bsn_cormat_fetch(bsn_cor *cor, int32_t *i_out, double *x_out);
 int bsn_cormat_free(bsn_cor *cor);
+/* measurement hook (bench.py --workload ld): figures of the last bsn_cormat / bsn_ld_scores /
+ * bsn_clumping_* call of this process: out[0] = variant pairs in the band, out[1] = 64 x 64 tile
+ * pairs, out[2] = total HIP-event time (ms) of the pair-statistics launches, out[3] = launches,
+ * out[4] = kernel (0: six products, fused epilogue; 1: six products, K split; 2: cross product only) */
+int bsn_ld_last_stats(double *out /* 5 */);
 /* _bigsnpr_ld_scores (6 args) src/ld-scores.cpp:83-105 */
 int bsn_ld_scores(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
                   double size, const double *pos, double *out);

@@ -170,3 +170,29 @@ def test_random_shape_sweep(ba, orc):
         ref = orc.bed_cprodVec(ob, yy, ir, ic, c, s)
         np.testing.assert_allclose(ba.bed_cprodVec(gb, yy, ir, ic, c, s), ref, rtol=0,
                                    atol=1e-9 * max(np.abs(ref).max(), 1e-300), err_msg="case %d" % it)
+
+
+def test_more_than_65535_variants_through_every_upload_path(ba, orc, tmp_path):
+    """grid.y of the per-variant kernels is capped at 65 535: uploads, repacks and read-backs of wider
+    matrices fold the variant index over grid.z — from a host payload, from a .bed file and from FBM
+    bytes, with an n that leaves pad bits in the last byte and pad bytes in the 256-B pitch."""
+    n, m = 37, 70001
+    ob = orc.fake_bed(n, m, seed=8)
+    ref_counts = orc.bed_col_counts(ob)
+    gb = ba.bed.from_payload(ob.payload, n, m)
+    np.testing.assert_array_equal(gb.download(), ob.payload)
+    np.testing.assert_array_equal(ba.bed_counts(gb), ref_counts)
+    base = str(tmp_path / "wide")
+    with open(base + ".bed", "wb") as f:
+        f.write(bytes([0x6C, 0x1B, 0x01]))
+        f.write(ob.payload.tobytes())
+    open(base + ".fam", "w").write("".join("f%d i%d 0 0 0 -9\n" % (i, i) for i in range(n)))
+    open(base + ".bim", "w").write("".join("1 s%d 0 %d A C\n" % (j, j + 1) for j in range(m)))
+    gf = ba.bed(base + ".bed")
+    np.testing.assert_array_equal(gf.download(), ob.payload)
+    np.testing.assert_array_equal(ba.bed_counts(gf), ref_counts)
+    G = orc.fbm_from_bed(ob)
+    gm = ba.bed.from_fbm(G.bytes)
+    np.testing.assert_array_equal(ba.bed_counts(gm), ref_counts)
+    cols = np.array([0, 65534, 65535, 65536, m - 1])
+    np.testing.assert_array_equal(ba.read_bed(gb, np.arange(n), cols), orc.read_bed(ob, None, cols))
