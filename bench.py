@@ -127,9 +127,13 @@ def main():
     ba.selftest()
     log("selftest ok")
     if a.workload == "ld":
-        out = ld_bench(a, ba, L)
-        real_stdout.write(json.dumps(out) + "\n")
-        real_stdout.flush()
+        out = ld_bench(a, ba, L, rank, world, dist, torch)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            real_stdout.write(json.dumps(out) + "\n")
+            real_stdout.flush()
         return
 
     comm = None
@@ -364,14 +368,18 @@ def ingest(ba, L, n, gb_size):
             pass
 
 
-def ld_bench(a, ba, L):
+def ld_bench(a, ba, L, rank=0, world=1, dist=None, torch=None):
     """config C5: bed_ld_scores + bed_cor on one chromosome (n x m 2-bit image in HBM), windows of
-    `window` variants.  roofline: int8 MFMA work of the pair-statistics kernel / its launch time."""
+    `window` variants; with N GPUs every rank holds a chromosome of its own (R/clumping.R:83-88 splits
+    by chromosome; no collective, weak scaling).  roofline: int8 MFMA work of the pair-statistics
+    kernel / its launch time."""
     import numpy as np
     n, m, W = a.n, a.m or 100000, a.window
-    gb = ba.bed.synthetic(n, m, seed=5)
+    gb = ba.bed.synthetic(n, m, seed=5 + rank)
     pos = np.arange(m, dtype=np.float64)
     L.bsn_device_sync()
+    if world > 1:
+        dist.barrier()
     res, stats = {}, {}
     for name, fn in (("bed_ld_scores", lambda: ba.bed_ld_scores(gb, size=W / 1000.0, infos_pos=pos)),
                      ("bed_cor", lambda: ba.bed_cor(gb, size=W / 1000.0, infos_pos=pos))):
@@ -383,6 +391,11 @@ def ld_bench(a, ba, L):
             fn()
         L.bsn_device_sync()
         res[name] = (time.perf_counter() - t0) / a.steps
+        if world > 1:   # slowest rank
+            dist.barrier()
+            t = torch.tensor([res[name]], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            res[name] = float(t.item())
         stats[name] = ba.ld.last_stats()
     st = stats["bed_ld_scores"]
     pairs = st["pairs"]
@@ -390,12 +403,13 @@ def ld_bench(a, ba, L):
     # (src/corr.cpp:54-75 restated as six GEMMs over the samples; one when no value is missing)
     ops = st["products"] * 2.0 * n * st["tile_pairs"] * 64 * 64
     achieved = ops / (st["stats_ms"] * 1e-3) / 1e12
-    return {"metric": "variant pairs/sec for bed_ld_scores, window %d variants" % W, "value": pairs / res["bed_ld_scores"],
-            "unit": "pairs/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+    return {"metric": "variant pairs/sec for bed_ld_scores, window %d variants" % W,
+            "value": world * pairs / res["bed_ld_scores"], "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * res["bed_ld_scores"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i8 planes, exact int32 MFMA accumulation, fp64 epilogue", "data": "synthetic",
             "config": {"workload": "bed_ld_scores / bed_cor on synthetic %dx%d 2-bit image, window %d variants (config C5)"
-                                   % (n, m, W), "n": n, "m": m, "window": W},
+                                   % (n, m, W), "n": n, "m": m, "window": W,
+                       "parallelism": "one chromosome per GPU, no collective" if world > 1 else "single GPU"},
             "pairs": pairs, "bed_cor_ms": 1e3 * res["bed_cor"],
             "roofline": {"bound": "mfma", "kernel": st["kernel"], "achieved": achieved, "peak": I8_PEAK_TOPS,
                          "unit": "TOP/s", "frac": achieved / I8_PEAK_TOPS, "traffic": None,

@@ -13,6 +13,6 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_
            "FETCH_SIZE GRBM_GUI_ACTIVE" \
            "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT -o g$i -- python $R/bench.py --no-cpu-baseline "$@" > $OUT/g$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT -o g$i -- python $R/bench.py --no-cpu-baseline --no-ingest "$@" > $OUT/g$i.log 2>&1
 done
 ls $OUT
