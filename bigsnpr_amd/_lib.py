@@ -58,6 +58,7 @@ SIGNATURES = {
     "bsn_bed_from_fbm": (C.c_int, [u8p, i64, i64, i64, C.POINTER(vp)]),
     "bsn_bed_synthetic": (C.c_int, [i64, i64, C.c_uint32, C.c_uint32, C.c_uint32, i64, C.POINTER(vp)]),
     "bsn_bed_close": (C.c_int, [vp]),
+    "bsn_bed_release_workspace": (C.c_int, [vp]),
     "bsn_bed_nrow": (i64, [vp]),
     "bsn_bed_ncol": (i64, [vp]),
     "bsn_bed_bytes": (i64, [vp]),

@@ -250,6 +250,15 @@ int bsn_bed_close(bsn_bed *bed) {
   });
 }
 
+int bsn_bed_release_workspace(bsn_bed *bed) {
+  return guarded([&] {
+    BSN_HIP(hipSetDevice(bed->device));
+    BSN_HIP(hipStreamSynchronize(bed->stream));
+    bed->svd_op.reset();
+    bed->svd_ws.reset();
+  });
+}
+
 int64_t bsn_bed_nrow(const bsn_bed *bed) { return bed->n; }
 int64_t bsn_bed_ncol(const bsn_bed *bed) { return bed->m; }
 int64_t bsn_bed_bytes(const bsn_bed *bed) { return bed->pitch * bed->m; }

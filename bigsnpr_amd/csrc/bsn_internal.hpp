@@ -91,24 +91,10 @@ __host__ __device__ inline uint32_t plink_from_dev(uint32_t w) {
 
 }  // namespace bsn
 
-// ---- the handle -------------------------------------------------------------
-// HBM layout: variant-major like the file (src/bed-acc.h:71-75): variant j occupies
-// bytes [j*pitch, j*pitch + n_byte); sample i sits in bits 2*(i%4) of byte i/4, in the
-// device coding above (0/1/2 = allele count, 3 = missing).  pitch = n_byte rounded up to
-// 256 B.  Pad samples (pad bits of the last real byte and all pad bytes) are 0 (genotype 0,
-// not missing) so that they contribute nothing to any plane product; kernels may therefore
-// run over [0, 4*pitch) samples.
-struct bsn_bed {
-  int64_t n = 0, m = 0, n_byte = 0, pitch = 0;
-  uint8_t *d_img = nullptr;
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  // number of missing genotypes per variant over ALL samples, -1 = not known yet; filled as a
-  // by-product of every full-row count (and at creation for FBM / NA-free synthetic images).
-  // An operator whose variants are all known to be complete skips the missing-value plane.
-  std::vector<int32_t> na_cnt;
-};
+struct bsn_bed;
+namespace bsn {
+struct SvdWorkspace;  // svd.hip
+}
 
 // RCCL communicator of a column-sharded solve (comm.hip); `comm` is an ncclComm_t
 struct bsn_comm {
@@ -155,6 +141,31 @@ struct bsn_op {
   bsn::DevBuf<double> d_meta;    // per-vector scale, sums
   bsn::DevBuf<double> d_yfull;   // full-length output before the row gather
 };
+
+// ---- the handle -------------------------------------------------------------
+// HBM layout: variant-major like the file (src/bed-acc.h:71-75): variant j occupies
+// bytes [j*pitch, j*pitch + n_byte); sample i sits in bits 2*(i%4) of byte i/4, in the
+// device coding above (0/1/2 = allele count, 3 = missing).  pitch = n_byte rounded up to
+// 256 B.  Pad samples (pad bits of the last real byte and all pad bytes) are 0 (genotype 0,
+// not missing) so that they contribute nothing to any plane product; kernels may therefore
+// run over [0, 4*pitch) samples.
+struct bsn_bed {
+  int64_t n = 0, m = 0, n_byte = 0, pitch = 0;
+  uint8_t *d_img = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // number of missing genotypes per variant over ALL samples, -1 = not known yet; filled as a
+  // by-product of every full-row count (and at creation for FBM / NA-free synthetic images).
+  // An operator whose variants are all known to be complete skips the missing-value plane.
+  std::vector<int32_t> na_cnt;
+  // Workspace of bsn_bed_randomsvd, kept between solves on this handle (basis, panels, quantised
+  // operands: ~4 GB at 400K x 1M) instead of being allocated and freed by every solve; released by
+  // bsn_bed_release_workspace or with the handle.
+  std::unique_ptr<bsn_op> svd_op;
+  std::shared_ptr<bsn::SvdWorkspace> svd_ws;
+};
+
 
 namespace bsn {
 

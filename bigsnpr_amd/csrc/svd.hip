@@ -5,6 +5,7 @@
 // (n x p doubles) and is a few percent of a step.
 #include <chrono>
 #include <cmath>
+#include <cstring>
 #include <memory>
 
 #include "bsn_internal.hpp"
@@ -324,7 +325,33 @@ __global__ void k_take_rows(const double *__restrict__ full, int64_t n, int cb, 
 //   Qfull = round(all-gather(W_r)); Q_r gets its rows
 // Without a communicator (and without the test hook) nr = n and every collective is skipped: the
 // single-GPU path is the same code.
+// device buffers of a solve; lives on the bed handle between solves (grow-only)
+struct SvdWorkspace {
+  DevBuf<double> Q, Z, W, partial, dsmall, Wsave, dorth, Wfull, Wblk, Qfull, dS, dU, dV, dUfull;
+  // pinned host staging for the small matrices that cross the bus every block step (Gram blocks,
+  // orthogonalisation coefficients): copies to pageable memory go through the runtime's own staging
+  // and were measured to cost milliseconds each once a process has run a few solves
+  double *h_pin = nullptr;
+  size_t h_pin_n = 0;
+  double *pinned(size_t count) {
+    if (count > h_pin_n) {
+      if (h_pin) (void)hipHostFree(h_pin);
+      h_pin = nullptr;
+      BSN_HIP(hipHostMalloc((void **)&h_pin, count * sizeof(double), hipHostMallocDefault));
+      h_pin_n = count;
+    }
+    return h_pin;
+  }
+  ~SvdWorkspace() {
+    if (h_pin) (void)hipHostFree(h_pin);
+  }
+};
+
 struct HipSvdBackend : SvdBackend {
+  SvdWorkspace &ws;
+  explicit HipSvdBackend(SvdWorkspace &w)
+      : ws(w), Q(w.Q), Z(w.Z), W(w.W), partial(w.partial), dsmall(w.dsmall), Wsave(w.Wsave), dorth(w.dorth),
+        Wfull(w.Wfull), Wblk(w.Wblk), Qfull(w.Qfull) {}
   bsn_op *op = nullptr;
   hipStream_t st = nullptr;
   bsn_allreduce_fn hook = nullptr;
@@ -333,13 +360,26 @@ struct HipSvdBackend : SvdBackend {
   int rank = 0, world = 1;
   bool dist = false;
   int64_t nr = 0, row0 = 0;  // rows of a sample block, first row of this rank's block
-  DevBuf<double> Q, Z, W, partial, dsmall, tmp, Wsave, dorth, Wfull, Wblk, Qfull;
+  DevBuf<double> &Q, &Z, &W, &partial, &dsmall, &Wsave, &dorth, &Wfull, &Wblk, &Qfull;
   std::vector<double> horth;
   int cap = 0, b = 0;
   int64_t rows_per = 0;
   int nrc = 0;
   bool rs_pending = false;
   int kmax = 0;
+  // host wall time per phase (BSN_TIMING=1): where a solve's time outside the streaming kernels goes
+  bool timing = false;
+  double t_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // alloc, At_Q, A_Z, grams, orth, round/copy, finalize, other
+  struct Tick {
+    HipSvdBackend *b;
+    int ph;
+    std::chrono::steady_clock::time_point t0;
+    Tick(HipSvdBackend *b_, int ph_) : b(b_), ph(ph_), t0(std::chrono::steady_clock::now()) {}
+    ~Tick() {
+      if (b->timing)
+        b->t_phase[ph] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+  };
 
   void setup_ranks() {
     if (comm) {
@@ -352,6 +392,7 @@ struct HipSvdBackend : SvdBackend {
     row0 = (int64_t)rank * nr;
   }
   void alloc(int cap_, int b_) override {
+    Tick tk(this, 0);
     if (b_ > kMaxB) fail("block size must be <= %d", kMaxB);
     cap = cap_;
     b = b_;
@@ -374,10 +415,7 @@ struct HipSvdBackend : SvdBackend {
       Wblk.ensure((size_t)world * nr * wide);
       Qfull.ensure((size_t)n * kMaxB);
     }
-    if (getenv("BSN_TIMING"))
-      std::fprintf(stderr, "[bsn svd] workspace alloc %.2f ms (Q %.2f GB, Z %.2f GB)\n",
-                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
-                   (double)nr * cap * 8e-9, (double)m_local * cap * 8e-9);
+    (void)t0;
   }
 
   // ---- collectives ------------------------------------------------------------------------
@@ -442,9 +480,11 @@ struct HipSvdBackend : SvdBackend {
   // the newest basis block with all n rows: Q itself on one GPU, the gathered copy otherwise
   const double *newest_block(int p0) const { return dist ? Qfull.p : Q.p + (int64_t)p0 * nr; }
   void At_Qblock(int p0, int cb) override {
+    Tick tk(this, 1);
     op_cprod(op, newest_block(p0), n, cb, Z.p + (int64_t)p0 * m_local, m_local);
   }
   void A_Zblock(int p0, int cb) override {
+    Tick tk(this, 2);
     op_prod(op, Z.p + (int64_t)p0 * m_local, m_local, cb, dist ? Wfull.p : W.p, n);
     if (dist) reduce_scatter_W(cb);
   }
@@ -453,8 +493,10 @@ struct HipSvdBackend : SvdBackend {
     gemm_tn_any(A, W.p, nr, p, cb, dsmall.p);
     BSN_HIP(hipGetLastError());
     ar_small(dsmall.p, (int64_t)p * cb);
-    BSN_HIP(hipMemcpyAsync(C_host, dsmall.p, (size_t)p * cb * 8, hipMemcpyDeviceToHost, st));
+    double *hp = ws.pinned((size_t)(cap + 4) * kMaxB * 4 + 1024);
+    BSN_HIP(hipMemcpyAsync(hp, dsmall.p, (size_t)p * cb * 8, hipMemcpyDeviceToHost, st));
     BSN_HIP(hipStreamSynchronize(st));
+    std::memcpy(C_host, hp, (size_t)p * cb * 8);
   }
   // dC (p x cb) = sum over ranks of A[:, :p]' W[:, :cb] on the local sample block
   void gemm_tn_dev(const double *A, int p, int cb, double *dC) {
@@ -479,6 +521,7 @@ struct HipSvdBackend : SvdBackend {
   }
   void round_W(int cb) override {
     if (cb <= 0) return;
+    Tick tk(this, 5);
     if (!dist) {
       round_cols(W.p, n, cb);
       return;
@@ -491,11 +534,14 @@ struct HipSvdBackend : SvdBackend {
     BSN_HIP(hipGetLastError());
   }
   void gram_to_host(const double *A, const double *B, int64_t rows, int p, int cb, double *out) {
+    Tick tk(this, 3);
     gemm_tn_any(A, B, rows, p, cb, dsmall.p);  // local part first: it overlaps the reduce-scatter of W
     BSN_HIP(hipGetLastError());
     ar_small(dsmall.p, (int64_t)p * cb);
-    BSN_HIP(hipMemcpyAsync(out, dsmall.p, (size_t)p * cb * 8, hipMemcpyDeviceToHost, st));
+    double *hp = ws.pinned((size_t)(cap + 4) * kMaxB * 4 + 1024);
+    BSN_HIP(hipMemcpyAsync(hp, dsmall.p, (size_t)p * cb * 8, hipMemcpyDeviceToHost, st));
     BSN_HIP(hipStreamSynchronize(st));
+    std::memcpy(out, hp, (size_t)p * cb * 8);
     op_poll_stats(op);
   }
   void ZtZ(int p, int p0, int cb, double *G) override {
@@ -508,7 +554,14 @@ struct HipSvdBackend : SvdBackend {
   // the device: one host synchronisation per block step instead of eleven.
   int orth_fused(int p, int cb, std::vector<double> &Cacc, std::vector<double> &Rout) override {
     if (cb <= 0 || cb > kMaxB) return -1;
+    Tick tk(this, 4);
     wait_rs();
+    hipEvent_t tev0 = nullptr, tev1 = nullptr;
+    if (timing) {
+      BSN_HIP(hipEventCreate(&tev0));
+      BSN_HIP(hipEventCreate(&tev1));
+      BSN_HIP(hipEventRecord(tev0, st));
+    }
     constexpr int B2 = kMaxB * kMaxB;
     // arena: [flag | Rout | C1 | C2] is downloaded in one piece; then G0, G, Ri, C3
     double *flag = dorth.p, *dRout = flag + 1, *C1 = dRout + B2, *C2 = C1 + (size_t)p * cb,
@@ -535,8 +588,18 @@ struct HipSvdBackend : SvdBackend {
     }
     BSN_HIP(hipGetLastError());
     horth.resize(nsmall);
-    BSN_HIP(hipMemcpyAsync(horth.data(), flag, nsmall * 8, hipMemcpyDeviceToHost, st));
+    double *hp = ws.pinned((size_t)(cap + 4) * kMaxB * 4 + 1024);
+    BSN_HIP(hipMemcpyAsync(hp, flag, nsmall * 8, hipMemcpyDeviceToHost, st));
+    if (timing) BSN_HIP(hipEventRecord(tev1, st));
     BSN_HIP(hipStreamSynchronize(st));
+    if (timing) {
+      float ms = 0;
+      BSN_HIP(hipEventElapsedTime(&ms, tev0, tev1));
+      t_phase[7] += ms;
+      (void)hipEventDestroy(tev0);
+      (void)hipEventDestroy(tev1);
+    }
+    std::memcpy(horth.data(), hp, nsmall * 8);
     op_poll_stats(op);
     if (horth[0] != 0.0) {  // rank deficient: undo and let the driver take the careful path
       BSN_HIP(hipMemcpyAsync(W.p, Wsave.p, (size_t)nr * cb * 8, hipMemcpyDeviceToDevice, st));
@@ -571,11 +634,12 @@ struct HipSvdBackend : SvdBackend {
     BSN_HIP(hipMemcpyAsync(Q.p + (int64_t)p0 * nr, W.p, (size_t)nr * r * 8, hipMemcpyDeviceToDevice, st));
   }
   void finalize(int pp, int k, const double *S, const double *dinv, double *u, double *v) override {
+    Tick tk(this, 6);
     wait_rs();
     std::vector<double> Sv((size_t)pp * k);
     for (int t = 0; t < k; t++)
       for (int i = 0; i < pp; i++) Sv[(size_t)i + (size_t)t * pp] = S[(size_t)i + (size_t)t * pp] * dinv[t];
-    DevBuf<double> dS, dU, dV, dUfull;
+    DevBuf<double> &dS = ws.dS, &dU = ws.dU, &dV = ws.dV, &dUfull = ws.dUfull;
     dS.ensure((size_t)pp * k * 2 + 16);
     dU.ensure((size_t)nr * k);
     dV.ensure((size_t)m_local * k);
@@ -642,8 +706,19 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     auto since = [&]() {
       return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     };
-    std::unique_ptr<bsn_op> guard(new bsn_op());
-    bsn_op *op = guard.get();
+    // operator and workspace of the previous solve on this handle are reused (grow-only buffers)
+    struct Lend {
+      bsn_bed *bed;
+      std::unique_ptr<bsn_op> op;
+      ~Lend() { bed->svd_op = std::move(op); }
+    } lend{bed, std::move(bed->svd_op)};
+    if (!lend.op) lend.op.reset(new bsn_op());
+    bsn_op *op = lend.op.get();
+    op->passes = 0;
+    op->stats_pending = false;
+    op->na_poll = false;
+    op->no_na = false;
+    if (!bed->svd_ws) bed->svd_ws = std::make_shared<SvdWorkspace>();
     int32_t n_bad = 0;
     bool fused = false;
     if (o->binom_scaling) {
@@ -670,7 +745,7 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     const double t_create = since();
     op->profile = true;
     if (o->slices > 7) fail("slices must be in 1..7");
-    HipSvdBackend bk;
+    HipSvdBackend bk(*bed->svd_ws);
     bk.op = op;
     bk.st = bed->stream;
     bk.n = n;
@@ -685,6 +760,7 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     if (bk.comm && bk.comm->device != bed->device) fail("the communicator was created on another device");
     if (bk.hook && (bk.rank < 0 || bk.rank >= bk.world)) fail("hook_rank %d of %d", bk.rank, bk.world);
     bk.setup_ranks();
+    bk.timing = getenv("BSN_TIMING") != nullptr;
     int64_t dim = bk.n < bk.m_total ? bk.n : bk.m_total;
     if (o->k > dim) fail("'k' is larger than the dimensions of the matrix.");
     SvdOptions so;
@@ -714,26 +790,50 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     so.verbose = o->verbose;
     BSN_HIP(hipEventRecord(bed->ev0, bed->stream));
     SvdResult r = block_lanczos_svd(bk, so, d, u, v);
-    if (o->verbose > 1)
-      std::fprintf(stderr, "[bsn svd] host wall: op_create %.2f ms, solve %.2f ms\n", t_create,
-                   since() - t_create);
+    const double t_solve = since() - t_create;
+    if (o->verbose > 1 || bk.timing)
+      std::fprintf(stderr,
+                   "[bsn svd] host wall ms: op_create %.2f, solve %.2f = alloc %.2f + A'Q %.2f + AZ %.2f + grams %.2f + "
+                   "orth %.2f (GPU events %.2f) + round %.2f + finalize %.2f + host algebra %.2f\n",
+                   t_create, t_solve, bk.t_phase[0], bk.t_phase[1], bk.t_phase[2], bk.t_phase[3], bk.t_phase[4],
+                   bk.t_phase[7], bk.t_phase[5], bk.t_phase[6],
+                   t_solve - (bk.t_phase[0] + bk.t_phase[1] + bk.t_phase[2] + bk.t_phase[3] + bk.t_phase[4] +
+                              bk.t_phase[5] + bk.t_phase[6]));
     BSN_HIP(hipEventRecord(bed->ev1, bed->stream));
     BSN_HIP(hipEventSynchronize(bed->ev1));
     float ms = 0;
     BSN_HIP(hipEventElapsedTime(&ms, bed->ev0, bed->ev1));
     if (fused) {
       // by-products of the counting pass: the scaling actually used, the > 50 % missing count of
-      // bed_colstats (src/bed-fun.cpp:40-41) and the per-variant completeness of the handle
-      std::vector<int32_t> cnt((size_t)4 * m);
-      BSN_HIP(hipMemcpy(cnt.data(), op->d_counts.p, (size_t)4 * m * 4, hipMemcpyDeviceToHost));
+      // bed_colstats (src/bed-fun.cpp:40-41) and the per-variant completeness of the handle.  They
+      // come back through the workspace's pinned staging buffer: blocking copies into pageable memory
+      // were measured to leave the runtime with ~4 ms wake-up latencies on every later stream
+      // synchronisation of the process (tools/gpu/r02_h.sh).
+      SvdWorkspace &ws = *bed->svd_ws;
+      const int64_t chunk = 1 << 20;  // elements per staged piece (8 MB of doubles)
+      double *hp = ws.pinned((size_t)chunk);
       if ((int64_t)bed->na_cnt.size() != bed->m) bed->na_cnt.assign((size_t)bed->m, -1);
-      for (int64_t j = 0; j < m; j++) {
-        const int32_t *c = &cnt[(size_t)4 * j];
-        bed->na_cnt[(size_t)(ind_col ? ind_col[j] : j)] = c[3];
-        if (2 * (int64_t)(c[0] + c[1] + c[2]) < n) n_bad++;
+      for (int64_t j0 = 0; j0 < m; j0 += chunk / 2) {   // 4 int32 per variant
+        const int64_t cnt = std::min<int64_t>(chunk / 2, m - j0);
+        BSN_HIP(hipMemcpyAsync(hp, op->d_counts.p + 4 * j0, (size_t)cnt * 16, hipMemcpyDeviceToHost, bed->stream));
+        BSN_HIP(hipStreamSynchronize(bed->stream));
+        const int32_t *c = (const int32_t *)hp;
+        for (int64_t j = 0; j < cnt; j++, c += 4) {
+          bed->na_cnt[(size_t)(ind_col ? ind_col[j0 + j] : j0 + j)] = c[3];
+          if (2 * (int64_t)(c[0] + c[1] + c[2]) < n) n_bad++;
+        }
       }
-      if (o->center_out) BSN_HIP(hipMemcpy(o->center_out, op->d_center.p, (size_t)m * 8, hipMemcpyDeviceToHost));
-      if (o->scale_out) BSN_HIP(hipMemcpy(o->scale_out, op->d_scale.p, (size_t)m * 8, hipMemcpyDeviceToHost));
+      for (int which = 0; which < 2; which++) {
+        double *dst = which == 0 ? o->center_out : o->scale_out;
+        const double *src = which == 0 ? op->d_center.p : op->d_scale.p;
+        if (!dst) continue;
+        for (int64_t j0 = 0; j0 < m; j0 += chunk) {
+          const int64_t cnt = std::min<int64_t>(chunk, m - j0);
+          BSN_HIP(hipMemcpyAsync(hp, src + j0, (size_t)cnt * 8, hipMemcpyDeviceToHost, bed->stream));
+          BSN_HIP(hipStreamSynchronize(bed->stream));
+          std::memcpy(dst + j0, hp, (size_t)cnt * 8);
+        }
+      }
     }
     if (!r.converged) {
       unconverged = true;

@@ -231,6 +231,10 @@ int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int
                       int64_t m, const double *center, const double *scale,
                       const bsn_svd_options *options, double *d, double *u, double *v,
                       bsn_svd_info *info);
+/* The device workspace of a solve (Krylov basis, panels, quantised operands: about
+ * 8 (n + m) (8 k + 4 block) bytes, 4 GB at 400K x 1M, k = 20) stays on the handle for the next
+ * solve (snp_autoSVD runs up to six in a row); this frees it early.  bsn_bed_close frees it too. */
+int bsn_bed_release_workspace(bsn_bed *bed);
 
 /* bed_tcrossprodSelf (R/bed-tcrossprodSelf.R:21-52): K[n x n] = A~ A~' accumulated over column
  * blocks of block_size (0 -> 1024) variants; center / scale of length m as returned by
