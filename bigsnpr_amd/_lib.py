@@ -73,6 +73,8 @@ SIGNATURES = {
     "bsn_bed_read_scaled": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, f64p]),
     "bsn_bed_cprod_planes": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, i64, f64p, f64p]),
     "bsn_bed_prod_and_rowsumssq": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, f64p, i64, f64p, f64p]),
+    "bsn_snp_prod_and_rowsumssq2": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, f64p, i64, f64p, f64p]),
+    "bsn_mult_lin_reg": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, i64, f64p]),
     "bsn_bed_to_fbm": (C.c_int, [vp, i64p, i64, i64p, i64, u8p]),
     "bsn_bed_subset_payload": (C.c_int, [vp, i64p, i64, i64p, i64, u8p]),
     "bsn_op_create": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, C.POINTER(vp)]),

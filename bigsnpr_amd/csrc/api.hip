@@ -6,6 +6,7 @@
 
 #include <cerrno>
 #include <cstring>
+#include <limits>
 #include <memory>
 
 #include <cstdlib>
@@ -45,8 +46,52 @@ static std::vector<int32_t> to_i32(const int64_t *ind, int64_t len, int64_t limi
   return v;
 }
 
+constexpr size_t kStagePiece = 8u << 20;
+
+static void stage_init(bsn_bed *b) {
+  for (int i = 0; i < 2; i++) {
+    if (!b->h_stage[i]) BSN_HIP(hipHostMalloc((void **)&b->h_stage[i], kStagePiece, hipHostMallocDefault));
+    if (!b->ev_stage[i]) BSN_HIP(hipEventCreateWithFlags(&b->ev_stage[i], hipEventDisableTiming));
+  }
+}
+
+void copy_h2d(bsn_bed *b, void *d_dst, const void *src, size_t bytes) {
+  stage_init(b);
+  int k = 0;
+  for (size_t off = 0; off < bytes; off += kStagePiece, k++) {
+    const size_t len = std::min(kStagePiece, bytes - off);
+    const int s = k & 1;
+    if (k >= 2) BSN_HIP(hipEventSynchronize(b->ev_stage[s]));  // its previous piece has left the buffer
+    std::memcpy(b->h_stage[s], (const uint8_t *)src + off, len);
+    BSN_HIP(hipMemcpyAsync((uint8_t *)d_dst + off, b->h_stage[s], len, hipMemcpyHostToDevice, b->stream));
+    BSN_HIP(hipEventRecord(b->ev_stage[s], b->stream));
+  }
+  BSN_HIP(hipStreamSynchronize(b->stream));
+}
+
+void copy_d2h(bsn_bed *b, void *dst, const void *d_src, size_t bytes) {
+  stage_init(b);
+  const size_t npiece = (bytes + kStagePiece - 1) / kStagePiece;
+  for (size_t k = 0; k <= npiece; k++) {
+    if (k < npiece) {  // launch piece k
+      const size_t off = k * kStagePiece, len = std::min(kStagePiece, bytes - off);
+      BSN_HIP(hipMemcpyAsync(b->h_stage[k & 1], (const uint8_t *)d_src + off, len, hipMemcpyDeviceToHost, b->stream));
+      BSN_HIP(hipEventRecord(b->ev_stage[k & 1], b->stream));
+    }
+    if (k >= 1) {  // drain piece k - 1 while piece k is on its way
+      const size_t off = (k - 1) * kStagePiece, len = std::min(kStagePiece, bytes - off);
+      BSN_HIP(hipEventSynchronize(b->ev_stage[(k - 1) & 1]));
+      std::memcpy((uint8_t *)dst + off, b->h_stage[(k - 1) & 1], len);
+    }
+  }
+}
+
 static void free_bed(bsn_bed *b) {
   if (!b) return;
+  for (int i = 0; i < 2; i++) {
+    if (b->h_stage[i]) (void)hipHostFree(b->h_stage[i]);
+    if (b->ev_stage[i]) (void)hipEventDestroy(b->ev_stage[i]);
+  }
   if (b->d_img) (void)hipFree(b->d_img);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -70,9 +115,7 @@ void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n, const 
   op->rows_identity = ident;
   if (!ident) {
     auto r = to_i32(ind_row, n, bed->n, "ind.row");
-    BSN_HIP(hipMemcpyAsync(op->d_rows.ensure((size_t)n), r.data(), (size_t)n * 4,
-                           hipMemcpyHostToDevice, bed->stream));
-    BSN_HIP(hipStreamSynchronize(bed->stream));
+    copy_h2d(bed, op->d_rows.ensure((size_t)n), r.data(), (size_t)n * 4);
   }
   // cols
   bool contig = true;
@@ -88,9 +131,7 @@ void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n, const 
     auto c = to_i32(ind_col, m, bed->m, "ind.col");
     int64_t m_pad = bsn::round_up(m, 64);
     c.resize((size_t)m_pad, c[0]);
-    BSN_HIP(hipMemcpyAsync(op->d_cols.ensure((size_t)m_pad), c.data(), (size_t)m_pad * 4,
-                           hipMemcpyHostToDevice, bed->stream));
-    BSN_HIP(hipStreamSynchronize(bed->stream));
+    copy_h2d(bed, op->d_cols.ensure((size_t)m_pad), c.data(), (size_t)m_pad * 4);
   }
   // missing-value knowledge (BSN_FORCE_NA_PLANE=1 keeps the general kernels, for A/B tests)
   op->no_na = false;
@@ -107,13 +148,9 @@ void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n, const 
   // centre / scale (defaults 0 / 1, R/bed-mult-vec.R:23-24)
   std::vector<double> tmp((size_t)m);
   for (int64_t j = 0; j < m; j++) tmp[(size_t)j] = center ? center[j] : 0.0;
-  BSN_HIP(hipMemcpyAsync(op->d_center.ensure((size_t)m), tmp.data(), (size_t)m * 8,
-                         hipMemcpyHostToDevice, bed->stream));
-  BSN_HIP(hipStreamSynchronize(bed->stream));
+  copy_h2d(bed, op->d_center.ensure((size_t)m), tmp.data(), (size_t)m * 8);
   for (int64_t j = 0; j < m; j++) tmp[(size_t)j] = scale ? scale[j] : 1.0;
-  BSN_HIP(hipMemcpyAsync(op->d_scale.ensure((size_t)m), tmp.data(), (size_t)m * 8,
-                         hipMemcpyHostToDevice, bed->stream));
-  BSN_HIP(hipStreamSynchronize(bed->stream));
+  copy_h2d(bed, op->d_scale.ensure((size_t)m), tmp.data(), (size_t)m * 8);
 }
 
 // counts for an arbitrary sub-view into a host 4 x m int32 array
@@ -129,13 +166,10 @@ void counts_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t 
     std::vector<double> w((size_t)bed->n, 0.0);
     for (int64_t i = 0; i < n; i++) w[(size_t)ind_row[i]] += 1.0;
     DevBuf<double> d_w;
-    BSN_HIP(hipMemcpyAsync(d_w.ensure((size_t)bed->n), w.data(), (size_t)bed->n * 8,
-                           hipMemcpyHostToDevice, bed->stream));
-    BSN_HIP(hipStreamSynchronize(bed->stream));
+    copy_h2d(bed, d_w.ensure((size_t)bed->n), w.data(), (size_t)bed->n * 8);
     counts_weighted(&op, d_w.p, n, d_counts.p);
   }
-  BSN_HIP(hipMemcpyAsync(res, d_counts.p, (size_t)4 * m * 4, hipMemcpyDeviceToHost, bed->stream));
-  BSN_HIP(hipStreamSynchronize(bed->stream));
+  copy_d2h(bed, res, d_counts.p, (size_t)4 * m * 4);
   if (op.rows_identity) {  // remember which variants are complete
     if ((int64_t)bed->na_cnt.size() != bed->m) bed->na_cnt.assign((size_t)bed->m, -1);
     for (int64_t j = 0; j < m; j++) bed->na_cnt[(size_t)(ind_col ? ind_col[j] : j)] = res[4 * j + 3];
@@ -323,15 +357,13 @@ static void matvec_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const i
   op.slices = 7;  // 56-bit fixed point: fp64-grade for a single vector, still one MFMA column block
   int64_t nin = transpose ? n : m, nout = transpose ? m : n;
   DevBuf<double> d_in, d_out;
-  BSN_HIP(hipMemcpyAsync(d_in.ensure((size_t)nin), x, (size_t)nin * 8, hipMemcpyHostToDevice,
-                         bed->stream));
+  copy_h2d(bed, d_in.ensure((size_t)nin), x, (size_t)nin * 8);
   d_out.ensure((size_t)nout);
   if (transpose)
     op_cprod(&op, d_in.p, nin, 1, d_out.p, nout);
   else
     op_prod(&op, d_in.p, nin, 1, d_out.p, nout);
-  BSN_HIP(hipMemcpyAsync(out, d_out.p, (size_t)nout * 8, hipMemcpyDeviceToHost, bed->stream));
-  BSN_HIP(hipStreamSynchronize(bed->stream));
+  copy_d2h(bed, out, d_out.p, (size_t)nout * 8);
 }
 
 int bsn_bed_prodvec(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
@@ -482,6 +514,79 @@ int bsn_bed_prod_and_rowsumssq(bsn_bed *bed, const int64_t *ind_row, int64_t n, 
     BSN_HIP(hipMemcpyAsync(XV, d_XV.p, (size_t)n * K * 8, hipMemcpyDeviceToHost, bed->stream));
     BSN_HIP(hipMemcpyAsync(rowSumsSq, d_r.p, (size_t)n * 8, hipMemcpyDeviceToHost, bed->stream));
     BSN_HIP(hipStreamSynchronize(bed->stream));
+  });
+}
+
+// _bigsnpr_multLinReg (5 args) src/multLinReg.cpp:8-86: K t-scores per variant.  The sums over the
+// samples are plane sums of the crossproduct kernel on the panels (U, U^2) at 56 bits plus the exact
+// genotype counts; the rest is the reference's expressions per (variant, column).  NA_REAL -> NaN.
+#pragma clang fp contract(off)
+int bsn_mult_lin_reg(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                     const double *U, int64_t K, double *res) {
+  return guarded([&] {
+    if (K <= 0) fail("'U' must have at least one column.");
+    bsn_op op;
+    fill_op(&op, bed, ind_row, n, ind_col, m, nullptr, nullptr);
+    op.slices = 7;
+    std::vector<double> X((size_t)n * 2 * K), tot((size_t)2 * K, 0.0);
+    for (int64_t k = 0; k < K; k++)
+      for (int64_t i = 0; i < n; i++) {
+        const double y = U[i + k * n];
+        X[(size_t)(i + k * n)] = y;
+        X[(size_t)(i + (K + k) * n)] = y * y;
+      }
+    for (int64_t k = 0; k < 2 * K; k++) {  // sum_i y and sum_i y^2 over the selected rows, in row order
+      double s = 0;
+      for (int64_t i = 0; i < n; i++) s += X[(size_t)(i + k * n)];
+      tot[(size_t)k] = s;
+    }
+    DevBuf<double> d_X, d_P, d_Q;
+    copy_h2d(bed, d_X.ensure((size_t)n * 2 * K), X.data(), (size_t)n * 2 * K * 8);
+    d_P.ensure((size_t)m * 2 * K);
+    d_Q.ensure((size_t)m * 2 * K);
+    op_cprod_raw(&op, d_X.p, n, (int)(2 * K), d_P.p, d_Q.p, m);
+    std::vector<double> P((size_t)m * 2 * K), Q((size_t)m * 2 * K);
+    copy_d2h(bed, P.data(), d_P.p, P.size() * 8);
+    copy_d2h(bed, Q.data(), d_Q.p, Q.size() * 8);
+    std::vector<int32_t> cnt((size_t)4 * m);
+    counts_host(bed, ind_row, n, ind_col, m, cnt.data());
+    const double qnan = std::numeric_limits<double>::quiet_NaN();
+    for (int64_t j = 0; j < m; j++) {
+      const int32_t *c = &cnt[(size_t)4 * j];
+      const int nona = (int)(n - c[3]);
+      const double xSum = (double)c[1] + 2.0 * c[2], xxSum = (double)c[1] + 4.0 * c[2];
+      const double deno_x = xxSum - xSum * xSum / nona;
+      for (int64_t k = 0; k < K; k++) {
+        const double xySum = P[(size_t)(j + k * m)];
+        const double ySum = tot[(size_t)k] - Q[(size_t)(j + k * m)];
+        const double yySum = tot[(size_t)(K + k)] - Q[(size_t)(j + (K + k) * m)];
+        const double num = xySum - xSum * ySum / nona;
+        const double deno_y = yySum - ySum * ySum / nona;
+        const double deno = deno_x * deno_y - num * num;
+        res[j + k * m] = (deno == 0 || nona < 2) ? qnan : num * std::sqrt((nona - 2) / deno);
+      }
+    }
+  });
+}
+#pragma clang fp contract(on)
+
+// _bigsnpr_prod_and_rowSumsSq2 (6 args) src/project-utils.cpp:12-43, the FBM.code256 twin: the FBM
+// accessor has no missing-value handling, so a missing code is NA_real and poisons its whole row of XV
+// and its rowSumsSq entry (:33-38) — reproduced with NaN from the per-sample missing counts.
+int bsn_snp_prod_and_rowsumssq2(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                                int64_t m, const double *center, const double *scale, const double *V,
+                                int64_t K, double *XV, double *rowSumsSq) {
+  int rc = bsn_bed_prod_and_rowsumssq(bed, ind_row, n, ind_col, m, center, scale, V, K, XV, rowSumsSq);
+  if (rc != 0) return rc;
+  return guarded([&] {
+    std::vector<int32_t> rcnt((size_t)4 * n);
+    if (bsn_bed_row_counts(bed, ind_row, n, ind_col, m, rcnt.data()) != 0) throw Error(bsn_last_error());
+    const double qnan = std::numeric_limits<double>::quiet_NaN();
+    for (int64_t i = 0; i < n; i++)
+      if (rcnt[(size_t)(4 * i + 3)] > 0) {
+        for (int64_t k = 0; k < K; k++) XV[i + k * n] = qnan;
+        rowSumsSq[i] = qnan;
+      }
   });
 }
 

@@ -164,6 +164,9 @@ struct bsn_bed {
   // bsn_bed_release_workspace or with the handle.
   std::unique_ptr<bsn_op> svd_op;
   std::shared_ptr<bsn::SvdWorkspace> svd_ws;
+  // two pinned staging buffers for host <-> device transfers of caller (pageable) memory, see copy_h2d
+  uint8_t *h_stage[2] = {nullptr, nullptr};
+  hipEvent_t ev_stage[2] = {nullptr, nullptr};
 };
 
 
@@ -190,6 +193,14 @@ void to_bytes(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_col
               uint8_t *d_out);
 void subset_pack(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t m,
                  uint8_t *d_out);
+
+// api.hip: transfers between caller memory (pageable) and the device, staged through the handle's two
+// pinned buffers in 8-MB pieces (host memcpy of piece k+1 overlaps the DMA of piece k); synchronous.
+// The runtime's own handling of pageable buffers was measured to leave every later stream
+// synchronisation of the process with a ~4 ms wake-up latency (tools/gpu/r02_h.sh), which costs a
+// solve 10 % — so no hot entry point hands pageable memory to hipMemcpy.
+void copy_h2d(bsn_bed *b, void *d_dst, const void *src, size_t bytes);
+void copy_d2h(bsn_bed *b, void *dst, const void *d_src, size_t bytes);
 
 // api.hip: operator over a sub-view; defer_scale leaves centre / scale unset (stats_pending path)
 void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,

@@ -666,8 +666,8 @@ struct HipSvdBackend : SvdBackend {
       all_gather_rows(dU.p, k, dUfull.p);
       ufull = dUfull.p;
     }
-    if (u) BSN_HIP(hipMemcpyAsync(u, ufull, (size_t)n * k * 8, hipMemcpyDeviceToHost, st));
-    if (v) BSN_HIP(hipMemcpyAsync(v, dV.p, (size_t)m_local * k * 8, hipMemcpyDeviceToHost, st));
+    if (u) copy_d2h(op->bed, u, ufull, (size_t)n * k * 8);
+    if (v) copy_d2h(op->bed, v, dV.p, (size_t)m_local * k * 8);
     BSN_HIP(hipStreamSynchronize(st));
   }
 };
@@ -733,9 +733,8 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
         counts_host(bed, ind_row, n, ind_col, m, cnt.data());
         std::vector<double> ce, sc;
         binom_scale_host(cnt, n, m, ce, sc, &n_bad);
-        BSN_HIP(hipMemcpyAsync(op->d_center.p, ce.data(), (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
-        BSN_HIP(hipMemcpyAsync(op->d_scale.p, sc.data(), (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
-        BSN_HIP(hipStreamSynchronize(bed->stream));
+        copy_h2d(bed, op->d_center.p, ce.data(), (size_t)m * 8);
+        copy_h2d(bed, op->d_scale.p, sc.data(), (size_t)m * 8);
         if (o->center_out) std::copy(ce.begin(), ce.end(), o->center_out);
         if (o->scale_out) std::copy(sc.begin(), sc.end(), o->scale_out);
       }
@@ -823,17 +822,8 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
           if (2 * (int64_t)(c[0] + c[1] + c[2]) < n) n_bad++;
         }
       }
-      for (int which = 0; which < 2; which++) {
-        double *dst = which == 0 ? o->center_out : o->scale_out;
-        const double *src = which == 0 ? op->d_center.p : op->d_scale.p;
-        if (!dst) continue;
-        for (int64_t j0 = 0; j0 < m; j0 += chunk) {
-          const int64_t cnt = std::min<int64_t>(chunk, m - j0);
-          BSN_HIP(hipMemcpyAsync(hp, src + j0, (size_t)cnt * 8, hipMemcpyDeviceToHost, bed->stream));
-          BSN_HIP(hipStreamSynchronize(bed->stream));
-          std::memcpy(dst + j0, hp, (size_t)cnt * 8);
-        }
-      }
+      if (o->center_out) copy_d2h(bed, o->center_out, op->d_center.p, (size_t)m * 8);
+      if (o->scale_out) copy_d2h(bed, o->scale_out, op->d_scale.p, (size_t)m * 8);
     }
     if (!r.converged) {
       unconverged = true;

@@ -1,14 +1,14 @@
 """multLinReg / snp_pcadapt / bed_pcadapt — host mirror of src/multLinReg.cpp and R/pcadapt.R
-(SURVEY.md §8f-2).  The sums over samples run on the GPU (plane sums of k_cprod at 56-bit
-fixed point + exact genotype counts); the K t-scores per variant are evaluated on the host with
-the reference's expressions.  The robust distance is the restated bigutilsr::dist_ogk of
+(SURVEY.md §8f-2).  bsn_mult_lin_reg: the sums over samples run on the GPU (plane sums of k_cprod at
+56-bit fixed point + exact genotype counts); the K t-scores per variant are evaluated inside the library
+with the reference's expressions.  The robust distance is the restated bigutilsr::dist_ogk of
 autosvd.py (parity unpinned for that step, as for autoSVD)."""
 import numpy as np
 
 from . import _lib
 from ._lib import check, f64p, i64p, ptr
 from .autosvd import dist_ogk
-from .bed import assert_lengths, bed_counts
+from .bed import assert_lengths
 from .ld import _ind
 
 
@@ -22,27 +22,10 @@ def multLinReg(obj, ind_row=None, ind_col=None, U=None, ncores=1):
     if U.shape[0] != ir.size:
         raise ValueError("Incompatibility between dimensions.")     # myassert_size(U.nrow(), n)
     K = U.shape[1]
-    X = np.asfortranarray(np.concatenate([U, U * U], axis=1))       # y and y^2 panels
-    P = np.empty((ic.size, 2 * K), dtype=np.float64, order="F")
-    Q = np.empty((ic.size, 2 * K), dtype=np.float64, order="F")
-    check(_lib.load().bsn_bed_cprod_planes(im.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p), ic.size,
-                                           X.ctypes.data_as(f64p), 2 * K, P.ctypes.data_as(f64p),
-                                           Q.ctypes.data_as(f64p)))
-    counts = bed_counts(im, ir, ic).astype(np.float64)               # exact, also for duplicated rows
-    nona = ir.size - counts[3]
-    xSum = counts[1] + 2.0 * counts[2]
-    xxSum = counts[1] + 4.0 * counts[2]
-    tot = X.sum(axis=0)                                              # sum_i y, sum_i y^2 over the rows
-    with np.errstate(all="ignore"):
-        deno_x = xxSum - xSum * xSum / nona
-        xySum = P[:, :K]
-        ySum = tot[None, :K] - Q[:, :K]
-        yySum = tot[None, K:] - Q[:, K:]
-        num = xySum - xSum[:, None] * ySum / nona[:, None]
-        deno_y = yySum - ySum * ySum / nona[:, None]
-        deno = deno_x[:, None] * deno_y - num * num
-        t = num * np.sqrt((nona[:, None] - 2) / deno)
-    t[(deno == 0) | (nona[:, None] < 2)] = np.nan
+    U = np.asfortranarray(U)
+    t = np.empty((ic.size, K), dtype=np.float64, order="F")
+    check(_lib.load().bsn_mult_lin_reg(im.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p), ic.size,
+                                       U.ctypes.data_as(f64p), K, t.ctypes.data_as(f64p)))
     return t
 
 

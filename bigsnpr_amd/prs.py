@@ -103,12 +103,18 @@ def prod_and_rowSumsSq2(G, ind_row, ind_col, center, scale, V):
     has no missing-value handling: a missing code is NA_real and poisons its whole row of XV and
     its rowSumsSq entry (src/project-utils.cpp:33-38), which is reproduced here (NaN)."""
     im, ir, ic = _ind(G, ind_row, ind_col)
-    XV, rs = prod_and_rowSumsSq(im, ir, ic, center, scale, V)
-    from .bed import bed_counts
-    has_na = bed_counts(im, ir, ic, byrow=True)[3] > 0
-    if has_na.any():
-        XV[has_na, :] = np.nan
-        rs[has_na] = np.nan
+    center, scale = as_f64(np.ravel(center)), as_f64(np.ravel(scale))
+    V = np.asfortranarray(np.asarray(V, dtype=np.float64))
+    if V.ndim == 1:
+        V = V[:, None]
+    if V.shape[0] != ic.size:
+        raise ValueError("Incompatibility between dimensions.")     # myassert_size(m, V.rows())
+    assert_lengths(center, ic); assert_lengths(scale, ic)
+    XV = np.empty((ir.size, V.shape[1]), dtype=np.float64, order="F")
+    rs = np.empty(ir.size)
+    check(_lib.load().bsn_snp_prod_and_rowsumssq2(im.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p), ic.size,
+                                                  ptr(center, f64p), ptr(scale, f64p), V.ctypes.data_as(f64p),
+                                                  V.shape[1], XV.ctypes.data_as(f64p), ptr(rs, f64p)))
     return XV, rs
 
 

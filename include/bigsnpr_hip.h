@@ -108,12 +108,24 @@ int bsn_bed_read_scaled(bsn_bed *bed, const int64_t *ind_row, int64_t n, const i
 int bsn_bed_cprod_planes(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
                          int64_t m, const double *X, int64_t K, double *P, double *Q);
 
+/* _bigsnpr_multLinReg (5 args) src/multLinReg.cpp:8-86, whole: res[m x K] column-major, the t-score of
+ * each variant regressed on each column of U (n x K) over its non-missing genotypes; NaN where the
+ * reference returns NA_REAL (zero denominator or fewer than two non-missing values). */
+int bsn_mult_lin_reg(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                     const double *U, int64_t K, double *res);
+
 /* _bigsnpr_prod_and_rowSumsSq (6 args) src/bed-fun.cpp:103-133 (the kernel of
  * bed_projectSelfPCA, R/bed-projectPCA.R:45-59): XV[n x K] = A~ V[m x K] and
  * rowSumsSq[i] = sum_j A~[i, j]^2, column-major host buffers. */
 int bsn_bed_prod_and_rowsumssq(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
                                int64_t m, const double *center, const double *scale, const double *V,
                                int64_t K, double *XV, double *rowSumsSq);
+
+/* _bigsnpr_prod_and_rowSumsSq2 (6 args) src/project-utils.cpp:12-43: the same on an FBM.code256 handle;
+ * rows that hold a missing code come back NaN (the FBM accessor yields NA_real there). */
+int bsn_snp_prod_and_rowsumssq2(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                                int64_t m, const double *center, const double *scale, const double *V,
+                                int64_t K, double *XV, double *rowSumsSq);
 
 /* The genotype-touching part of snp_grid_PRS (R/SCT.R:201-262), which in the
  * reference is one snp_PRS call (R/PRS.R:36-76 -> bigstatsr::big_prodVec) per clumping set:
