@@ -5,6 +5,7 @@
 #include <unistd.h>
 
 #include <cerrno>
+#include <cmath>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -248,20 +249,87 @@ int bsn_bed_open(const char *path, int64_t n, int64_t m, bsn_bed **out) {
   });
 }
 
+// FBM.code256 -> device image.  The 256 decoded values decide the image kind:
+//   all of them in {0, 1, 2, NA}          -> 2-bit image (CODE_012, CODE_IMPUTE_PRED, ...): every entry point
+//   on a grid v_off + v_step k, |k| <= 127 -> byte image (CODE_DOSAGE: 0.00 .. 2.00 by 0.01): colstats and
+//                                             the products (and what is built on them: PRS, SVD)
+//   anything else                          -> refused (there is no exact integer image of it)
+static void fbm_open(const uint8_t *bytes, int64_t n, int64_t m, int64_t ld, const double *code256, bsn_bed **out) {
+  require_gpu();
+  if (ld < n) fail("Incompatibility between dimensions.");
+  bool calls = true;
+  double vmin = 0, vmax = 0;
+  int nval = 0;
+  for (int c = 0; c < 256; c++) {
+    const double v = code256[c];
+    if (std::isnan(v)) continue;
+    if (!(v == 0.0 || v == 1.0 || v == 2.0)) calls = false;
+    if (nval == 0 || v < vmin) vmin = v;
+    if (nval == 0 || v > vmax) vmax = v;
+    nval++;
+  }
+  if (nval == 0) fail("'code256' holds no value");
+  uint8_t lut[256];
+  std::unique_ptr<bsn_bed, void (*)(bsn_bed *)> b(new bsn_bed(), free_bed);
+  if (calls) {
+    for (int c = 0; c < 256; c++) lut[c] = std::isnan(code256[c]) ? 3 : (uint8_t)code256[c];
+    image_alloc(b.get(), n, m, 2);
+    image_from_fbm(b.get(), bytes, ld, lut);
+    // FBMs of imputed data have no missing value: one count pass settles it for every later operator
+    std::vector<int32_t> cnt((size_t)4 * m);
+    counts_host(b.get(), nullptr, n, nullptr, m, cnt.data());
+  } else {
+    // smallest positive difference between two values as the step, mid-range as the offset
+    double step = 0;
+    for (int a = 0; a < 256; a++)
+      for (int c = 0; c < 256; c++) {
+        const double d = code256[a] - code256[c];
+        if (d > 1e-12 * (std::fabs(vmax) + std::fabs(vmin) + 1) && (step == 0 || d < step)) step = d;
+      }
+    // values like 0.07 are not exactly k * 0.01 in binary: accept a relative deviation of 1e-9 of a step
+    const double half = std::round((vmax - vmin) / step / 2.0);
+    const double off = vmin + half * step;
+    bool ok = step > 0 && (vmax - vmin) / step <= 254.5;
+    for (int c = 0; c < 256 && ok; c++) {
+      if (std::isnan(code256[c])) {
+        lut[c] = 0x80;
+        continue;
+      }
+      const double kf = (code256[c] - off) / step, kr = std::round(kf);
+      if (std::fabs(kf - kr) > 1e-9 || kr < -127 || kr > 127) ok = false;
+      lut[c] = (uint8_t)(int8_t)kr;
+    }
+    if (!ok)
+      fail("this 'code256' table is not supported on the GPU: its values are neither genotype calls (0, 1, 2, NA) "
+           "nor on a regular grid of at most 255 steps (like CODE_DOSAGE)");
+    image_alloc(b.get(), n, m, 8);
+    b->v_off = off;
+    b->v_step = step;
+    image_from_fbm(b.get(), bytes, ld, lut);
+    // which variants are complete (no missing value): the products then skip the missing-value plane
+    DevBuf<long long> d_st;
+    stats8(b.get(), nullptr, n, nullptr, 0, m, d_st.ensure((size_t)3 * m));
+    std::vector<long long> st((size_t)3 * m);
+    copy_d2h(b.get(), st.data(), d_st.p, st.size() * 8);
+    b->na_cnt.resize((size_t)m);
+    for (int64_t j = 0; j < m; j++) b->na_cnt[(size_t)j] = (int32_t)st[(size_t)(3 * j + 2)];
+  }
+  *out = b.release();
+}
+
 int bsn_bed_from_fbm(const uint8_t *bytes, int64_t n, int64_t m, int64_t ld, bsn_bed **out) {
   return guarded([&] {
-    require_gpu();
-    if (ld < n) fail("Incompatibility between dimensions.");
-    std::unique_ptr<bsn_bed, void (*)(bsn_bed *)> b(new bsn_bed(), free_bed);
-    image_alloc(b.get(), n, m);
-    image_from_fbm(b.get(), bytes, ld);
-    {  // FBMs of imputed data have no missing value: one count pass settles it for every later operator
-      std::vector<int32_t> cnt((size_t)4 * m);
-      counts_host(b.get(), nullptr, n, nullptr, m, cnt.data());
-    }
-    *out = b.release();
+    double code[256];
+    for (int c = 0; c < 256; c++) code[c] = c < 3 ? (double)c : std::numeric_limits<double>::quiet_NaN();
+    fbm_open(bytes, n, m, ld, code, out);  // CODE_012, R/bigSNP-class.R:7
   });
 }
+
+int bsn_fbm_open(const uint8_t *bytes, int64_t n, int64_t m, int64_t ld, const double *code256, bsn_bed **out) {
+  return guarded([&] { fbm_open(bytes, n, m, ld, code256, out); });
+}
+
+int bsn_bed_bits(const bsn_bed *bed) { return bed->bits; }
 
 int bsn_bed_synthetic(int64_t n, int64_t m, uint32_t seed, uint32_t npop, uint32_t na16,
                       int64_t j_begin, bsn_bed **out) {
@@ -428,15 +496,37 @@ int bsn_bed_colstats(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int6
 int bsn_snp_colstats(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
                      int64_t m, double *sumX, double *denoX) {
   return guarded([&] {
-    // src/colstats.cpp:22-32: no NA handling, denominator n; a code-3 byte counts as 3
+    // src/colstats.cpp:22-32: no NA handling, denominator n.  The accessor decodes a missing code to
+    // NA_real (code256 is passed as is, :14), which poisons the sums of its column: NaN here.
+    const double qnan = std::numeric_limits<double>::quiet_NaN();
+    if (bed->bits == 8) {
+      bsn_op op;
+      fill_op(&op, bed, ind_row, n, ind_col, m, nullptr, nullptr);
+      DevBuf<long long> d_st;
+      stats8(bed, op.rows_identity ? nullptr : op.d_rows.p, n, op.cols_contig ? nullptr : op.d_cols.p, op.col0, m,
+             d_st.ensure((size_t)3 * m));
+      std::vector<long long> st((size_t)3 * m);
+      copy_d2h(bed, st.data(), d_st.p, st.size() * 8);
+      const double a = bed->v_off, h = bed->v_step;
+      for (int64_t j = 0; j < m; j++) {
+        const double s1 = (double)st[(size_t)(3 * j)], s2 = (double)st[(size_t)(3 * j + 1)];
+        // sum v = n a + h S1;  sum v^2 = n a^2 + 2 a h S1 + h^2 S2   (v = a + h k, exact integer S1, S2)
+        const double xSum = (double)n * a + h * s1;
+        const double xxSum = (double)n * a * a + 2.0 * a * h * s1 + h * h * s2;
+        const bool na = st[(size_t)(3 * j + 2)] > 0;
+        sumX[j] = na ? qnan : xSum;
+        denoX[j] = na ? qnan : xxSum - xSum * xSum / n;
+      }
+      return;
+    }
     std::vector<int32_t> cnt((size_t)4 * m);
     counts_host(bed, ind_row, n, ind_col, m, cnt.data());
     for (int64_t j = 0; j < m; j++) {
       const int32_t *c = &cnt[(size_t)4 * j];
-      double xSum = (double)c[1] + 2.0 * c[2] + 3.0 * c[3];
-      double xxSum = (double)c[1] + 4.0 * c[2] + 9.0 * c[3];
-      sumX[j] = xSum;
-      denoX[j] = xxSum - xSum * xSum / n;
+      double xSum = (double)c[1] + 2.0 * c[2];
+      double xxSum = (double)c[1] + 4.0 * c[2];
+      sumX[j] = c[3] > 0 ? qnan : xSum;
+      denoX[j] = c[3] > 0 ? qnan : xxSum - xSum * xSum / n;
     }
   });
 }

@@ -151,6 +151,13 @@ struct bsn_op {
 // run over [0, 4*pitch) samples.
 struct bsn_bed {
   int64_t n = 0, m = 0, n_byte = 0, pitch = 0;
+  // bits = 2: the 2-bit image described above.  bits = 8 (FBM.code256 whose decoded values lie on a
+  // grid v = v_off + v_step k, |k| <= 127, e.g. CODE_DOSAGE: 0.00 .. 2.00 by 0.01, R/bigSNP-class.R:13):
+  // one int8 k per genotype, -128 = missing, variant j at j * pitch, pitch = n rounded up to 256 B,
+  // pad samples 0.  The byte IS the int8 MFMA operand; sums of k are exact integers and the affine map
+  // back to values is applied in fp64 at the end.
+  int bits = 2;
+  double v_off = 0.0, v_step = 1.0;
   uint8_t *d_img = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;
@@ -173,10 +180,16 @@ struct bsn_bed {
 namespace bsn {
 
 // image.hip
-void image_alloc(bsn_bed *b, int64_t n, int64_t m);
+void image_alloc(bsn_bed *b, int64_t n, int64_t m, int bits = 2);
 void image_from_host(bsn_bed *b, const uint8_t *payload, int64_t n_byte_src);
 void image_from_file(bsn_bed *b, int fd, int64_t offset, int64_t n_byte_src);
-void image_from_fbm(bsn_bed *b, const uint8_t *bytes, int64_t ld);
+// FBM bytes -> device image through a 256-entry byte look-up (lut[byte] = device code 0..3 for a 2-bit
+// image, int8 grid index or 0x80 for a byte image); pinned double-buffered upload
+void image_from_fbm(bsn_bed *b, const uint8_t *bytes, int64_t ld, const uint8_t *lut);
+// byte image: per-variant sums of k, k^2 and number of missing values over all file rows (d_rows ==
+// NULL) or over a row list (with multiplicity); out: 3 x m int64 (S1, S2, nNA)
+void stats8(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t col0, int64_t m,
+            long long *d_out);
 void image_generate(bsn_bed *b, uint32_t seed, uint32_t npop, uint32_t na16, int64_t j_begin);
 void image_download(bsn_bed *b, uint8_t *payload_out);
 // counts for variants cols[0..m) (device list or contiguous from col0) over all file rows;
@@ -218,6 +231,7 @@ void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, 
 void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z, int64_t ldz);
 void op_cprod_raw(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_P, double *d_Q,
                   int64_t ld);  // P = sum_i g0 x, Q = sum_i na x (m x nvec each)
+void require_bits(const bsn_bed *b, int bits, const char *what);  // fails with a clear message otherwise
 void op_row_sums_sq(bsn_op *op, double *d_out);
 void op_row_counts(bsn_op *op, double *d_out);  // n doubles: sum_j A~[i, j]^2
 // weighted code counts: d_w = per-file-row integer weights (n_file doubles); out 4 x m

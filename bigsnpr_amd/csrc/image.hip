@@ -7,6 +7,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cstring>
 #include <atomic>
 #include <thread>
 #include <vector>
@@ -49,11 +50,12 @@ __global__ void k_recode_fix(uint8_t *img, int64_t pitch, int64_t n, int64_t n_b
 
 constexpr int64_t kPadRows = 64;  // extra all-zero rows after the last variant
 
-void image_alloc(bsn_bed *b, int64_t n, int64_t m) {
+void image_alloc(bsn_bed *b, int64_t n, int64_t m, int bits) {
   if (n <= 0 || m <= 0) fail("n and p must be positive.");
   b->n = n;
   b->m = m;
-  b->n_byte = (n + 3) / 4;
+  b->bits = bits;
+  b->n_byte = bits == 8 ? n : (n + 3) / 4;
   b->pitch = round_up(b->n_byte, kPitchAlign);
   BSN_HIP(hipGetDevice(&b->device));
   BSN_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
@@ -149,9 +151,13 @@ void image_from_file(bsn_bed *b, int fd, int64_t offset, int64_t n_byte_src) {
 }
 
 // ---------------------------------------------------------------------------
-// FBM.code256 bytes (CODE_012: 0,1,2, else NA) -> 2-bit device codes (0, 1, 2, 3 = NA)
+// FBM.code256 bytes -> device image through a 256-entry byte look-up.
+// 2-bit image: lut[byte] = device code 0..3 (four source bytes per image byte).
 __global__ void k_pack_fbm(const uint8_t *src, int64_t ld, int64_t n, int64_t n_byte, uint8_t *img,
-                           int64_t pitch, int64_t ncols) {
+                           int64_t pitch, int64_t ncols, const uint8_t *__restrict__ lut) {
+  __shared__ uint8_t sl[256];
+  sl[threadIdx.x & 255] = lut[threadIdx.x & 255];
+  __syncthreads();
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t j = blockIdx.y;
   if (b >= n_byte || j >= ncols) return;
@@ -160,33 +166,178 @@ __global__ void k_pack_fbm(const uint8_t *src, int64_t ld, int64_t n, int64_t n_
   for (int e = 0; e < 4; e++) {
     int64_t i = b * 4 + e;
     uint32_t code = 0;
-    if (i < n) {
-      uint8_t v = col[i];
-      code = v < 3 ? v : 3u;
-    }
+    if (i < n) code = sl[col[i]];
     out |= code << (2 * e);
   }
   img[j * pitch + b] = (uint8_t)out;
 }
+// byte image: lut[byte] = grid index k as int8, 0x80 for a missing value; pad samples 0
+__global__ void k_pack_fbm8(const uint8_t *src, int64_t ld, int64_t n, uint8_t *img, int64_t pitch,
+                            int64_t ncols, const uint8_t *__restrict__ lut) {
+  __shared__ uint8_t sl[256];
+  sl[threadIdx.x & 255] = lut[threadIdx.x & 255];
+  __syncthreads();
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t j = blockIdx.y;
+  if (i >= pitch || j >= ncols) return;
+  img[j * pitch + i] = i < n ? sl[src[j * ld + i]] : (uint8_t)0;
+}
 
-void image_from_fbm(bsn_bed *b, const uint8_t *bytes, int64_t ld) {
-  int64_t cols_per = (int64_t)((256ull << 20) / (size_t)ld);
+// Column chunks of the host matrix go through two pinned buffers (filled by a few threads, the
+// source may be a page-cache mapping of a .bk file) while the previous chunk is on its way to the
+// device and being packed — the same pipeline as image_from_file.
+void image_from_fbm(bsn_bed *b, const uint8_t *bytes, int64_t ld, const uint8_t *lut) {
+  const int64_t chunk_bytes = 256ll << 20;
+  int64_t cols_per = chunk_bytes / ld;
   if (cols_per < 1) cols_per = 1;
   if (cols_per > 65535) cols_per = 65535;
-  DevBuf<uint8_t> tmp;
-  tmp.ensure((size_t)cols_per * (size_t)ld);
-  for (int64_t j = 0; j < b->m; j += cols_per) {
-    int64_t cnt = (b->m - j < cols_per) ? b->m - j : cols_per;
-    BSN_HIP(hipMemcpyAsync(tmp.p, bytes + j * ld, (size_t)cnt * (size_t)ld, hipMemcpyHostToDevice,
-                           b->stream));
-    dim3 grid((unsigned)((b->n_byte + 255) / 256), (unsigned)cnt);
-    hipLaunchKernelGGL(k_pack_fbm, grid, dim3(256), 0, b->stream, tmp.p, ld, b->n, b->n_byte,
-                       b->d_img + j * b->pitch, b->pitch, cnt);
-    BSN_HIP(hipGetLastError());
-    BSN_HIP(hipStreamSynchronize(b->stream));
+  uint8_t *pin[2] = {nullptr, nullptr};
+  hipEvent_t done[2];
+  struct Cleanup {
+    uint8_t **pin;
+    hipEvent_t *ev;
+    int nev = 0;
+    ~Cleanup() {
+      for (int i = 0; i < 2; i++)
+        if (pin[i]) (void)hipHostFree(pin[i]);
+      for (int i = 0; i < nev; i++) (void)hipEventDestroy(ev[i]);
+    }
+  } cleanup{pin, done};
+  for (int i = 0; i < 2; i++) {
+    BSN_HIP(hipHostMalloc((void **)&pin[i], (size_t)(cols_per * ld), hipHostMallocDefault));
+    BSN_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    cleanup.nev = i + 1;
   }
-  finish_image(b, 0);
+  DevBuf<uint8_t> tmp[2], d_lut;
+  tmp[0].ensure((size_t)cols_per * (size_t)ld);
+  tmp[1].ensure((size_t)cols_per * (size_t)ld);
+  BSN_HIP(hipMemcpy(d_lut.ensure(256), lut, 256, hipMemcpyHostToDevice));
+  unsigned hw = std::thread::hardware_concurrency();
+  const int nthr = (int)std::max(1u, std::min(16u, hw ? hw / 2 : 4u));
+  int k = 0;
+  for (int64_t j = 0; j < b->m; j += cols_per, k++) {
+    const int64_t cnt = std::min(cols_per, b->m - j);
+    const int64_t total = cnt * ld;
+    uint8_t *dst = pin[k & 1];
+    if (k >= 2) BSN_HIP(hipEventSynchronize(done[k & 1]));  // its previous chunk has been packed
+    std::vector<std::thread> th;
+    const int64_t slice = (total + nthr - 1) / nthr;
+    for (int t = 0; t < nthr; t++) {
+      const int64_t lo = (int64_t)t * slice, hi = std::min(total, lo + slice);
+      if (lo >= hi) break;
+      th.emplace_back([=] { std::memcpy(dst + lo, bytes + j * ld + lo, (size_t)(hi - lo)); });
+    }
+    for (auto &t : th) t.join();
+    BSN_HIP(hipMemcpyAsync(tmp[k & 1].p, dst, (size_t)total, hipMemcpyHostToDevice, b->stream));
+    if (b->bits == 8) {
+      dim3 grid((unsigned)((b->pitch + 255) / 256), (unsigned)cnt);
+      hipLaunchKernelGGL(k_pack_fbm8, grid, dim3(256), 0, b->stream, tmp[k & 1].p, ld, b->n,
+                         b->d_img + j * b->pitch, b->pitch, cnt, d_lut.p);
+    } else {
+      dim3 grid((unsigned)((b->n_byte + 255) / 256), (unsigned)cnt);
+      hipLaunchKernelGGL(k_pack_fbm, grid, dim3(256), 0, b->stream, tmp[k & 1].p, ld, b->n, b->n_byte,
+                         b->d_img + j * b->pitch, b->pitch, cnt, d_lut.p);
+    }
+    BSN_HIP(hipGetLastError());
+    BSN_HIP(hipEventRecord(done[k & 1], b->stream));
+  }
+  if (b->bits == 8)
+    BSN_HIP(hipMemsetAsync(b->d_img + b->m * b->pitch, 0, (size_t)(kPadRows * b->pitch), b->stream));
+  else
+    finish_image(b, 0);
   BSN_HIP(hipStreamSynchronize(b->stream));
+}
+
+// ---- byte image statistics -----------------------------------------------------------------
+// value plane of a register of four int8 grid indices: missing (0x80) -> 0; `na` gets 1 per missing byte
+__device__ __forceinline__ uint32_t val8(uint32_t w, uint32_t &na) {
+  const uint32_t t = w ^ 0x80808080u;
+  const uint32_t y = (t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;   // bit 7 set iff the low 7 bits are non-zero
+  const uint32_t z = ~(y | t | 0x7F7F7F7Fu);             // 0x80 iff the byte of w is 0x80
+  na = z >> 7;
+  return w & ~(z | (z - na));                            // per byte 0x80 | 0x7F: no borrow across bytes
+}
+__device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) {
+  int s = c;
+#pragma unroll
+  for (int e = 0; e < 4; e++) s += (int)(int8_t)(a >> (8 * e)) * (int)(int8_t)(b >> (8 * e));
+  return s;
+}
+// one wave per variant, all file rows, 16 B per lane per iteration
+__global__ __launch_bounds__(256) void k_stats8(const uint8_t *img, int64_t pitch, const int32_t *cols,
+                                                int64_t col0, int64_t m, long long *out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+  if (j >= m) return;
+  const int64_t col = cols ? (int64_t)cols[j] : col0 + j;
+  const uint4 *row = (const uint4 *)(img + col * pitch);
+  long long s1 = 0, s2 = 0;
+  int nna = 0;
+  for (int64_t t = lane; t < pitch / 16; t += 64) {
+    const uint4 v = row[t];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    int a1 = 0, a2 = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      uint32_t na;
+      const uint32_t x = val8(w[q], na);
+      a1 = dot4(x, 0x01010101u, a1);
+      a2 = dot4(x, x, a2);
+      nna += __popc(na);
+    }
+    s1 += a1;
+    s2 += a2;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_down(s1, off);
+    s2 += __shfl_down(s2, off);
+    nna += __shfl_down(nna, off);
+  }
+  if (lane == 0) {
+    out[3 * j + 0] = s1;
+    out[3 * j + 1] = s2;
+    out[3 * j + 2] = nna;
+  }
+}
+// row list (any order, duplicates count as often as they occur): one wave per variant, byte gathers
+__global__ __launch_bounds__(256) void k_stats8_rows(const uint8_t *img, int64_t pitch, const int32_t *rows,
+                                                     int64_t n, const int32_t *cols, int64_t col0, int64_t m,
+                                                     long long *out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+  if (j >= m) return;
+  const int64_t col = cols ? (int64_t)cols[j] : col0 + j;
+  const int8_t *row = (const int8_t *)(img + col * pitch);
+  long long s1 = 0, s2 = 0;
+  int nna = 0;
+  for (int64_t i = lane; i < n; i += 64) {
+    const int k = row[rows[i]];
+    if (k == -128) nna++;
+    else {
+      s1 += k;
+      s2 += k * k;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_down(s1, off);
+    s2 += __shfl_down(s2, off);
+    nna += __shfl_down(nna, off);
+  }
+  if (lane == 0) {
+    out[3 * j + 0] = s1;
+    out[3 * j + 1] = s2;
+    out[3 * j + 2] = nna;
+  }
+}
+void stats8(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t col0, int64_t m,
+            long long *d_out) {
+  if (d_rows)
+    hipLaunchKernelGGL(k_stats8_rows, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, b->stream, b->d_img, b->pitch,
+                       d_rows, n, d_cols, col0, m, d_out);
+  else
+    hipLaunchKernelGGL(k_stats8, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, b->stream, b->d_img, b->pitch, d_cols,
+                       col0, m, d_out);
+  BSN_HIP(hipGetLastError());
 }
 
 // ---------------------------------------------------------------------------
@@ -265,6 +416,7 @@ __global__ void k_unpad(const uint8_t *img, int64_t pitch, int64_t n, int64_t n_
 }
 
 void image_download(bsn_bed *b, uint8_t *payload_out) {
+  require_bits(b, 2, "the .bed payload download");
   int64_t rows_per = (int64_t)((256ull << 20) / (size_t)b->n_byte);
   if (rows_per < 1) rows_per = 1;
   if (rows_per > 65535) rows_per = 65535;
@@ -324,6 +476,7 @@ __global__ __launch_bounds__(256) void k_counts(const uint8_t *img, int64_t pitc
 
 void counts_all_rows(bsn_bed *b, const int32_t *d_cols, int64_t col0, int64_t m,
                      int32_t *d_counts) {
+  require_bits(b, 2, "bed_counts");
   hipLaunchKernelGGL(k_counts, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, b->stream, b->d_img,
                      b->pitch, d_cols, col0, m, b->pitch * 4 - b->n, d_counts);
   BSN_HIP(hipGetLastError());
@@ -348,6 +501,7 @@ __global__ void k_read_dense(const uint8_t *img, int64_t pitch, const int32_t *r
 void read_dense(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t m,
                 const double *d_center, const double *d_scale, int32_t na_val, int32_t *d_out_i,
                 double *d_out_d) {
+  require_bits(b, 2, "read_bed");
   int64_t gy = m < 65535 ? m : 65535, gz = (m + 65534) / 65535;
   dim3 grid((unsigned)((n + 255) / 256), (unsigned)gy, (unsigned)gz);
   hipLaunchKernelGGL(k_read_dense, grid, dim3(256), 0, b->stream, b->d_img, b->pitch, d_rows, n,
@@ -390,6 +544,7 @@ __global__ void k_subset_pack(const uint8_t *img, int64_t pitch, const int32_t *
 
 void to_bytes(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t m,
               uint8_t *d_out) {
+  require_bits(b, 2, "readbina2");
   int64_t gy = m < 65535 ? m : 65535, gz = (m + 65534) / 65535;
   hipLaunchKernelGGL(k_to_bytes, dim3((unsigned)((n + 255) / 256), (unsigned)gy, (unsigned)gz), dim3(256),
                      0, b->stream, b->d_img, b->pitch, d_rows, n, d_cols, m, d_out);
@@ -398,6 +553,7 @@ void to_bytes(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_col
 
 void subset_pack(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t m,
                  uint8_t *d_out) {
+  require_bits(b, 2, "writebina");
   int64_t nb = (n + 3) / 4;
   int64_t gy = m < 65535 ? m : 65535, gz = (m + 65534) / 65535;
   hipLaunchKernelGGL(k_subset_pack, dim3((unsigned)((nb + 255) / 256), (unsigned)gy, (unsigned)gz),

@@ -78,8 +78,11 @@ __global__ void k_scatter_rows(const double *X, int64_t ldx, const int32_t *rows
 // mode 0 (cprod): value = X[k, v]                       for k < len
 // mode 1 (prod) : value a = X[k, v]/scale[k], b = c*a; the digit planes hold a and b - 3a
 // mode 2 (prod, raw plane weights): a = X[k, v], b = center[k, v] (a second panel)
+// vstep / voff / raw3: the value of a genotype is voff + vstep k (2-bit image: k = allele count, 1 / 0);
+// mode 1 quantises a = vstep X / scale and b = (c - voff) X / scale; raw3: the k plane holds 3 for a
+// missing value (raw 2-bit codes), so the second digit plane carries b - 3 a
 __global__ void k_absmax(const double *X, int64_t ldx, int64_t len, const double *center,
-                         const double *scale, int mode, VecMeta *meta) {
+                         const double *scale, int mode, VecMeta *meta, double vstep, double voff, int raw3) {
   int v = blockIdx.y;
   double mx = 0;
   unsigned long long bad = 0;
@@ -89,10 +92,11 @@ __global__ void k_absmax(const double *X, int64_t ldx, int64_t len, const double
     if (mode == 1) {
       double s = scale ? scale[k] : 1.0, c = center ? center[k] : 0.0;
       a = a / s;
-      const double b = c * a;
+      const double b = (c - voff) * a;
+      a *= vstep;
       const double b3 = fabs(b - 3.0 * a);  // the second digit plane (missing-value plane weights)
       if (!(fabs(b) <= 1.79e308)) bad++; else mx = fmax(mx, fabs(b));
-      if (b3 <= 1.79e308) mx = fmax(mx, b3);
+      if (raw3 && b3 <= 1.79e308) mx = fmax(mx, b3);
     } else if (mode == 2) {  // raw second plane: center[] is W2 (same shape as X)
       double b = center ? fabs(center[k + v * ldx]) : 0.0;
       if (!(b <= 1.79e308)) bad++; else mx = fmax(mx, b);
@@ -149,7 +153,8 @@ template <int S, int PERM>
 __global__ __launch_bounds__(64) void k_quant(const double *__restrict__ X, int64_t ldx, int64_t len,
                                               int64_t len_pad, const double *__restrict__ center,
                                               const double *__restrict__ scale, int mode, int ncol,
-                                              VecMeta *meta, int8_t *__restrict__ q) {
+                                              VecMeta *meta, int8_t *__restrict__ q, double vstep, double voff,
+                                              int raw3) {
   __shared__ double sa[64 * 17], sb[64 * 17];
   const int tid = threadIdx.x, v = blockIdx.y;
   const int64_t kb = (int64_t)blockIdx.x * 64 + tid;  // 16-block index of this thread
@@ -177,7 +182,8 @@ __global__ __launch_bounds__(64) void k_quant(const double *__restrict__ X, int6
     double a = xa[it], b = 0;
     if (mode == 1) {
       a = a / xs[it];
-      b = xc[it] * a;
+      b = (xc[it] - voff) * a;
+      a *= vstep;
     } else if (mode == 2) {
       b = xc[it];
     }
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(64) void k_quant(const double *__restrict__ X, int6
       shi2 += B >> 24; slo2 += B & 0xFFFFFF;
       // scaled product: the genotype plane is the raw code (3 for a missing value), so the
       // missing-value plane carries c w - 3 w, in exact integers: 3 A + (B - 3 A) - B == 0
-      if (mode == 1) B -= 3 * A;
+      if (raw3) B -= 3 * A;
       const int pos = PERM ? ((e & 3) * 4 + (e >> 2)) : e;
 #pragma unroll
       for (int s = 0; s < S; s++) {
@@ -715,6 +721,216 @@ __global__ void k_prod_final(const int32_t *__restrict__ acc, int64_t n_pad, int
 }
 
 // ---------------------------------------------------------------------------
+// Byte image (bsn_bed::bits == 8): one int8 grid index k per genotype, 0x80 = missing.  The loaded
+// bytes ARE the MFMA operand (after zeroing the missing marker when the data has any); 1 B per genotype
+// makes both products plainly HBM-bound (1 - 2 MFMA per 16 B instead of 8).
+__device__ __forceinline__ uint32_t val8m(uint32_t w, uint32_t &na) {
+  const uint32_t t = w ^ 0x80808080u;
+  const uint32_t y = (t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+  const uint32_t z = ~(y | t | 0x7F7F7F7Fu);  // 0x80 iff the byte of w is 0x80
+  na = z >> 7;
+  return w & ~(z | (z - na));
+}
+
+// k_cprod8: contraction over samples.  One wave owns 16 variants for the whole sample range; the 8 waves
+// of a workgroup share the digit panel of the current 256-sample chunk through LDS (double-buffered).
+//   A operand: lane l -> variant row (l&15), k-group (l>>4): 16 B = 16 samples;  B: digit column (l&15)
+template <int NB, bool HASNA, bool CONTIG>
+__global__ __launch_bounds__(512) void k_cprod8(const uint8_t *__restrict__ img, int64_t pitch,
+                                                const int32_t *__restrict__ cols, int64_t col0, int64_t m,
+                                                const int8_t *__restrict__ xq, int32_t *__restrict__ acc_out,
+                                                int64_t m_out) {
+  constexpr int KC = 256, LD = KC / 64, NCOL = 16 * NB, XS = KC / 16 * NCOL, WAVES = 8, NT = 64 * WAVES;
+  constexpr int NPL = HASNA ? 2 : 1;
+  __shared__ uint4 xs[2][XS];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int64_t snp_base = ((int64_t)blockIdx.x * WAVES + wave) * 16;
+  int64_t j = snp_base + c;
+  if (j > m - 1) j = m - 1;
+  const int64_t col = CONTIG ? col0 + j : (int64_t)cols[j];
+  const uint8_t *rowp = img + col * pitch + g * 16;
+  const int nchunks = (int)(pitch / KC);
+  const uint4 *xq4 = (const uint4 *)xq;
+  v4i acc[NPL][NB];
+#pragma unroll
+  for (int p = 0; p < NPL; p++)
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) acc[p][nb] = v4i{0, 0, 0, 0};
+  static_assert(XS <= NT, "digit staging");
+  uint4 ga[2][LD], xr = {0, 0, 0, 0};
+#pragma unroll
+  for (int it = 0; it < LD; it++) ga[0][it] = *(const uint4 *)(rowp + it * 64);
+  if (tid < XS) xs[0][tid] = xq4[tid];
+#pragma unroll
+  for (int it = 0; it < LD; it++) ga[1][it] = *(const uint4 *)(rowp + (nchunks > 1 ? KC : 0) + it * 64);
+  __syncthreads();
+  auto chunk = [&](auto SETC, const int ch) {
+    constexpr int SET = decltype(SETC)::value;
+    const int ch1 = ch + 1 < nchunks ? ch + 1 : nchunks - 1, ch2 = ch + 2 < nchunks ? ch + 2 : nchunks - 1;
+    if (tid < XS) xr = xq4[(int64_t)ch1 * XS + tid];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < LD; it++) {
+      const uint4 w = ga[SET][it];
+      v4i val, na;
+      if constexpr (HASNA) {
+        uint32_t n0, n1, n2, n3;
+        val = v4i{(int)val8m(w.x, n0), (int)val8m(w.y, n1), (int)val8m(w.z, n2), (int)val8m(w.w, n3)};
+        na = v4i{(int)n0, (int)n1, (int)n2, (int)n3};
+      } else {
+        val = v4i{(int)w.x, (int)w.y, (int)w.z, (int)w.w};
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) {
+        const uint4 bv = xs[SET][(it * 4 + g) * NCOL + nb * 16 + c];
+        const v4i b = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
+        acc[0][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(val, b, acc[0][nb], 0, 0, 0);
+        if constexpr (HASNA) acc[1][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(na, b, acc[1][nb], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < LD; it++) ga[SET][it] = *(const uint4 *)(rowp + (int64_t)ch2 * KC + it * 64);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < XS) xs[SET ^ 1][tid] = xr;
+    __syncthreads();
+  };
+  for (int ch = 0; ch < nchunks; ch += 2) {
+    chunk(std::integral_constant<int, 0>{}, ch);
+    if (ch + 1 < nchunks) chunk(std::integral_constant<int, 1>{}, ch + 1);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int64_t jo = snp_base + g * 4 + r;
+    if (jo < m) {
+#pragma unroll
+      for (int p = 0; p < NPL; p++)
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) acc_out[((int64_t)p * m_out + jo) * NCOL + nb * 16 + c] = acc[p][nb][r];
+    }
+  }
+}
+
+// z[j, v] = (vstep P + (voff - c_j) (Sx - Q)) / (s_j qs):  value = voff + vstep k on non-missing genotypes
+__global__ void k_cprod_final8(const int32_t *acc, int64_t m, int ncol, int S, const VecMeta *meta,
+                               const double *center, const double *scale, double *Z, int64_t ldz, int has_q,
+                               double vstep, double voff) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int v = blockIdx.y;
+  if (j >= m) return;
+  const double P = horner(acc + j * ncol + v * S, S);
+  const double Q = has_q ? horner(acc + (m + j) * ncol + v * S, S) : 0.0;
+  const double Sx = (double)meta[v].sum_hi * 16777216.0 + (double)meta[v].sum_lo;
+  const double c = center ? center[j] : 0.0, s = scale ? scale[j] : 1.0, qs = meta[v].qscale;
+  double z = qs > 0 ? (vstep * P + (voff - c) * (Sx - Q)) / (s * qs) : 0.0 / s;
+  if (meta[v].nonfinite) z = __longlong_as_double(0x7ff8000000000000LL);
+  Z[j + v * ldz] = z;
+}
+
+// k_prod8: contraction over variants on the variant-major byte image.  One wave owns 64 samples
+// (16 sample groups x 4) and walks a range of variants 64 at a time: 16 dword loads per lane (16 variants
+// x 4 samples), four 4x4 byte transposes, then per sample one operand of 16 variants.
+template <int NB, bool HASNA, bool CONTIG>
+__global__ __launch_bounds__(256) void k_prod8(const uint8_t *__restrict__ img, int64_t pitch,
+                                               const int32_t *__restrict__ cols, int64_t col0, int64_t m_pad,
+                                               int64_t mc, const int8_t *__restrict__ wq,
+                                               int32_t *__restrict__ acc_out, int64_t n_pad) {
+  constexpr int NCOL = 16 * NB, WS = 8 * NCOL;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, sg = lane & 15, g = lane >> 4;
+  const int64_t wbase = ((int64_t)blockIdx.x * 4 + wave) * 64;  // first sample of this wave
+  const int64_t wbyte = wbase + sg * 4;
+  const int64_t j0 = (int64_t)blockIdx.y * mc;
+  int64_t j1 = j0 + mc;
+  if (j1 > m_pad) j1 = m_pad;
+  if (j0 >= j1) return;
+  const uint4 *wq4 = (const uint4 *)wq;
+  v4i acc[4][NB];
+#pragma unroll
+  for (int u = 0; u < 4; u++)
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) acc[u][nb] = v4i{0, 0, 0, 0};
+  __shared__ uint4 ws[2][WS];
+  static_assert(WS <= 256, "digit staging");
+  const int wtid = tid & (WS - 1);
+  uint32_t X[2][16];
+  auto load = [&](int64_t jb, uint32_t *dst) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int64_t jj = jb + g * 16 + r;
+      const int64_t col = CONTIG ? col0 + jj : (int64_t)cols[jj];
+      dst[r] = *(const uint32_t *)(img + col * pitch + wbyte);
+    }
+  };
+  const int64_t jlast = j1 - 64;
+  uint4 wreg = {0, 0, 0, 0};
+  ws[0][wtid] = wq4[(j0 / 16) * 2 * NCOL + wtid];
+  load(j0, X[0]);
+  load(j0 + 64 < j1 ? j0 + 64 : jlast, X[1]);
+  __syncthreads();
+  auto step = [&](auto SETC, const int64_t jb) {
+    constexpr int SET = decltype(SETC)::value;
+    const int64_t jn1 = jb + 64 < j1 ? jb + 64 : jlast, jn2 = jb + 128 < j1 ? jb + 128 : jlast;
+    wreg = wq4[(jn1 / 16) * 2 * NCOL + wtid];
+    v4i aw[NB], awc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      const uint4 t0 = ws[SET][(g * 2 + 0) * NCOL + nb * 16 + sg], t1 = ws[SET][(g * 2 + 1) * NCOL + nb * 16 + sg];
+      aw[nb] = v4i{(int)t0.x, (int)t0.y, (int)t0.z, (int)t0.w};
+      awc[nb] = v4i{(int)t1.x, (int)t1.y, (int)t1.z, (int)t1.w};
+    }
+    uint32_t T[4][4];  // T[q][r4]: byte b = sample q of variant 4 r4 + b
+#pragma unroll
+    for (int r4 = 0; r4 < 4; r4++) {
+      const uint32_t x0 = X[SET][4 * r4], x1 = X[SET][4 * r4 + 1], x2 = X[SET][4 * r4 + 2], x3 = X[SET][4 * r4 + 3];
+      const uint32_t lo01 = perm8(x1, x0, 0x05010400u), hi01 = perm8(x1, x0, 0x07030602u);
+      const uint32_t lo23 = perm8(x3, x2, 0x05010400u), hi23 = perm8(x3, x2, 0x07030602u);
+      T[0][r4] = perm8(lo23, lo01, 0x05040100u);
+      T[1][r4] = perm8(lo23, lo01, 0x07060302u);
+      T[2][r4] = perm8(hi23, hi01, 0x05040100u);
+      T[3][r4] = perm8(hi23, hi01, 0x07060302u);
+    }
+    load(jn2, X[SET]);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      v4i val, na;
+      if constexpr (HASNA) {
+        uint32_t n0, n1, n2, n3;
+        val = v4i{(int)val8m(T[q][0], n0), (int)val8m(T[q][1], n1), (int)val8m(T[q][2], n2), (int)val8m(T[q][3], n3)};
+        na = v4i{(int)n0, (int)n1, (int)n2, (int)n3};
+      } else {
+        val = v4i{(int)T[q][0], (int)T[q][1], (int)T[q][2], (int)T[q][3]};
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) {
+        acc[q][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[nb], val, acc[q][nb], 0, 0, 0);
+        if constexpr (HASNA) acc[q][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(awc[nb], na, acc[q][nb], 0, 0, 0);
+      }
+    }
+    ws[SET ^ 1][wtid] = wreg;
+    __syncthreads();
+  };
+  for (int64_t jb = j0; jb < j1; jb += 128) {
+    step(std::integral_constant<int, 0>{}, jb);
+    if (jb + 64 < j1) step(std::integral_constant<int, 1>{}, jb + 64);
+  }
+  if (wbase < n_pad) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int64_t i = wbase + sg * 4 + u;
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++)
+        *(v4i *)(acc_out + (((int64_t)blockIdx.y * n_pad + i) * NCOL + nb * 16 + 4 * g)) = acc[u][nb];
+    }
+  }
+}
+
+void require_bits(const bsn_bed *b, int bits, const char *what) {
+  if (b->bits != bits)
+    fail("%s is not available for this handle: it needs %s", what,
+         bits == 2 ? "a 2-bit genotype image (.bed, or an FBM.code256 whose codes decode to 0 / 1 / 2 / NA)"
+                   : "a byte (dosage) image");
+}
+
+// ---------------------------------------------------------------------------
 void prof_begin(bsn_op *op, int kind) {
   if (!op->profile) return;
   hipEvent_t a, b;
@@ -747,18 +963,24 @@ void prof_collect(bsn_op *op, double ms[2], int count[2]) {
 }
 
 static int pick_nb(int ncols_needed) { return ncols_needed <= 16 ? 1 : 2; }
+// samples a variant row is padded to (the digit panels and partial buffers are that long)
+static inline int64_t n_padded(const bsn_bed *b) { return b->bits == 8 ? b->pitch : b->pitch * 4; }
 
 static void quantise(bsn_op *op, const double *d_X, int64_t ldx, int64_t len, int64_t len_pad,
                      int nvec, int mode, int S, int ncol, int permute, int exact_int,
                      VecMeta *meta, int8_t *q, const double *d_W2 = nullptr) {
   hipStream_t st = op->bed->stream;
+  const bool bytes = op->bed->bits == 8;
+  const double vstep = bytes ? op->bed->v_step : 1.0, voff = bytes ? op->bed->v_off : 0.0;
+  const int raw3 = (!bytes && mode == 1) ? 1 : 0;
+  if (bytes) permute = 0;  // the byte image holds the samples of a 16-block in natural order
   hipLaunchKernelGGL(k_meta_clear, dim3(1), dim3(64), 0, st, meta, nvec);
   if (!exact_int) {
     int gx = (int)((len + 1023) / 1024);
     if (gx > 256) gx = 256;
     hipLaunchKernelGGL(k_absmax, dim3(gx, nvec), dim3(1024), 0, st, d_X, ldx, len,
                        mode == 1 ? op->d_center.p : mode == 2 ? d_W2 : nullptr,
-                       mode == 1 ? op->d_scale.p : nullptr, mode, meta);
+                       mode == 1 ? op->d_scale.p : nullptr, mode, meta, vstep, voff, raw3);
   }
   hipLaunchKernelGGL(k_set_qscale, dim3(1), dim3(64), 0, st, meta, nvec, S, exact_int);
   int nplanes = mode >= 1 ? 2 : 1;
@@ -771,10 +993,10 @@ static void quantise(bsn_op *op, const double *d_X, int64_t ldx, int64_t len, in
   case SV:                                                                                             \
     if (permute)                                                                                       \
       hipLaunchKernelGGL((k_quant<SV, 1>), qgrid, dim3(64), 0, st, d_X, ldx, len, len_pad, qc, qsc, mode, \
-                         ncol, meta, q);                                                               \
+                         ncol, meta, q, vstep, voff, raw3);                                            \
     else                                                                                               \
       hipLaunchKernelGGL((k_quant<SV, 0>), qgrid, dim3(64), 0, st, d_X, ldx, len, len_pad, qc, qsc, mode, \
-                         ncol, meta, q);                                                               \
+                         ncol, meta, q, vstep, voff, raw3);                                            \
     break;
   switch (S) {
     BSN_QUANT(1) BSN_QUANT(2) BSN_QUANT(3) BSN_QUANT(4) BSN_QUANT(5) BSN_QUANT(6) BSN_QUANT(7) BSN_QUANT(8)
@@ -945,7 +1167,7 @@ void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z,
   const int vmax = 32 / S;  // vectors per launch (NB <= 2)
   if (nvec <= 0) return;
   const double *xsrc = scatter_rows_if_needed(op, d_X, &ldx, nvec);
-  const int64_t npad = b->pitch * 4;
+  const int64_t npad = n_padded(b);
   VecMeta *meta = (VecMeta *)op->d_meta.ensure(8 * 64);
   for (int v0 = 0; v0 < nvec; v0 += vmax) {
     int nv = nvec - v0 < vmax ? nvec - v0 : vmax;
@@ -954,6 +1176,29 @@ void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z,
     int32_t *acc = op->d_acc.ensure((size_t)2 * op->m * 32);
     quantise(op, xsrc + (int64_t)v0 * ldx, ldx, b->n, npad, nv, 0, S, ncol, 1, 0, meta, q);
     prof_begin(op, 0);
+    if (b->bits == 8) {
+      const dim3 grid8((unsigned)((op->m + 127) / 128));
+      const int32_t *cols8 = op->cols_contig ? nullptr : op->d_cols.p;
+#define BSN_CPROD8(NBV, NAV, CV)                                                                          \
+  hipLaunchKernelGGL((k_cprod8<NBV, NAV, CV>), grid8, dim3(512), 0, b->stream, b->d_img, b->pitch, cols8, \
+                     op->col0, op->m, q, acc, op->m)
+      if (NB == 1) {
+        if (op->no_na) { if (op->cols_contig) BSN_CPROD8(1, false, true); else BSN_CPROD8(1, false, false); }
+        else { if (op->cols_contig) BSN_CPROD8(1, true, true); else BSN_CPROD8(1, true, false); }
+      } else {
+        if (op->no_na) { if (op->cols_contig) BSN_CPROD8(2, false, true); else BSN_CPROD8(2, false, false); }
+        else { if (op->cols_contig) BSN_CPROD8(2, true, true); else BSN_CPROD8(2, true, false); }
+      }
+#undef BSN_CPROD8
+      BSN_HIP(hipGetLastError());
+      prof_end(op);
+      op->passes++;
+      hipLaunchKernelGGL(k_cprod_final8, dim3((unsigned)((op->m + 255) / 256), nv), dim3(256), 0, b->stream, acc,
+                         op->m, ncol, S, meta, op->d_center.p, op->d_scale.p, d_Z + (int64_t)v0 * ldz, ldz,
+                         op->no_na ? 0 : 1, b->v_step, b->v_off);
+      BSN_HIP(hipGetLastError());
+      continue;
+    }
     if (op->stats_pending) {
       if (!op->rows_identity) fail("internal: fused scaling statistics need all samples");
       launch_cprod<2, true, true>(op, NB, q, acc, kLutRaw, kLutNA, 0, op->d_counts.ensure((size_t)4 * op->m + 4));
@@ -1032,11 +1277,11 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
   if (nvec <= 0) return;
   // k_prod addresses a 64-variant step with 32-bit offsets from its first row
   if (b->pitch >= ((int64_t)1 << 24)) fail("more than 6.7e7 samples are not supported by the product kernel");
-  const int64_t npad = b->pitch * 4;
+  const int64_t npad = n_padded(b);
   const int64_t m_pad = round_up(op->m, 64);
   VecMeta *meta = (VecMeta *)op->d_meta.ensure(8 * 64);
   // K split so that the grid has a few thousand workgroups
-  int64_t wgx = npad / 1024;
+  int64_t wgx = b->bits == 8 ? npad / 256 : npad / 1024;  // workgroups along the samples
   int ky = (int)((4096 + wgx - 1) / wgx);
   int64_t steps = m_pad / 64;
   if (ky > steps) ky = (int)steps;
@@ -1061,6 +1306,24 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
              d_W2 ? d_W2 + (int64_t)v0 * ldx : nullptr);
     dim3 grid((unsigned)wgx, (unsigned)ky);
     prof_begin(op, 1);
+    if (b->bits == 8) {
+      if (mode != 1) fail("internal: plane products are not defined on a byte image");
+      const dim3 grid8 = grid;
+      const int64_t npad8 = npad;
+      const int32_t *cols8 = op->d_cols.p;
+#define BSN_PROD8(NBV, NAV, CV)                                                                          \
+  hipLaunchKernelGGL((k_prod8<NBV, NAV, CV>), grid8, dim3(256), 0, b->stream, b->d_img, b->pitch, cols8, \
+                     op->col0, m_pad, mc, q, acc, npad8)
+      if (NB == 1) {
+        if (op->no_na) { if (op->cols_contig) BSN_PROD8(1, false, true); else BSN_PROD8(1, false, false); }
+        else { if (op->cols_contig) BSN_PROD8(1, true, true); else BSN_PROD8(1, true, false); }
+      } else {
+        if (op->no_na) { if (op->cols_contig) BSN_PROD8(2, false, true); else BSN_PROD8(2, false, false); }
+        else { if (op->cols_contig) BSN_PROD8(2, true, true); else BSN_PROD8(2, true, false); }
+      }
+#undef BSN_PROD8
+      BSN_HIP(hipGetLastError());
+    } else
     if (op->cols_contig) {
       if (NB == 1) launch_prod<1, true>(op, grid, m_pad, mc, q, acc, npad, lutP, lutQ, has_q);
       else launch_prod<2, true>(op, grid, m_pad, mc, q, acc, npad, lutP, lutQ, has_q);
@@ -1099,12 +1362,13 @@ __global__ void k_cprod_raw_final(const int32_t *acc, int64_t m, int ncol, int S
 
 void op_cprod_raw(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_P, double *d_Q,
                   int64_t ld) {
+  require_bits(op->bed, 2, "the plane sums of multLinReg");
   bsn_bed *b = op->bed;
   const int S = op->slices;
   const int vmax = 32 / S;
   if (nvec <= 0) return;
   const double *xsrc = scatter_rows_if_needed(op, d_X, &ldx, nvec);
-  const int64_t npad = b->pitch * 4;
+  const int64_t npad = n_padded(b);
   VecMeta *meta = (VecMeta *)op->d_meta.ensure(8 * 64);
   for (int v0 = 0; v0 < nvec; v0 += vmax) {
     int nv = nvec - v0 < vmax ? nvec - v0 : vmax;
@@ -1139,6 +1403,7 @@ __global__ void k_rowsq_weights(const double *center, const double *scale, int64
 }
 
 void op_row_sums_sq(bsn_op *op, double *d_out) {
+  require_bits(op->bed, 2, "prod_and_rowSumsSq");
   bsn_bed *bed = op->bed;
   DevBuf<double> w;
   double *a = w.ensure((size_t)3 * op->m), *b2 = a + op->m, *d = b2 + op->m;
@@ -1157,6 +1422,7 @@ void op_row_sums_sq(bsn_op *op, double *d_out) {
 // fixed-point image of 1.0 is a power of two and the plane sums are integers < 2^31.
 // d_out: 3 x n doubles (n2, n1, nNA per selected row).
 void op_row_counts(bsn_op *op, double *d_out) {
+  require_bits(op->bed, 2, "bed_counts(byrow = TRUE)");
   bsn_bed *bed = op->bed;
   std::vector<double> ones((size_t)op->m, 1.0);
   DevBuf<double> w;
@@ -1184,9 +1450,10 @@ __global__ void k_counts_final(const int32_t *acc, int64_t m, int ncol, int S, i
 }
 
 void counts_weighted(bsn_op *op, const double *d_w, int64_t n_sub, int32_t *d_counts) {
+  require_bits(op->bed, 2, "bed_counts");
   bsn_bed *b = op->bed;
   const int S = 4;
-  const int64_t npad = b->pitch * 4;
+  const int64_t npad = n_padded(b);
   VecMeta *meta = (VecMeta *)op->d_meta.ensure(8 * 64);
   int8_t *q = op->d_q.ensure((size_t)npad * 64);
   int32_t *acc = op->d_acc.ensure((size_t)3 * op->m * 16);

@@ -15,23 +15,32 @@ from ._lib import as_f64, check, f64p, i32p, i64p, ptr, vp
 from .bed import (_check_ind, assert_lengths, bed, bed_colstats, cols_along, rows_along)
 
 CODE_012 = np.array([0, 1, 2] + [np.nan] * 253)  # R/bigSNP-class.R:7
+CODE_DOSAGE = np.array([0, 1, 2, np.nan, 0, 1, 2] + list(np.round(np.arange(201) * 0.01, 2)) + [np.nan] * 48)  # :13
+CODE_IMPUTE_PRED = np.array([0, 1, 2, np.nan, 0, 1, 2] + [np.nan] * 249)  # R/bigSNP-class.R:10
 
 
 class FBM_code256:
-    """bigstatsr's FBM.code256 with CODE_012, held on the device as a 2-bit image."""
+    """bigstatsr's FBM.code256 (n x m bytes + a 256-entry decode table) held on the device
+    (bsn_fbm_open): tables that decode to genotype calls (CODE_012, CODE_IMPUTE_PRED) become the 2-bit
+    image and support every snp_* function; tables on a regular grid (CODE_DOSAGE) become a byte image
+    that supports snp_colstats / snp_MAF / snp_scale*, big_prodVec / big_cprodVec / snp_PRS and
+    big_randomSVD; anything else is refused by the library."""
 
     def __init__(self, bytes_nm, code=CODE_012):
-        a = np.asarray(bytes_nm, dtype=np.uint8)
+        a = np.asfortranarray(np.asarray(bytes_nm, dtype=np.uint8))
         if a.ndim != 2:
             raise ValueError("a genotype FBM is a matrix")
-        code = np.asarray(code, dtype=np.float64)
-        ok = (code[:3] == np.array([0, 1, 2])).all() and np.isnan(code[3:]).all()
-        if not ok:
-            raise NotImplementedError("only the CODE_012 coding is supported on the GPU path")
+        code = np.ascontiguousarray(code, dtype=np.float64)
+        if code.size != 256:
+            raise ValueError("'code256' must have 256 values")
         self.code256 = code
         self.nrow, self.ncol = a.shape
-        self._bed = bed.from_fbm(a)
-        self._has_na = bool((a > 2).any())
+        h = vp()
+        check(_lib.load().bsn_fbm_open(a.ctypes.data_as(_lib.u8p), self.nrow, self.ncol, self.nrow,
+                                       ptr(code, f64p), C.byref(h)))
+        self._bed = bed(_handle=h, _n=self.nrow, _m=self.ncol)
+        self.bits = int(_lib.load().bsn_bed_bits(h))
+        self._has_na = bool(np.isnan(code[np.unique(a)]).any())
 
     @property
     def handle(self):
@@ -42,12 +51,28 @@ class FBM_code256:
         return (self.nrow, self.ncol)
 
 
-def snp_fake(n, m, rng=None):
-    """R/fake.R:27-54: a bigSNP-like dict with an all-NA FBM.code256; fill
-    `obj["genotypes_bytes"]` and call `snp_attach_bytes` to upload."""
+def snp_fake(n, m):
+    """R/fake.R:27-54: the skeleton of a bigSNP — an n x m genotype byte matrix filled with the
+    missing code 3 (CODE_012), `fam` and `map` with the reference's default columns.  Fill
+    ``obj["genotypes"]`` and hand it to ``FBM_code256`` to put it on the device."""
     seq_m = np.arange(1, m + 1)
-    return dict(genotypes=None, fam=dict(sample_ID=["ind_%d" % i for i in range(1, n + 1)]),
-                map=dict(chromosome=np.ones(m, dtype=np.int64), physical_pos=seq_m * 1000))
+    return dict(genotypes=np.full((n, m), 3, dtype=np.uint8),
+                fam=dict(family_ID=["fam_%d" % i for i in range(1, n + 1)],
+                         sample_ID=["ind_%d" % i for i in range(1, n + 1)],
+                         paternal_ID=np.zeros(n, dtype=np.int64), maternal_ID=np.zeros(n, dtype=np.int64),
+                         sex=np.zeros(n, dtype=np.int64), affection=np.full(n, -9, dtype=np.int64)),
+                map=dict(chromosome=np.ones(m, dtype=np.int64), marker_ID=["snp_%d" % j for j in seq_m],
+                         genetic_dist=np.zeros(m, dtype=np.int64), physical_pos=seq_m * 1000,
+                         allele1=["A"] * m, allele2=["T"] * m))
+
+
+def _no_missing(G, what):
+    """bigstatsr's FBM products have no missing-value handling: a missing code decodes to NA_real and
+    turns every result it touches into NA.  Rather than return such a vector (or, worse, a finite one
+    that silently took the value for 0), the GPU path refuses."""
+    if isinstance(G, FBM_code256) and G._has_na:
+        raise ValueError("%s: the FBM has missing values (bigstatsr would return NA); impute first "
+                         "(snp_fastImputeSimple)." % what)
 
 
 def _image(obj):
@@ -275,12 +300,30 @@ def snp_MAF(G, ind_row=None, ind_col=None, nploidy=2, ncores=1):
     return np.minimum(af, 1 - af)
 
 
+def big_prodVec(X, y_col, ind_row=None, ind_col=None, center=None, scale=None, ncores=1):
+    """bigstatsr::big_prodVec for an FBM.code256 (external; callers R/PRS.R:5, R/autoSVD.R:129-134):
+    ((X[ind.row, ind.col] - center) / scale) %*% y.col, centre / scale defaulting to 0 / 1."""
+    from .bed import bed_prodVec
+    _no_missing(X, "big_prodVec")
+    im, ir, ic = _ind(X, ind_row, ind_col)
+    return bed_prodVec(im, y_col, ir, ic, center, scale)
+
+
+def big_cprodVec(X, y_row, ind_row=None, ind_col=None, center=None, scale=None, ncores=1):
+    """bigstatsr::big_cprodVec: crossprod((X[ind.row, ind.col] - center) / scale, y.row)"""
+    from .bed import bed_cprodVec
+    _no_missing(X, "big_cprodVec")
+    im, ir, ic = _ind(X, ind_row, ind_col)
+    return bed_cprodVec(im, y_row, ir, ic, center, scale)
+
+
 def big_randomSVD(X, fun_scaling=None, ind_row=None, ind_col=None, k=10, tol=1e-4, verbose=False,
                   ncores=1, **kw):
     """The FBM entry of the partial SVD as snp_autoSVD calls it (R/autoSVD.R:129-134;
     bigstatsr::big_randomSVD is external): same device solver as bed_randomSVD, on the
     FBM's 2-bit image."""
     from .svd import bed_randomSVD
+    _no_missing(X, "big_randomSVD")
     im, ir, ic = _ind(X, ind_row, ind_col)
     fs = snp_scaleBinom() if fun_scaling is None else fun_scaling
     return bed_randomSVD(im, fun_scaling=lambda obj, ind_row, ind_col, ncores=1: fs(X, ind_row, ind_col, ncores),

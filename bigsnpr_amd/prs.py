@@ -4,13 +4,14 @@ import numpy as np
 from . import _lib
 from ._lib import as_f64, check, f64p, i64p, ptr
 from .bed import _args, assert_lengths, bed_prodVec, bed_scaleBinom
-from .ld import _ind, _r_order_decreasing
+from .ld import _ind, _no_missing, _r_order_decreasing
 
 
 def prodVecRev(G, betas_col, same_col, ind_row, ind_col):
     """R/PRS.R:3-7: big_prodVec(G, (2 * same - 1) * beta, ind.row, ind.col) + 2 * sum(beta[!same]).
     big_prodVec is bigstatsr's unscaled FBM product (external); here the same streaming
     kernel as bed_prodVec with center 0 / scale 1 on the FBM's 2-bit image."""
+    _no_missing(G, "snp_PRS")
     im, ir, ic = _ind(G, ind_row, ind_col)
     betas_col = as_f64(betas_col)
     same_col = np.asarray(same_col, dtype=bool)

@@ -54,6 +54,16 @@ int bsn_bed_from_host(const uint8_t *payload, int64_t n, int64_t m, int64_t n_by
  * CODE_012 coding (R/bigSNP-class.R:7: 0,1,2, everything else NA) repacked to 2 bits
  * on the device; the FBM twin of bedXPtr for snp_* functions (src/colstats.cpp:13-14). */
 int bsn_bed_from_fbm(const uint8_t *bytes, int64_t n, int64_t m, int64_t ld, bsn_bed **out);
+/* The same for any FBM.code256: `code256` is the object's 256-entry decode table (R/bigSNP-class.R:7-13).
+ * Tables that decode to genotype calls only (0 / 1 / 2 / NA: CODE_012, CODE_IMPUTE_PRED) give the 2-bit
+ * image and every entry point of this header.  Tables whose values lie on a regular grid of at most 255
+ * steps (CODE_DOSAGE: calls, imputed calls and dosages 0.00 .. 2.00 by 0.01) give a BYTE image — one int8
+ * grid index per genotype, exact integer sums, the affine map back to values applied in fp64 — which
+ * serves bsn_snp_colstats, bsn_bed_prodvec / bsn_bed_cprodvec (big_prodVec / big_cprodVec and so snp_PRS),
+ * bsn_op_* and bsn_bed_randomsvd with explicit centre / scale; the other entry points fail on it with a
+ * message.  Any other table is refused. */
+int bsn_fbm_open(const uint8_t *bytes, int64_t n, int64_t m, int64_t ld, const double *code256, bsn_bed **out);
+int bsn_bed_bits(const bsn_bed *bed); /* 2 or 8 */
 /* synthetic matrix generated directly in HBM (DESIGN.md "Synthetic inputs");
  * byte-identical to oracle/bsn_oracle.c:orc_fake_bed */
 int bsn_bed_synthetic(int64_t n, int64_t m, uint32_t seed, uint32_t npop, uint32_t na16,

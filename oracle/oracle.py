@@ -393,6 +393,29 @@ def bed_clumping(bed, infos_chr, infos_pos, ind_row=None, S=None, thr_r2=0.2, si
     return np.sort(np.concatenate(kept)) if kept else np.zeros(0, dtype=np.int64)
 
 
+def fbm_prodVec(G, x, ind_row=None, ind_col=None):
+    """bigstatsr::big_prodVec without centre / scale (external; plain definition y = G[ir, ic] x on the
+    decoded values, oracle/bsn_oracle.c:orc_fbm_prodVec)"""
+    ir = np.arange(G.n, dtype=np.int64) if ind_row is None else _i64(ind_row)
+    ic = np.arange(G.m, dtype=np.int64) if ind_col is None else _i64(ind_col)
+    x, flat, y = _f64(x), G.flat(), np.empty(ir.size)
+    lib().orc_fbm_prodVec(_p(flat, C.c_uint8), C.c_int64(G.n), _p(G.code256, C.c_double), _p(ir, C.c_int64),
+                          C.c_int64(ir.size), _p(ic, C.c_int64), C.c_int64(ic.size), _p(x, C.c_double),
+                          _p(y, C.c_double))
+    return y
+
+
+def fbm_cprodVec(G, x, ind_row=None, ind_col=None):
+    """bigstatsr::big_cprodVec without centre / scale: z = G[ir, ic]' x (orc_fbm_cprodVec)"""
+    ir = np.arange(G.n, dtype=np.int64) if ind_row is None else _i64(ind_row)
+    ic = np.arange(G.m, dtype=np.int64) if ind_col is None else _i64(ind_col)
+    x, flat, z = _f64(x), G.flat(), np.empty(ic.size)
+    lib().orc_fbm_cprodVec(_p(flat, C.c_uint8), C.c_int64(G.n), _p(G.code256, C.c_double), _p(ir, C.c_int64),
+                           C.c_int64(ir.size), _p(ic, C.c_int64), C.c_int64(ic.size), _p(x, C.c_double),
+                           _p(z, C.c_double))
+    return z
+
+
 def prodVecRev(G, betas_col, same_col, ind_row, ind_col):
     """R/PRS.R:3-7"""
     betas_col = _f64(betas_col)

@@ -1,0 +1,180 @@
+"""FBM.code256 objects on the device: the byte-per-genotype matrix with any of
+the reference's decode tables (R/bigSNP-class.R:7-13).
+
+* CODE_012 / CODE_IMPUTE_PRED decode to genotype calls: 2-bit image, every snp_* function.
+* CODE_DOSAGE decodes to a grid of dosages: byte image (one int8 grid index per genotype, exact integer
+  sums) for snp_colstats, big_prodVec / big_cprodVec (bigstatsr, external: restated as the plain products
+  on decoded values, oracle/bsn_oracle.c:orc_fbm_*), snp_PRS and big_randomSVD.
+Parity bar: 1e-9 relative (north_star: 1e-6), indices sampled with replacement as the reference's tests do."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ba():
+    import bigsnpr_amd
+    return bigsnpr_amd
+
+
+def _close(got, ref, tol=1e-9):
+    scale = np.nanmax(np.abs(ref)) if np.size(ref) else 1.0
+    np.testing.assert_allclose(got, ref, rtol=0, atol=tol * max(scale, 1e-300))
+
+
+def _dosage_bytes(rng, n, m, with_na):
+    """bytes the way bigsnpr writes imputed data: calls 0-2, imputed calls 4-6, dosages 7-207; 3 = missing"""
+    a = rng.integers(7, 208, size=(n, m), dtype=np.int64)
+    calls = rng.random((n, m)) < 0.3
+    a[calls] = rng.integers(0, 3, size=int(calls.sum()))
+    imp = rng.random((n, m)) < 0.1
+    a[imp] = rng.integers(4, 7, size=int(imp.sum()))
+    if with_na:
+        a[rng.random((n, m)) < 0.02] = 3
+        a[:, 5] = 3                      # an all-missing variant
+    return a.astype(np.uint8)
+
+
+@pytest.mark.parametrize("n,m", [(517, 300), (1003, 777), (64, 130)])
+def test_dosage_colstats_and_products(ba, orc, n, m):
+    rng = np.random.default_rng(n + m)
+    raw = _dosage_bytes(rng, n, m, with_na=False)
+    Go = orc.FBM256(raw, ba.CODE_DOSAGE)
+    G = ba.FBM_code256(raw, ba.CODE_DOSAGE)
+    assert G.bits == 8 and not G._has_na
+    ir = rng.choice(n, n // 2, replace=True)
+    ic = rng.choice(m, m // 2, replace=True)
+    for rows, cols in ((None, None), (ir, ic)):
+        st, ref = ba.snp_colstats(G, rows, cols), orc.snp_colstats(Go, rows, cols)
+        _close(st["sumX"], ref["sumX"], 1e-12)
+        _close(st["denoX"], ref["denoX"], 1e-9)
+        nr, nc = (n if rows is None else rows.size), (m if cols is None else cols.size)
+        x, y = rng.normal(size=nc), rng.normal(size=nr)
+        rr = np.arange(n) if rows is None else rows
+        cc = np.arange(m) if cols is None else cols
+        _close(ba.big_prodVec(G, x, rows, cols), orc.fbm_prodVec(Go, x, rr, cc))
+        _close(ba.big_cprodVec(G, y, rows, cols), orc.fbm_cprodVec(Go, y, rr, cc))
+        # centre / scale: ((X - c) / s) x  ==  X (x / s) - sum(c x / s)
+        c, s = rng.normal(size=nc), rng.uniform(0.5, 2.0, size=nc)
+        _close(ba.big_prodVec(G, x, rows, cols, c, s), orc.fbm_prodVec(Go, x / s, rr, cc) - np.sum(c * x / s))
+        _close(ba.big_cprodVec(G, y, rows, cols, c, s), (orc.fbm_cprodVec(Go, y, rr, cc) - c * y.sum()) / s)
+    maf, af = ba.snp_MAF(G), orc.snp_colstats(Go)["sumX"] / (2.0 * n)
+    _close(maf, np.minimum(af, 1 - af), 1e-12)
+
+
+def test_dosage_with_missing_values(ba, orc):
+    """the accessor of the reference has no missing-value handling (src/colstats.cpp:14-27): a column
+    with a missing code has NA statistics, and the bigstatsr products would be NA: the GPU path says so"""
+    rng = np.random.default_rng(3)
+    n, m = 400, 90
+    raw = _dosage_bytes(rng, n, m, with_na=True)
+    Go, G = orc.FBM256(raw, ba.CODE_DOSAGE), ba.FBM_code256(raw, ba.CODE_DOSAGE)
+    assert G.bits == 8 and G._has_na
+    st, ref = ba.snp_colstats(G), orc.snp_colstats(Go)
+    bad = (raw == 3).any(axis=0)
+    assert np.isnan(st["sumX"][bad]).all() and np.isnan(ref["sumX"][bad]).all()
+    _close(st["sumX"][~bad], ref["sumX"][~bad], 1e-12)
+    _close(st["denoX"][~bad], ref["denoX"][~bad], 1e-9)
+    with pytest.raises(ValueError, match="missing values"):
+        ba.big_prodVec(G, np.ones(m))
+    # the library itself treats a missing value as "contributes nothing" (mean-imputed after centring),
+    # like bedAccScaled: checked against the oracle on the complete columns + explicit zeros
+    ok = np.nonzero(~bad)[0]
+    from bigsnpr_amd.bed import bed_prodVec, bed_cprodVec
+    x, y = rng.normal(size=ok.size), rng.normal(size=n)
+    dec = ba.CODE_DOSAGE[raw[:, ok]]
+    c = np.nanmean(dec, axis=0)
+    A = np.where(np.isnan(dec), 0.0, dec - c)
+    _close(bed_prodVec(G._bed, x, None, ok, c, None), A @ x)
+    _close(bed_cprodVec(G._bed, y, None, ok, c, None), A.T @ y)
+
+
+def test_dosage_prs_and_svd(ba, orc):
+    rng = np.random.default_rng(11)
+    n, m = 700, 1500
+    # dosages around planted population structure so that the spectrum has a gap
+    pop = rng.integers(0, 3, size=n)
+    f = rng.uniform(0.1, 0.9, size=(3, m))
+    dos = np.clip(np.round((2 * f[pop] + 0.15 * rng.normal(size=(n, m))) * 100), 0, 200).astype(np.int64)
+    raw = (dos + 7).astype(np.uint8)
+    Go, G = orc.FBM256(raw, ba.CODE_DOSAGE), ba.FBM_code256(raw, ba.CODE_DOSAGE)
+    betas = rng.normal(size=m)
+    same = rng.random(m) < 0.7
+    lp = rng.uniform(0, 6, size=m)
+    got = ba.snp_PRS(G, betas, same_keep=same, lpS_keep=lp, thr_list=[1, 3, 5])
+    ref = orc.snp_PRS(Go, betas, same_keep=same, lpS_keep=lp, thr_list=[1, 3, 5])
+    _close(got, ref)
+    res = ba.big_randomSVD(G, ba.snp_scaleBinom(), k=5, tol=1e-10, slices=7)
+    dec = ba.CODE_DOSAGE[raw]
+    af = dec.sum(0) / (2.0 * n)
+    A = (dec - 2 * af) / np.sqrt(2 * af * (1 - af))
+    d = np.linalg.svd(A, compute_uv=False)[:5]
+    np.testing.assert_allclose(res["d"], d, rtol=1e-9)
+    # default settings (16-bit panels): singular values within the north_star bar
+    res = ba.big_randomSVD(G, ba.snp_scaleBinom(), k=5)
+    np.testing.assert_allclose(res["d"], d, rtol=1e-6)
+
+
+def test_code_tables(ba, orc, golden_dir, example_bed):
+    """CODE_IMPUTE_PRED (bytes 4-6 are imputed calls) shares the 2-bit image with CODE_012; a table that
+    is neither calls nor a grid is refused"""
+    G012 = orc.fbm_from_bed(example_bed)
+    raw = G012.bytes.copy()
+    flip = np.random.default_rng(0).random(raw.shape) < 0.3
+    raw[flip] += 4                                    # 0,1,2 -> 4,5,6: same decoded values
+    G = ba.FBM_code256(raw, ba.CODE_IMPUTE_PRED)
+    assert G.bits == 2
+    ref = orc.snp_colstats(G012)
+    st = ba.snp_colstats(G)
+    np.testing.assert_array_equal(st["sumX"], ref["sumX"])
+    np.testing.assert_array_equal(st["denoX"], ref["denoX"])
+    bad = np.full(256, np.nan)
+    bad[:4] = [0.0, 1.0, np.pi, 2.0]
+    with pytest.raises(ba.BsnError, match="not supported on the GPU"):
+        ba.FBM_code256(raw[:50, :50] % 4, bad)
+    # what the byte image cannot do says so
+    Gd = ba.FBM_code256((raw[:60, :80] % 3 + 7).astype(np.uint8), ba.CODE_DOSAGE)
+    with pytest.raises(ba.BsnError, match="2-bit genotype image"):
+        ba.snp_cor(Gd)
+
+
+def test_fbm_products_on_calls_with_replacement(ba, orc, example_bed):
+    """a9 on the CODE_012 image: big_prodVec / big_cprodVec == the plain products on decoded values
+    (oracle), rows and columns sampled WITH replacement, with and without centre / scale"""
+    Go = orc.fbm_from_bed(example_bed)
+    G = ba.FBM_code256(Go.bytes)
+    rng = np.random.default_rng(8)
+    n, m = Go.n, Go.m
+    ir, ic = rng.choice(n, 300, replace=True), rng.choice(m, 2000, replace=True)
+    x, y = rng.normal(size=ic.size), rng.normal(size=ir.size)
+    _close(ba.big_prodVec(G, x, ir, ic), orc.fbm_prodVec(Go, x, ir, ic))
+    _close(ba.big_cprodVec(G, y, ir, ic), orc.fbm_cprodVec(Go, y, ir, ic))
+    c, s = rng.normal(size=ic.size), rng.uniform(0.5, 2, size=ic.size)
+    _close(ba.big_prodVec(G, x, ir, ic, c, s), orc.fbm_prodVec(Go, x / s, ir, ic) - np.sum(c * x / s))
+    _close(ba.big_cprodVec(G, y, ir, ic, c, s), (orc.fbm_cprodVec(Go, y, ir, ic) - c * y.sum()) / s)
+    _close(ba.big_cprodVec(G, np.ones(n)), orc.snp_colstats(Go)["sumX"], 1e-12)
+
+
+def test_c2_fbm_ingest_at_full_size(ba):
+    """config C2: a 50 000 x 200 000 FBM.code256 (10 GB at one byte per genotype) really goes through
+    bsn_fbm_open — pinned double-buffered upload, repack to the 2-bit image on the device — and the image
+    equals the one the generator writes directly (the bytes are its decoded genotypes)."""
+    n, m = 50000, 200000
+    ref = ba.bed.synthetic(n, m, seed=77)
+    chunk = 20000
+    raw = np.empty((n, m), dtype=np.uint8, order="F")
+    for j in range(0, m, chunk):
+        raw[:, j:j + chunk] = ba.bed_to_bytes(ref, None, np.arange(j, min(m, j + chunk)))
+    import time
+    t0 = time.perf_counter()
+    G = ba.FBM_code256(raw)
+    dt = time.perf_counter() - t0
+    assert G.bits == 2
+    np.testing.assert_array_equal(ba.bed_counts(G._bed), ba.bed_counts(ref))
+    rng = np.random.default_rng(0)
+    y = rng.normal(size=n)
+    np.testing.assert_array_equal(ba.bed_cprodVec(G._bed, y), ba.bed_cprodVec(ref, y))
+    cols = rng.choice(m, 300, replace=False)
+    np.testing.assert_array_equal(ba.read_bed(G._bed, np.arange(n), cols), ba.read_bed(ref, np.arange(n), cols))
+    print("C2 FBM ingest: %.2f s for %.1f GB (%.1f GB/s)" % (dt, n * m / 1e9, n * m / 1e9 / dt))

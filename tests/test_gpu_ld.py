@@ -142,3 +142,43 @@ def test_ld_errors(ba, golden_dir):
         ba.bed_cor(gb, infos_pos=np.arange(gb.ncol)[::-1])
     with pytest.raises(ba.BsnError, match="duplicated"):
         ba.bed_cor(gb, ind_row=np.array([0, 1, 1, 2]))
+
+
+def test_clumping_at_a_threshold_that_sits_on_a_pair(ba, orc, golden_dir, missing_bed):
+    """bed_clumping_chr decides `r2 > thr` per pair (src/clumping-bed.cpp:69-76).  The reference
+    accumulates r over the samples in fp64 (error ~1e-13 relative); the GPU evaluates it from exact
+    integer plane sums.  With the threshold placed ON the r2 of a pair that decides a variant's fate, the
+    two sides of it must both agree with the oracle at a margin a thousand times that rounding noise;
+    exactly on it, either side's answer is legitimate (it is a rounding-level tie)."""
+    path = os.path.join(golden_dir, "example-missing.bed")
+    gb = ba.bed(path)
+    chrom, pos = orc.read_bim(path)
+    n, m = missing_bed.n, missing_bed.m
+    # the scaled matrix of the reference (missing -> 0) and r2 of all pairs in its window, as it computes them
+    st = orc.bed_colstats(missing_bed)
+    center, scale = st["sumX"] / st["nb_nona_col"], np.sqrt(st["denoX"])
+    g = orc.read_bed(missing_bed, na_val=-1).astype(np.float64)
+    A = np.where(g < 0, 0.0, (g - center) / scale)
+    base = orc.bed_clumping(missing_bed, chrom, pos, thr_r2=0.2)
+    # pairs (kept variant, pruned neighbour): their r2 exceeded 0.2 — pick a few and put the threshold on them
+    pruned = np.setdiff1d(np.arange(m), base)
+    rng = np.random.default_rng(0)
+    tested = 0
+    for j0 in rng.permutation(pruned)[:40]:
+        near = base[(chrom[base] == chrom[j0]) & (np.abs(pos[base] - pos[j0]) <= 500e3)]
+        if near.size == 0:
+            continue
+        r2 = np.array([np.sum(A[:, j] * A[:, j0]) ** 2 for j in near])
+        t = float(r2.max())
+        if not (0.2 < t < 0.95):
+            continue
+        for thr in (t * (1 - 1e-10), t * (1 + 1e-10)):
+            np.testing.assert_array_equal(ba.bed_clumping(gb, thr_r2=thr, size=500),
+                                          orc.bed_clumping(missing_bed, chrom, pos, thr_r2=thr, size=500))
+        on = ba.bed_clumping(gb, thr_r2=t, size=500)
+        sides = [orc.bed_clumping(missing_bed, chrom, pos, thr_r2=x, size=500) for x in (t * (1 - 1e-10), t * (1 + 1e-10))]
+        assert any(np.array_equal(on, s_) for s_ in sides)
+        tested += 1
+        if tested == 4:
+            break
+    assert tested >= 2

@@ -234,3 +234,22 @@ def test_fake_bed_is_deterministic_and_structured(orc):
     counts = orc.bed_col_counts(b1)
     assert 0.001 < counts[3].sum() / (403 * 257) < 0.03   # ~1 % missing
     assert counts[:3].min(1).min() >= 0 and (counts[1] > 0).mean() > 0.9
+
+
+def test_fbm_products_are_the_plain_definition(orc, example_bed):
+    """orc_fbm_prodVec / orc_fbm_cprodVec (bigstatsr's products are external: restated as y = G x, z = G' x
+    on decoded values) against numpy on the decoded matrix, for CODE_012 and a dosage table, with
+    indices sampled with replacement"""
+    rng = np.random.default_rng(1)
+    G = orc.fbm_from_bed(example_bed)
+    dosage = np.array([0, 1, 2, np.nan, 0, 1, 2] + list(np.round(np.arange(201) * 0.01, 2)) + [np.nan] * 48)
+    raw = rng.integers(7, 208, size=(120, 90)).astype(np.uint8)
+    for obj, dec in ((G, G.bytes.astype(np.float64)), (orc.FBM256(raw, dosage), dosage[raw])):
+        ir, ic = rng.choice(obj.n, 70, replace=True), rng.choice(obj.m, 60, replace=True)
+        x, y = rng.normal(size=ic.size), rng.normal(size=ir.size)
+        A = dec[np.ix_(ir, ic)]
+        np.testing.assert_allclose(orc.fbm_prodVec(obj, x, ir, ic), A @ x, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(orc.fbm_cprodVec(obj, y, ir, ic), A.T @ y, rtol=1e-12, atol=1e-12)
+        st = orc.snp_colstats(obj, ir, ic)
+        np.testing.assert_allclose(st["sumX"], A.sum(0), rtol=1e-12)
+        np.testing.assert_allclose(st["denoX"], (A * A).sum(0) - A.sum(0) ** 2 / ir.size, rtol=1e-9, atol=1e-9)
