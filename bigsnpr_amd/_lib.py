@@ -58,6 +58,7 @@ SIGNATURES = {
     "bsn_bed_from_fbm": (C.c_int, [u8p, i64, i64, i64, C.POINTER(vp)]),
     "bsn_fbm_open": (C.c_int, [u8p, i64, i64, i64, f64p, C.POINTER(vp)]),
     "bsn_bed_bits": (C.c_int, [vp]),
+    "bsn_bed_na_known": (i64, [vp]),
     "bsn_bed_synthetic": (C.c_int, [i64, i64, C.c_uint32, C.c_uint32, C.c_uint32, i64, C.POINTER(vp)]),
     "bsn_bed_close": (C.c_int, [vp]),
     "bsn_bed_release_workspace": (C.c_int, [vp]),

@@ -105,54 +105,71 @@ def rollmean(x, size):
 
 
 def medcouple(x):
-    """Medcouple (Brys, Hubert & Struyf 2004) by bisection on the kernel value: the kernel
-    h(xi, xj) = ((xi - med) - (med - xj)) / (xi - xj), xi >= med >= xj, is monotone in both
-    arguments, so #{h <= t} is a sum of searchsorted counts."""
+    """Medcouple (Brys, Hubert & Struyf 2004): the median of the kernel
+        h(xi, xj) = ((xi - med) - (med - xj)) / (xi - xj),   xi >= med >= xj,
+    over all such pairs; for pairs tied AT the median (xi = xj = med) the kernel is defined through
+    their order among the m ties, h = sign(m - 1 - i - j) with i, j the positions among the tied values
+    on each side (the convention of robustbase::mc and of the original paper).  The kernel is monotone
+    in both arguments, so #{h <= t} is a sum of searchsorted counts and the median is found by bisection
+    on t, followed by a snap to the nearest attained kernel value (the median IS a kernel value)."""
     x = np.sort(np.asarray(x, dtype=np.float64))
     n = x.size
     if n < 3:
         return 0.0
     med = np.median(x)
-    up = x[x >= med] - med          # >= 0, ascending
-    lo = (med - x[x <= med])[::-1]  # >= 0, ascending
+    up = x[x >= med] - med          # zi+ >= 0, ascending
+    lo = (med - x[x <= med])[::-1]  # zj- >= 0 ... as positive distances, ascending
     if up[-1] == 0 or lo[-1] == 0:
         return 0.0 if up[-1] == lo[-1] else (1.0 if lo[-1] == 0 else -1.0)
-    total = up.size * lo.size
+    upp, lop = up[up > 0], lo[lo > 0]
+    k0 = int(np.sum(up == 0))       # number of values tied at the median (the same on both sides)
+    # kernel values of the pairs that involve a tie, as explicit lists (few):
+    #   (u > 0, l = 0): h = +1;  (u = 0, l > 0): h = -1;  (u = 0, l = 0): sign(k0 - 1 - i - j)
+    n_plus = upp.size * k0
+    n_minus = k0 * lop.size
+    ii, jj = np.meshgrid(np.arange(k0), np.arange(k0), indexing="ij")
+    tie = np.sign(k0 - 1 - ii - jj).ravel() if k0 else np.zeros(0)
+    total = upp.size * lop.size + n_plus + n_minus + tie.size
 
-    upp = up[up > 0]
-    n0u, n0l = int(np.sum(up == 0)), int(np.sum(lo == 0))   # elements equal to the median
+    def count_le(t):  # number of pairs with h <= t
+        if t >= 1:
+            return total
+        if t < -1:
+            return 0
+        # regular pairs: (u - l) / (u + l) <= t  <=>  l >= u (1 - t) / (1 + t)
+        c = 0
+        if t > -1:
+            thr = upp * (1 - t) / (1 + t)
+            c = int(np.sum(lop.size - np.searchsorted(lop, thr, side="left")))
+        return c + n_minus + int(np.sum(tie <= t))       # the +1 pairs only at t >= 1
 
-    def count_le(t):  # pairs with (u - l) / (u + l) <= t  <=>  l >= u (1 - t) / (1 + t)
-        thr = upp * (1 - t) / (1 + t)
-        c = int(np.sum(lo.size - np.searchsorted(lo, thr, side="left")))
-        # rows with u == med: h = -1 against every l > 0, and 0 against l == med (the kernel
-        # of tied medians is taken as 0, exact for the single tie of an odd-length sample)
-        c += n0u * (lo.size - n0l) + (n0u * n0l if t >= 0 else 0)
-        return c
+    def kth(k):  # k-th smallest kernel value (1-based) by bisection, then snapped to an attained value
+        a, b = -1.0, 1.0
+        if count_le(-1.0) >= k:
+            return -1.0
+        for _ in range(200):
+            mid = 0.5 * (a + b)
+            if count_le(mid) >= k:
+                b = mid
+            else:
+                a = mid
+            if b - a < 1e-15:
+                break
+        # attained values near b: ties give exactly -1, 0, +1; regular pairs (u - l) / (u + l)
+        cand = [v for v in (-1.0, 0.0, 1.0) if abs(v - b) < 1e-9]
+        if upp.size and lop.size:
+            # for each u the l that brings the kernel closest to b
+            l_star = upp * (1 - b) / (1 + b) if b > -1 else np.full(upp.size, np.inf)
+            idx = np.clip(np.searchsorted(lop, l_star), 0, lop.size - 1)
+            for d in (-1, 0):
+                l = lop[np.clip(idx + d, 0, lop.size - 1)]
+                cand.extend(((upp - l) / (upp + l)).tolist())
+        cand = np.asarray(cand)
+        return float(cand[np.argmin(np.abs(cand - b))])
 
-    k = (total + 1) // 2  # lower median rank
-    a, b = -1.0, 1.0
-    for _ in range(100):
-        mid = 0.5 * (a + b)
-        if count_le(mid) >= k:
-            b = mid
-        else:
-            a = mid
-        if b - a < 1e-14:
-            break
     if total % 2 == 1:
-        return b
-    # even number of pairs: average the two middle order statistics
-    a2, b2 = b, 1.0
-    for _ in range(100):
-        mid = 0.5 * (a2 + b2)
-        if count_le(mid) >= k + 1:
-            b2 = mid
-        else:
-            a2 = mid
-        if b2 - a2 < 1e-14:
-            break
-    return 0.5 * (b + b2)
+        return kth((total + 1) // 2)
+    return 0.5 * (kth(total // 2) + kth(total // 2 + 1))
 
 
 def tukey_mc_up(x, coef=None, alpha=0.05, a=-4.0, b=3.0):

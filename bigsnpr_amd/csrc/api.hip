@@ -35,8 +35,15 @@ static void require_gpu() {
          e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
 }
 
+// a NULL index list means the first `len` rows / columns, everywhere in this ABI
 static std::vector<int32_t> to_i32(const int64_t *ind, int64_t len, int64_t limit, const char *what) {
   std::vector<int32_t> v((size_t)len);
+  if (!ind) {
+    if (len > limit)
+      fail("Tested %lld < %lld. Subscript out of bounds (%s).", (long long)(len - 1), (long long)limit, what);
+    for (int64_t i = 0; i < len; i++) v[(size_t)i] = (int32_t)i;
+    return v;
+  }
   for (int64_t i = 0; i < len; i++) {
     if (ind[i] < 0 || ind[i] >= limit)
       // bigstatsr vec_int_to_size(): "Tested %s < %s. Subscript out of bounds."
@@ -108,7 +115,9 @@ void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n, const 
   op->bed = bed;
   op->n = n;
   op->m = m;
-  // rows
+  // rows (NULL: the first n)
+  if (!ind_row && n > bed->n)
+    fail("Tested %lld < %lld. Subscript out of bounds (ind.row).", (long long)(n - 1), (long long)bed->n);
   bool ident = (n == bed->n);
   if (ind_row) {
     for (int64_t i = 0; ident && i < n; i++) ident = (ind_row[i] == i);
@@ -165,7 +174,7 @@ void counts_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t 
     counts_all_rows(bed, op.cols_contig ? nullptr : op.d_cols.p, op.col0, m, d_counts.p);
   } else {
     std::vector<double> w((size_t)bed->n, 0.0);
-    for (int64_t i = 0; i < n; i++) w[(size_t)ind_row[i]] += 1.0;
+    for (int64_t i = 0; i < n; i++) w[(size_t)(ind_row ? ind_row[i] : i)] += 1.0;
     DevBuf<double> d_w;
     copy_h2d(bed, d_w.ensure((size_t)bed->n), w.data(), (size_t)bed->n * 8);
     counts_weighted(&op, d_w.p, n, d_counts.p);
@@ -330,6 +339,16 @@ int bsn_fbm_open(const uint8_t *bytes, int64_t n, int64_t m, int64_t ld, const d
 }
 
 int bsn_bed_bits(const bsn_bed *bed) { return bed->bits; }
+
+int64_t bsn_bed_na_known(const bsn_bed *bed) {
+  if ((int64_t)bed->na_cnt.size() != bed->m) return -1;
+  int64_t tot = 0;
+  for (int32_t c : bed->na_cnt) {
+    if (c < 0) return -1;
+    tot += c;
+  }
+  return tot;
+}
 
 int bsn_bed_synthetic(int64_t n, int64_t m, uint32_t seed, uint32_t npop, uint32_t na16,
                       int64_t j_begin, bsn_bed **out) {

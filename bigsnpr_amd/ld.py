@@ -40,7 +40,7 @@ class FBM_code256:
                                        ptr(code, f64p), C.byref(h)))
         self._bed = bed(_handle=h, _n=self.nrow, _m=self.ncol)
         self.bits = int(_lib.load().bsn_bed_bits(h))
-        self._has_na = bool(np.isnan(code[np.unique(a)]).any())
+        self._has_na = int(_lib.load().bsn_bed_na_known(h)) != 0   # counted on the device at creation
 
     @property
     def handle(self):

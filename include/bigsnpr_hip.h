@@ -64,6 +64,9 @@ int bsn_bed_from_fbm(const uint8_t *bytes, int64_t n, int64_t m, int64_t ld, bsn
  * message.  Any other table is refused. */
 int bsn_fbm_open(const uint8_t *bytes, int64_t n, int64_t m, int64_t ld, const double *code256, bsn_bed **out);
 int bsn_bed_bits(const bsn_bed *bed); /* 2 or 8 */
+/* total number of missing genotypes of the image if a full count has seen every variant (FBM handles
+ * know it from their creation), -1 otherwise */
+int64_t bsn_bed_na_known(const bsn_bed *bed);
 /* synthetic matrix generated directly in HBM (DESIGN.md "Synthetic inputs");
  * byte-identical to oracle/bsn_oracle.c:orc_fake_bed */
 int bsn_bed_synthetic(int64_t n, int64_t m, uint32_t seed, uint32_t npop, uint32_t na16,

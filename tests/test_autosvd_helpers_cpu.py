@@ -92,3 +92,60 @@ def test_get_intervals():
                                   [[1, 3], [9, 10], [20, 23]])
     assert A.getIntervals(np.array([5]), n=2).shape == (0, 2)
     assert A.getIntervals(np.array([1, 3, 5]), n=2).shape == (0, 2)
+
+
+# ---- worked values from the publications / manuals the restatements follow -------------------------
+def test_medcouple_worked_examples():
+    """robustbase::mc help page (the implementation bigutilsr calls): mc(1:5) is 0 for a symmetric
+    sample and mc(c(1, 2, 7, 9, 10)) = -1/3 — by the kernel of Brys, Hubert & Struyf (2004), J. Comput.
+    Graph. Statist. 13(4), eq. (2.2): the nine values -1, -1, -1/2, -3/7, -1/3, -1/4, 0, 1, 1 have median
+    -1/3.  Ties at the median follow the paper's rule h = sign(m - 1 - i - j) (its section 2.1): on
+    (1, 2, 2, 2, 3, 5, 9) the brute-force median of all 4 x 5 kernel values is 0.875."""
+    assert A.medcouple(np.arange(1, 6)) == 0.0
+    assert abs(A.medcouple([1, 2, 7, 9, 10]) + 1.0 / 3.0) < 1e-12
+    assert abs(A.medcouple([1, 2, 2, 2, 3, 5, 9]) - 0.875) < 1e-12
+    # a sample and its mirror image have opposite medcouples (the paper's property 2)
+    x = np.array([0.3, 0.9, 1.4, 2.2, 2.3, 4.0, 7.5, 11.0])
+    assert abs(A.medcouple(x) + A.medcouple(-x)) < 1e-12
+    # location and scale invariance (property 1)
+    assert abs(A.medcouple(3.0 + 2.5 * x) - A.medcouple(x)) < 1e-12
+
+
+def test_adjusted_boxplot_fence_worked_example():
+    """Hubert & Vandervieren (2008), Comput. Statist. Data Anal. 52, eq. (5): upper fence
+    Q3 + 1.5 exp(3 MC) IQR for MC >= 0 and Q3 + 1.5 exp(4 MC) IQR for MC < 0.  On (1, 2, 7, 9, 10):
+    Q1 = 2, Q3 = 9 (type-7 quantiles), MC = -1/3  ->  9 + 1.5 exp(-4/3) 7 = 11.76779..."""
+    assert abs(A.tukey_mc_up([1, 2, 7, 9, 10], coef=1.5) - (9 + 10.5 * np.exp(-4.0 / 3.0))) < 1e-12
+    x = [1, 2, 2, 2, 3, 5, 9]                                    # MC = 0.875 >= 0
+    q1, q3 = np.quantile(x, [0.25, 0.75])
+    assert abs(A.tukey_mc_up(x, coef=1.5) - (q3 + 1.5 * np.exp(3 * 0.875) * (q3 - q1))) < 1e-12
+
+
+def test_tau_scale_properties_of_maronna_zamar():
+    """Maronna & Zamar (2002), Technometrics 44(4), section 2: the tau-scale with c1 = 4.5, c2 = 3 is
+    affine equivariant and Fisher-consistent at the normal; robustbase::scaleTau2 (consistency = TRUE)
+    divides by E[rho_c2] accordingly.  On the quantile grid of N(0, 1) (no sampling noise) it returns
+    1 within the discretisation error, and mu is the centre of symmetry."""
+    from scipy.stats import norm
+    z = norm.ppf((np.arange(1, 20002) - 0.5) / 20001)
+    mu, s = A.scale_tau2(z, mu_too=True)
+    assert abs(s - 1.0) < 2e-3 and abs(mu) < 1e-10
+    mu2, s2 = A.scale_tau2(5.0 - 3.0 * z, mu_too=True)
+    assert abs(s2 - 3.0 * s) < 1e-9 and abs(mu2 - 5.0) < 1e-9
+    assert A.scale_tau2(np.array([2.0, 2.0, 2.0, 2.0, 7.0])) == 0.0     # MAD = 0 -> scale 0 (robustbase returns 0)
+
+
+def test_rollmean_invariants():
+    """bigutilsr::rollmean (Privé et al. 2020, Bioinformatics 36(16), 'Efficient toolkit implementing best
+    practices for PCA of population genetic data', section 2.2: Gaussian-weighted rolling mean used to
+    smooth the outlier statistic along the genome): weights are positive and symmetric, so constants are
+    preserved, size = 0 is the identity, a linear trend is preserved away from the edges, and the output
+    never leaves the range of the input."""
+    x = np.linspace(-3, 5, 400)
+    for size in (1, 5, 20):
+        y = A.rollmean(x, size)
+        np.testing.assert_allclose(y[size:-size], x[size:-size], atol=1e-12)
+        assert y.min() >= x.min() - 1e-12 and y.max() <= x.max() + 1e-12
+        np.testing.assert_allclose(A.rollmean(np.full(100, 2.5), size), 2.5, rtol=1e-15)
+    r = np.random.default_rng(0).normal(size=100)
+    assert A.rollmean(r, 0) is r or np.array_equal(A.rollmean(r, 0), r)

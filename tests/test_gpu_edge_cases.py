@@ -196,3 +196,28 @@ def test_more_than_65535_variants_through_every_upload_path(ba, orc, tmp_path):
     np.testing.assert_array_equal(ba.bed_counts(gm), ref_counts)
     cols = np.array([0, 65534, 65535, 65536, m - 1])
     np.testing.assert_array_equal(ba.read_bed(gb, np.arange(n), cols), orc.read_bed(ob, None, cols))
+
+
+def test_null_index_lists_mean_the_leading_rows_and_columns(ba, orc):
+    """every entry point of the C ABI reads a NULL ind_row / ind_col as 'the first n / m' (never a
+    dereference), also when n is smaller than the matrix; too large an n is the subscript error"""
+    import ctypes as C
+    from bigsnpr_amd import _lib
+    from bigsnpr_amd._lib import f64p, i32p, ptr
+    L = _lib.load()
+    n, m, ns, ms = 203, 150, 77, 60
+    ob = orc.fake_bed(n, m, seed=2)
+    gb = ba.bed.from_payload(ob.payload, n, m)
+    ir, ic = np.arange(ns), np.arange(ms)
+    cnt = np.empty((ms, 4), dtype=np.int32)
+    _lib.check(L.bsn_bed_col_counts(gb.handle, None, ns, None, ms, ptr(cnt, i32p)))
+    np.testing.assert_array_equal(cnt.T, orc.bed_col_counts(ob, ir, ic))
+    x, y = np.random.default_rng(0).normal(size=ms), np.empty(ns)
+    _lib.check(L.bsn_bed_prodvec(gb.handle, None, ns, None, ms, None, None, ptr(x, f64p), ptr(y, f64p)))
+    ref = orc.bed_prodVec(ob, x, ir, ic, np.zeros(ms), np.ones(ms))
+    np.testing.assert_allclose(y, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    out = np.empty((ms, ns), dtype=np.int32)
+    _lib.check(L.bsn_bed_read(gb.handle, None, ns, None, ms, -1, ptr(out, i32p)))
+    np.testing.assert_array_equal(out.T, orc.read_bed(ob, ir, ic, na_val=-1))
+    assert L.bsn_bed_col_counts(gb.handle, None, n + 1, None, ms, ptr(cnt, i32p)) != 0
+    assert b"Subscript out of bounds" in L.bsn_last_error()
