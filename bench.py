@@ -186,10 +186,12 @@ def main():
     bytes_per_launch = ((n + 3) // 4) * m_local               # algorithmic: 2-bit payload of the shard
     kern = {}
     for key, name in (("prod", "k_prod (A~ panel, contraction over variants)"),
-                      ("cprod", "k_cprod (A~' panel, contraction over samples)")):
+                      ("cprod", "k_cprod (A~' panel, contraction over samples)"),
+                      ("cprod_stats", "k_cprod<STATS> (first A~' pass of a solve: also counts the codes of every variant)")):
         ms = sum(r[key + "_ms"] for r in infos)
         cnt = sum(r["n_" + key] for r in infos)
-        kern[key] = dict(name=name, total_ms=ms, launches=cnt, avg_ms=ms / max(cnt, 1))
+        if cnt:
+            kern[key] = dict(name=name, total_ms=ms, launches=cnt, avg_ms=ms / cnt)
     dom_key = max(kern, key=lambda k_: kern[k_]["total_ms"])
     dom = kern[dom_key]
     # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside

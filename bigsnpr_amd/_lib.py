@@ -35,7 +35,8 @@ class SvdInfo(C.Structure):
                 ("converged", C.c_int32), ("max_rel_resid", C.c_double), ("gpu_ms", C.c_double),
                 ("cprod_ms", C.c_double), ("prod_ms", C.c_double), ("n_cprod", C.c_int32),
                 ("n_prod", C.c_int32), ("block", C.c_int32), ("slices", C.c_int32),
-                ("n_bad", C.c_int32), ("fused_stats", C.c_int32)]
+                ("n_bad", C.c_int32), ("fused_stats", C.c_int32), ("cprod_stats_ms", C.c_double),
+                ("n_cprod_stats", C.c_int32)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check that every symbol

@@ -122,7 +122,8 @@ struct bsn_op {
   int64_t col0 = 0;
   int slices = 4;
   int64_t passes = 0;         // streaming launches over the image issued so far
-  // per-launch HIP-event timing of the two streaming kernels (kind 0 = k_cprod, 1 = k_prod)
+  // per-launch HIP-event timing of the streaming kernels (kind 0 = k_cprod, 1 = k_prod, 2 = the k_cprod
+  // launch that also counts the codes, first pass of a solve with fused scaling statistics)
   bool profile = false;
   std::vector<hipEvent_t> ev_begin, ev_end;
   std::vector<int> ev_kind;
@@ -241,6 +242,6 @@ void selftest();
 void prof_begin(bsn_op *op, int kind);
 void prof_end(bsn_op *op);
 // sums the recorded launches: ms[kind], count[kind]; clears the records
-void prof_collect(bsn_op *op, double ms[2], int count[2]);
+void prof_collect(bsn_op *op, double ms[3], int count[3]);  // kind 2: k_cprod carrying the code counts
 
 }  // namespace bsn

@@ -287,6 +287,85 @@ __global__ __launch_bounds__(64) void k_pair_xy64(const uint8_t *__restrict__ im
       }
 }
 
+// Byte image (dosage grid, bsn_bed::bits == 8): the cross product of the grid indices, sum_i k_i k'_i,
+// for a 64 x 64 tile pair.  The loaded bytes are the MFMA operands (no decode; `rowmask` zeroes the
+// samples that are not selected, and the pad samples).  |k| <= 127, so one int32 accumulator holds at most
+// 131 072 samples: the sample range is cut into slices of that size, slice s of a pair accumulates into
+// plane s of its statistics block (atomics over the K splits inside a slice), and the fill kernel adds
+// the slices in fp64 (exact).  Only data without missing values take this path.
+__global__ __launch_bounds__(64) void k_pair_xy8(const uint8_t *__restrict__ img, int64_t pitch,
+                                                 const int32_t *__restrict__ cols,
+                                                 const int2 *__restrict__ pairs,
+                                                 const uint8_t *__restrict__ rowmask, int64_t kbytes_per_split,
+                                                 int splits_per_slice, int32_t *__restrict__ stats) {
+  const int lane = threadIdx.x;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int2 pr = pairs[blockIdx.x];
+  const uint8_t *pa[4], *pb[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    pa[s] = img + (int64_t)cols[pr.x * TB + s * 16 + r16] * pitch + g * 16;
+    pb[s] = img + (int64_t)cols[pr.y * TB + s * 16 + r16] * pitch + g * 16;
+  }
+  const int64_t b0 = (int64_t)blockIdx.y * kbytes_per_split;
+  int64_t b1 = b0 + kbytes_per_split;
+  if (b1 > pitch) b1 = pitch;
+  if (b0 >= b1) return;
+  v4i acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = v4i{0, 0, 0, 0};
+  for (int64_t kb = b0; kb < b1; kb += 64) {  // 64 samples per step
+    const uint4 mk = *(const uint4 *)(rowmask + kb + g * 16);
+    v4i A[4], B[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const uint4 a = *(const uint4 *)(pa[s] + kb), b = *(const uint4 *)(pb[s] + kb);
+      A[s] = v4i{(int)(a.x & mk.x), (int)(a.y & mk.y), (int)(a.z & mk.z), (int)(a.w & mk.w)};
+      B[s] = v4i{(int)(b.x & mk.x), (int)(b.y & mk.y), (int)(b.z & mk.z), (int)(b.w & mk.w)};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i], B[j], acc[i][j], 0, 0, 0);
+  }
+  const int slice = (int)blockIdx.y / splits_per_slice;
+  int32_t *out = stats + ((int64_t)blockIdx.x * 6 + slice) * TB * TB;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) atomicAdd(out + (i * 16 + 4 * g + r) * TB + j * 16 + r16, acc[i][j][r]);
+}
+
+// byte image: band entries from the sliced cross products and the per-variant totals of the grid
+// indices.  Pearson's r is invariant under the affine map value = voff + vstep k, so modes 0 / 1 use the
+// reference's expressions on the exact integer sums of k; mode 2 (clumping_chr: the caller's sumX / denoX
+// are in value units, src/clumping.cpp:66-73) first maps the cross product to value units.
+__global__ void k_band_fill8(const int32_t *__restrict__ stats, int nslice, const int2 *__restrict__ pairs,
+                             int npairs, int64_t m, const int64_t *__restrict__ lo, int64_t W,
+                             const double *__restrict__ thr, int mode, const double *__restrict__ v1,
+                             const double *__restrict__ v2, double nrows, double *__restrict__ band,
+                             const double *__restrict__ cx, const double *__restrict__ cxx, double vstep,
+                             double voff) {
+  const int pi = blockIdx.x;
+  if (pi >= npairs) return;
+  const int2 pr = pairs[pi];
+  const int32_t *st = stats + (int64_t)pi * 6 * TB * TB;
+  for (int e = threadIdx.x; e < TB * TB; e += blockDim.x) {
+    const int row = e / TB, col = e % TB;
+    const int64_t j0 = (int64_t)pr.x * TB + row, j = (int64_t)pr.y * TB + col;
+    if (j0 >= m || j >= j0 || j < lo[j0]) continue;
+    double xy = 0;
+    for (int s = 0; s < nslice; s++) xy += (double)st[(s * TB + row) * TB + col];
+    if (mode == 2) xy = vstep * vstep * xy + voff * (v1[j] + v1[j0]) - nrows * voff * voff;
+    band[j0 * W + (j0 - j - 1)] =
+        pair_value(mode, xy, cx[j0], cxx[j0], cx[j], cxx[j], (int)nrows, thr, v1, v2, j0, j, nrows);
+  }
+}
+
 // second stage of the K-split / cross-product-only paths: statistics buffer -> band entries
 __global__ void k_band_fill(const int32_t *__restrict__ stats, const int2 *__restrict__ pairs,
                             int npairs, int64_t m, const int64_t *__restrict__ lo, int64_t W,
@@ -418,6 +497,7 @@ struct BandJob {
   DevBuf<int2> d_pairs;
   DevBuf<int64_t> d_lo;
   DevBuf<uint32_t> d_mask;
+  DevBuf<uint8_t> d_mask8;  // byte image: 0xFF per selected sample
   DevBuf<double> d_band, d_thr, d_v1, d_v2, d_cx, d_cxx;
   bool complete = false;  // no missing value among the selected samples of the selected variants
   bool use_mask = false;
@@ -447,7 +527,6 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
                        const int64_t *ind_col, int64_t m, const double *pos, double size,
                        bool two_sided = false) {
   if (n <= 0 || m <= 0) fail("'ind.row' and 'ind.col' can't be empty.");
-  require_bits(bed, 2, "windowed LD (snp_cor / snp_ld_scores / snp_clumping)");
   BSN_HIP(hipSetDevice(bed->device));
   J.bed = bed;
   J.n = n;
@@ -467,39 +546,73 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
     cols[(size_t)j] = (int32_t)c;
   }
   BSN_HIP(hipMemcpyAsync(J.d_cols.ensure((size_t)m_pad), cols.data(), (size_t)m_pad * 4, hipMemcpyHostToDevice, bed->stream));
-  // rows: keep-mask, 2 bits per sample (also removes the pad samples, which are coded as
-  // non-missing genotype 0 in the image).  Duplicated rows are not supported on this path.
-  J.use_mask = true;
-  {
-    std::vector<uint32_t> mask((size_t)(bed->pitch / 4), 0u);
+  if (bed->bits == 8) {
+    // byte image: byte mask of the selected samples, per-variant totals of the grid indices over them
+    std::vector<uint8_t> mask((size_t)bed->pitch, 0);
+    std::vector<int32_t> rows32((size_t)n);
+    bool ident = (n == bed->n);
     for (int64_t i = 0; i < n; i++) {
       int64_t r = ind_row ? ind_row[i] : i;
       if (r < 0 || r >= bed->n) fail("Tested %lld < %lld. Subscript out of bounds (ind.row).", (long long)r, (long long)bed->n);
-      uint32_t bit = 3u << (2 * (r & 15));
-      if (mask[(size_t)(r >> 4)] & bit) fail("duplicated 'ind.row' are not supported by the GPU LD path");
-      mask[(size_t)(r >> 4)] |= bit;
+      if (mask[(size_t)r]) fail("duplicated 'ind.row' are not supported by the GPU LD path");
+      mask[(size_t)r] = 0xFF;
+      rows32[(size_t)i] = (int32_t)r;
+      ident = ident && r == i;
     }
-    BSN_HIP(hipMemcpyAsync(J.d_mask.ensure(mask.size()), mask.data(), mask.size() * 4, hipMemcpyHostToDevice, bed->stream));
-    BSN_HIP(hipStreamSynchronize(bed->stream));
-  }
-  // per-variant totals over the selected samples; when nothing is missing there, Sum x, Sum x^2 and
-  // the pair count of every pair are these totals and only the cross product needs the GEMM
-  {
-    std::vector<int32_t> cnt((size_t)4 * m);
-    counts_host(bed, ind_row, n, ind_col, m, cnt.data());
-    int64_t na = 0;
+    copy_h2d(bed, J.d_mask8.ensure(mask.size()), mask.data(), mask.size());
+    DevBuf<int32_t> d_rows;
+    if (!ident) copy_h2d(bed, d_rows.ensure((size_t)n), rows32.data(), (size_t)n * 4);
+    DevBuf<long long> d_st;
+    stats8(bed, ident ? nullptr : d_rows.p, n, J.d_cols.p, 0, m, d_st.ensure((size_t)3 * m));
+    std::vector<long long> st((size_t)3 * m);
+    copy_d2h(bed, st.data(), d_st.p, st.size() * 8);
     std::vector<double> cx((size_t)m), cxx((size_t)m);
     for (int64_t j = 0; j < m; j++) {
-      const int32_t *c = &cnt[(size_t)4 * j];
-      na += c[3];
-      cx[(size_t)j] = (double)c[1] + 2.0 * c[2];
-      cxx[(size_t)j] = (double)c[1] + 4.0 * c[2];
+      if (st[(size_t)(3 * j + 2)] > 0)
+        fail("windowed LD on a dosage FBM needs data without missing values (variant %lld has %lld among the "
+             "selected samples); impute first", (long long)j, (long long)st[(size_t)(3 * j + 2)]);
+      cx[(size_t)j] = (double)st[(size_t)(3 * j)];
+      cxx[(size_t)j] = (double)st[(size_t)(3 * j + 1)];
     }
-    J.complete = (na == 0) && !getenv("BSN_FORCE_NA_PLANE");
-    if (J.complete) {
-      BSN_HIP(hipMemcpyAsync(J.d_cx.ensure((size_t)m), cx.data(), (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
-      BSN_HIP(hipMemcpyAsync(J.d_cxx.ensure((size_t)m), cxx.data(), (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
+    J.complete = true;
+    J.use_mask = true;
+    copy_h2d(bed, J.d_cx.ensure((size_t)m), cx.data(), (size_t)m * 8);
+    copy_h2d(bed, J.d_cxx.ensure((size_t)m), cxx.data(), (size_t)m * 8);
+  } else {
+    // rows: keep-mask, 2 bits per sample (also removes the pad samples, which are coded as
+    // non-missing genotype 0 in the image).  Duplicated rows are not supported on this path.
+    J.use_mask = true;
+    {
+      std::vector<uint32_t> mask((size_t)(bed->pitch / 4), 0u);
+      for (int64_t i = 0; i < n; i++) {
+        int64_t r = ind_row ? ind_row[i] : i;
+        if (r < 0 || r >= bed->n) fail("Tested %lld < %lld. Subscript out of bounds (ind.row).", (long long)r, (long long)bed->n);
+        uint32_t bit = 3u << (2 * (r & 15));
+        if (mask[(size_t)(r >> 4)] & bit) fail("duplicated 'ind.row' are not supported by the GPU LD path");
+        mask[(size_t)(r >> 4)] |= bit;
+      }
+      BSN_HIP(hipMemcpyAsync(J.d_mask.ensure(mask.size()), mask.data(), mask.size() * 4, hipMemcpyHostToDevice, bed->stream));
       BSN_HIP(hipStreamSynchronize(bed->stream));
+    }
+    // per-variant totals over the selected samples; when nothing is missing there, Sum x, Sum x^2 and
+    // the pair count of every pair are these totals and only the cross product needs the GEMM
+    {
+      std::vector<int32_t> cnt((size_t)4 * m);
+      counts_host(bed, ind_row, n, ind_col, m, cnt.data());
+      int64_t na = 0;
+      std::vector<double> cx((size_t)m), cxx((size_t)m);
+      for (int64_t j = 0; j < m; j++) {
+        const int32_t *c = &cnt[(size_t)4 * j];
+        na += c[3];
+        cx[(size_t)j] = (double)c[1] + 2.0 * c[2];
+        cxx[(size_t)j] = (double)c[1] + 4.0 * c[2];
+      }
+      J.complete = (na == 0) && !getenv("BSN_FORCE_NA_PLANE");
+      if (J.complete) {
+        BSN_HIP(hipMemcpyAsync(J.d_cx.ensure((size_t)m), cx.data(), (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
+        BSN_HIP(hipMemcpyAsync(J.d_cxx.ensure((size_t)m), cxx.data(), (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
+        BSN_HIP(hipStreamSynchronize(bed->stream));
+      }
     }
   }
   // tile pairs of the band
@@ -530,6 +643,53 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
   BSN_HIP(hipEventCreate(&e1));
   float ms_total = 0;
   BandOut bo{J.m, J.W, J.d_lo.p, d_thr, d_v1, d_v2, nrows, J.d_band.p, mode};
+  if (bed->bits == 8) {
+    if (mode == 3) fail("internal: the bed clumping formula does not apply to a byte image");
+    const int64_t slice_bytes = 131072;  // samples per int32 accumulator slice
+    const int nslice = (int)((bed->pitch + slice_bytes - 1) / slice_bytes);
+    if (nslice > 6) fail("windowed LD on a dosage FBM supports at most %lld samples", (long long)(6 * slice_bytes));
+    J.d_stats.ensure((size_t)std::min(batch, J.npairs) * 6 * TB * TB);
+    for (int64_t p0 = 0; p0 < J.npairs; p0 += batch) {
+      const int64_t np = std::min(batch, J.npairs - p0);
+      // K splits never straddle a slice: one slice -> any 64-byte-aligned split of the row; several ->
+      // a power-of-two number of splits per 131 072-byte slice
+      const int64_t sl = std::min<int64_t>(slice_bytes, bed->pitch);
+      const int64_t want = std::max<int64_t>(1, 8192 / (np * nslice));
+      int sps;
+      int64_t kb;
+      if (nslice == 1) {
+        sps = (int)std::min<int64_t>(want, sl / 256);
+        if (sps < 1) sps = 1;
+        kb = round_up((sl + sps - 1) / sps, 64);
+        sps = (int)((sl + kb - 1) / kb);
+      } else {
+        sps = 1;
+        while (sps * 2 <= want && sps < 512) sps *= 2;
+        kb = sl / sps;
+      }
+      BSN_HIP(hipMemsetAsync(J.d_stats.p, 0, (size_t)np * 6 * TB * TB * 4, bed->stream));
+      BSN_HIP(hipEventRecord(e0, bed->stream));
+      hipLaunchKernelGGL(k_pair_xy8, dim3((unsigned)np, (unsigned)(sps * nslice)), dim3(64), 0, bed->stream,
+                         bed->d_img, bed->pitch, J.d_cols.p, J.d_pairs.p + p0, J.d_mask8.p, kb, sps, J.d_stats.p);
+      BSN_HIP(hipGetLastError());
+      BSN_HIP(hipEventRecord(e1, bed->stream));
+      hipLaunchKernelGGL(k_band_fill8, dim3((unsigned)np), dim3(256), 0, bed->stream, J.d_stats.p, nslice,
+                         J.d_pairs.p + p0, (int)np, J.m, J.d_lo.p, J.W, d_thr, mode, d_v1, d_v2, nrows, J.d_band.p,
+                         J.d_cx.p, J.d_cxx.p, bed->v_step, bed->v_off);
+      BSN_HIP(hipGetLastError());
+      BSN_HIP(hipEventSynchronize(e1));
+      float ms = 0;
+      BSN_HIP(hipEventElapsedTime(&ms, e0, e1));
+      ms_total += ms;
+      ls.launches += 1;
+    }
+    ls.kernel = 2;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    ls.stats_ms = ms_total;
+    g_ld_stats = ls;
+    return;
+  }
   for (int64_t p0 = 0; p0 < J.npairs; p0 += batch) {
     const int64_t np = std::min(batch, J.npairs - p0);
     // K split: enough workgroups to fill the chip when there are few tile pairs

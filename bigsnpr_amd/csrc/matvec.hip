@@ -945,9 +945,9 @@ void prof_end(bsn_op *op) {
   if (!op->profile) return;
   BSN_HIP(hipEventRecord(op->ev_end.back(), op->bed->stream));
 }
-void prof_collect(bsn_op *op, double ms[2], int count[2]) {
-  ms[0] = ms[1] = 0;
-  count[0] = count[1] = 0;
+void prof_collect(bsn_op *op, double ms[3], int count[3]) {
+  ms[0] = ms[1] = ms[2] = 0;
+  count[0] = count[1] = count[2] = 0;
   for (size_t i = 0; i < op->ev_begin.size(); i++) {
     BSN_HIP(hipEventSynchronize(op->ev_end[i]));
     float t = 0;
@@ -1175,7 +1175,7 @@ void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z,
     int8_t *q = op->d_q.ensure((size_t)npad * 32 * 2);
     int32_t *acc = op->d_acc.ensure((size_t)2 * op->m * 32);
     quantise(op, xsrc + (int64_t)v0 * ldx, ldx, b->n, npad, nv, 0, S, ncol, 1, 0, meta, q);
-    prof_begin(op, 0);
+    prof_begin(op, op->stats_pending ? 2 : 0);  // the pass that carries the code counts is timed apart
     if (b->bits == 8) {
       const dim3 grid8((unsigned)((op->m + 127) / 128));
       const int32_t *cols8 = op->cols_contig ? nullptr : op->d_cols.p;

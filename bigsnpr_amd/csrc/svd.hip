@@ -843,13 +843,15 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       info->converged = r.converged;
       info->max_rel_resid = r.max_rel_resid;
       info->gpu_ms = ms;
-      double pms[2];
-      int pc[2];
+      double pms[3];
+      int pc[3];
       prof_collect(op, pms, pc);
       info->cprod_ms = pms[0];
       info->prod_ms = pms[1];
       info->n_cprod = pc[0];
       info->n_prod = pc[1];
+      info->cprod_stats_ms = pms[2];
+      info->n_cprod_stats = pc[2];
       info->block = so.block;
       info->slices = op->slices;
     }

@@ -23,8 +23,9 @@ class FBM_code256:
     """bigstatsr's FBM.code256 (n x m bytes + a 256-entry decode table) held on the device
     (bsn_fbm_open): tables that decode to genotype calls (CODE_012, CODE_IMPUTE_PRED) become the 2-bit
     image and support every snp_* function; tables on a regular grid (CODE_DOSAGE) become a byte image
-    that supports snp_colstats / snp_MAF / snp_scale*, big_prodVec / big_cprodVec / snp_PRS and
-    big_randomSVD; anything else is refused by the library."""
+    that supports snp_colstats / snp_MAF / snp_scale*, big_prodVec / big_cprodVec / snp_PRS,
+    big_randomSVD and — for data without missing values — snp_cor / snp_ld_scores / snp_clumping;
+    anything else is refused by the library."""
 
     def __init__(self, bytes_nm, code=CODE_012):
         a = np.asfortranarray(np.asarray(bytes_nm, dtype=np.uint8))
@@ -129,7 +130,10 @@ def _cor0(obj, ind_row, ind_col, size, alpha, thr_r2, fill_diag, infos_pos):
     assert_sorted(pos)
     # a pair of variants shares at least n - na_x - na_y samples
     from .bed import bed_counts
-    na = bed_counts(im, ir, ic)[3].astype(np.int64)
+    if int(_lib.load().bsn_bed_bits(im.handle)) == 8:
+        na = np.zeros(ic.size, dtype=np.int64)    # a byte (dosage) image is only accepted without missing values
+    else:
+        na = bed_counts(im, ir, ic)[3].astype(np.int64)
     top2 = np.sort(na)[-2:].sum() if na.size > 1 else int(na.sum())
     thr = as_f64(_cor_thresholds(ir.size, alpha, thr_r2, n_min=ir.size - int(top2)))
     p = np.empty(ic.size + 1, dtype=np.int32)

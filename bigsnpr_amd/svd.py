@@ -66,4 +66,5 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
                 max_rel_resid=info.max_rel_resid, gpu_ms=info.gpu_ms,
                 cprod_ms=info.cprod_ms, prod_ms=info.prod_ms, n_cprod=info.n_cprod,
                 n_prod=info.n_prod, block=info.block, slices=info.slices,
-                fused_stats=bool(info.fused_stats))
+                fused_stats=bool(info.fused_stats), cprod_stats_ms=info.cprod_stats_ms,
+                n_cprod_stats=info.n_cprod_stats)

@@ -245,14 +245,15 @@ typedef struct fbm_cache {
 } fbm_cache;
 static fbm_cache *g_fbm = NULL;
 
-static bsn_bed *upload_fbm(const char *bk, int64_t n, int64_t m) {
+static bsn_bed *upload_fbm(const char *bk, int64_t n, int64_t m, const double *code256) {
   int fd = open(bk, O_RDONLY);
   if (fd < 0) Rf_error("cannot open backing file '%s'", bk);
   void *map = mmap(NULL, (size_t) (n * m), PROT_READ, MAP_PRIVATE, fd, 0);
   close(fd);
   if (map == MAP_FAILED) Rf_error("cannot map backing file '%s'", bk);
   bsn_bed *img = NULL;
-  int rc = bsn_bed_from_fbm((const uint8_t *) map, n, m, n, &img);
+  /* the object's own decode table (CODE_012, CODE_IMPUTE_PRED, CODE_DOSAGE ...; NA_real_ is a NaN) */
+  int rc = bsn_fbm_open((const uint8_t *) map, n, m, n, code256, &img);
   munmap(map, (size_t) (n * m));
   if (rc != 0) Rf_error("%s", bsn_last_error());
   return img;
@@ -261,6 +262,10 @@ static bsn_bed *get_image(SEXP obj) {
   if (!has_field(obj, "code256")) return get_bed(obj);
   const char *bk = CHAR(STRING_ELT(field(obj, "backingfile"), 0));
   int64_t n = (int64_t) Rf_asReal(field(obj, "nrow")), m = (int64_t) Rf_asReal(field(obj, "ncol"));
+  SEXP code = PROTECT(field(obj, "code256"));
+  if (TYPEOF(code) != REALSXP || XLENGTH(code) != 256) Rf_error("'code256' must be 256 doubles");
+  const double *code256 = REAL(code);
+  UNPROTECT(1);   /* owned by the FBM object for the duration of the call */
   struct stat st;
   if (stat(bk, &st) != 0) Rf_error("cannot stat backing file '%s'", bk);
   for (fbm_cache *c = g_fbm; c; c = c->next)
@@ -268,12 +273,12 @@ static bsn_bed *get_image(SEXP obj) {
       if (c->size == st.st_size && c->mtime == st.st_mtim.tv_sec && c->mtime_ns == st.st_mtim.tv_nsec)
         return c->img;
       bsn_bed_close(c->img);                       /* the file changed under the handle */
-      c->img = upload_fbm(bk, n, m);
+      c->img = upload_fbm(bk, n, m, code256);
       c->size = st.st_size; c->mtime = st.st_mtim.tv_sec; c->mtime_ns = st.st_mtim.tv_nsec;
       return c->img;
     }
   fbm_cache *c = (fbm_cache *) malloc(sizeof(fbm_cache));
-  c->path = strdup(bk); c->img = upload_fbm(bk, n, m);
+  c->path = strdup(bk); c->img = upload_fbm(bk, n, m, code256);
   c->size = st.st_size; c->mtime = st.st_mtim.tv_sec; c->mtime_ns = st.st_mtim.tv_nsec;
   c->next = g_fbm; g_fbm = c;
   return c->img;

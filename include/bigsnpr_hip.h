@@ -60,8 +60,9 @@ int bsn_bed_from_fbm(const uint8_t *bytes, int64_t n, int64_t m, int64_t ld, bsn
  * steps (CODE_DOSAGE: calls, imputed calls and dosages 0.00 .. 2.00 by 0.01) give a BYTE image — one int8
  * grid index per genotype, exact integer sums, the affine map back to values applied in fp64 — which
  * serves bsn_snp_colstats, bsn_bed_prodvec / bsn_bed_cprodvec (big_prodVec / big_cprodVec and so snp_PRS),
- * bsn_op_* and bsn_bed_randomsvd with explicit centre / scale; the other entry points fail on it with a
- * message.  Any other table is refused. */
+ * bsn_op_*, bsn_bed_randomsvd with explicit centre / scale and, for data without missing values,
+ * bsn_cormat / bsn_ld_scores / bsn_clumping_chr(_cached) in the FBM mode; the other entry points fail on it
+ * with a message.  Any other table is refused. */
 int bsn_fbm_open(const uint8_t *bytes, int64_t n, int64_t m, int64_t ld, const double *code256, bsn_bed **out);
 int bsn_bed_bits(const bsn_bed *bed); /* 2 or 8 */
 /* total number of missing genotypes of the image if a full count has seen every variant (FBM handles
@@ -248,6 +249,8 @@ typedef struct bsn_svd_info {
   int32_t block, slices; /* vectors per pass and int8 slices actually used */
   int32_t n_bad;      /* binom_scaling: variants with > 50 % missing values (src/bed-fun.cpp:40-41) */
   int32_t fused_stats;/* 1 if the scaling statistics rode along the first crossproduct pass */
+  double cprod_stats_ms; /* the k_cprod launches that also counted the codes (not in cprod_ms) */
+  int32_t n_cprod_stats;
 } bsn_svd_info;
 /* Returns 0 on success, 1 on error, and 2 when the solve ran to the end of its basis without all
  * k residuals meeting tol (outputs are filled with the best available triplets, bsn_last_error()

@@ -136,7 +136,7 @@ def test_code_tables(ba, orc, golden_dir, example_bed):
     # what the byte image cannot do says so
     Gd = ba.FBM_code256((raw[:60, :80] % 3 + 7).astype(np.uint8), ba.CODE_DOSAGE)
     with pytest.raises(ba.BsnError, match="2-bit genotype image"):
-        ba.snp_cor(Gd)
+        ba.bed_counts(Gd._bed)
 
 
 def test_fbm_products_on_calls_with_replacement(ba, orc, example_bed):
@@ -178,3 +178,45 @@ def test_c2_fbm_ingest_at_full_size(ba):
     cols = rng.choice(m, 300, replace=False)
     np.testing.assert_array_equal(ba.read_bed(G._bed, np.arange(n), cols), ba.read_bed(ref, np.arange(n), cols))
     print("C2 FBM ingest: %.2f s for %.1f GB (%.1f GB/s)" % (dt, n * m / 1e9, n * m / 1e9 / dt))
+
+
+def _dosage_panel(rng, n, m):
+    """dosages with local correlation (an AR(1) latent along the variants) so that windows hold real LD"""
+    z = rng.normal(size=(n, m))
+    for j in range(1, m):
+        z[:, j] = 0.8 * z[:, j - 1] + 0.6 * z[:, j]
+    f = rng.uniform(0.1, 0.9, size=m)
+    from scipy.stats import norm
+    dos = np.clip(np.round(200 * norm.cdf(z + norm.ppf(f))), 0, 200).astype(np.int64)
+    return (dos + 7).astype(np.uint8)
+
+
+def test_dosage_ld_matches_oracle(ba, orc):
+    """snp_cor / snp_ld_scores / snp_clumping on a CODE_DOSAGE FBM without missing values: the byte image's
+    cross products are exact integers and r is affine-invariant, so the oracle's corMat (kind = 1: the FBM
+    accessor with the dosage table, src/corr.cpp:113-118) is met to 1e-9 with the identical sparsity
+    pattern, the LD scores to 1e-9, and the clumping keeps the identical variants."""
+    rng = np.random.default_rng(21)
+    n, m = 900, 700
+    raw = _dosage_panel(rng, n, m)
+    Go, G = orc.FBM256(raw, ba.CODE_DOSAGE), ba.FBM_code256(raw, ba.CODE_DOSAGE)
+    assert G.bits == 8
+    pos = np.cumsum(rng.integers(1, 3000, size=m)).astype(np.float64)
+    ir = np.sort(rng.choice(n, 600, replace=False))
+    for rows, kw in ((None, dict(size=40, infos_pos=pos)), (ir, dict(size=25, infos_pos=pos, alpha=0.05)),
+                     (None, dict(size=30, thr_r2=0.1))):
+        got = ba.snp_cor(G, ind_row=rows, **kw)
+        ri, rp, rx = orc.snp_cor(Go, ind_row=rows, **kw)           # CSC slots i, p, x (R/corr.R:43-47)
+        np.testing.assert_array_equal(got.p, rp)
+        np.testing.assert_array_equal(got.i, ri)
+        np.testing.assert_allclose(got.x, rx, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(ba.snp_ld_scores(G, size=40, infos_pos=pos),
+                               orc.ld_scores(Go, size=40, infos_pos=pos), rtol=1e-9)
+    chrom = np.repeat([1, 2], [400, 300])
+    for kw in (dict(thr_r2=0.2, infos_pos=pos), dict(thr_r2=0.05, size=20), dict(thr_r2=0.3, infos_pos=pos, ind_row=ir)):
+        np.testing.assert_array_equal(ba.snp_clumping(G, chrom, **kw), orc.snp_clumping(Go, chrom, **kw))
+    # missing values: refused with a message (the six pairwise-complete sums need planes the byte image lacks)
+    raw2 = raw.copy()
+    raw2[5, 7] = 3
+    with pytest.raises(ba.BsnError, match="without missing values"):
+        ba.snp_cor(ba.FBM_code256(raw2, ba.CODE_DOSAGE), size=10)

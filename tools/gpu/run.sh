@@ -1,0 +1,9 @@
+#!/bin/bash
+# usage: tools/gpu/run.sh <timeout-seconds> <script>   — builds both libraries HERE first (the snapshot
+# carries the .so files to the GPU box), then runs the script there
+set -e
+cd "$(dirname "$0")/../.."
+python -m bigsnpr_amd.build > /dev/null
+python -m bigsnpr_amd.build --ablation > /dev/null
+(cd oracle && make -s)
+exec /usr/local/graft/bin/gpurun --timeout "$1" -- "bash $2"
