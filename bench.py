@@ -53,6 +53,8 @@ def parse():
                     help="go through the RCCL communicator even with one rank (self-test)")
     ap.add_argument("--cpu-sample-cols", type=int, default=0)
     ap.add_argument("--verbose", type=int, default=0, help="1: residual trajectory of every solve on stderr")
+    ap.add_argument("--warm-start", type=int, default=0, help="warm-start iterations (0 = library default 1, -1 = none)")
+    ap.add_argument("--warm-den", type=int, default=0, help="warm start on the leading 1/N of the variants (0 = 16)")
     return ap.parse_args()
 
 
@@ -163,7 +165,8 @@ def main():
 
     def step():
         return ba.bed_randomSVD(gb, k=a.k, tol=a.tol, block=a.block, slices=a.slices, comm=comm,
-                                m_total=m_total, return_uv=False, verbose=a.verbose)
+                                m_total=m_total, return_uv=False, verbose=a.verbose, warm_start=a.warm_start,
+                                warm_denominator=a.warm_den)
 
     for _ in range(a.warmup):
         step()
@@ -181,7 +184,9 @@ def main():
 
     # streaming passes over the image: the A~ / A~' panel applications, + 1 when the scaling statistics
     # were a pass of their own (they ride along the first crossproduct pass otherwise)
-    passes = sum(r["nops"] + (0 if r["fused_stats"] else 1) for r in infos)
+    # warm-start launches stream only a fraction of the variants: counted as that fraction of a pass
+    passes = sum(r["nops"] - r["warm_launches"] * (1.0 - r["warm_fraction"]) + (0 if r["fused_stats"] else 1)
+                 for r in infos)
     value = m_total * passes / wall                           # whole job, all ranks
     bytes_per_launch = ((n + 3) // 4) * m_local               # algorithmic: 2-bit payload of the shard
     kern = {}
@@ -223,6 +228,8 @@ def main():
         "passes_per_solve": passes / a.steps,
         "niter": infos[-1]["niter"], "converged": infos[-1]["converged"],
         "scaling_statistics": "ride along the first crossproduct pass" if infos[-1]["fused_stats"] else "own pass",
+        "warm_start": {"launches": infos[-1]["warm_launches"], "fraction_of_variants": infos[-1]["warm_fraction"],
+                       "ms": infos[-1]["warm_ms"]},
         "end_to_end_cols_per_s": m_total * a.steps / wall,
         "hbm_GBps_whole_solve": passes * ((n + 3) // 4) * m_total / wall / 1e9,
         "hbm_frac_whole_solve": passes * ((n + 3) // 4) * m_total / wall / 1e9 / HBM_PEAK_GBS / world,

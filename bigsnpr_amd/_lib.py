@@ -27,7 +27,8 @@ class SvdOptions(C.Structure):
                 ("verbose", C.c_int32), ("m_total", C.c_int64), ("allreduce", ALLREDUCE_FN),
                 ("allreduce_ctx", C.c_void_p), ("hook_rank", C.c_int32), ("hook_world", C.c_int32),
                 ("comm", C.c_void_p), ("binom_scaling", C.c_int32),
-                ("center_out", C.POINTER(C.c_double)), ("scale_out", C.POINTER(C.c_double))]
+                ("center_out", C.POINTER(C.c_double)), ("scale_out", C.POINTER(C.c_double)),
+                ("warm_start", C.c_int32), ("warm_denominator", C.c_int32)]
 
 
 class SvdInfo(C.Structure):
@@ -36,7 +37,8 @@ class SvdInfo(C.Structure):
                 ("cprod_ms", C.c_double), ("prod_ms", C.c_double), ("n_cprod", C.c_int32),
                 ("n_prod", C.c_int32), ("block", C.c_int32), ("slices", C.c_int32),
                 ("n_bad", C.c_int32), ("fused_stats", C.c_int32), ("cprod_stats_ms", C.c_double),
-                ("n_cprod_stats", C.c_int32)]
+                ("n_cprod_stats", C.c_int32), ("warm_launches", C.c_int32), ("warm_fraction", C.c_double),
+                ("warm_ms", C.c_double)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check that every symbol

@@ -125,6 +125,7 @@ struct bsn_op {
   // per-launch HIP-event timing of the streaming kernels (kind 0 = k_cprod, 1 = k_prod, 2 = the k_cprod
   // launch that also counts the codes, first pass of a solve with fused scaling statistics)
   bool profile = false;
+  int prof_kind_override = -1;  // >= 0: every launch is filed under this kind (3 = warm-start launches on a subset)
   std::vector<hipEvent_t> ev_begin, ev_end;
   std::vector<int> ev_kind;
   ~bsn_op() {
@@ -242,6 +243,6 @@ void selftest();
 void prof_begin(bsn_op *op, int kind);
 void prof_end(bsn_op *op);
 // sums the recorded launches: ms[kind], count[kind]; clears the records
-void prof_collect(bsn_op *op, double ms[3], int count[3]);  // kind 2: k_cprod carrying the code counts
+void prof_collect(bsn_op *op, double ms[4], int count[4]);  // kind 2: k_cprod carrying the code counts; 3: warm start
 
 }  // namespace bsn

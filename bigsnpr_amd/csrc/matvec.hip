@@ -933,6 +933,7 @@ void require_bits(const bsn_bed *b, int bits, const char *what) {
 // ---------------------------------------------------------------------------
 void prof_begin(bsn_op *op, int kind) {
   if (!op->profile) return;
+  if (op->prof_kind_override >= 0) kind = op->prof_kind_override;
   hipEvent_t a, b;
   BSN_HIP(hipEventCreate(&a));
   BSN_HIP(hipEventCreate(&b));
@@ -945,9 +946,9 @@ void prof_end(bsn_op *op) {
   if (!op->profile) return;
   BSN_HIP(hipEventRecord(op->ev_end.back(), op->bed->stream));
 }
-void prof_collect(bsn_op *op, double ms[3], int count[3]) {
-  ms[0] = ms[1] = ms[2] = 0;
-  count[0] = count[1] = count[2] = 0;
+void prof_collect(bsn_op *op, double ms[4], int count[4]) {
+  ms[0] = ms[1] = ms[2] = ms[3] = 0;
+  count[0] = count[1] = count[2] = count[3] = 0;
   for (size_t i = 0; i < op->ev_begin.size(); i++) {
     BSN_HIP(hipEventSynchronize(op->ev_end[i]));
     float t = 0;

@@ -367,6 +367,29 @@ struct HipSvdBackend : SvdBackend {
   int nrc = 0;
   bool rs_pending = false;
   int kmax = 0;
+  // warm start on a leading subset of this rank's variants
+  int64_t m_op_full = 0, m_sub = 0;
+  bool fused_stats = false;
+  int warm_launches = 0, warm_den = 16;
+  bool subset(bool on) override {
+    if (on) {
+      m_op_full = op->m;
+      m_sub = (op->m / warm_den) / 256 * 256;
+      if (m_sub < 16384) return false;  // small matrices: a full pass is cheap, the thinning too noisy
+      op->m = m_sub;
+      op->prof_kind_override = 3;
+      return true;
+    }
+    op->m = m_op_full;
+    op->prof_kind_override = -1;
+    warm_launches += 2;
+    if (fused_stats) {  // the counting pass saw the subset only: count again on the first full pass
+      op->stats_pending = true;
+      op->na_poll = false;
+      op->no_na = false;
+    }
+    return true;
+  }
   // host wall time per phase (BSN_TIMING=1): where a solve's time outside the streaming kernels goes
   bool timing = false;
   double t_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // alloc, At_Q, A_Z, grams, orth, round/copy, finalize, other
@@ -715,6 +738,7 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     if (!lend.op) lend.op.reset(new bsn_op());
     bsn_op *op = lend.op.get();
     op->passes = 0;
+    op->prof_kind_override = -1;
     op->stats_pending = false;
     op->na_poll = false;
     op->no_na = false;
@@ -760,6 +784,8 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     if (bk.hook && (bk.rank < 0 || bk.rank >= bk.world)) fail("hook_rank %d of %d", bk.rank, bk.world);
     bk.setup_ranks();
     bk.timing = getenv("BSN_TIMING") != nullptr;
+    bk.fused_stats = fused;
+    bk.warm_den = o->warm_denominator >= 2 ? o->warm_denominator : 16;
     int64_t dim = bk.n < bk.m_total ? bk.n : bk.m_total;
     if (o->k > dim) fail("'k' is larger than the dimensions of the matrix.");
     SvdOptions so;
@@ -784,6 +810,7 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       op->slices = ss;
     }
     so.resid_floor = 1.2 * std::ldexp(1.0, -8 * op->slices);
+    so.warm = o->warm_start < 0 ? 0 : (o->warm_start == 0 ? 1 : o->warm_start);
     so.max_basis = o->max_basis;
     so.seed = o->seed ? o->seed : 1;
     so.verbose = o->verbose;
@@ -843,8 +870,8 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       info->converged = r.converged;
       info->max_rel_resid = r.max_rel_resid;
       info->gpu_ms = ms;
-      double pms[3];
-      int pc[3];
+      double pms[4];
+      int pc[4];
       prof_collect(op, pms, pc);
       info->cprod_ms = pms[0];
       info->prod_ms = pms[1];
@@ -852,6 +879,9 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       info->n_prod = pc[1];
       info->cprod_stats_ms = pms[2];
       info->n_cprod_stats = pc[2];
+      info->warm_ms = pms[3];
+      info->warm_launches = bk.warm_launches;
+      info->warm_fraction = bk.m_sub > 0 && bk.m_op_full > 0 ? (double)bk.m_sub / (double)bk.m_op_full : 0.0;
       info->block = so.block;
       info->slices = op->slices;
     }

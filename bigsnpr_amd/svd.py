@@ -18,7 +18,7 @@ from .bed import _args, assert_bed, bed_scaleBinom
 
 def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=None, k=10,
                   tol=1e-4, verbose=False, ncores=1, block=0, slices=0, max_basis=0, seed=1,
-                  comm=None, allreduce=None, rank=0, world=1, m_total=0, return_uv=True):
+                  comm=None, allreduce=None, rank=0, world=1, m_total=0, return_uv=True, warm_start=0, warm_denominator=0):
     """Partial SVD of the scaled matrix.  Extra (non-reference) arguments: ``block``
     (vectors per streaming pass), ``slices`` (int8 slices per fp64 value); column-sharded
     multi-GPU: ``comm`` (a bigsnpr_amd.Comm: the exchange runs inside the library over RCCL),
@@ -38,6 +38,7 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
         center = np.ascontiguousarray(ms["center"], dtype=np.float64)
         scale = np.ascontiguousarray(ms["scale"], dtype=np.float64)
     opts.k, opts.tol, opts.block, opts.slices = int(k), float(tol), int(block), int(slices)
+    opts.warm_start, opts.warm_denominator = int(warm_start), int(warm_denominator)
     opts.max_basis, opts.seed, opts.verbose, opts.m_total = int(max_basis), int(seed), int(verbose), int(m_total)
     cb = None
     if comm is not None:
@@ -67,4 +68,5 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
                 cprod_ms=info.cprod_ms, prod_ms=info.prod_ms, n_cprod=info.n_cprod,
                 n_prod=info.n_prod, block=info.block, slices=info.slices,
                 fused_stats=bool(info.fused_stats), cprod_stats_ms=info.cprod_stats_ms,
-                n_cprod_stats=info.n_cprod_stats)
+                n_cprod_stats=info.n_cprod_stats, warm_launches=info.warm_launches,
+                warm_fraction=info.warm_fraction, warm_ms=info.warm_ms)

@@ -234,6 +234,11 @@ typedef struct bsn_svd_options {
    * scale_out (length m each, may be NULL). */
   int32_t binom_scaling;
   double *center_out, *scale_out;
+  /* warm start: power iterations of the random start block on the leading 1/16 of the variants before
+   * the first full pass (each costs two streaming launches over that subset, 1/8 of a pass together).
+   * 0 -> 1 (default), n > 0 -> n, -1 -> none.  Matrices with fewer than 262 144 variants skip it. */
+  int32_t warm_start;
+  int32_t warm_denominator; /* the subset is the leading 1 / warm_denominator of the variants (0 -> 16) */
 } bsn_svd_options;
 typedef struct bsn_svd_info {
   int32_t niter;      /* block steps */
@@ -251,6 +256,10 @@ typedef struct bsn_svd_info {
   int32_t fused_stats;/* 1 if the scaling statistics rode along the first crossproduct pass */
   double cprod_stats_ms; /* the k_cprod launches that also counted the codes (not in cprod_ms) */
   int32_t n_cprod_stats;
+  int32_t warm_launches; /* streaming launches of the warm start, each over warm_fraction of the variants
+                            (they are counted in nops and in the kernel timings too) */
+  double warm_fraction;
+  double warm_ms;        /* HIP-event time of those launches (not in cprod_ms / prod_ms) */
 } bsn_svd_info;
 /* Returns 0 on success, 1 on error, and 2 when the solve ran to the end of its basis without all
  * k residuals meeting tol (outputs are filled with the best available triplets, bsn_last_error()

@@ -102,3 +102,22 @@ def test_bed_svd_equals_fbm_svd(ba, orc, golden_dir, example_bed):
     sc = ba.snp_scaleBinom()(G)
     np.testing.assert_array_equal(sc["center"], 2 * af)
     np.testing.assert_array_equal(ba.snp_colstats(G)["denoX"], st["denoX"])
+
+
+def test_warm_start_on_a_variant_subset(ba):
+    """the start block gets one power iteration on the leading 1/16 of the variants before the first full
+    pass (matrices with >= 262 144 variants): same singular values, never more block steps, and the two
+    launches over the subset are reported"""
+    n, m, k = 3000, 300000, 10
+    gb = ba.bed.synthetic(n, m, seed=13)
+    cold = ba.bed_randomSVD(gb, k=k, warm_start=-1)
+    warm = ba.bed_randomSVD(gb, k=k)
+    assert cold["warm_launches"] == 0 and warm["warm_launches"] == 2
+    assert abs(warm["warm_fraction"] - 1.0 / 16) < 1e-3
+    assert warm["converged"] and warm["niter"] <= cold["niter"]
+    np.testing.assert_allclose(warm["d"], cold["d"], rtol=1e-6)
+    np.testing.assert_array_equal(warm["center"], cold["center"])      # the counting pass is redone on all variants
+    tight = ba.bed_randomSVD(gb, k=k, tol=1e-10, slices=7, return_uv=False)
+    np.testing.assert_allclose(warm["d"], tight["d"], rtol=1e-6)
+    small = ba.bed_randomSVD(ba.bed.synthetic(1000, 5000, seed=1), k=5)
+    assert small["warm_launches"] == 0
