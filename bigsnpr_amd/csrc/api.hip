@@ -479,7 +479,7 @@ int bsn_bed_row_counts(bsn_bed *bed, const int64_t *ind_row, int64_t n, const in
     d_c.ensure((size_t)3 * n);
     op_row_counts(&op, d_c.p);
     std::vector<double> c((size_t)3 * n);
-    BSN_HIP(hipMemcpy(c.data(), d_c.p, (size_t)3 * n * 8, hipMemcpyDeviceToHost));
+    copy_d2h(bed, c.data(), d_c.p, (size_t)3 * n * 8);
     for (int64_t i = 0; i < n; i++) {
       const int64_t n2 = (int64_t)c[(size_t)i], n1 = (int64_t)c[(size_t)(n + i)], na = (int64_t)c[(size_t)(2 * n + i)];
       res[4 * i + 0] = (int32_t)(m - n1 - n2 - na);
@@ -559,11 +559,11 @@ static void read_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int
   auto c = to_i32(ind_col, m, bed->m, "ind.col");
   DevBuf<int32_t> d_r, d_c, d_oi;
   DevBuf<double> d_ce, d_sc, d_od;
-  BSN_HIP(hipMemcpy(d_r.ensure((size_t)n), r.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-  BSN_HIP(hipMemcpy(d_c.ensure((size_t)m), c.data(), (size_t)m * 4, hipMemcpyHostToDevice));
+  copy_h2d(bed, d_r.ensure((size_t)n), r.data(), (size_t)n * 4);
+  copy_h2d(bed, d_c.ensure((size_t)m), c.data(), (size_t)m * 4);
   if (out_d) {
-    BSN_HIP(hipMemcpy(d_ce.ensure((size_t)m), center, (size_t)m * 8, hipMemcpyHostToDevice));
-    BSN_HIP(hipMemcpy(d_sc.ensure((size_t)m), scale, (size_t)m * 8, hipMemcpyHostToDevice));
+    copy_h2d(bed, d_ce.ensure((size_t)m), center, (size_t)m * 8);
+    copy_h2d(bed, d_sc.ensure((size_t)m), scale, (size_t)m * 8);
     d_od.ensure((size_t)n * m);
   } else {
     d_oi.ensure((size_t)n * m);
@@ -571,9 +571,9 @@ static void read_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int
   read_dense(bed, d_r.p, n, d_c.p, m, d_ce.p, d_sc.p, na_val, d_oi.p, d_od.p);
   BSN_HIP(hipStreamSynchronize(bed->stream));
   if (out_d)
-    BSN_HIP(hipMemcpy(out_d, d_od.p, (size_t)n * m * 8, hipMemcpyDeviceToHost));
+    copy_d2h(bed, out_d, d_od.p, (size_t)n * m * 8);
   else
-    BSN_HIP(hipMemcpy(out_i, d_oi.p, (size_t)n * m * 4, hipMemcpyDeviceToHost));
+    copy_d2h(bed, out_i, d_oi.p, (size_t)n * m * 4);
 }
 
 int bsn_bed_read(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
@@ -595,12 +595,12 @@ int bsn_bed_cprod_planes(bsn_bed *bed, const int64_t *ind_row, int64_t n, const 
     fill_op(&op, bed, ind_row, n, ind_col, m, nullptr, nullptr);
     op.slices = 7;
     DevBuf<double> d_X, d_P, d_Q;
-    BSN_HIP(hipMemcpyAsync(d_X.ensure((size_t)n * K), X, (size_t)n * K * 8, hipMemcpyHostToDevice, bed->stream));
+    copy_h2d(bed, d_X.ensure((size_t)n * K), X, (size_t)n * K * 8);
     d_P.ensure((size_t)m * K);
     d_Q.ensure((size_t)m * K);
     op_cprod_raw(&op, d_X.p, n, (int)K, d_P.p, d_Q.p, m);
-    BSN_HIP(hipMemcpyAsync(P, d_P.p, (size_t)m * K * 8, hipMemcpyDeviceToHost, bed->stream));
-    BSN_HIP(hipMemcpyAsync(Q, d_Q.p, (size_t)m * K * 8, hipMemcpyDeviceToHost, bed->stream));
+    copy_d2h(bed, P, d_P.p, (size_t)m * K * 8);
+    copy_d2h(bed, Q, d_Q.p, (size_t)m * K * 8);
     BSN_HIP(hipStreamSynchronize(bed->stream));
   });
 }
@@ -615,13 +615,13 @@ int bsn_bed_prod_and_rowsumssq(bsn_bed *bed, const int64_t *ind_row, int64_t n, 
     fill_op(&op, bed, ind_row, n, ind_col, m, center, scale);
     op.slices = 7;
     DevBuf<double> d_V, d_XV, d_r;
-    BSN_HIP(hipMemcpyAsync(d_V.ensure((size_t)m * K), V, (size_t)m * K * 8, hipMemcpyHostToDevice, bed->stream));
+    copy_h2d(bed, d_V.ensure((size_t)m * K), V, (size_t)m * K * 8);
     d_XV.ensure((size_t)n * K);
     d_r.ensure((size_t)n);
     op_prod(&op, d_V.p, m, (int)K, d_XV.p, n);
     op_row_sums_sq(&op, d_r.p);
-    BSN_HIP(hipMemcpyAsync(XV, d_XV.p, (size_t)n * K * 8, hipMemcpyDeviceToHost, bed->stream));
-    BSN_HIP(hipMemcpyAsync(rowSumsSq, d_r.p, (size_t)n * 8, hipMemcpyDeviceToHost, bed->stream));
+    copy_d2h(bed, XV, d_XV.p, (size_t)n * K * 8);
+    copy_d2h(bed, rowSumsSq, d_r.p, (size_t)n * 8);
     BSN_HIP(hipStreamSynchronize(bed->stream));
   });
 }
@@ -747,8 +747,7 @@ int bsn_snp_grid_prs(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int6
         bsn_op op;
         fill_op(&op, bed, ind_row, n, cols.data(), mb, nullptr, nullptr);
         op.slices = slices > 0 ? slices : 7;
-        BSN_HIP(hipMemcpyAsync(d_V.ensure((size_t)mb * C), V.data(), (size_t)mb * C * 8, hipMemcpyHostToDevice,
-                               bed->stream));
+        copy_h2d(bed, d_V.ensure((size_t)mb * C), V.data(), (size_t)mb * C * 8);
         op_prod(&op, d_V.p, mb, (int)C, d_Y.p, n);
         hipLaunchKernelGGL(k_prs_accum, dim3(nblk), dim3(256), 0, bed->stream, d_Y.p, n, C, d_last.p, d_out.p,
                            T, b - 1);
@@ -760,7 +759,7 @@ int bsn_snp_grid_prs(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int6
         BSN_HIP(hipGetLastError());
       }
     }
-    BSN_HIP(hipMemcpyAsync(out, d_out.p, (size_t)n * C * T * 8, hipMemcpyDeviceToHost, bed->stream));
+    copy_d2h(bed, out, d_out.p, (size_t)n * C * T * 8);
     BSN_HIP(hipStreamSynchronize(bed->stream));
   });
 }
@@ -773,15 +772,15 @@ static void convert_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const 
   auto c = to_i32(ind_col, m, bed->m, "ind.col");
   DevBuf<int32_t> d_r, d_c;
   DevBuf<uint8_t> d_o;
-  BSN_HIP(hipMemcpy(d_r.ensure((size_t)n), r.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-  BSN_HIP(hipMemcpy(d_c.ensure((size_t)m), c.data(), (size_t)m * 4, hipMemcpyHostToDevice));
+  copy_h2d(bed, d_r.ensure((size_t)n), r.data(), (size_t)n * 4);
+  copy_h2d(bed, d_c.ensure((size_t)m), c.data(), (size_t)m * 4);
   const size_t bytes = packed ? (size_t)((n + 3) / 4) * m : (size_t)n * m;
   d_o.ensure(bytes);
   if (packed)
     subset_pack(bed, d_r.p, n, d_c.p, m, d_o.p);
   else
     to_bytes(bed, d_r.p, n, d_c.p, m, d_o.p);
-  BSN_HIP(hipMemcpyAsync(out, d_o.p, bytes, hipMemcpyDeviceToHost, bed->stream));
+  copy_d2h(bed, out, d_o.p, bytes);
   BSN_HIP(hipStreamSynchronize(bed->stream));
 }
 

@@ -428,8 +428,7 @@ void image_download(bsn_bed *b, uint8_t *payload_out) {
     hipLaunchKernelGGL(k_unpad, grid, dim3(256), 0, b->stream, b->d_img + j * b->pitch, b->pitch,
                        b->n, b->n_byte, tmp.p);
     BSN_HIP(hipGetLastError());
-    BSN_HIP(hipMemcpyAsync(payload_out + j * b->n_byte, tmp.p, (size_t)cnt * (size_t)b->n_byte,
-                           hipMemcpyDeviceToHost, b->stream));
+    copy_d2h(b, payload_out + j * b->n_byte, tmp.p, (size_t)cnt * (size_t)b->n_byte);
     BSN_HIP(hipStreamSynchronize(b->stream));
   }
 }

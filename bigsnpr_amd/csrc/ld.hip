@@ -545,7 +545,7 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
     if (c < 0 || c >= bed->m) fail("Tested %lld < %lld. Subscript out of bounds (ind.col).", (long long)c, (long long)bed->m);
     cols[(size_t)j] = (int32_t)c;
   }
-  BSN_HIP(hipMemcpyAsync(J.d_cols.ensure((size_t)m_pad), cols.data(), (size_t)m_pad * 4, hipMemcpyHostToDevice, bed->stream));
+  copy_h2d(bed, J.d_cols.ensure((size_t)m_pad), cols.data(), (size_t)m_pad * 4);
   if (bed->bits == 8) {
     // byte image: byte mask of the selected samples, per-variant totals of the grid indices over them
     std::vector<uint8_t> mask((size_t)bed->pitch, 0);
@@ -591,7 +591,7 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
         if (mask[(size_t)(r >> 4)] & bit) fail("duplicated 'ind.row' are not supported by the GPU LD path");
         mask[(size_t)(r >> 4)] |= bit;
       }
-      BSN_HIP(hipMemcpyAsync(J.d_mask.ensure(mask.size()), mask.data(), mask.size() * 4, hipMemcpyHostToDevice, bed->stream));
+      copy_h2d(bed, J.d_mask.ensure(mask.size()), mask.data(), mask.size() * 4);
       BSN_HIP(hipStreamSynchronize(bed->stream));
     }
     // per-variant totals over the selected samples; when nothing is missing there, Sum x, Sum x^2 and
@@ -609,8 +609,8 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
       }
       J.complete = (na == 0) && !getenv("BSN_FORCE_NA_PLANE");
       if (J.complete) {
-        BSN_HIP(hipMemcpyAsync(J.d_cx.ensure((size_t)m), cx.data(), (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
-        BSN_HIP(hipMemcpyAsync(J.d_cxx.ensure((size_t)m), cxx.data(), (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
+        copy_h2d(bed, J.d_cx.ensure((size_t)m), cx.data(), (size_t)m * 8);
+        copy_h2d(bed, J.d_cxx.ensure((size_t)m), cxx.data(), (size_t)m * 8);
         BSN_HIP(hipStreamSynchronize(bed->stream));
       }
     }
@@ -622,8 +622,8 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
     for (int64_t Jt = Jlo; Jt <= I; Jt++) pairs.push_back(int2{(int)I, (int)Jt});
   }
   J.npairs = (int64_t)pairs.size();
-  BSN_HIP(hipMemcpyAsync(J.d_pairs.ensure(pairs.size()), pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice, bed->stream));
-  BSN_HIP(hipMemcpyAsync(J.d_lo.ensure((size_t)m), J.lo.data(), (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
+  copy_h2d(bed, J.d_pairs.ensure(pairs.size()), pairs.data(), pairs.size() * sizeof(int2));
+  copy_h2d(bed, J.d_lo.ensure((size_t)m), J.lo.data(), (size_t)m * 8);
   BSN_HIP(hipStreamSynchronize(bed->stream));  // host vectors go out of scope
   // statistics in batches of tile pairs (bounded scratch)
   J.d_band.ensure((size_t)m * (size_t)W);
@@ -764,7 +764,7 @@ int bsn_cormat(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *i
     std::unique_ptr<bsn_cor> C(new bsn_cor());
     BandJob &J = C->job;
     band_stats(J, bed, ind_row, n, ind_col, m, pos, size);
-    BSN_HIP(hipMemcpyAsync(J.d_thr.ensure((size_t)n), thr, (size_t)n * 8, hipMemcpyHostToDevice, bed->stream));
+    copy_h2d(bed, J.d_thr.ensure((size_t)n), thr, (size_t)n * 8);
     band_run(J, 0, J.d_thr.p, nullptr, nullptr, (double)n);
     DevBuf<int32_t> d_cnt;
     d_cnt.ensure((size_t)m);
@@ -772,7 +772,7 @@ int bsn_cormat(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *i
                        J.d_lo.p, J.W, m, fill_diag, d_cnt.p);
     BSN_HIP(hipGetLastError());
     std::vector<int32_t> cnt((size_t)m);
-    BSN_HIP(hipMemcpyAsync(cnt.data(), d_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost, bed->stream));
+    copy_d2h(bed, cnt.data(), d_cnt.p, (size_t)m * 4);
     BSN_HIP(hipStreamSynchronize(bed->stream));
     int64_t nnz = 0;
     p_out[0] = 0;
@@ -782,7 +782,7 @@ int bsn_cormat(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *i
       p_out[j + 1] = (int32_t)nnz;
     }
     C->nnz = nnz;
-    BSN_HIP(hipMemcpyAsync(C->d_p.ensure((size_t)m + 1), p_out, (size_t)(m + 1) * 4, hipMemcpyHostToDevice, bed->stream));
+    copy_h2d(bed, C->d_p.ensure((size_t)m + 1), p_out, (size_t)(m + 1) * 4);
     C->d_i.ensure((size_t)std::max<int64_t>(nnz, 1));
     C->d_x.ensure((size_t)std::max<int64_t>(nnz, 1));
     hipLaunchKernelGGL(k_cor_fill, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, bed->stream, J.d_band.p,
@@ -810,8 +810,8 @@ int bsn_cormat_fetch(bsn_cor *c, int32_t *i_out, double *x_out) {
   return guarded([&] {
     BSN_HIP(hipSetDevice(c->job.bed->device));
     if (c->nnz > 0) {
-      BSN_HIP(hipMemcpy(i_out, c->d_i.p, (size_t)c->nnz * 4, hipMemcpyDeviceToHost));
-      BSN_HIP(hipMemcpy(x_out, c->d_x.p, (size_t)c->nnz * 8, hipMemcpyDeviceToHost));
+      copy_d2h(c->job.bed, i_out, c->d_i.p, (size_t)c->nnz * 4);
+      copy_d2h(c->job.bed, x_out, c->d_x.p, (size_t)c->nnz * 8);
     }
   });
 }
@@ -831,7 +831,7 @@ int bsn_ld_scores(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t
     hipLaunchKernelGGL(k_ld_sum, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, bed->stream, J.d_band.p,
                        J.d_lo.p, J.W, m, d_ld.p);
     BSN_HIP(hipGetLastError());
-    BSN_HIP(hipMemcpyAsync(out, d_ld.p, (size_t)m * 8, hipMemcpyDeviceToHost, bed->stream));
+    copy_d2h(bed, out, d_ld.p, (size_t)m * 8);
     BSN_HIP(hipStreamSynchronize(bed->stream));
   });
 }
@@ -853,8 +853,8 @@ static void clumping_grid(bsn_bed *bed, const int64_t *ind_row, int64_t n, const
   for (int64_t g = 1; g < n_grid; g++) size_max = std::max(size_max, sizes[g]);
   BandJob J;
   band_stats(J, bed, ind_row, n, ind_col, m, pos, size_max, true);
-  BSN_HIP(hipMemcpyAsync(J.d_v1.ensure((size_t)m), aux1, (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
-  BSN_HIP(hipMemcpyAsync(J.d_v2.ensure((size_t)m), aux2, (size_t)m * 8, hipMemcpyHostToDevice, bed->stream));
+  copy_h2d(bed, J.d_v1.ensure((size_t)m), aux1, (size_t)m * 8);
+  copy_h2d(bed, J.d_v2.ensure((size_t)m), aux2, (size_t)m * 8);
   band_run(J, mode == 0 ? 2 : 3, nullptr, J.d_v1.p, J.d_v2.p, (double)n);
   // distinct thresholds -> one bit image each
   std::vector<double> uthr;
@@ -880,7 +880,7 @@ static void clumping_grid(bsn_bed *bed, const int64_t *ind_row, int64_t n, const
       BSN_HIP(hipGetLastError());
       std::vector<unsigned long long> &dst = side == 0 ? bitsL[t] : bitsU[t];
       dst.resize((size_t)m * (size_t)Wq);
-      BSN_HIP(hipMemcpyAsync(dst.data(), d_bits.p, dst.size() * 8, hipMemcpyDeviceToHost, bed->stream));
+      copy_d2h(bed, dst.data(), d_bits.p, dst.size() * 8);
       BSN_HIP(hipStreamSynchronize(bed->stream));
     }
   }

@@ -1427,8 +1427,7 @@ void op_row_counts(bsn_op *op, double *d_out) {
   bsn_bed *bed = op->bed;
   std::vector<double> ones((size_t)op->m, 1.0);
   DevBuf<double> w;
-  BSN_HIP(hipMemcpyAsync(w.ensure((size_t)op->m), ones.data(), (size_t)op->m * 8, hipMemcpyHostToDevice,
-                         bed->stream));
+  copy_h2d(bed, w.ensure((size_t)op->m), ones.data(), (size_t)op->m * 8);
   prod_planes(op, w.p, nullptr, op->m, 1, d_out, op->n, 2, kLutHom2, 0u, 0, 0.0, 7);
   prod_planes(op, w.p, nullptr, op->m, 1, d_out + op->n, op->n, 2, kLutHet, 0u, 0, 0.0, 7);
   prod_planes(op, w.p, nullptr, op->m, 1, d_out + 2 * op->n, op->n, 2, kLutNA, 0u, 0, 0.0, 7);

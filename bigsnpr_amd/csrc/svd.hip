@@ -639,7 +639,7 @@ struct HipSvdBackend : SvdBackend {
   void WtW(int cb, double *G) override { gemm_tn(W.p, cb, cb, G); }
   void W_minus_QC(int p, int cb, const double *C) override {
     wait_rs();
-    BSN_HIP(hipMemcpyAsync(dsmall.p, C, (size_t)p * cb * 8, hipMemcpyHostToDevice, st));
+    copy_h2d(op->bed, dsmall.p, C, (size_t)p * cb * 8);
     hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((nr + 255) / 256)), dim3(256), kTP * kMaxB * 8, st,
                        Q.p, nr, p, dsmall.p, cb, W.p, nr, 1.0, -1.0, W.p, nr, nr);
     BSN_HIP(hipGetLastError());
@@ -647,7 +647,7 @@ struct HipSvdBackend : SvdBackend {
   }
   void W_times(int cb, int r, const double *M) override {
     wait_rs();
-    BSN_HIP(hipMemcpyAsync(dsmall.p, M, (size_t)cb * r * 8, hipMemcpyHostToDevice, st));
+    copy_h2d(op->bed, dsmall.p, M, (size_t)cb * r * 8);
     hipLaunchKernelGGL(k_right_mult, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, W.p, nr, nr,
                        cb, r, dsmall.p);
     BSN_HIP(hipGetLastError());
@@ -666,8 +666,8 @@ struct HipSvdBackend : SvdBackend {
     dS.ensure((size_t)pp * k * 2 + 16);
     dU.ensure((size_t)nr * k);
     dV.ensure((size_t)m_local * k);
-    BSN_HIP(hipMemcpyAsync(dS.p, S, (size_t)pp * k * 8, hipMemcpyHostToDevice, st));
-    BSN_HIP(hipMemcpyAsync(dS.p + (size_t)pp * k, Sv.data(), (size_t)pp * k * 8, hipMemcpyHostToDevice, st));
+    copy_h2d(op->bed, dS.p, S, (size_t)pp * k * 8);
+    copy_h2d(op->bed, dS.p + (size_t)pp * k, Sv.data(), (size_t)pp * k * 8);
     for (int c0 = 0; c0 < k && pp > 0; c0 += kMaxB) {
       int nc = k - c0 < kMaxB ? k - c0 : kMaxB;
       hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((nr + 255) / 256)), dim3(256), kTP * kMaxB * 8, st,
@@ -955,7 +955,7 @@ extern "C" int bsn_bed_tcrossprod(bsn_bed *bed, const int64_t *ind_row, int64_t 
     }
     DevBuf<int32_t> d_rows, d_cols;
     DevBuf<double> d_K, d_A, d_c, d_s;
-    BSN_HIP(hipMemcpy(d_rows.ensure((size_t)n), rows.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    copy_h2d(bed, d_rows.ensure((size_t)n), rows.data(), (size_t)n * 4);
     BSN_HIP(hipMemsetAsync(d_K.ensure((size_t)n * n), 0, (size_t)n * n * 8, bed->stream));
     d_A.ensure((size_t)n * block_size);
     d_cols.ensure((size_t)block_size);
@@ -969,15 +969,15 @@ extern "C" int bsn_bed_tcrossprod(bsn_bed *bed, const int64_t *ind_row, int64_t 
         if (c < 0 || c >= bed->m) fail("Tested %lld < %lld. Subscript out of bounds (ind.col).", (long long)c, (long long)bed->m);
         cols[(size_t)j] = (int32_t)c;
       }
-      BSN_HIP(hipMemcpyAsync(d_cols.p, cols.data(), (size_t)bsz * 4, hipMemcpyHostToDevice, bed->stream));
-      BSN_HIP(hipMemcpyAsync(d_c.p, center + c0, (size_t)bsz * 8, hipMemcpyHostToDevice, bed->stream));
-      BSN_HIP(hipMemcpyAsync(d_s.p, scale + c0, (size_t)bsz * 8, hipMemcpyHostToDevice, bed->stream));
+      copy_h2d(bed, d_cols.p, cols.data(), (size_t)bsz * 4);
+      copy_h2d(bed, d_c.p, center + c0, (size_t)bsz * 8);
+      copy_h2d(bed, d_s.p, scale + c0, (size_t)bsz * 8);
       read_dense(bed, d_rows.p, n, d_cols.p, bsz, d_c.p, d_s.p, 0, nullptr, d_A.p);
       dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64));
       hipLaunchKernelGGL(k_syrk_f64, grid, dim3(256), 0, bed->stream, d_A.p, n, bsz, d_K.p);
       BSN_HIP(hipGetLastError());
       BSN_HIP(hipStreamSynchronize(bed->stream));  // `cols` is reused
     }
-    BSN_HIP(hipMemcpy(K, d_K.p, (size_t)n * n * 8, hipMemcpyDeviceToHost));
+    copy_d2h(bed, K, d_K.p, (size_t)n * n * 8);
   });
 }
