@@ -288,7 +288,8 @@ def snp_autoSVD(G, infos_chr, infos_pos=None, ind_row=None, ind_col=None, fun_sc
         infos_pos = np.asarray(infos_pos)
         if infos_pos.size != im.ncol:
             raise ValueError(ERROR_DIM)
-    fun_scaling = snp_scaleBinom() if fun_scaling is None else fun_scaling
+    # fun_scaling = None stands for the default snp_scaleBinom(): big_randomSVD then evaluates it inside
+    # the solve (no separate statistics pass per outlier-removal round)
     size = (100.0 / thr_r2 if thr_r2 is not None and not np.isnan(thr_r2) else 500.0) if size is None else size
     maf_nok = None
     if min_mac > 0 and min_maf > 0:

@@ -375,7 +375,9 @@ struct HipSvdBackend : SvdBackend {
     if (on) {
       m_op_full = op->m;
       m_sub = (op->m / warm_den) / 256 * 256;
-      if (m_sub < 16384) return false;  // small matrices: a full pass is cheap, the thinning too noisy
+      // small matrices: a full pass is cheap and the thinned matrix too noisy.  The thinned operator is
+      // the sum over ranks of the shards' subsets, so the size that matters is the one over all ranks.
+      if (m_total / warm_den < 16384 || m_sub < 1024) return false;
       op->m = m_sub;
       op->prof_kind_override = 3;
       return true;

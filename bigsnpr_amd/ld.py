@@ -327,8 +327,15 @@ def big_randomSVD(X, fun_scaling=None, ind_row=None, ind_col=None, k=10, tol=1e-
     bigstatsr::big_randomSVD is external): same device solver as bed_randomSVD, on the
     FBM's 2-bit image."""
     from .svd import bed_randomSVD
+    from .bed import bed_scaleBinom
     _no_missing(X, "big_randomSVD")
     im, ir, ic = _ind(X, ind_row, ind_col)
+    if fun_scaling is None and int(_lib.load().bsn_bed_bits(im.handle)) == 2:
+        # the default snp_scaleBinom() on data without missing values is bed_scaleBinom's formula with
+        # nb_nona = n (R/binom-scaling.R:62-77 vs :133-142): evaluated inside the solve, its counts ride
+        # along the first crossproduct pass
+        return bed_randomSVD(im, fun_scaling=bed_scaleBinom, ind_row=ir, ind_col=ic, k=k, tol=tol,
+                             verbose=verbose, ncores=ncores, **kw)
     fs = snp_scaleBinom() if fun_scaling is None else fun_scaling
     return bed_randomSVD(im, fun_scaling=lambda obj, ind_row, ind_col, ncores=1: fs(X, ind_row, ind_col, ncores),
                          ind_row=ir, ind_col=ic, k=k, tol=tol, verbose=verbose, ncores=ncores, **kw)

@@ -236,7 +236,8 @@ typedef struct bsn_svd_options {
   double *center_out, *scale_out;
   /* warm start: power iterations of the random start block on the leading 1/16 of the variants before
    * the first full pass (each costs two streaming launches over that subset, 1/8 of a pass together).
-   * 0 -> 1 (default), n > 0 -> n, -1 -> none.  Matrices with fewer than 262 144 variants skip it. */
+   * 0 -> 1 (default), n > 0 -> n, -1 -> none.  Matrices with fewer than 262 144 variants (over all ranks)
+   * skip it. */
   int32_t warm_start;
   int32_t warm_denominator; /* the subset is the leading 1 / warm_denominator of the variants (0 -> 16) */
 } bsn_svd_options;

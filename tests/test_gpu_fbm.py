@@ -220,3 +220,16 @@ def test_dosage_ld_matches_oracle(ba, orc):
     raw2[5, 7] = 3
     with pytest.raises(ba.BsnError, match="without missing values"):
         ba.snp_cor(ba.FBM_code256(raw2, ba.CODE_DOSAGE), size=10)
+
+
+def test_default_scaling_of_big_randomsvd_rides_along_the_first_pass(ba, orc, example_bed):
+    """big_randomSVD(G) with the default snp_scaleBinom() == the explicit scaling function, field by field
+    (the default is evaluated inside the solve: R/binom-scaling.R:62-77 on complete data is bed_scaleBinom's
+    formula with nb_nona = n)"""
+    G = ba.FBM_code256(orc.fbm_from_bed(example_bed).bytes)
+    a = ba.big_randomSVD(G, k=6, tol=1e-10, slices=7)
+    b = ba.big_randomSVD(G, ba.snp_scaleBinom(), k=6, tol=1e-10, slices=7)
+    assert a["fused_stats"] and not b["fused_stats"]
+    np.testing.assert_array_equal(a["center"], b["center"])
+    np.testing.assert_array_equal(a["scale"], b["scale"])
+    np.testing.assert_allclose(a["d"], b["d"], rtol=1e-12)
