@@ -210,7 +210,8 @@ void subset_pack(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_
                  uint8_t *d_out);
 
 // api.hip: transfers between caller memory (pageable) and the device, staged through the handle's two
-// pinned buffers in 8-MB pieces (host memcpy of piece k+1 overlaps the DMA of piece k); synchronous.
+// pinned buffers in 32-MB pieces (host copy of piece k+1, on a few threads, overlaps the DMA of piece k);
+// synchronous.
 // The runtime's own handling of pageable buffers was measured to leave every later stream
 // synchronisation of the process with a ~4 ms wake-up latency (tools/gpu/r02_h.sh), which costs a
 // solve 10 % — so no hot entry point hands pageable memory to hipMemcpy.

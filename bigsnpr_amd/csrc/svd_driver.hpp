@@ -80,6 +80,10 @@ struct SvdOptions {
   // pass (a fraction of a pass each): the Krylov space then starts inside the dominant subspace of a
   // thinned matrix instead of at noise, which lowers every later residual by a constant factor
   int warm = 0;
+  // (Only the START block may come from a thinned operator.  Running early block steps with a thinned
+  // expansion W = A_thin Z was tried in round 2: the basis then no longer satisfies A A' Q_j in
+  // span(Q_1 .. Q_j+1), the residual of a Ritz pair is no longer carried by the last coupling block
+  // alone, and the solver "converged" to sigma_1 off by 5e-4 with an estimated residual of 7e-6.)
   // relative residual that the rounding of the basis blocks leaves on a converged pair (about
   // 1.2 * 2^(-8 slices), measured); added to the estimate before it is compared with tol.  (Combining
   // the two in quadrature was tried: at 400K x 1M it stops the default solve one block step earlier, at
