@@ -29,6 +29,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# multi-process GPU work on this pool: dmabuf IPC only (the driver exports this too; keep it in any
+# environment built here), and single-node RCCL bootstraps over loopback (the container hostname may not
+# resolve to a usable interface)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 I8_PEAK_TOPS = 5000.0      # MI355X_MICROARCH.md / SURVEY.md §8d: dense int8 MFMA peak (2x the 2.5 PFLOP/s bf16)
 

@@ -374,10 +374,14 @@ struct HipSvdBackend : SvdBackend {
   bool subset(bool on) override {
     if (on) {
       m_op_full = op->m;
-      m_sub = (op->m / warm_den) / 256 * 256;
       // small matrices: a full pass is cheap and the thinned matrix too noisy.  The thinned operator is
-      // the sum over ranks of the shards' subsets, so the size that matters is the one over all ranks.
-      if (m_total / warm_den < 16384 || m_sub < 1024) return false;
+      // the sum over ranks of the shards' subsets, so the size that matters is the one over all ranks;
+      // the decision is taken from quantities that are identical on every rank (a rank that skipped the
+      // warm start while the others run its collectives would hang them).
+      const int64_t m_lo = m_total / (world > 0 ? world : 1);
+      const int64_t ms = (m_lo / warm_den) / 256 * 256;
+      if (m_total / warm_den < 16384 || ms < 256) return false;
+      m_sub = ms < op->m ? ms : op->m;
       op->m = m_sub;
       op->prof_kind_override = 3;
       return true;
