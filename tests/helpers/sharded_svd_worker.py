@@ -17,6 +17,7 @@ import torch.distributed as dist
 
 def main():
     n, m, k, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    tol = float(sys.argv[5]) if len(sys.argv) > 5 else 1e-9
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import bigsnpr_amd as ba
@@ -32,15 +33,17 @@ def main():
         dist.all_reduce(t)
         _lib.check(L.bsn_memcpy_h2d(C.c_void_p(ptr), host.ctypes.data_as(C.c_void_p), count * 8))
 
-    res = ba.bed_randomSVD(gb, k=k, tol=1e-9, allreduce=allreduce, rank=rank, world=world, m_total=m)
+    res = ba.bed_randomSVD(gb, k=k, tol=tol, allreduce=allreduce, rank=rank, world=world, m_total=m)
     # every rank must have taken the same decisions and hold the same d and u
     d_all = [None] * world
     dist.all_gather_object(d_all, (res["d"].tolist(), res["niter"], float(np.abs(res["u"]).sum())))
     v_all = [None] * world
     dist.all_gather_object(v_all, res["v"])
     if rank == 0:
-        json.dump(dict(d=res["d"].tolist(), niter=res["niter"], same=all(x == d_all[0] for x in d_all),
-                       v=np.concatenate(v_all, axis=0).tolist(), u0=res["u"][:, 0].tolist()), open(out, "w"))
+        json.dump(dict(d=res["d"].tolist(), niter=res["niter"], warm_launches=res["warm_launches"],
+                       same=all(x == d_all[0] for x in d_all),
+                       v=np.concatenate(v_all, axis=0).tolist() if m <= 50000 else [],
+                       u0=res["u"][:, 0].tolist()), open(out, "w"))
     dist.barrier()
     dist.destroy_process_group()
 
