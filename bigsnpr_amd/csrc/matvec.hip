@@ -257,8 +257,10 @@ __global__ __launch_bounds__(64) void k_quant(const double *__restrict__ X, int6
 // CONTIG: the variants are col0 .. col0+m-1; the genotype loads are then buffer loads with a
 // scalar descriptor based at the workgroup's first row, one 32-bit lane offset per tile and a scalar
 // chunk offset, so that addressing costs no VALU (global loads spend a 64-bit add on each).
+// TAG only changes the kernel's name: the launches of the warm start (a fraction of the variants) run as
+// <..., TAG = 1> so that a kernel trace does not average them into the full passes.
 template <int NB, int NPLANE, int KC, bool RAW0, bool STATS, bool CONTIG, int ABL = 0, int TILES = 2,
-          int WAVES = 8, int MINW = 1>
+          int WAVES = 8, int MINW = 1, int TAG = 0>
 __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__restrict__ img, int64_t pitch,
                                                const int32_t *__restrict__ cols, int64_t col0,
                                                int64_t m, const int8_t *__restrict__ xq,
@@ -518,7 +520,8 @@ __global__ void k_cprod_final(const int32_t *acc, int64_t m, int ncol, int S, co
 //   B operand: lane l -> sample group (l&15), same 16 variants, sample u of the group
 //   D        : lane l -> sample group (l&15), digit columns 4*(l>>4)+r
 // RAWP: the P plane is the device code itself (no look-up).
-template <int NB, bool CONTIG, bool RAWP, bool HASQ = true, int WAVES = 4, int ABL = 0, int UG = 1, int SETS = 2>
+template <int NB, bool CONTIG, bool RAWP, bool HASQ = true, int WAVES = 4, int ABL = 0, int UG = 1, int SETS = 2,
+          int TAG = 0>
 __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__ img, int64_t pitch,
                                               const int32_t *__restrict__ cols, int64_t col0,
                                               int64_t m_pad, int64_t mc,
@@ -1076,10 +1079,14 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
 #define BSN_LAUNCH_CPROD_C(NBV, ABLV, CONTIGV)                                                          \
   hipLaunchKernelGGL((k_cprod<NBV, NPLANE, KC, RAW0, STATS, CONTIGV, ABLV, 2, 8, 1>), grid, dim3(512), 0, \
                      b->stream, b->d_img, b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad)
-#define BSN_LAUNCH_CPROD(NBV, ABLV)                     \
-  do {                                                  \
-    if (op->cols_contig) BSN_LAUNCH_CPROD_C(NBV, ABLV, true); \
-    else BSN_LAUNCH_CPROD_C(NBV, 0, false);             \
+#define BSN_LAUNCH_CPROD(NBV, ABLV)                                                                       \
+  do {                                                                                                    \
+    if (op->cols_contig && op->prof_kind_override == 3)                                                   \
+      hipLaunchKernelGGL((k_cprod<NBV, NPLANE, KC, RAW0, STATS, true, 0, 2, 8, 1, 1>), grid, dim3(512), 0, \
+                         b->stream, b->d_img, b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2, \
+                         counts, npad);                                                                   \
+    else if (op->cols_contig) BSN_LAUNCH_CPROD_C(NBV, ABLV, true);                                        \
+    else BSN_LAUNCH_CPROD_C(NBV, 0, false);                                                               \
   } while (0)
 #ifdef BSN_ABLATION
   // BSN_TUNE = 11 / 12 / 13 / 15 / 16 / 17 / 18 / 19: no MFMA / no decode / neither / no barrier /
@@ -1254,7 +1261,14 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
     }
   }
 #endif
-  if (lutP == kLutRaw) {
+  if (lutP == kLutRaw && op->prof_kind_override == 3) {  // warm-start launch: same kernel under its own name
+    if (has_q)
+      hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 1, 2, 1>), grid, dim3(256), 0, b->stream, b->d_img,
+                         b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
+    else
+      hipLaunchKernelGGL((k_prod<NB, CONTIG, true, false, 4, 0, 1, 2, 1>), grid, dim3(256), 0, b->stream, b->d_img,
+                         b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
+  } else if (lutP == kLutRaw) {
     if (has_q) BSN_LAUNCH_PROD(true, true, 0);
     else BSN_LAUNCH_PROD(true, false, 0);
   } else {
