@@ -9,7 +9,9 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 #include <cstdlib>
@@ -56,6 +58,89 @@ static std::vector<int32_t> to_i32(const int64_t *ind, int64_t len, int64_t limi
   return v;
 }
 
+// ---- cache of released device blocks (bsn_internal.hpp) ---------------------------------
+namespace {
+struct DevCache {
+  std::mutex mu;
+  std::multimap<size_t, void *> free_blocks[16];  // per device, keyed by block size
+  size_t held[16] = {0};
+};
+DevCache &dev_cache() {
+  static DevCache *c = new DevCache();  // never destroyed: blocks may be released during process exit
+  return *c;
+}
+// sizes are rounded to 2^k or 1.5 * 2^k (>= 4 KiB) so that a repeated call finds its blocks again
+size_t size_class(size_t bytes) {
+  size_t c = 4096;
+  while (c < bytes) {
+    if (c + c / 2 >= bytes) return c + c / 2;
+    c *= 2;
+  }
+  return c;
+}
+}  // namespace
+
+void *dev_alloc(size_t bytes, size_t *granted, int *device) {
+  if (bytes == 0) bytes = 1;
+  int dev = 0;
+  BSN_HIP(hipGetDevice(&dev));
+  *device = dev;
+  const bool cached = bytes <= kDevCacheMaxBlock && dev < 16;
+  const size_t want = cached ? size_class(bytes) : bytes;
+  if (cached) {
+    DevCache &c = dev_cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    auto it = c.free_blocks[dev].find(want);
+    if (it != c.free_blocks[dev].end()) {
+      void *p = it->second;
+      c.free_blocks[dev].erase(it);
+      c.held[dev] -= want;
+      *granted = want;
+      return p;
+    }
+  }
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e == hipErrorOutOfMemory) {  // give the cached blocks back and try once more
+    (void)hipGetLastError();
+    dev_cache_flush();
+    e = hipMalloc(&p, want);
+  }
+  if (e != hipSuccess) fail("HIP error %s allocating %zu bytes of device memory", hipGetErrorString(e), want);
+  *granted = want;
+  return p;
+}
+
+void dev_release(void *p, size_t granted, int dev) {
+  if (!p) return;
+  DevCache &c = dev_cache();
+  if (granted <= kDevCacheMaxBlock && dev >= 0 && dev < 16 && size_class(granted) == granted) {
+    // hipFree's ordering: nothing on the device still uses the block once it can be handed out again
+    int cur = dev;
+    (void)hipGetDevice(&cur);
+    if (cur != dev) (void)hipSetDevice(dev);
+    (void)hipDeviceSynchronize();
+    if (cur != dev) (void)hipSetDevice(cur);
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (c.held[dev] + granted <= kDevCacheMaxTotal) {
+      c.free_blocks[dev].emplace(granted, p);
+      c.held[dev] += granted;
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+
+void dev_cache_flush() {
+  DevCache &c = dev_cache();
+  std::lock_guard<std::mutex> lk(c.mu);
+  for (int d = 0; d < 16; d++) {
+    for (auto &kv : c.free_blocks[d]) (void)hipFree(kv.second);
+    c.free_blocks[d].clear();
+    c.held[d] = 0;
+  }
+}
+
 constexpr size_t kStagePiece = 32u << 20;
 
 static void stage_init(bsn_bed *b) {
@@ -85,25 +170,28 @@ static void host_copy(void *dst, const void *src, size_t len) {
   for (auto &t : th) t.join();
 }
 
+// Host -> device through the two pinned staging buffers, ordered on the handle's stream.  Returns as
+// soon as the caller's memory has been read (the last pieces may still be on their way: whatever uses
+// d_dst is queued behind them on the same stream).
 void copy_h2d(bsn_bed *b, void *d_dst, const void *src, size_t bytes) {
   stage_init(b);
-  int k = 0;
-  for (size_t off = 0; off < bytes; off += kStagePiece, k++) {
+  for (size_t off = 0; off < bytes; off += kStagePiece) {
     const size_t len = std::min(kStagePiece, bytes - off);
-    const int s = k & 1;
-    if (k >= 2) BSN_HIP(hipEventSynchronize(b->ev_stage[s]));  // its previous piece has left the buffer
+    const int s = (int)(b->stage_next++ & 1);
+    if (b->stage_busy[s]) BSN_HIP(hipEventSynchronize(b->ev_stage[s]));  // its previous piece has left the buffer
     host_copy(b->h_stage[s], (const uint8_t *)src + off, len);
     BSN_HIP(hipMemcpyAsync((uint8_t *)d_dst + off, b->h_stage[s], len, hipMemcpyHostToDevice, b->stream));
     BSN_HIP(hipEventRecord(b->ev_stage[s], b->stream));
+    b->stage_busy[s] = true;
   }
-  BSN_HIP(hipStreamSynchronize(b->stream));
 }
 
+// Device -> host; complete when it returns.
 void copy_d2h(bsn_bed *b, void *dst, const void *d_src, size_t bytes) {
   stage_init(b);
   const size_t npiece = (bytes + kStagePiece - 1) / kStagePiece;
   for (size_t k = 0; k <= npiece; k++) {
-    if (k < npiece) {  // launch piece k
+    if (k < npiece) {  // launch piece k (stream order puts it behind any upload still reading the buffer)
       const size_t off = k * kStagePiece, len = std::min(kStagePiece, bytes - off);
       BSN_HIP(hipMemcpyAsync(b->h_stage[k & 1], (const uint8_t *)d_src + off, len, hipMemcpyDeviceToHost, b->stream));
       BSN_HIP(hipEventRecord(b->ev_stage[k & 1], b->stream));
@@ -114,6 +202,7 @@ void copy_d2h(bsn_bed *b, void *dst, const void *d_src, size_t bytes) {
       host_copy((uint8_t *)dst + off, b->h_stage[(k - 1) & 1], len);
     }
   }
+  b->stage_busy[0] = b->stage_busy[1] = false;  // every event recorded so far has completed
 }
 
 static void free_bed(bsn_bed *b) {
@@ -127,6 +216,11 @@ static void free_bed(bsn_bed *b) {
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
+}
+
+__global__ void k_fill_f64(double *p, int64_t n, double v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
 }
 
 void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
@@ -178,35 +272,97 @@ void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n, const 
     return;
   }
   // centre / scale (defaults 0 / 1, R/bed-mult-vec.R:23-24)
-  std::vector<double> tmp((size_t)m);
-  for (int64_t j = 0; j < m; j++) tmp[(size_t)j] = center ? center[j] : 0.0;
-  copy_h2d(bed, op->d_center.ensure((size_t)m), tmp.data(), (size_t)m * 8);
-  for (int64_t j = 0; j < m; j++) tmp[(size_t)j] = scale ? scale[j] : 1.0;
-  copy_h2d(bed, op->d_scale.ensure((size_t)m), tmp.data(), (size_t)m * 8);
+  op->d_center.ensure((size_t)m);
+  op->d_scale.ensure((size_t)m);
+  if (center) copy_h2d(bed, op->d_center.p, center, (size_t)m * 8);
+  else BSN_HIP(hipMemsetAsync(op->d_center.p, 0, (size_t)m * 8, bed->stream));
+  if (scale) {
+    copy_h2d(bed, op->d_scale.p, scale, (size_t)m * 8);
+  } else {
+    hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, bed->stream, op->d_scale.p, m, 1.0);
+    BSN_HIP(hipGetLastError());
+  }
 }
 
-// counts for an arbitrary sub-view into a host 4 x m int32 array
-void counts_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
-                 int64_t m, int32_t *res) {
-  bsn_op op;
-  fill_op(&op, bed, ind_row, n, ind_col, m, nullptr, nullptr);
-  DevBuf<int32_t> d_counts;
-  d_counts.ensure((size_t)4 * m);
-  if (op.rows_identity) {
-    counts_all_rows(bed, op.cols_contig ? nullptr : op.d_cols.p, op.col0, m, d_counts.p);
+// counts of the codes 0, 1, 2, missing of every selected variant over the selected rows, 4 x m int32 on
+// the device
+static void counts_device(bsn_op *op, const int64_t *ind_row, int64_t n, int32_t *d_counts) {
+  bsn_bed *bed = op->bed;
+  if (op->rows_identity) {
+    counts_all_rows(bed, op->cols_contig ? nullptr : op->d_cols.p, op->col0, op->m, d_counts);
   } else {
     std::vector<double> w((size_t)bed->n, 0.0);
     for (int64_t i = 0; i < n; i++) w[(size_t)(ind_row ? ind_row[i] : i)] += 1.0;
     DevBuf<double> d_w;
     copy_h2d(bed, d_w.ensure((size_t)bed->n), w.data(), (size_t)bed->n * 8);
-    counts_weighted(&op, d_w.p, n, d_counts.p);
+    counts_weighted(op, d_w.p, n, d_counts);
+    BSN_HIP(hipStreamSynchronize(bed->stream));  // d_w is released on return
   }
+}
+
+// the same into a host 4 x m int32 array
+void counts_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                 int64_t m, int32_t *res) {
+  bsn_op op;
+  fill_op(&op, bed, ind_row, n, ind_col, m, nullptr, nullptr, true);
+  DevBuf<int32_t> d_counts;
+  d_counts.ensure((size_t)4 * m);
+  counts_device(&op, ind_row, n, d_counts.p);
   copy_d2h(bed, res, d_counts.p, (size_t)4 * m * 4);
   if (op.rows_identity) {  // remember which variants are complete
     if ((int64_t)bed->na_cnt.size() != bed->m) bed->na_cnt.assign((size_t)bed->m, -1);
     for (int64_t j = 0; j < m; j++) bed->na_cnt[(size_t)(ind_col ? ind_col[j] : j)] = res[4 * j + 3];
   }
 }
+
+// ---- multLinReg on the device ----------------------------------------------------------------
+// X = [U, U^2] (n x 2K) and the column totals sum_i y, sum_i y^2 (one workgroup per column, fixed order)
+__global__ __launch_bounds__(1024) void k_mlr_prepare(const double *U, int64_t n, int K, double *X, double *tot) {
+  const int k = blockIdx.x;
+  double s1 = 0, s2 = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const double y = U[i + (int64_t)k * n], yy = y * y;
+    X[i + (int64_t)k * n] = y;
+    X[i + (int64_t)(K + k) * n] = yy;
+    s1 += y;
+    s2 += yy;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_down(s1, off);
+    s2 += __shfl_down(s2, off);
+  }
+  __shared__ double sm[2][16];
+  if ((threadIdx.x & 63) == 0) sm[0][threadIdx.x >> 6] = s1, sm[1][threadIdx.x >> 6] = s2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; w++) s1 += sm[0][w], s2 += sm[1][w];
+    tot[k] = s1;
+    tot[K + k] = s2;
+  }
+}
+
+// src/multLinReg.cpp:36-57 per (variant, column) from the plane sums: P = sum g y over the non-missing,
+// Q = sum of y (columns < K) / y^2 (columns >= K) over the MISSING samples, counts = code counts
+#pragma clang fp contract(off)
+__global__ void k_mlr_final(const double *P, const double *Q, int64_t ld, const int32_t *counts, const double *tot,
+                            int64_t m, int K, int64_t n, bool has_q, double *res) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  if (j >= m) return;
+  const int4 c = *(const int4 *)(counts + 4 * j);
+  const int nona = (int)(n - c.w);
+  const double xSum = (double)c.y + 2.0 * c.z, xxSum = (double)c.y + 4.0 * c.z;
+  const double deno_x = xxSum - xSum * xSum / nona;
+  const double xySum = P[j + (int64_t)k * ld];
+  const double ySum = tot[k] - (has_q ? Q[j + (int64_t)k * ld] : 0.0);
+  const double yySum = tot[K + k] - (has_q ? Q[j + (int64_t)(K + k) * ld] : 0.0);
+  const double num = xySum - xSum * ySum / nona;
+  const double deno_y = yySum - ySum * ySum / nona;
+  const double deno = deno_x * deno_y - num * num;
+  res[j + (int64_t)k * m] = (deno == 0 || nona < 2) ? __longlong_as_double(0x7ff8000000000000LL)
+                                                    : num * sqrt((nona - 2) / deno);
+}
+#pragma clang fp contract(on)
 
 }  // namespace bsn
 
@@ -651,55 +807,36 @@ int bsn_bed_prod_and_rowsumssq(bsn_bed *bed, const int64_t *ind_row, int64_t n, 
 // _bigsnpr_multLinReg (5 args) src/multLinReg.cpp:8-86: K t-scores per variant.  The sums over the
 // samples are plane sums of the crossproduct kernel on the panels (U, U^2) at 56 bits plus the exact
 // genotype counts; the rest is the reference's expressions per (variant, column).  NA_REAL -> NaN.
-#pragma clang fp contract(off)
 int bsn_mult_lin_reg(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
                      const double *U, int64_t K, double *res) {
   return guarded([&] {
     if (K <= 0) fail("'U' must have at least one column.");
+    if (K > 1024) fail("'U' has too many columns.");
     bsn_op op;
-    fill_op(&op, bed, ind_row, n, ind_col, m, nullptr, nullptr);
+    fill_op(&op, bed, ind_row, n, ind_col, m, nullptr, nullptr, true);
     op.slices = 7;
-    std::vector<double> X((size_t)n * 2 * K), tot((size_t)2 * K, 0.0);
-    for (int64_t k = 0; k < K; k++)
-      for (int64_t i = 0; i < n; i++) {
-        const double y = U[i + k * n];
-        X[(size_t)(i + k * n)] = y;
-        X[(size_t)(i + (K + k) * n)] = y * y;
-      }
-    for (int64_t k = 0; k < 2 * K; k++) {  // sum_i y and sum_i y^2 over the selected rows, in row order
-      double s = 0;
-      for (int64_t i = 0; i < n; i++) s += X[(size_t)(i + k * n)];
-      tot[(size_t)k] = s;
-    }
-    DevBuf<double> d_X, d_P, d_Q;
-    copy_h2d(bed, d_X.ensure((size_t)n * 2 * K), X.data(), (size_t)n * 2 * K * 8);
-    d_P.ensure((size_t)m * 2 * K);
-    d_Q.ensure((size_t)m * 2 * K);
-    op_cprod_raw(&op, d_X.p, n, (int)(2 * K), d_P.p, d_Q.p, m);
-    std::vector<double> P((size_t)m * 2 * K), Q((size_t)m * 2 * K);
-    copy_d2h(bed, P.data(), d_P.p, P.size() * 8);
-    copy_d2h(bed, Q.data(), d_Q.p, Q.size() * 8);
-    std::vector<int32_t> cnt((size_t)4 * m);
-    counts_host(bed, ind_row, n, ind_col, m, cnt.data());
-    const double qnan = std::numeric_limits<double>::quiet_NaN();
-    for (int64_t j = 0; j < m; j++) {
-      const int32_t *c = &cnt[(size_t)4 * j];
-      const int nona = (int)(n - c[3]);
-      const double xSum = (double)c[1] + 2.0 * c[2], xxSum = (double)c[1] + 4.0 * c[2];
-      const double deno_x = xxSum - xSum * xSum / nona;
-      for (int64_t k = 0; k < K; k++) {
-        const double xySum = P[(size_t)(j + k * m)];
-        const double ySum = tot[(size_t)k] - Q[(size_t)(j + k * m)];
-        const double yySum = tot[(size_t)(K + k)] - Q[(size_t)(j + (K + k) * m)];
-        const double num = xySum - xSum * ySum / nona;
-        const double deno_y = yySum - ySum * ySum / nona;
-        const double deno = deno_x * deno_y - num * num;
-        res[j + k * m] = (deno == 0 || nona < 2) ? qnan : num * std::sqrt((nona - 2) / deno);
-      }
-    }
+    DevBuf<double> d_U, d_X, d_P, d_Q, d_tot, d_res;
+    DevBuf<int32_t> d_counts;
+    copy_h2d(bed, d_U.ensure((size_t)n * K), U, (size_t)n * K * 8);
+    d_X.ensure((size_t)n * 2 * K);
+    d_tot.ensure((size_t)2 * K);
+    hipLaunchKernelGGL(k_mlr_prepare, dim3((unsigned)K), dim3(1024), 0, bed->stream, d_U.p, n, (int)K, d_X.p, d_tot.p);
+    BSN_HIP(hipGetLastError());
+    counts_device(&op, ind_row, n, d_counts.ensure((size_t)4 * m));
+    // complete data (known from an earlier counting pass): the sums over the missing samples are zero and the
+    // squared columns are not needed at all
+    const bool has_q = !op.no_na;
+    const int nvec = (int)(has_q ? 2 * K : K);
+    d_P.ensure((size_t)m * nvec);
+    d_Q.ensure((size_t)m * nvec);
+    op_cprod_raw(&op, d_X.p, n, nvec, d_P.p, d_Q.p, m);
+    d_res.ensure((size_t)m * K);
+    hipLaunchKernelGGL(k_mlr_final, dim3((unsigned)((m + 255) / 256), (unsigned)K), dim3(256), 0, bed->stream, d_P.p,
+                       d_Q.p, m, d_counts.p, d_tot.p, m, (int)K, n, has_q, d_res.p);
+    BSN_HIP(hipGetLastError());
+    copy_d2h(bed, res, d_res.p, (size_t)m * K * 8);
   });
 }
-#pragma clang fp contract(on)
 
 // _bigsnpr_prod_and_rowSumsSq2 (6 args) src/project-utils.cpp:12-43, the FBM.code256 twin: the FBM
 // accessor has no missing-value handling, so a missing code is NA_real and poisons its whole row of XV

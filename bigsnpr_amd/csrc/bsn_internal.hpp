@@ -45,24 +45,37 @@ int guarded(F &&f) {
 }
 
 // ---- device buffer ------------------------------------------------------------
+// Work buffers come from a small per-device cache of released blocks (api.hip): a one-shot entry such
+// as bsn_bed_prodvec needs about ten of them, and hipMalloc / hipFree pairs cost more than its kernel
+// on a matrix of a few GB.  A release keeps hipFree's ordering (the device is idle when the block
+// changes hands); blocks above kDevCacheMaxBlock bypass the cache.
+constexpr size_t kDevCacheMaxBlock = (size_t)256 << 20;
+constexpr size_t kDevCacheMaxTotal = (size_t)2 << 30;
+void *dev_alloc(size_t bytes, size_t *granted, int *device);
+void dev_release(void *p, size_t granted, int device);
+void dev_cache_flush();
+
 template <class T>
 struct DevBuf {
   T *p = nullptr;
   size_t n = 0;
+  size_t granted = 0;  // bytes of the block behind p
+  int device = 0;      // and the device it lives on
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) dev_release(p, granted, device);
     p = nullptr;
     n = 0;
+    granted = 0;
   }
   // grow-only
   T *ensure(size_t count) {
     if (count > n) {
       release();
-      BSN_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+      p = (T *)dev_alloc(count * sizeof(T), &granted, &device);
       n = count;
     }
     return p;
@@ -176,6 +189,8 @@ struct bsn_bed {
   // two pinned staging buffers for host <-> device transfers of caller (pageable) memory, see copy_h2d
   uint8_t *h_stage[2] = {nullptr, nullptr};
   hipEvent_t ev_stage[2] = {nullptr, nullptr};
+  bool stage_busy[2] = {false, false};  // ev_stage[i] marks a transfer that may still read h_stage[i]
+  unsigned stage_next = 0;
 };
 
 

@@ -292,7 +292,9 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
   // 16 B of tile t at byte `off` (uniform) of the variant row
   auto gload = [&](const int t, const int off) -> uint4 {
     if constexpr (CONTIG) {
-      const v4u r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[t], off, 0);
+      // ablation 64 / 128: nt / sc1 cache policy on the genotype stream (correct results)
+      constexpr int AUX = ((ABL & 64) ? 2 : 0) | ((ABL & 128) ? 16 : 0);
+      const v4u r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[t], off, AUX);
       return uint4{r.x, r.y, r.z, r.w};
     } else {
       return *(const uint4 *)(rowp[t] + off);
@@ -567,7 +569,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
           (void *)(img + (col0 + jb) * pitch), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
       for (int r = 0; r < 16; r++)
-        dst[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)lane_off, r * (int)pitch, 0);
+        dst[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)lane_off, r * (int)pitch,
+                                                                 ((ABL & 64) ? 2 : 0) | ((ABL & 128) ? 16 : 0));
     } else {
       const int4 *ip = (const int4 *)(cols + jb + g * 16);
 #pragma unroll
@@ -1090,9 +1093,17 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
   } while (0)
 #ifdef BSN_ABLATION
   // BSN_TUNE = 11 / 12 / 13 / 15 / 16 / 17 / 18 / 19: no MFMA / no decode / neither / no barrier /
-  // no LDS operand reads / no genotype loads / no LDS at all / compute only
+  // no LDS operand reads / no genotype loads / no LDS at all / compute only;
+  // 31 / 32 / 33: nt / sc1 / nt + sc1 cache policy on the genotype loads (correct results)
   if constexpr (NPLANE == 2 && RAW0 && !STATS) {
     const int abl = tune_variant();
+    if (NB == 1 && abl >= 31 && abl <= 33) {
+      if (abl == 31) BSN_LAUNCH_CPROD(1, 64);
+      else if (abl == 32) BSN_LAUNCH_CPROD(1, 128);
+      else BSN_LAUNCH_CPROD(1, 192);
+      BSN_HIP(hipGetLastError());
+      return;
+    }
     if (NB == 1 && abl >= 11 && abl <= 19) {
       if (abl == 11) BSN_LAUNCH_CPROD(1, 1);
       else if (abl == 12) BSN_LAUNCH_CPROD(1, 2);
@@ -1237,6 +1248,13 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
 #ifdef BSN_ABLATION
   if constexpr (NB == 1 && CONTIG) {  // BSN_TUNE = 61 .. 64: no MFMA / no decode / memory skeleton / compute only
     const int tv = tune_variant();
+    if (tv >= 81 && tv <= 83 && lutP == kLutRaw && has_q) {  // nt / sc1 / both on the genotype loads
+      if (tv == 81) BSN_LAUNCH_PROD(true, true, 64);
+      else if (tv == 82) BSN_LAUNCH_PROD(true, true, 128);
+      else BSN_LAUNCH_PROD(true, true, 192);
+      BSN_HIP(hipGetLastError());
+      return;
+    }
     if (tv >= 61 && tv <= 64 && lutP == kLutRaw && has_q) {
       if (tv == 61) BSN_LAUNCH_PROD(true, true, 1);
       else if (tv == 62) BSN_LAUNCH_PROD(true, true, 2);
