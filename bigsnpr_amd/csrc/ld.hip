@@ -535,8 +535,20 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
   int64_t W = 1;
   for (int64_t j0 = 0; j0 < m; j0++) W = std::max(W, j0 - J.lo[(size_t)j0]);
   J.W = W;
-  if ((double)m * (double)W * 8.0 > 64e9) fail("LD band of %lld x %lld does not fit the 64 GB budget",
-                                               (long long)m, (long long)W);
+  {
+    // the dense band (m x W fp64) lives in HBM next to the image: what the device has free, minus room for
+    // the statistics buffers and the caller's outputs
+    const double need = (double)m * (double)W * 8.0;
+    if (need > 32e9) {
+      dev_cache_flush();
+      size_t free_b = 0, total_b = 0;
+      BSN_HIP(hipMemGetInfo(&free_b, &total_b));
+      if (need > (double)free_b - 4e9)
+        fail("LD band of %lld x %lld (%.1f GB) does not fit the %.1f GB of free device memory; use a smaller "
+             "window or call it per chromosome / per block of variants",
+             (long long)m, (long long)W, need / 1e9, (double)free_b / 1e9);
+    }
+  }
   // columns (padded to the tile size with a valid column)
   const int64_t mt = (m + TB - 1) / TB, m_pad = mt * TB;
   std::vector<int32_t> cols((size_t)m_pad);

@@ -894,96 +894,3 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
   });
   return rc != 0 ? rc : (unconverged ? 2 : 0);
 }
-
-
-// ---------------------------------------------------------------------------------------
-// bed_tcrossprodSelf (R/bed-tcrossprodSelf.R:21-52): K = sum over column blocks of
-// A~_b A~_b', with A~_b materialised dense on the device (read_bed_scaled,
-// src/bed-mat-acc.cpp:30-49) and the product on the fp64 MFMA (v_mfma_f64_16x16x4_f64).
-// Only sensible for small n (K is n x n doubles), exactly like the reference.
-namespace bsn {
-typedef double v4d __attribute__((ext_vector_type(4)));
-
-// C[n x n] += A[n x b] A', column-major; one wave per 32 x 32 block of C (2 x 2 MFMA tiles)
-__global__ __launch_bounds__(256) void k_syrk_f64(const double *__restrict__ A, int64_t n, int64_t b,
-                                                  double *__restrict__ Cm) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int r16 = lane & 15, kq = lane >> 4;
-  const int64_t i0 = ((int64_t)blockIdx.x * 2 + (wave >> 1)) * 32;
-  const int64_t j0 = ((int64_t)blockIdx.y * 2 + (wave & 1)) * 32;
-  if (i0 >= n || j0 >= n) return;
-  v4d acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; a++)
-#pragma unroll
-    for (int c = 0; c < 2; c++) acc[a][c] = v4d{0, 0, 0, 0};
-  for (int64_t k = 0; k < b; k += 4) {
-    const int64_t kk = k + kq;
-    double av[2], bv[2];
-#pragma unroll
-    for (int a = 0; a < 2; a++) {
-      const int64_t i = i0 + a * 16 + r16, j = j0 + a * 16 + r16;
-      av[a] = (kk < b && i < n) ? A[i + kk * n] : 0.0;
-      bv[a] = (kk < b && j < n) ? A[j + kk * n] : 0.0;
-    }
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int c = 0; c < 2; c++)
-        acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[c], acc[a][c], 0, 0, 0);
-  }
-  // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
-#pragma unroll
-  for (int a = 0; a < 2; a++)
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int64_t i = i0 + a * 16 + kq + 4 * r, j = j0 + c * 16 + r16;
-        if (i < n && j < n) Cm[i + j * n] += acc[a][c][r];
-      }
-}
-}  // namespace bsn
-
-extern "C" int bsn_bed_tcrossprod(bsn_bed *bed, const int64_t *ind_row, int64_t n,
-                                  const int64_t *ind_col, int64_t m, const double *center,
-                                  const double *scale, int64_t block_size, double *K) {
-  return guarded([&] {
-    if (n <= 0 || m <= 0) fail("'ind.row' and 'ind.col' can't be empty.");
-    if ((double)n * (double)n * 8.0 > 32e9) fail("n x n result does not fit: use bed_randomSVD");
-    BSN_HIP(hipSetDevice(bed->device));
-    if (block_size <= 0) block_size = 1024;
-    std::vector<int32_t> rows((size_t)n);
-    for (int64_t i = 0; i < n; i++) {
-      int64_t r = ind_row ? ind_row[i] : i;
-      if (r < 0 || r >= bed->n) fail("Tested %lld < %lld. Subscript out of bounds (ind.row).", (long long)r, (long long)bed->n);
-      rows[(size_t)i] = (int32_t)r;
-    }
-    DevBuf<int32_t> d_rows, d_cols;
-    DevBuf<double> d_K, d_A, d_c, d_s;
-    copy_h2d(bed, d_rows.ensure((size_t)n), rows.data(), (size_t)n * 4);
-    BSN_HIP(hipMemsetAsync(d_K.ensure((size_t)n * n), 0, (size_t)n * n * 8, bed->stream));
-    d_A.ensure((size_t)n * block_size);
-    d_cols.ensure((size_t)block_size);
-    d_c.ensure((size_t)block_size);
-    d_s.ensure((size_t)block_size);
-    std::vector<int32_t> cols((size_t)block_size);
-    for (int64_t c0 = 0; c0 < m; c0 += block_size) {
-      const int64_t bsz = std::min(block_size, m - c0);
-      for (int64_t j = 0; j < bsz; j++) {
-        int64_t c = ind_col ? ind_col[c0 + j] : c0 + j;
-        if (c < 0 || c >= bed->m) fail("Tested %lld < %lld. Subscript out of bounds (ind.col).", (long long)c, (long long)bed->m);
-        cols[(size_t)j] = (int32_t)c;
-      }
-      copy_h2d(bed, d_cols.p, cols.data(), (size_t)bsz * 4);
-      copy_h2d(bed, d_c.p, center + c0, (size_t)bsz * 8);
-      copy_h2d(bed, d_s.p, scale + c0, (size_t)bsz * 8);
-      read_dense(bed, d_rows.p, n, d_cols.p, bsz, d_c.p, d_s.p, 0, nullptr, d_A.p);
-      dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64));
-      hipLaunchKernelGGL(k_syrk_f64, grid, dim3(256), 0, bed->stream, d_A.p, n, bsz, d_K.p);
-      BSN_HIP(hipGetLastError());
-      BSN_HIP(hipStreamSynchronize(bed->stream));  // `cols` is reused
-    }
-    copy_d2h(bed, K, d_K.p, (size_t)n * n * 8);
-  });
-}

@@ -274,9 +274,10 @@ int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int
  * solve (snp_autoSVD runs up to six in a row); this frees it early.  bsn_bed_close frees it too. */
 int bsn_bed_release_workspace(bsn_bed *bed);
 
-/* bed_tcrossprodSelf (R/bed-tcrossprodSelf.R:21-52): K[n x n] = A~ A~' accumulated over column
- * blocks of block_size (0 -> 1024) variants; center / scale of length m as returned by
- * fun.scaling.  K is column-major (symmetric). */
+/* bed_tcrossprodSelf (R/bed-tcrossprodSelf.R:21-52): K[n x n] = A~ A~'; center / scale of length m as
+ * returned by fun.scaling.  block_size is the reference's RAM block (R/bed-tcrossprodSelf.R:40-49) and is
+ * ignored: the genotypes are decoded inside the fp64-MFMA kernel, nothing dense is materialised.  K is
+ * column-major and exactly symmetric (the upper triangle is computed, the lower one mirrored). */
 int bsn_bed_tcrossprod(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
                        int64_t m, const double *center, const double *scale, int64_t block_size,
                        double *K);

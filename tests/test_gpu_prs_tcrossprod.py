@@ -63,6 +63,31 @@ def test_tcrossprod_self(ba, orc, golden_dir, example_bed, missing_bed):
     np.testing.assert_allclose(K2, K2ref, rtol=0, atol=1e-10 * np.abs(K2ref).max())
 
 
+def test_tcrossprod_self_tiles_and_slabs(ba, orc):
+    """the tiled kernel beyond one 128-sample tile: n not a multiple of 16, missing values, all rows (word
+    decode) against the oracle, a permuted / repeated row selection (byte gather) against the same matrix
+    re-indexed, a scattered variant selection, and exact symmetry (only the upper tiles are computed)"""
+    bo = orc.fake_bed(1003, 2500, seed=77, na16=1310)
+    gb = ba.bed.from_payload(bo.payload, bo.n, bo.m)
+    sc = orc.bed_scaleBinom(bo)
+    ic = np.nonzero(sc["scale"] > 0)[0]
+    K, _ = ba.bed_tcrossprodSelf(gb, ind_col=ic)
+    Kref, _ = orc.bed_tcrossprodSelf(bo, None, ic)
+    scale_ = np.abs(Kref).max()
+    np.testing.assert_allclose(K, Kref, rtol=0, atol=1e-10 * scale_)
+    np.testing.assert_array_equal(K, K.T)
+    rng = np.random.default_rng(5)
+    ir = np.concatenate([rng.permutation(bo.n)[:700], [3, 3, 1002]])
+    fs = lambda obj, ind_row, ind_col, ncores=1: dict(center=sc["center"][ind_col], scale=sc["scale"][ind_col])
+    Kall, _ = ba.bed_tcrossprodSelf(gb, fun_scaling=fs, ind_col=ic)
+    Ksub, _ = ba.bed_tcrossprodSelf(gb, fun_scaling=fs, ind_row=ir, ind_col=ic)
+    np.testing.assert_allclose(Ksub, Kall[np.ix_(ir, ir)], rtol=0, atol=1e-11 * scale_)
+    ic2 = ic[rng.permutation(ic.size)[:900]]
+    K3, _ = ba.bed_tcrossprodSelf(gb, fun_scaling=fs, ind_col=ic2)
+    K3ref, _ = orc.bed_tcrossprodSelf(bo, None, np.sort(ic2))
+    np.testing.assert_allclose(K3, K3ref, rtol=0, atol=1e-10 * scale_)
+
+
 def test_prod_and_rowsumssq_and_self_projection(ba, orc, golden_dir, missing_bed, example_bed):
     """src/bed-fun.cpp:103-133 + tests/testthat/test-2-pca-project.R (simple projection):
     projecting the SVD's own rows gives u d, and rowSumsSq == rowSums(X^2)"""
