@@ -131,6 +131,14 @@ void dev_release(void *p, size_t granted, int dev) {
   (void)hipFree(p);
 }
 
+size_t dev_cache_held() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+  DevCache &c = dev_cache();
+  std::lock_guard<std::mutex> lk(c.mu);
+  return c.held[dev];
+}
+
 void dev_cache_flush() {
   DevCache &c = dev_cache();
   std::lock_guard<std::mutex> lk(c.mu);

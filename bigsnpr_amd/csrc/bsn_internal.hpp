@@ -54,6 +54,7 @@ constexpr size_t kDevCacheMaxTotal = (size_t)2 << 30;
 void *dev_alloc(size_t bytes, size_t *granted, int *device);
 void dev_release(void *p, size_t granted, int device);
 void dev_cache_flush();
+size_t dev_cache_held();  // bytes of released blocks held for the current device (handed back on demand)
 
 template <class T>
 struct DevBuf {

@@ -540,9 +540,9 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
     // the statistics buffers and the caller's outputs
     const double need = (double)m * (double)W * 8.0;
     if (need > 32e9) {
-      dev_cache_flush();
       size_t free_b = 0, total_b = 0;
       BSN_HIP(hipMemGetInfo(&free_b, &total_b));
+      free_b += dev_cache_held();
       if (need > (double)free_b - 4e9)
         fail("LD band of %lld x %lld (%.1f GB) does not fit the %.1f GB of free device memory; use a smaller "
              "window or call it per chromosome / per block of variants",
@@ -848,38 +848,81 @@ int bsn_ld_scores(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t
   });
 }
 
-// Greedy clumping inside one chromosome for a grid of (size, thr) pairs that share one r2
-// band: the band is computed once at the largest window and thresholded on the device once
-// per distinct thr; this replaces the sparse r2 cache that clumping_chr_cached threads
-// through the grid loops of R/SCT.R:100-131.  mode 0: FBM formula (aux1 = sumX, aux2 = denoX);
-// mode 1: bed formula (aux1 = center, aux2 = scale).  keep[g * m + j] receives 0 / 1.
-static void clumping_grid(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
-                          int64_t m, int mode, const double *aux1, const double *aux2,
-                          const int32_t *ordInd, const int32_t *rankInd, const double *pos,
-                          int64_t n_grid, const double *sizes, const double *thrs, int32_t *keep_out) {
-  if (n_grid <= 0) return;
-  for (int64_t k = 0; k < m; k++)
-    if (ordInd[k] < 0 || ordInd[k] >= m || rankInd[k] < 0 || rankInd[k] >= m)
-      fail("'ordInd' / 'rankInd' out of bounds");
-  double size_max = sizes[0];
-  for (int64_t g = 1; g < n_grid; g++) size_max = std::max(size_max, sizes[g]);
+// ---- greedy clumping inside one chromosome --------------------------------------------------
+// mode 0: FBM formula (aux1 = sumX, aux2 = denoX, src/clumping.cpp:66-73); mode 1: bed formula (aux1 = center,
+// aux2 = scale, src/clumping-bed.cpp:62-76).
+//
+// The rank-ordered sweep of src/clumping.cpp:33-88 (sequential order == the reference's result for any
+// ncores, tests/testthat/test-7-OpenMP.R:104-115).  When j0 is visited, the neighbours that which_to_check
+// (src/clumping-utils.h:12-43) would return and that are still kept are exactly the KEPT variants visited
+// before it, so "is there one with r2 > thr" is
+//   (bitsL[j0] AND kept[j0-1 .. j0-nL]) OR (bitsU[j0] AND kept[j0+1 .. j0+nU])  !=  0,
+// evaluated 64 neighbours per word on two bit sets of the kept variants (ascending, and reversed for the
+// earlier neighbours).  bitsL / bitsU are the thresholded r2 band (k_band_gt / k_band_gt_upper).
+typedef unsigned long long u64;
+
+static bool any_and(const u64 *A, const u64 *K, int64_t kbase, int64_t len) {
+  for (int64_t q = 0; q * 64 < len; q++) {
+    u64 a = A[q];
+    const int64_t rem = len - q * 64;
+    if (rem < 64) a &= (1ull << rem) - 1ull;
+    if (!a) continue;
+    const int64_t bpos = kbase + q * 64;
+    const int sh = (int)(bpos & 63);
+    u64 kwd = K[bpos >> 6] >> sh;
+    if (sh) kwd |= K[(bpos >> 6) + 1] << (64 - sh);
+    if (a & kwd) return true;
+  }
+  return false;
+}
+
+// number of earlier / later neighbours of every variant inside the window (positions are sorted)
+static void window_counts(const double *pos, int64_t m, double size, std::vector<int64_t> &nL,
+                          std::vector<int64_t> &nU) {
+  nL.resize((size_t)m);
+  nU.resize((size_t)m);
+  int64_t l = 0, u = 0;
+  for (int64_t j0 = 0; j0 < m; j0++) {
+    const double pos_min = pos[j0] - size, pos_max = pos[j0] + size;
+    while (l < j0 && !(pos[l] >= pos_min)) l++;
+    if (u < j0) u = j0;
+    while (u + 1 < m && pos[u + 1] <= pos_max) u++;
+    nL[(size_t)j0] = j0 - l;
+    nU[(size_t)j0] = u - j0;
+  }
+}
+
+// the kept variants as two bit sets (ascending and reversed), as the sweep reads them
+struct KeptBits {
+  int64_t m;
+  std::vector<u64> fwd, rev;
+  explicit KeptBits(int64_t m_) : m(m_), fwd((size_t)(m_ + 63) / 64 + 2, 0ull), rev((size_t)(m_ + 63) / 64 + 2, 0ull) {}
+  void add(int64_t j) {
+    fwd[(size_t)(j >> 6)] |= 1ull << (j & 63);
+    const int64_t r = m - 1 - j;
+    rev[(size_t)(r >> 6)] |= 1ull << (r & 63);
+  }
+  bool hit(const u64 *BL, const u64 *BU, int64_t Wq, int64_t j0, int64_t nl, int64_t nu) const {
+    return any_and(BL + (size_t)j0 * (size_t)Wq, rev.data(), m - j0, nl) ||
+           any_and(BU + (size_t)j0 * (size_t)Wq, fwd.data(), j0 + 1, nu);
+  }
+};
+
+// r2 band of the listed variants at window `size`, thresholded at every uthr[t] into the two host bit
+// images of the sweep; returns the words per variant
+static int64_t clump_bits(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                          int mode, const double *aux1, const double *aux2, const double *pos, double size,
+                          const std::vector<double> &uthr, std::vector<std::vector<u64>> &bitsL,
+                          std::vector<std::vector<u64>> &bitsU) {
   BandJob J;
-  band_stats(J, bed, ind_row, n, ind_col, m, pos, size_max, true);
+  band_stats(J, bed, ind_row, n, ind_col, m, pos, size, true);
   copy_h2d(bed, J.d_v1.ensure((size_t)m), aux1, (size_t)m * 8);
   copy_h2d(bed, J.d_v2.ensure((size_t)m), aux2, (size_t)m * 8);
   band_run(J, mode == 0 ? 2 : 3, nullptr, J.d_v1.p, J.d_v2.p, (double)n);
-  // distinct thresholds -> one bit image each
-  std::vector<double> uthr;
-  std::vector<int> thr_id((size_t)n_grid);
-  for (int64_t g = 0; g < n_grid; g++) {
-    size_t t = 0;
-    while (t < uthr.size() && !(uthr[t] == thrs[g])) t++;
-    if (t == uthr.size()) uthr.push_back(thrs[g]);
-    thr_id[(size_t)g] = (int)t;
-  }
   const int64_t Wq = (J.W + 63) / 64;
-  std::vector<std::vector<unsigned long long>> bitsL(uthr.size()), bitsU(uthr.size());
-  DevBuf<unsigned long long> d_bits;
+  bitsL.assign(uthr.size(), {});
+  bitsU.assign(uthr.size(), {});
+  DevBuf<u64> d_bits;
   d_bits.ensure((size_t)m * (size_t)Wq);
   for (size_t t = 0; t < uthr.size(); t++) {
     for (int side = 0; side < 2; side++) {
@@ -890,67 +933,148 @@ static void clumping_grid(bsn_bed *bed, const int64_t *ind_row, int64_t n, const
         hipLaunchKernelGGL(k_band_gt_upper, dim3((unsigned)m), dim3(256), 0, bed->stream, J.d_band.p, J.d_lo.p,
                            J.W, Wq, m, uthr[t], d_bits.p);
       BSN_HIP(hipGetLastError());
-      std::vector<unsigned long long> &dst = side == 0 ? bitsL[t] : bitsU[t];
+      std::vector<u64> &dst = side == 0 ? bitsL[t] : bitsU[t];
       dst.resize((size_t)m * (size_t)Wq);
       copy_d2h(bed, dst.data(), d_bits.p, dst.size() * 8);
-      BSN_HIP(hipStreamSynchronize(bed->stream));
     }
   }
-  J.d_band.release();
-  J.d_stats.release();
-  // The rank-ordered sweep of src/clumping.cpp:33-88 (sequential order == the reference's result for
-  // any ncores, tests/testthat/test-7-OpenMP.R:104-115).  When j0 is visited, the neighbours that
-  // which_to_check (src/clumping-utils.h:12-43) would return and that are still kept are exactly the
-  // KEPT variants visited before it, so "is there one with r2 > thr" is
-  //   (bitsL[j0] AND kept[j0-1 .. j0-nL]) OR (bitsU[j0] AND kept[j0+1 .. j0+nU])  !=  0,
-  // evaluated 64 neighbours per word on two bit sets of the kept variants (ascending, and
-  // reversed for the earlier neighbours).
-  const size_t kw = (size_t)(m + 63) / 64 + 2;
-  std::vector<unsigned long long> kept(kw), kept_rev(kw);
-  std::vector<int64_t> nL((size_t)m), nU((size_t)m);
-  auto any_and = [](const unsigned long long *A, const unsigned long long *K, int64_t kbase, int64_t len) {
-    for (int64_t q = 0; q * 64 < len; q++) {
-      unsigned long long a = A[q];
-      const int64_t rem = len - q * 64;
-      if (rem < 64) a &= (1ull << rem) - 1ull;
-      if (!a) continue;
-      const int64_t bpos = kbase + q * 64;
-      const int sh = (int)(bpos & 63);
-      unsigned long long kwd = K[bpos >> 6] >> sh;
-      if (sh) kwd |= K[(bpos >> 6) + 1] << (64 - sh);
-      if (a & kwd) return true;
+  BSN_HIP(hipStreamSynchronize(bed->stream));
+  return Wq;
+}
+
+// widest window, in variants, of a two-sided window of `size`
+static int64_t window_width(const double *pos, int64_t m, double size) {
+  std::vector<int64_t> lo;
+  window_bounds(pos, m, size, true, lo);
+  int64_t W = 1;
+  for (int64_t j0 = 0; j0 < m; j0++) W = std::max(W, j0 - lo[(size_t)j0]);
+  return W;
+}
+
+// One (size, thr) point whose dense band (m x W fp64) does not fit: the pairs the reference evaluates are
+// only (candidate, KEPT variant inside its window) — src/clumping.cpp:52-79 skips pruned neighbours — so the
+// variants are taken in rank order in batches, and each batch gets the band of the SUB-LIST "kept so far +
+// this batch" (sorted by position), which is narrow because the kept variants are sparse exactly when the
+// window is wide (small thr).  The batch grows with the kept set, so at most about half of a sub-band is
+// kept x kept pairs that were already known.  Same sweep, same bits, same result as the dense path.
+static void clump_lazy(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                       int mode, const double *aux1, const double *aux2, const int32_t *ordInd,
+                       const double *pos, double size, double thr, int32_t *keep, double budget_bytes,
+                       int64_t batch_min) {
+  std::vector<char> kept((size_t)m, 0), in_batch((size_t)m, 0);
+  std::vector<int64_t> L, sub_cols, idx_in_L((size_t)m, -1), nL, nU;
+  std::vector<double> sub_pos, sub_a1, sub_a2;
+  std::vector<std::vector<u64>> bl, bu;
+  const std::vector<double> uthr(1, thr);
+  int64_t n_kept = 0, k_next = 0;
+  while (k_next < m) {
+    int64_t B = std::max<int64_t>(batch_min, n_kept);
+    for (;;) {
+      B = std::min<int64_t>(B, m - k_next);
+      for (int64_t k = k_next; k < k_next + B; k++) in_batch[(size_t)ordInd[k]] = 1;
+      L.clear();
+      for (int64_t j = 0; j < m; j++)
+        if (kept[(size_t)j] || in_batch[(size_t)j]) L.push_back(j);
+      sub_pos.resize(L.size());
+      for (size_t i = 0; i < L.size(); i++) sub_pos[i] = pos[L[i]];
+      const int64_t Wsub = window_width(sub_pos.data(), (int64_t)L.size(), size);
+      if ((double)L.size() * (double)Wsub * 8.0 <= budget_bytes) break;
+      for (int64_t k = k_next; k < k_next + B; k++) in_batch[(size_t)ordInd[k]] = 0;
+      if (B <= 64)
+        fail("clumping: %lld kept variants within windows of up to %lld of them do not fit the device "
+             "memory budget (%.1f GB); use a smaller window", (long long)n_kept, (long long)Wsub,
+             budget_bytes / 1e9);
+      B /= 2;
     }
-    return false;
-  };
-  for (int64_t g = 0; g < n_grid; g++) {
-    const unsigned long long *BL = bitsL[(size_t)thr_id[(size_t)g]].data();
-    const unsigned long long *BU = bitsU[(size_t)thr_id[(size_t)g]].data();
-    const double size = sizes[g];
-    int32_t *keep = keep_out + g * m;
-    // window of this grid point in index units (positions are sorted)
-    {
-      int64_t l = 0, u = 0;
-      for (int64_t j0 = 0; j0 < m; j0++) {
-        const double pos_min = pos[j0] - size, pos_max = pos[j0] + size;
-        while (l < j0 && !(pos[l] >= pos_min)) l++;
-        if (u < j0) u = j0;
-        while (u + 1 < m && pos[u + 1] <= pos_max) u++;
-        nL[(size_t)j0] = j0 - l;
-        nU[(size_t)j0] = u - j0;
+    const int64_t ml = (int64_t)L.size();
+    sub_cols.resize((size_t)ml);
+    sub_a1.resize((size_t)ml);
+    sub_a2.resize((size_t)ml);
+    for (int64_t i = 0; i < ml; i++) {
+      const int64_t j = L[(size_t)i];
+      sub_cols[(size_t)i] = ind_col ? ind_col[j] : j;
+      sub_a1[(size_t)i] = aux1[j];
+      sub_a2[(size_t)i] = aux2[j];
+      idx_in_L[(size_t)j] = i;
+    }
+    const int64_t Wq = clump_bits(bed, ind_row, n, sub_cols.data(), ml, mode, sub_a1.data(), sub_a2.data(),
+                                  sub_pos.data(), size, uthr, bl, bu);
+    window_counts(sub_pos.data(), ml, size, nL, nU);
+    KeptBits kb(ml);
+    for (int64_t i = 0; i < ml; i++)
+      if (kept[(size_t)L[(size_t)i]]) kb.add(i);
+    for (int64_t k = k_next; k < k_next + B; k++) {
+      const int64_t j0 = ordInd[k], li = idx_in_L[(size_t)j0];
+      const bool pruned = kb.hit(bl[0].data(), bu[0].data(), Wq, li, nL[(size_t)li], nU[(size_t)li]);
+      keep[j0] = pruned ? 0 : 1;
+      in_batch[(size_t)j0] = 0;
+      if (!pruned) {
+        kb.add(li);
+        kept[(size_t)j0] = 1;
+        n_kept++;
       }
     }
-    std::fill(kept.begin(), kept.end(), 0ull);
-    std::fill(kept_rev.begin(), kept_rev.end(), 0ull);
+    k_next += B;
+  }
+}
+
+// A grid of (size, thr) points (clumping_chr_cached threads a sparse r2 cache through the grid loops of
+// R/SCT.R:100-131): the points whose dense band fits the device share ONE band, computed at their largest
+// window and thresholded on the device once per distinct thr; the others go through clump_lazy one by
+// one.  keep[g * m + j] receives 0 / 1.
+static void clumping_grid(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                          int64_t m, int mode, const double *aux1, const double *aux2,
+                          const int32_t *ordInd, const int32_t *rankInd, const double *pos,
+                          int64_t n_grid, const double *sizes, const double *thrs, int32_t *keep_out) {
+  if (n_grid <= 0) return;
+  for (int64_t k = 0; k < m; k++)
+    if (ordInd[k] < 0 || ordInd[k] >= m || rankInd[k] < 0 || rankInd[k] >= m)
+      fail("'ordInd' / 'rankInd' out of bounds");
+  BSN_HIP(hipSetDevice(bed->device));
+  // memory for one band: what the device has free, less room for statistics buffers and bit images
+  // (BSN_CLUMP_BAND_BUDGET, bytes, overrides it: the tests force the lazy path with it)
+  size_t free_b = 0, total_b = 0;
+  BSN_HIP(hipMemGetInfo(&free_b, &total_b));
+  const double avail = std::max(1e9, ((double)(free_b + dev_cache_held()) - 8e9) * 0.8);
+  double budget = avail;
+  if (const char *e = getenv("BSN_CLUMP_BAND_BUDGET")) budget = atof(e);
+  int64_t batch_min = 8192;
+  if (const char *e = getenv("BSN_CLUMP_LAZY_BATCH")) batch_min = std::max<int64_t>(1, atoll(e));
+  std::vector<int64_t> dense;
+  for (int64_t g = 0; g < n_grid; g++) {
+    const int64_t Wg = window_width(pos, m, sizes[g]);
+    if ((double)m * (double)Wg * 8.0 <= budget)
+      dense.push_back(g);
+    else
+      clump_lazy(bed, ind_row, n, ind_col, m, mode, aux1, aux2, ordInd, pos, sizes[g], thrs[g], keep_out + g * m,
+                 std::min(avail, 16e9), batch_min);
+  }
+  if (dense.empty()) return;
+  double size_max = sizes[dense[0]];
+  for (int64_t g : dense) size_max = std::max(size_max, sizes[g]);
+  // distinct thresholds -> one pair of bit images each
+  std::vector<double> uthr;
+  std::vector<int> thr_id((size_t)n_grid, 0);
+  for (int64_t g : dense) {
+    size_t t = 0;
+    while (t < uthr.size() && !(uthr[t] == thrs[g])) t++;
+    if (t == uthr.size()) uthr.push_back(thrs[g]);
+    thr_id[(size_t)g] = (int)t;
+  }
+  std::vector<std::vector<u64>> bitsL, bitsU;
+  const int64_t Wq = clump_bits(bed, ind_row, n, ind_col, m, mode, aux1, aux2, pos, size_max, uthr, bitsL, bitsU);
+  std::vector<int64_t> nL, nU;
+  for (int64_t g : dense) {
+    const u64 *BL = bitsL[(size_t)thr_id[(size_t)g]].data();
+    const u64 *BU = bitsU[(size_t)thr_id[(size_t)g]].data();
+    int32_t *keep = keep_out + g * m;
+    window_counts(pos, m, sizes[g], nL, nU);  // window of this grid point in index units
+    KeptBits kb(m);
     for (int64_t k = 0; k < m; k++) {
       const int64_t j0 = ordInd[k];
-      const bool pruned = any_and(BL + (size_t)j0 * (size_t)Wq, kept_rev.data(), m - j0, nL[(size_t)j0]) ||
-                          any_and(BU + (size_t)j0 * (size_t)Wq, kept.data(), j0 + 1, nU[(size_t)j0]);
+      const bool pruned = kb.hit(BL, BU, Wq, j0, nL[(size_t)j0], nU[(size_t)j0]);
       keep[j0] = pruned ? 0 : 1;
-      if (!pruned) {
-        kept[(size_t)(j0 >> 6)] |= 1ull << (j0 & 63);
-        const int64_t r = m - 1 - j0;
-        kept_rev[(size_t)(r >> 6)] |= 1ull << (r & 63);
-      }
+      if (!pruned) kb.add(j0);
     }
   }
 }

@@ -128,6 +128,40 @@ def test_clumping_identical_to_oracle(ba, orc, golden_dir, example_bed):
     assert np.isin(keep, keep2).mean() > 0.98
 
 
+@pytest.mark.parametrize("batch", [37, 400])
+def test_clumping_wide_windows_lazy_path(ba, orc, golden_dir, example_bed, monkeypatch, batch):
+    """Windows whose dense r2 band would not fit the device take the batched candidate-vs-kept path
+    (clump_lazy, ld.hip).  Forced here with a tiny band budget: the kept indices must stay bit-identical to
+    the oracle (and hence to the dense path) for FBM and bed formulas, wide and narrow windows, a row subset
+    with exclusions, and through the grid entry of snp_grid_clumping."""
+    path = os.path.join(golden_dir, "example.bed")
+    chrom, pos = orc.read_bim(path)
+    Go = orc.fbm_from_bed(example_bed)
+    rng = np.random.default_rng(12)
+    ir = np.sort(rng.choice(example_bed.n, 350, replace=False))
+    excl = rng.choice(example_bed.m, 300, replace=False)
+    S = rng.uniform(size=example_bed.m)
+    cases = (dict(thr_r2=0.01, infos_pos=pos, size=20000), dict(thr_r2=0.2, infos_pos=pos, size=500),
+             dict(thr_r2=0.05, size=3000), dict(thr_r2=0.3, infos_pos=pos, ind_row=ir, exclude=excl, size=5000),
+             dict(thr_r2=0.1, infos_pos=pos, S=S, size=2000))
+    refs = [orc.snp_clumping(Go, chrom, **kw) for kw in cases]
+    bed_ref = orc.bed_clumping(example_bed, chrom, pos, ind_row=ir, thr_r2=0.02, size=10000)
+    monkeypatch.setenv("BSN_CLUMP_BAND_BUDGET", "20000")      # bytes: no chromosome's band fits
+    monkeypatch.setenv("BSN_CLUMP_LAZY_BATCH", str(batch))
+    G = ba.FBM_code256(Go.bytes)
+    gb = ba.bed(path)
+    for kw, ref in zip(cases, refs):
+        np.testing.assert_array_equal(ba.snp_clumping(G, chrom, **kw), ref)
+    np.testing.assert_array_equal(ba.bed_clumping(gb, ind_row=ir, thr_r2=0.02, size=10000), bed_ref)
+    lpval = -np.log10(rng.uniform(size=Go.m))
+    kw = dict(grid_thr_r2=(0.02, 0.5), grid_base_size=(100, 400))
+    res = ba.snp_grid_clumping(G, chrom, pos, lpval, **kw)
+    ref, _, _ = orc.snp_grid_clumping(Go, chrom, pos, lpval, **kw)
+    for a, b in zip(res, ref):
+        for u, v in zip(a, b):
+            np.testing.assert_array_equal(u, v)
+
+
 def test_clumping_with_missing_values(ba, orc, golden_dir, missing_bed):
     path = os.path.join(golden_dir, "example-missing.bed")
     gb = ba.bed(path)

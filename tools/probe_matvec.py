@@ -13,14 +13,24 @@ ap.add_argument("--m", type=int, default=100000)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--nvecs", type=str, default="1,4,8")
 ap.add_argument("--slices", type=int, default=4)
+ap.add_argument("--dosage", action="store_true", help="byte image of a dosage FBM (uploaded from the host) instead of the 2-bit image")
 a = ap.parse_args()
 L = _lib.load()
 ba.selftest()
 t0 = time.time()
-gb = ba.bed.synthetic(a.n, a.m)
+if a.dosage:
+    rng0 = np.random.default_rng(3)
+    base_m = min(a.m, 10000)
+    base = rng0.integers(7, 208, size=(base_m, a.n), dtype=np.uint8)      # CODE_DOSAGE grid 0, 0.01, ..., 2
+    host = np.concatenate([base] * ((a.m + base_m - 1) // base_m), axis=0)[:a.m]
+    G = ba.FBM_code256(host.T, code=ba.CODE_DOSAGE)
+    gb = G._bed
+    bytes_pass = a.n * a.m
+else:
+    gb = ba.bed.synthetic(a.n, a.m)
+    bytes_pass = ((a.n + 3) // 4) * a.m
 L.bsn_device_sync()
 print("generate %.2fs, image %.2f GB" % (time.time() - t0, gb.hbm_bytes() / 1e9), flush=True)
-bytes_pass = ((a.n + 3) // 4) * a.m
 
 def timed(fn, reps):
     fn(); L.bsn_device_sync()
@@ -31,9 +41,13 @@ def timed(fn, reps):
     L.bsn_timer_stop(gb.handle, C.byref(ms))
     return ms.value / reps
 
-t = timed(lambda: ba.bed_counts(gb), 1)
-print(json.dumps(dict(kernel="counts(host api)", ms=t, GBps=bytes_pass / t / 1e6)), flush=True)
-sc = ba.bed_scaleBinom(gb)
+if a.dosage:
+    st = ba.snp_colstats(G)
+    sc = dict(center=st["sumX"] / a.n, scale=np.sqrt(st["denoX"] / (a.n - 1)))
+else:
+    t = timed(lambda: ba.bed_counts(gb), 1)
+    print(json.dumps(dict(kernel="counts(host api)", ms=t, GBps=bytes_pass / t / 1e6)), flush=True)
+    sc = ba.bed_scaleBinom(gb)
 op = ba.ScaledOp(gb, None, None, sc["center"], sc["scale"], slices=a.slices)
 rng = np.random.default_rng(0)
 for nv in [int(v) for v in a.nvecs.split(",")]:
