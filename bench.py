@@ -46,8 +46,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["svd", "ld"], default="svd")
-    ap.add_argument("--n", type=int, default=400000)
-    ap.add_argument("--m", type=int, default=0, help="total SNP columns over all ranks (svd: 1e6, ld: 1e5)")
+    ap.add_argument("--n", "--samples", type=int, default=400000)
+    ap.add_argument("--m", "--variants", type=int, default=0, help="total SNP columns over all ranks (svd: 1e6, ld: 1e5)")
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--block", type=int, default=0, help="vectors per pass (0 = library default: 8 at tol 1e-4)")
     ap.add_argument("--tol", type=float, default=1e-4)
@@ -130,9 +130,15 @@ def main():
     import bigsnpr_amd as ba
     from bigsnpr_amd import _lib
     L = _lib.load()
-    _lib.check(L.bsn_set_device(local_rank))
+    # one process per GPU; if the launcher already narrowed the visible devices to one per process
+    # (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES), the only device is index 0
+    ndev = ba.device_count()
+    if ndev < 1:
+        raise SystemExit("no HIP device is visible")
+    device = local_rank % ndev
+    _lib.check(L.bsn_set_device(device))
     if torch is not None and torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(device)
     ba.selftest()
     log("selftest ok")
     if a.workload == "ld":
@@ -146,11 +152,40 @@ def main():
         return
 
     comm = None
+    hook = None
     if world > 1 or a.force_dist:
-        uid = [ba.Comm.unique_id() if rank == 0 else None]
+        err = None
+        try:
+            uid = [ba.Comm.unique_id() if rank == 0 else None]
+        except Exception as e:          # RCCL cannot be loaded on rank 0: every rank must learn it
+            uid, err = [None], e
         if world > 1:
             dist.broadcast_object_list(uid, src=0)
-        comm = ba.Comm(uid[0], rank, world)
+        if uid[0] is not None:
+            try:
+                comm = ba.Comm(uid[0], rank, world)
+            except Exception as e:
+                err = e
+        if world > 1:                   # all ranks take the same path
+            import torch as _t
+            ok = _t.tensor([1 if comm is not None else 0])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                comm = None
+                log("in-library RCCL communicator unavailable (%s): falling back to the host all-reduce hook (gloo)" % err)
+                import ctypes as _C
+                import numpy as _np
+
+                def hook(ptr, count):
+                    host = _np.empty(count)
+                    _lib.check(L.bsn_memcpy_d2h(host.ctypes.data_as(_C.c_void_p), _C.c_void_p(ptr), count * 8))
+                    t = _t.from_numpy(host)
+                    dist.all_reduce(t)
+                    _lib.check(L.bsn_memcpy_h2d(_C.c_void_p(ptr), host.ctypes.data_as(_C.c_void_p), count * 8))
+        elif comm is None:
+            raise err
 
     n, m_total = a.n, a.m or 1000000
     j0 = (m_total * rank) // world
@@ -172,6 +207,7 @@ def main():
 
     def step():
         return ba.bed_randomSVD(gb, k=a.k, tol=a.tol, block=a.block, slices=a.slices, comm=comm,
+                                allreduce=hook, rank=rank, world=world,
                                 m_total=m_total, return_uv=False, verbose=a.verbose, warm_start=a.warm_start,
                                 warm_denominator=a.warm_den)
 
@@ -231,7 +267,9 @@ def main():
                    "n": n, "m_total": m_total, "m_per_gpu": m_local, "block": blk, "slices": sl, "tol": a.tol,
                    "parallelism": ("columns sharded x%d; in-library RCCL: reduce-scatter of the n x %d panel by "
                                    "sample blocks, b x p Gram all-reduces, all-gather of the basis block"
-                                   % (world, blk)) if comm else "single GPU"},
+                                   % (world, blk)) if comm else
+                                  ("columns sharded x%d; FALLBACK: host all-reduce hook over gloo (RCCL communicator "
+                                   "unavailable)" % world if hook else "single GPU")},
         "passes_per_solve": passes / a.steps,
         "niter": infos[-1]["niter"], "converged": infos[-1]["converged"],
         "scaling_statistics": "ride along the first crossproduct pass" if infos[-1]["fused_stats"] else "own pass",

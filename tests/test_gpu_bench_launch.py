@@ -1,0 +1,48 @@
+"""bench.py as the driver launches it for N > 1 (`python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N ...`), on the one GPU of the test box: two ranks share device 0, RCCL refuses that, and the script
+must fall back — on every rank together — to the host all-reduce hook instead of dying.  What is checked is
+the launch path around the solver: rendezvous, column sharding, the one JSON line on rank 0's stdout, whole-job
+aggregation, and that the sharded solve finds the singular values of the single-rank one."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--steps", "2", "--warmup", "1", "--samples", "20000", "--variants", "60000", "--k", "5",
+        "--no-cpu-baseline", "--no-ingest"]
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]          # the ONE line of the bench contract
+    return json.loads(lines[0]), r.stderr
+
+
+def test_two_ranks_on_one_gpu_fall_back_and_agree():
+    one, _ = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    two, err = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                     "--master-addr", "127.0.0.1", "--master-port", port, "bench.py", "--gpus", "2"] + ARGS)
+    assert "falling back to the host all-reduce hook" in err
+    assert two["n_gpus"] == 2 and two["steps"] == 2 and two["warmup"] == 1
+    assert two["config"]["m_total"] == 60000 and two["config"]["m_per_gpu"] == 30000
+    assert "FALLBACK" in two["config"]["parallelism"]
+    assert two["converged"] and one["converged"]
+    np.testing.assert_allclose(two["sigma"], one["sigma"], rtol=1e-6)
+    for rec in (one, two):
+        assert rec["value"] > 0 and rec["unit"] == "SNP-cols/s" and rec["roofline"]["bound"] == "hbm"
+        # whole-job value = total columns x passes / wall
+        np.testing.assert_allclose(rec["value"],
+                                   rec["config"]["m_total"] * rec["passes_per_solve"] / (rec["ms_per_step"] * 1e-3),
+                                   rtol=1e-9)
