@@ -99,6 +99,8 @@ void *dev_alloc(size_t bytes, size_t *granted, int *device) {
       return p;
     }
   }
+  static const bool trace = getenv("BSN_ALLOC_TRACE") != nullptr;  // every real allocation on stderr
+  if (trace) std::fprintf(stderr, "[bsn alloc] hipMalloc %zu bytes (asked %zu)\n", want, bytes);
   void *p = nullptr;
   hipError_t e = hipMalloc(&p, want);
   if (e == hipErrorOutOfMemory) {  // give the cached blocks back and try once more
@@ -128,6 +130,8 @@ void dev_release(void *p, size_t granted, int dev) {
       return;
     }
   }
+  static const bool trace = getenv("BSN_ALLOC_TRACE") != nullptr;
+  if (trace) std::fprintf(stderr, "[bsn alloc] hipFree %zu bytes\n", granted);
   (void)hipFree(p);
 }
 

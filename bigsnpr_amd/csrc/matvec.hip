@@ -1316,6 +1316,9 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
   // K split so that the grid has a few thousand workgroups
   int64_t wgx = b->bits == 8 ? npad / 256 : npad / 1024;  // workgroups along the samples
   int ky = (int)((4096 + wgx - 1) / wgx);
+#ifdef BSN_ABLATION
+  if (const char *e = getenv("BSN_KY")) ky = atoi(e);  // grid-shape sweep (correct results)
+#endif
   int64_t steps = m_pad / 64;
   if (ky > steps) ky = (int)steps;
   if (ky > 64) ky = 64;

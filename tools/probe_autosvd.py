@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""snp_autoSVD end to end on a synthetic 2-bit image with 22 chromosomes (run on the GPU box):
+where the time of the whole pipeline goes (MAF filter, clumping, SVD rounds + outlier detection)."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bigsnpr_amd as ba
+from bigsnpr_amd import ld as ldm, autosvd
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=400000)
+ap.add_argument("--m", type=int, default=250000)
+a = ap.parse_args()
+gb = ba.bed.synthetic(a.n, a.m)
+chrom = np.repeat(np.arange(1, 23), (a.m + 21) // 22)[:a.m]
+pos = np.arange(a.m) * 2000.0                       # 250 variants per 500-kb window side
+T = {}
+def timed(name, fn):
+    def w(*x, **k):
+        t0 = time.perf_counter(); r = fn(*x, **k); T[name] = T.get(name, 0.0) + time.perf_counter() - t0
+        return r
+    return w
+autosvd.snp_MAF = timed("snp_MAF", autosvd.snp_MAF)
+autosvd.snp_clumping = timed("snp_clumping", autosvd.snp_clumping)
+autosvd.big_randomSVD = timed("big_randomSVD", autosvd.big_randomSVD)
+t0 = time.perf_counter()
+res = ba.snp_autoSVD(gb, chrom, pos, k=10, verbose=True)
+tot = time.perf_counter() - t0
+print("total %.2f s; %s; other (outlier detection, host) %.2f s; kept %d of %d variants"
+      % (tot, ", ".join("%s %.2f s" % kv for kv in T.items()), tot - sum(T.values()), res["subset"].size, a.m))

@@ -13,6 +13,7 @@ ap.add_argument("--m", type=int, default=100000)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--nvecs", type=str, default="1,4,8")
 ap.add_argument("--slices", type=int, default=4)
+ap.add_argument("--subset", type=float, default=0.0, help="random sorted subset of this fraction of the variants (non-contiguous ind.col)")
 ap.add_argument("--dosage", action="store_true", help="byte image of a dosage FBM (uploaded from the host) instead of the 2-bit image")
 a = ap.parse_args()
 L = _lib.load()
@@ -48,8 +49,15 @@ else:
     t = timed(lambda: ba.bed_counts(gb), 1)
     print(json.dumps(dict(kernel="counts(host api)", ms=t, GBps=bytes_pass / t / 1e6)), flush=True)
     sc = ba.bed_scaleBinom(gb)
-op = ba.ScaledOp(gb, None, None, sc["center"], sc["scale"], slices=a.slices)
 rng = np.random.default_rng(0)
+ic = None
+if a.subset > 0:
+    ic = np.sort(rng.choice(a.m, int(a.m * a.subset), replace=False))
+    sc = dict(center=sc["center"][ic], scale=sc["scale"][ic])
+    bytes_pass = bytes_pass // a.m * ic.size
+    a.m = ic.size
+    print("subset of %d variants" % ic.size, flush=True)
+op = ba.ScaledOp(gb, None, ic, sc["center"], sc["scale"], slices=a.slices)
 for nv in [int(v) for v in a.nvecs.split(",")]:
     X = ba.DeviceArray.from_numpy(rng.normal(size=(a.m, nv)))
     R = ba.DeviceArray.from_numpy(rng.normal(size=(a.n, nv)))

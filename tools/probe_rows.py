@@ -95,6 +95,3 @@ if not a.skip_fbm:
     lp = rng.uniform(0, 10, size=m)
     line(tag, "snp_PRS (11 thresholds)",
          timed(lambda: ba.snp_PRS(G, beta, lpS_keep=lp, thr_list=np.linspace(0, 9, 11))), nb)
-    t = timed(lambda: ba.big_randomSVD(G, k=10), 1)
-    info = ba.big_randomSVD(G, k=10)
-    line(tag, "big_randomSVD k=10", t, nb * (info["nops"] + 1), nops=int(info["nops"]), niter=int(info["niter"]))
