@@ -275,6 +275,9 @@ def main():
         "scaling_statistics": "ride along the first crossproduct pass" if infos[-1]["fused_stats"] else "own pass",
         "warm_start": {"launches": infos[-1]["warm_launches"], "fraction_of_variants": infos[-1]["warm_fraction"],
                        "ms": infos[-1]["warm_ms"]},
+        "image_layout": ("streaming kernels read the tiled second copy (64 variants x 1024 samples per 16-KB tile; built once "
+                         "per handle before the first solve, + %.0f GB of HBM)" % (bytes_per_launch / 1e9))
+                        if infos[-1]["tiled"] else "variant-major image only",
         "end_to_end_cols_per_s": m_total * a.steps / wall,
         "hbm_GBps_whole_solve": passes * ((n + 3) // 4) * m_total / wall / 1e9,
         "hbm_frac_whole_solve": passes * ((n + 3) // 4) * m_total / wall / 1e9 / HBM_PEAK_GBS / world,

@@ -38,7 +38,7 @@ class SvdInfo(C.Structure):
                 ("n_prod", C.c_int32), ("block", C.c_int32), ("slices", C.c_int32),
                 ("n_bad", C.c_int32), ("fused_stats", C.c_int32), ("cprod_stats_ms", C.c_double),
                 ("n_cprod_stats", C.c_int32), ("warm_launches", C.c_int32), ("warm_fraction", C.c_double),
-                ("warm_ms", C.c_double)]
+                ("warm_ms", C.c_double), ("tiled", C.c_int32)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check that every symbol
@@ -61,6 +61,7 @@ SIGNATURES = {
     "bsn_bed_from_fbm": (C.c_int, [u8p, i64, i64, i64, C.POINTER(vp)]),
     "bsn_fbm_open": (C.c_int, [u8p, i64, i64, i64, f64p, C.POINTER(vp)]),
     "bsn_bed_bits": (C.c_int, [vp]),
+    "bsn_bed_tile": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "bsn_bed_na_known": (i64, [vp]),
     "bsn_bed_synthetic": (C.c_int, [i64, i64, C.c_uint32, C.c_uint32, C.c_uint32, i64, C.POINTER(vp)]),
     "bsn_bed_close": (C.c_int, [vp]),

@@ -168,6 +168,12 @@ class bed:
     def hbm_bytes(self):
         return int(_lib.load().bsn_bed_bytes(self.handle))
 
+    def tile(self):
+        """builds the streaming-layout copy of the image ahead of time (bsn_bed_tile); True if it exists"""
+        built = C.c_int(0)
+        check(_lib.load().bsn_bed_tile(self.handle, C.byref(built)))
+        return bool(built.value)
+
     def download(self):
         out = np.empty(((self.nrow + 3) // 4) * self.ncol, dtype=np.uint8)
         check(_lib.load().bsn_bed_download(self.handle, ptr(out, u8p)))

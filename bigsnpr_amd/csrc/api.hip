@@ -224,6 +224,7 @@ static void free_bed(bsn_bed *b) {
     if (b->ev_stage[i]) (void)hipEventDestroy(b->ev_stage[i]);
   }
   if (b->d_img) (void)hipFree(b->d_img);
+  if (b->d_tiled) (void)hipFree(b->d_tiled);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -558,6 +559,14 @@ int bsn_bed_close(bsn_bed *bed) {
       (void)hipSetDevice(bed->device);
       free_bed(bed);
     }
+  });
+}
+
+int bsn_bed_tile(bsn_bed *bed, int *built) {
+  return guarded([&] {
+    BSN_HIP(hipSetDevice(bed->device));
+    const bool ok = image_tile(bed);
+    if (built) *built = ok ? 1 : 0;
   });
 }
 

@@ -175,6 +175,13 @@ struct bsn_bed {
   int bits = 2;
   double v_off = 0.0, v_step = 1.0;
   uint8_t *d_img = nullptr;
+  // Second copy of a 2-bit image in the STREAMING layout (image.hip, image_tile): tiles of 64 variants x
+  // 256 B (1024 samples), tile (vb, sb) at ((vb * pitch / 256) + sb) * 16 KB, variant v of the block at
+  // v * 256 inside it.  k_cprod / k_prod read it when the operator covers a 64-aligned contiguous range of
+  // variants: what a wave touches per step is then one contiguous 4 - 16 KB run instead of 16 - 64 pieces
+  // 100 KB apart.  Built on demand when the device has the room, freed with the handle.
+  uint8_t *d_tiled = nullptr;
+  bool tiled_tried = false;
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -199,6 +206,7 @@ namespace bsn {
 
 // image.hip
 void image_alloc(bsn_bed *b, int64_t n, int64_t m, int bits = 2);
+bool image_tile(bsn_bed *b);  // true when the streaming-layout copy exists (builds it if memory allows)
 void image_from_host(bsn_bed *b, const uint8_t *payload, int64_t n_byte_src);
 void image_from_file(bsn_bed *b, int fd, int64_t offset, int64_t n_byte_src);
 // FBM bytes -> device image through a 256-entry byte look-up (lut[byte] = device code 0..3 for a 2-bit

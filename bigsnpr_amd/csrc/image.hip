@@ -65,6 +65,49 @@ void image_alloc(bsn_bed *b, int64_t n, int64_t m, int bits) {
   BSN_HIP(hipMalloc((void **)&b->d_img, bytes));
 }
 
+// ---- streaming layout (second copy) --------------------------------------------------------
+// One workgroup copies one 16-KB tile: 64 variants x 256 B.  Source rows are read 256 B at a time (16 lanes
+// x 16 B), the tile is written front to back; variants past the end are written as zeros.
+__global__ __launch_bounds__(256) void k_tile_image(const uint8_t *__restrict__ img, int64_t pitch, int64_t m,
+                                                    uint8_t *__restrict__ tiled) {
+  const int64_t SB = pitch >> 8;
+  const int64_t sb = blockIdx.x, vb = (int64_t)blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (vb * 64 >= m) return;
+  const int seg = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+  uint4 *dst = (uint4 *)(tiled + (vb * SB + sb) * 16384);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int row = r0 + 16 * i;
+    const int64_t j = vb * 64 + row;
+    uint4 v = {0, 0, 0, 0};
+    if (j < m) v = *(const uint4 *)(img + j * pitch + sb * 256 + seg * 16);
+    dst[row * 16 + seg] = v;
+  }
+}
+
+bool image_tile(bsn_bed *b) {
+  if (b->d_tiled) return true;
+  if (b->tiled_tried || b->bits != 2 || getenv("BSN_NO_TILED")) return false;
+  b->tiled_tried = true;
+  BSN_HIP(hipSetDevice(b->device));
+  const int64_t nvb = (b->m + 63) / 64;
+  const size_t bytes = (size_t)nvb * 64 * (size_t)b->pitch;
+  // leave room for the workspace of a solve and for the other entry points' buffers
+  size_t free_b = 0, total_b = 0;
+  BSN_HIP(hipMemGetInfo(&free_b, &total_b));
+  if ((double)(free_b + dev_cache_held()) < (double)bytes + 24e9) return false;
+  if (hipMalloc((void **)&b->d_tiled, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    b->d_tiled = nullptr;
+    return false;
+  }
+  const int64_t gy = nvb < 65535 ? nvb : 65535, gz = (nvb + 65534) / 65535;
+  hipLaunchKernelGGL(k_tile_image, dim3((unsigned)(b->pitch >> 8), (unsigned)gy, (unsigned)gz), dim3(256), 0,
+                     b->stream, b->d_img, b->pitch, b->m, b->d_tiled);
+  BSN_HIP(hipGetLastError());
+  return true;
+}
+
 // recode = 1: the rows hold .bed codes (uploads); 0: device codes already (FBM repack)
 static void finish_image(bsn_bed *b, int recode) {
   const int64_t gy = b->m < 65535 ? b->m : 65535, gz = (b->m + 65534) / 65535;

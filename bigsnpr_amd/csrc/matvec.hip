@@ -259,8 +259,10 @@ __global__ __launch_bounds__(64) void k_quant(const double *__restrict__ X, int6
 // chunk offset, so that addressing costs no VALU (global loads spend a 64-bit add on each).
 // TAG only changes the kernel's name: the launches of the warm start (a fraction of the variants) run as
 // <..., TAG = 1> so that a kernel trace does not average them into the full passes.
+// TILED (with CONTIG, col0 a multiple of 64): `img` is the streaming-layout copy (bsn_internal.hpp): variant
+// a, byte o of its row at ((a >> 6) * (pitch >> 8) + (o >> 8)) * 16384 + (a & 63) * 256 + (o & 255).
 template <int NB, int NPLANE, int KC, bool RAW0, bool STATS, bool CONTIG, int ABL = 0, int TILES = 2,
-          int WAVES = 8, int MINW = 1, int TAG = 0>
+          int WAVES = 8, int MINW = 1, int TAG = 0, bool TILED = false>
 __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__restrict__ img, int64_t pitch,
                                                const int32_t *__restrict__ cols, int64_t col0,
                                                int64_t m, const int8_t *__restrict__ xq,
@@ -284,17 +286,22 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
     if (j > m - 1) j = m - 1;
     int64_t col = CONTIG ? col0 + j : (int64_t)cols[j];
     rowp[t] = img + col * pitch + g * 16;
-    voff[t] = (uint32_t)((j - wg_base) * pitch + g * 16);
+    voff[t] = TILED ? (uint32_t)((((j - wg_base) >> 6) * (pitch >> 8)) * 16384 + (j & 63) * 256 + g * 16)
+                    : (uint32_t)((j - wg_base) * pitch + g * 16);
   }
+  static_assert(!TILED || (CONTIG && (WAVES * 16 * TILES) % 64 == 0), "streaming layout: whole 64-variant blocks");
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)(img + (col0 + (CONTIG ? wg_base : 0)) * pitch), 0, 0x7fffffff, 0x00020000);
+      (void *)(TILED ? img + (((col0 + wg_base) >> 6) * (pitch >> 8)) * 16384
+                     : img + (col0 + (CONTIG ? wg_base : 0)) * pitch),
+      0, 0x7fffffff, 0x00020000);
   typedef unsigned int v4u __attribute__((ext_vector_type(4)));
   // 16 B of tile t at byte `off` (uniform) of the variant row
   auto gload = [&](const int t, const int off) -> uint4 {
     if constexpr (CONTIG) {
       // ablation 64 / 128: nt / sc1 cache policy on the genotype stream (correct results)
       constexpr int AUX = ((ABL & 64) ? 2 : 0) | ((ABL & 128) ? 16 : 0);
-      const v4u r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[t], off, AUX);
+      const int soff = TILED ? ((off >> 8) << 14) + (off & 255) : off;
+      const v4u r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[t], soff, AUX);
       return uint4{r.x, r.y, r.z, r.w};
     } else {
       return *(const uint4 *)(rowp[t] + off);
@@ -522,8 +529,9 @@ __global__ void k_cprod_final(const int32_t *acc, int64_t m, int ncol, int S, co
 //   B operand: lane l -> sample group (l&15), same 16 variants, sample u of the group
 //   D        : lane l -> sample group (l&15), digit columns 4*(l>>4)+r
 // RAWP: the P plane is the device code itself (no look-up).
+// TILED: `img` is the streaming-layout copy; a step of the workgroup (64 variants x 256 B) is one tile.
 template <int NB, bool CONTIG, bool RAWP, bool HASQ = true, int WAVES = 4, int ABL = 0, int UG = 1, int SETS = 2,
-          int TAG = 0>
+          int TAG = 0, bool TILED = false>
 __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__ img, int64_t pitch,
                                               const int32_t *__restrict__ cols, int64_t col0,
                                               int64_t m_pad, int64_t mc,
@@ -565,12 +573,21 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
     if (CONTIG) {
       // buffer loads: scalar descriptor (re-based per step) + scalar row offset + one 32-bit lane
       // offset, so the 16 addresses of a step cost no VALU (global loads took a 64-bit add each)
+      if constexpr (TILED) {
+        static_assert(WAVES == 4, "streaming layout: one workgroup = one 256-B column block");
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(img + (((col0 + jb) >> 6) * (pitch >> 8) + blockIdx.x) * 16384), 0, 0x7fffffff, 0x00020000);
+        const int toff = g * 4096 + wave * 64 + sg * 4;
+#pragma unroll
+        for (int r = 0; r < 16; r++) dst[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, toff, r * 256, 0);
+      } else {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
           (void *)(img + (col0 + jb) * pitch), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
       for (int r = 0; r < 16; r++)
         dst[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)lane_off, r * (int)pitch,
                                                                  ((ABL & 64) ? 2 : 0) | ((ABL & 128) ? 16 : 0));
+      }
     } else {
       const int4 *ip = (const int4 *)(cols + jb + g * 16);
 #pragma unroll
@@ -1069,6 +1086,15 @@ __global__ __launch_bounds__(1024) void k_na_total(const int32_t *counts, int64_
   }
 }
 
+// the streaming-layout copy serves an operator over a 64-aligned contiguous range of variants
+static bool use_tiled(const bsn_op *op) {
+#ifdef BSN_ABLATION
+  // the ablation variants exist on the plain image only (41 - 46: workgroup shapes on the tiled copy)
+  if (tune_variant() != 0 && !(tune_variant() >= 41 && tune_variant() <= 46)) return false;
+#endif
+  return op->bed->d_tiled != nullptr && op->cols_contig && (op->col0 & 63) == 0;
+}
+
 template <int NPLANE, bool RAW0, bool STATS>
 static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint32_t l0,
                          uint32_t l1, uint32_t l2, int32_t *counts = nullptr) {
@@ -1079,6 +1105,41 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
   dim3 grid((unsigned)((op->m + 255) / 256));
   const int32_t *cols = op->cols_contig ? nullptr : op->d_cols.p;
   const int32_t npad = (int32_t)(b->pitch * 4 - b->n);
+  if (use_tiled(op)) {
+#define BSN_LAUNCH_CPROD_T(NBV, WV, TAGV)                                                                     \
+  hipLaunchKernelGGL((k_cprod<NBV, NPLANE, KC, RAW0, STATS, true, 0, 2, WV, 1, TAGV, true>),                  \
+                     dim3((unsigned)((op->m + 32 * WV - 1) / (32 * WV))), dim3(64 * WV), 0, b->stream,        \
+                     b->d_tiled, b->pitch, nullptr, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad)
+#ifdef BSN_ABLATION
+    // BSN_TUNE = 41 .. 46: (tiles per wave, waves, samples per chunk) on the tiled copy; correct results
+    if (NB == 1 && tune_variant() >= 41 && tune_variant() <= 46 && op->prof_kind_override != 3) {
+#define BSN_SHAPE_T(TILESV, WAVESV, KCV)                                                                  \
+  hipLaunchKernelGGL((k_cprod<1, NPLANE, KCV, RAW0, STATS, true, 0, TILESV, WAVESV, 1, 0, true>),         \
+                     dim3((unsigned)((op->m + 16 * TILESV * WAVESV - 1) / (16 * TILESV * WAVESV))),       \
+                     dim3(64 * WAVESV), 0, b->stream, b->d_tiled, b->pitch, nullptr, op->col0, op->m, q,  \
+                     acc, op->m, l0, l1, l2, counts, npad)
+      const int tv = tune_variant();
+      if (tv == 41) BSN_SHAPE_T(4, 4, 512);
+      else if (tv == 42) BSN_SHAPE_T(4, 8, 512);
+      else if (tv == 43) BSN_SHAPE_T(4, 2, 512);
+      else if (tv == 44) BSN_SHAPE_T(2, 8, 1024);
+      else if (tv == 45) BSN_SHAPE_T(4, 4, 1024);
+      else BSN_SHAPE_T(2, 16, 512);
+#undef BSN_SHAPE_T
+      BSN_HIP(hipGetLastError());
+      return;
+    }
+#endif
+    if (NB == 1) {
+      if (op->prof_kind_override == 3) BSN_LAUNCH_CPROD_T(1, 8, 1);
+      else BSN_LAUNCH_CPROD_T(1, 8, 0);
+    } else {
+      BSN_LAUNCH_CPROD_T(2, 16, 0);
+    }
+#undef BSN_LAUNCH_CPROD_T
+    BSN_HIP(hipGetLastError());
+    return;
+  }
 #define BSN_LAUNCH_CPROD_C(NBV, ABLV, CONTIGV)                                                          \
   hipLaunchKernelGGL((k_cprod<NBV, NPLANE, KC, RAW0, STATS, CONTIGV, ABLV, 2, 8, 1>), grid, dim3(512), 0, \
                      b->stream, b->d_img, b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad)
@@ -1279,6 +1340,24 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
     }
   }
 #endif
+  if constexpr (CONTIG) {
+    if (use_tiled(op)) {  // streaming-layout copy: same arithmetic, contiguous 16-KB steps
+#define BSN_LAUNCH_PROD_T(RAWP, HASQ, TAGV)                                                                 \
+  hipLaunchKernelGGL((k_prod<NB, true, RAWP, HASQ, 4, 0, 1, 2, TAGV, true>), grid, dim3(256), 0, b->stream, \
+                     b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ)
+      const bool warm = op->prof_kind_override == 3;
+      if (lutP == kLutRaw) {
+        if (has_q) { if (warm) BSN_LAUNCH_PROD_T(true, true, 1); else BSN_LAUNCH_PROD_T(true, true, 0); }
+        else { if (warm) BSN_LAUNCH_PROD_T(true, false, 1); else BSN_LAUNCH_PROD_T(true, false, 0); }
+      } else {
+        if (has_q) BSN_LAUNCH_PROD_T(false, true, 0);
+        else BSN_LAUNCH_PROD_T(false, false, 0);
+      }
+#undef BSN_LAUNCH_PROD_T
+      BSN_HIP(hipGetLastError());
+      return;
+    }
+  }
   if (lutP == kLutRaw && op->prof_kind_override == 3) {  // warm-start launch: same kernel under its own name
     if (has_q)
       hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 1, 2, 1>), grid, dim3(256), 0, b->stream, b->d_img,

@@ -771,6 +771,9 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     } else {
       fill_op(op, bed, ind_row, n, ind_col, m, center, scale);
     }
+    // a solve streams the image a dozen times: give the two streaming kernels their layout (a second copy in
+    // 64-variant x 256-B tiles, one extra pass of copying, kept on the handle) when the device has the room
+    if (op->cols_contig && (op->col0 & 63) == 0 && m >= 4096) image_tile(bed);
     const double t_create = since();
     op->profile = true;
     if (o->slices > 7) fail("slices must be in 1..7");
@@ -890,6 +893,7 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       info->warm_fraction = bk.m_sub > 0 && bk.m_op_full > 0 ? (double)bk.m_sub / (double)bk.m_op_full : 0.0;
       info->block = so.block;
       info->slices = op->slices;
+      info->tiled = (bed->d_tiled != nullptr && op->cols_contig && (op->col0 & 63) == 0) ? 1 : 0;
     }
   });
   return rc != 0 ? rc : (unconverged ? 2 : 0);

@@ -1,0 +1,67 @@
+"""The streaming-layout copy of the image (bsn_bed_tile: tiles of 64 variants x 1024 samples) must not change a
+single bit of any result: the streaming kernels do the same integer arithmetic on the same genotypes, only the
+addresses differ.  Shapes are chosen off every alignment (samples not a multiple of 1024 or 4, variants not a
+multiple of 64), with missing values, for one and two MFMA column blocks, full and sub-range operators, the
+warm-start launches, and the solve with the fused scaling statistics."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ba():
+    import bigsnpr_amd
+    return bigsnpr_amd
+
+
+def test_products_bit_identical_on_the_tiled_copy(ba, orc, monkeypatch):
+    n, m = 3001, 5003
+    ob = orc.fake_bed(n, m, seed=5, na16=1300)
+    gb = ba.bed.from_payload(ob.payload, n, m)
+    sc = orc.bed_scaleBinom(ob)
+    ok = sc["scale"] > 0
+    ce, sa = np.where(ok, sc["center"], 0.0), np.where(ok, sc["scale"], 1.0)
+    rng = np.random.default_rng(0)
+    x, y = rng.normal(size=m), rng.normal(size=n)
+    views = [np.arange(m), np.arange(128, 128 + 3000), np.arange(7, 7 + 2000), np.arange(4992, m)]
+
+    def run():
+        out = []
+        for ic in views:
+            out.append(ba.bed_prodVec(gb, x[ic], None, ic, ce[ic], sa[ic]))
+            out.append(ba.bed_cprodVec(gb, y, None, ic, ce[ic], sa[ic]))
+        V = rng.normal(size=(m, 5))
+        rng2 = np.random.default_rng(9)
+        out.extend(ba.prod_and_rowSumsSq(gb, ba.rows_along(gb), ba.cols_along(gb), ce, sa, rng2.normal(size=(m, 5))))
+        out.append(ba.multLinReg(gb, None, None, rng2.normal(size=(n, 3))))
+        return out
+
+    plain = run()
+    ref = orc.bed_prodVec(ob, x, None, np.arange(m), ce, sa, 4)
+    assert np.abs(plain[0] - ref).max() <= 1e-9 * np.abs(ref).max()
+    assert gb.tile() is True
+    tiled = run()
+    for a, b in zip(plain, tiled):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(ba.bed_counts(gb), orc.bed_col_counts(ob))      # other kernels: untouched
+
+
+@pytest.mark.parametrize("block", [0, 16])
+def test_solve_bit_identical_with_and_without_the_tiled_copy(ba, monkeypatch, block):
+    n, m, k = 2500, 290000 if block == 0 else 9000, 6      # 290 000 variants: with the warm start
+    res = {}
+    for tiled in (False, True):
+        if tiled:
+            monkeypatch.delenv("BSN_NO_TILED", raising=False)
+        else:
+            monkeypatch.setenv("BSN_NO_TILED", "1")
+        gb = ba.bed.synthetic(n, m, seed=13)
+        res[tiled] = ba.bed_randomSVD(gb, k=k, block=block)
+        assert res[tiled]["tiled"] == int(tiled)
+        gb.close()
+    a, b = res[False], res[True]
+    assert a["niter"] == b["niter"] and a["nops"] == b["nops"] and a["warm_launches"] == b["warm_launches"]
+    assert a["warm_launches"] == (2 if block == 0 else 0)
+    for key in ("d", "u", "v", "center", "scale"):
+        np.testing.assert_array_equal(a[key], b[key])

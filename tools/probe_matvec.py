@@ -30,6 +30,8 @@ if a.dosage:
 else:
     gb = ba.bed.synthetic(a.n, a.m)
     bytes_pass = ((a.n + 3) // 4) * a.m
+if os.environ.get("BSN_PROBE_TILE") and not a.dosage:
+    print("tiled copy:", gb.tile(), flush=True)
 L.bsn_device_sync()
 print("generate %.2fs, image %.2f GB" % (time.time() - t0, gb.hbm_bytes() / 1e9), flush=True)
 
