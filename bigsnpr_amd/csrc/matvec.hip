@@ -605,19 +605,23 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
   const int64_t jlast = j1 - 64;
   ws[0][wtid] = wq4[(j0 / 16) * 2 * NCOL + wtid];
   load(j0, X[0]);
-  if constexpr (SETS == 2) load(j0 + 64 < j1 ? j0 + 64 : jlast, X[1]);
+  if constexpr (SETS >= 2) load(j0 + 64 < j1 ? j0 + 64 : jlast, X[1]);
+  if constexpr (SETS >= 3) load(j0 + 128 < j1 ? j0 + 128 : jlast, X[2]);
   __syncthreads();
+  int wpar = 0;  // SETS == 3: the LDS digit buffer alternates per step, the register set goes round three
 
   auto step = [&](auto SETC, const int64_t jb) {
     constexpr int SET = decltype(SETC)::value;
     const int64_t jn1 = jb + 64 < j1 ? jb + 64 : jlast, jn2 = jb + 128 < j1 ? jb + 128 : jlast;
+    const int64_t jn3 = jb + 192 < j1 ? jb + 192 : jlast;
+    const int WB = SETS == 3 ? wpar : SET;  // LDS buffer of this step's digits
     wreg = wq4[(jn1 / 16) * 2 * NCOL + wtid];  // next step's digits: registers now, LDS later
     __builtin_amdgcn_sched_barrier(0);
     v4i aw[NB], awc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
-      uint4 t0 = ws[SET][(g * 2 + 0) * NCOL + nb * 16 + sg];
-      uint4 t1 = ws[SET][(g * 2 + 1) * NCOL + nb * 16 + sg];
+      uint4 t0 = ws[WB][(g * 2 + 0) * NCOL + nb * 16 + sg];
+      uint4 t1 = ws[WB][(g * 2 + 1) * NCOL + nb * 16 + sg];
       aw[nb] = v4i{(int)t0.x, (int)t0.y, (int)t0.z, (int)t0.w};
       awc[nb] = v4i{(int)t1.x, (int)t1.y, (int)t1.z, (int)t1.w};
     }
@@ -625,7 +629,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
     uint32_t T[4][4];
 #pragma unroll
     for (int r4 = 0; r4 < 4; r4++) {
-      constexpr int XS_ = SETS == 2 ? SET : 0;
+      constexpr int XS_ = SETS >= 2 ? SET : 0;
       const uint32_t x0 = X[XS_][4 * r4], x1 = X[XS_][4 * r4 + 1], x2 = X[XS_][4 * r4 + 2],
                      x3 = X[XS_][4 * r4 + 3];
       const uint32_t lo01 = perm8(x1, x0, 0x05010400u);  // x0.b0 x1.b0 x0.b1 x1.b1
@@ -640,9 +644,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
     __builtin_amdgcn_sched_barrier(0);
     if (ABL & 32) {  // ablation: no genotype loads after the prologue
 #pragma unroll
-      for (int r = 0; r < 16; r++) X[SETS == 2 ? SET : 0][r] += (uint32_t)jn2;
+      for (int r = 0; r < 16; r++) X[SETS >= 2 ? SET : 0][r] += (uint32_t)jn2;
     } else {
-      load(SETS == 2 ? jn2 : jn1, X[SETS == 2 ? SET : 0]);
+      load(SETS == 3 ? jn3 : (SETS == 2 ? jn2 : jn1), X[SETS >= 2 ? SET : 0]);
     }
     __builtin_amdgcn_sched_barrier(0);
     // G samples are decoded together and their MFMAs interleaved (g0 of all, then na of all);
@@ -685,12 +689,21 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
           }
         }
       }
-    ws[SET ^ 1][wtid] = wreg;
+    ws[WB ^ 1][wtid] = wreg;
+    wpar ^= 1;
     __syncthreads();
   };
-  for (int64_t jb = j0; jb < j1; jb += 128) {
-    step(std::integral_constant<int, 0>{}, jb);
-    if (jb + 64 < j1) step(std::integral_constant<int, 1>{}, jb + 64);
+  if constexpr (SETS == 3) {
+    for (int64_t jb = j0; jb < j1; jb += 192) {
+      step(std::integral_constant<int, 0>{}, jb);
+      if (jb + 64 < j1) step(std::integral_constant<int, 1>{}, jb + 64);
+      if (jb + 128 < j1) step(std::integral_constant<int, 2>{}, jb + 128);
+    }
+  } else {
+    for (int64_t jb = j0; jb < j1; jb += 128) {
+      step(std::integral_constant<int, 0>{}, jb);
+      if (jb + 64 < j1) step(std::integral_constant<int, 1>{}, jb + 64);
+    }
   }
   // raw accumulators: acc_out[ky][sample][NCOL], lane holds columns nb*16 + 4g .. +3
   if (active) {
@@ -1321,6 +1334,17 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
       else if (tv == 62) BSN_LAUNCH_PROD(true, true, 2);
       else if (tv == 63) BSN_LAUNCH_PROD(true, true, 3);
       else BSN_LAUNCH_PROD(true, true, 32);
+      BSN_HIP(hipGetLastError());
+      return;
+    }
+    // BSN_TUNE = 74 / 75: three genotype register sets (prefetch three steps ahead) on the plain / tiled image
+    if ((tv == 74 || tv == 75) && lutP == kLutRaw && has_q) {
+      if (tv == 75 && b->d_tiled && (op->col0 & 63) == 0)
+        hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 1, 3, 0, true>), grid, dim3(256), 0, b->stream,
+                           b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
+      else
+        hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 1, 3>), grid, dim3(256), 0, b->stream, b->d_img,
+                           b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
       BSN_HIP(hipGetLastError());
       return;
     }

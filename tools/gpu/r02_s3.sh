@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+export BSN_LIB_PATH=$PWD/bigsnpr_amd/libbigsnpr_hip_abl.so
+P="python tools/probe_matvec.py --n 400000 --m 500000 --nvecs 8 --slices 2 --reps 8"
+for rep in 1 2; do
+for t in 0 74; do BSN_TUNE=$t timeout 300 $P 2>&1 | grep '"prod"' | sed "s/^/plain tune $t: /"; done
+for t in 0 75; do BSN_PROBE_TILE=1 BSN_TUNE=$t timeout 300 $P 2>&1 | grep '"prod"' | sed "s/^/tiled tune $t: /"; done
+done
