@@ -574,10 +574,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
       // buffer loads: scalar descriptor (re-based per step) + scalar row offset + one 32-bit lane
       // offset, so the 16 addresses of a step cost no VALU (global loads took a 64-bit add each)
       if constexpr (TILED) {
-        static_assert(WAVES == 4, "streaming layout: one workgroup = one 256-B column block");
+        // a wave owns 64 B of a 256-B column block: four waves per tile, WAVES / 4 tiles per workgroup and step
+        static_assert(WAVES % 4 == 0, "streaming layout: whole 256-B column blocks per workgroup");
+        const int64_t sbw = __builtin_amdgcn_readfirstlane(active ? (int)((blockIdx.x * WAVES + wave) >> 2) : 0);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(img + (((col0 + jb) >> 6) * (pitch >> 8) + blockIdx.x) * 16384), 0, 0x7fffffff, 0x00020000);
-        const int toff = g * 4096 + wave * 64 + sg * 4;
+            (void *)(img + (((col0 + jb) >> 6) * (pitch >> 8) + sbw) * 16384), 0, 0x7fffffff, 0x00020000);
+        const int toff = g * 4096 + (wave & 3) * 64 + sg * 4;
 #pragma unroll
         for (int r = 0; r < 16; r++) dst[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, toff, r * 256, 0);
       } else {
@@ -1103,7 +1105,7 @@ __global__ __launch_bounds__(1024) void k_na_total(const int32_t *counts, int64_
 static bool use_tiled(const bsn_op *op) {
 #ifdef BSN_ABLATION
   // the ablation variants exist on the plain image only (41 - 46: workgroup shapes on the tiled copy)
-  if (tune_variant() != 0 && !(tune_variant() >= 41 && tune_variant() <= 46)) return false;
+  if (tune_variant() != 0 && !(tune_variant() >= 41 && tune_variant() <= 48)) return false;
 #endif
   return op->bed->d_tiled != nullptr && op->cols_contig && (op->col0 & 63) == 0;
 }
@@ -1119,13 +1121,16 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
   const int32_t *cols = op->cols_contig ? nullptr : op->d_cols.p;
   const int32_t npad = (int32_t)(b->pitch * 4 - b->n);
   if (use_tiled(op)) {
-#define BSN_LAUNCH_CPROD_T(NBV, WV, TAGV)                                                                     \
-  hipLaunchKernelGGL((k_cprod<NBV, NPLANE, KC, RAW0, STATS, true, 0, 2, WV, 1, TAGV, true>),                  \
-                     dim3((unsigned)((op->m + 32 * WV - 1) / (32 * WV))), dim3(64 * WV), 0, b->stream,        \
+    // 4 tiles per wave on the tiled copy (a wave = one 64-variant block, 512 variants share a digit panel): 2 %
+    // faster than the 2-tile shape there, and slower on the plain image (profiles/r02_ablation.txt)
+#define BSN_LAUNCH_CPROD_T(NBV, TV, WV, TAGV)                                                                    \
+  hipLaunchKernelGGL((k_cprod<NBV, NPLANE, KC, RAW0, STATS, true, 0, TV, WV, 1, TAGV, true>),                    \
+                     dim3((unsigned)((op->m + 16 * TV * WV - 1) / (16 * TV * WV))), dim3(64 * WV), 0, b->stream, \
                      b->d_tiled, b->pitch, nullptr, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad)
 #ifdef BSN_ABLATION
-    // BSN_TUNE = 41 .. 46: (tiles per wave, waves, samples per chunk) on the tiled copy; correct results
-    if (NB == 1 && tune_variant() >= 41 && tune_variant() <= 46 && op->prof_kind_override != 3) {
+    // BSN_TUNE = 41 .. 48: (tiles per wave, waves, samples per chunk) on the tiled copy; correct results
+    // (48 = 2 x 8 x 512, the shape used on the plain image)
+    if (NB == 1 && tune_variant() >= 41 && tune_variant() <= 48 && op->prof_kind_override != 3) {
 #define BSN_SHAPE_T(TILESV, WAVESV, KCV)                                                                  \
   hipLaunchKernelGGL((k_cprod<1, NPLANE, KCV, RAW0, STATS, true, 0, TILESV, WAVESV, 1, 0, true>),         \
                      dim3((unsigned)((op->m + 16 * TILESV * WAVESV - 1) / (16 * TILESV * WAVESV))),       \
@@ -1137,17 +1142,21 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
       else if (tv == 43) BSN_SHAPE_T(4, 2, 512);
       else if (tv == 44) BSN_SHAPE_T(2, 8, 1024);
       else if (tv == 45) BSN_SHAPE_T(4, 4, 1024);
-      else BSN_SHAPE_T(2, 16, 512);
+      else if (tv == 46) BSN_SHAPE_T(2, 16, 512);
+      else if (tv == 47) BSN_SHAPE_T(4, 16, 512);
+      else BSN_SHAPE_T(2, 8, 512);
 #undef BSN_SHAPE_T
       BSN_HIP(hipGetLastError());
       return;
     }
 #endif
     if (NB == 1) {
-      if (op->prof_kind_override == 3) BSN_LAUNCH_CPROD_T(1, 8, 1);
-      else BSN_LAUNCH_CPROD_T(1, 8, 0);
+      // (the counting variant needs 150 registers with 4 tiles - one workgroup per CU - and keeps 2)
+      constexpr int TV = STATS ? 2 : 4;
+      if (op->prof_kind_override == 3) BSN_LAUNCH_CPROD_T(1, TV, 8, 1);
+      else BSN_LAUNCH_CPROD_T(1, TV, 8, 0);
     } else {
-      BSN_LAUNCH_CPROD_T(2, 16, 0);
+      BSN_LAUNCH_CPROD_T(2, 2, 16, 0);
     }
 #undef BSN_LAUNCH_CPROD_T
     BSN_HIP(hipGetLastError());
@@ -1334,6 +1343,14 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
       else if (tv == 62) BSN_LAUNCH_PROD(true, true, 2);
       else if (tv == 63) BSN_LAUNCH_PROD(true, true, 3);
       else BSN_LAUNCH_PROD(true, true, 32);
+      BSN_HIP(hipGetLastError());
+      return;
+    }
+    // BSN_TUNE = 76: 8-wave workgroups on the tiled copy (two tiles per step share one digit panel)
+    if (tv == 76 && lutP == kLutRaw && has_q && b->d_tiled && (op->col0 & 63) == 0) {
+      hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 8, 0, 1, 2, 0, true>), dim3((grid.x + 1) / 2, grid.y),
+                         dim3(512), 0, b->stream, b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP,
+                         lutQ);
       BSN_HIP(hipGetLastError());
       return;
     }
