@@ -47,32 +47,41 @@ constexpr int kLdsRow = kTile + 16;  // doubles per k-row in LDS: 16 of padding 
 //   the 144-double row pitch the 64 lanes of a wave then hit every bank exactly twice per store.
 //   gather (any ind.row): one byte load and one table load per value (thread = one sample of both tiles x 8
 //   variants).
-template <bool IDENT>
-__global__ __launch_bounds__(256, 2) void k_tcross(const uint8_t *__restrict__ img, int64_t pitch,
-                                                    const int32_t *__restrict__ rows, const int32_t *__restrict__ cols,
-                                                    int64_t col0, int64_t n, int64_t m, int64_t m_slab,
-                                                    const double *__restrict__ T, const int2 *__restrict__ pairs,
-                                                    double *__restrict__ Kout) {
+template <bool IDENT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void k_tcross(const uint8_t *__restrict__ img, int64_t pitch,
+                                                          const int32_t *__restrict__ rows,
+                                                          const int32_t *__restrict__ cols, int64_t col0, int64_t n,
+                                                          int64_t m, int64_t m_slab, const double *__restrict__ T,
+                                                          const int2 *__restrict__ pairs, double *__restrict__ Kout) {
+  // WAVES = 4: 2 x 2 waves of 64 x 64 (16 MFMA tiles, 128 accumulator registers, 2 waves per SIMD);
+  // WAVES = 8: 2 x 4 waves of 64 x 32 (8 tiles, 64 registers, 4 waves per SIMD: the decode of one wave and the
+  // barrier of its workgroup hide behind the MFMAs of three others)
+  constexpr int NT = 64 * WAVES;
+  constexpr int WCOLS = WAVES / 2;         // waves along the columns of the tile
+  constexpr int TB = (kTile / WCOLS) / 16;  // MFMA tiles per wave along the columns (4 or 2)
+  constexpr int SPT = 2 * kChunk * kTile / NT;  // IDENT: samples decoded per thread and chunk (16 or 8)
+  constexpr int VPT = kChunk * kTile / NT;      // gather: variants per thread and chunk (8 or 4)
   __shared__ double sA[2][kChunk * kLdsRow];
   __shared__ double sB[2][kChunk * kLdsRow];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r16 = lane & 15, kq = lane >> 4;
-  const int wi = wave >> 1, wj = wave & 1;
+  const int wi = wave / WCOLS, wj = wave % WCOLS;
   const int2 pr = pairs[blockIdx.x];
   const int64_t i0 = (int64_t)pr.x * kTile, j0 = (int64_t)pr.y * kTile;
   const int64_t v_lo = (int64_t)blockIdx.y * m_slab;
   const int64_t v_hi = v_lo + m_slab < m ? v_lo + m_slab : m;
   if (v_lo >= v_hi) return;
 
-  // ---- gather decode: this thread fills row `dr` of both operand tiles for 8 of the chunk's 16 variants
-  const int dr = tid & (kTile - 1), dh = tid >> 7;
+  // ---- gather decode: this thread fills row `dr` of both operand tiles for VPT of the chunk's 16 variants
+  const int dr = tid & (kTile - 1), dg = tid >> 7;
   int64_t offa = 0, offb = 0;
   int sha = 0, shb = 0;
   bool oka = false, okb = false;
-  double va[8], vb[8];
-  // ---- IDENT decode: one word = 16 samples of variant `dq` of tile `dh` (0: rows i0.., 1: rows j0..)
-  const int dq = (tid & 127) >> 3, dw = tid & 7;
-  const int64_t rbase = (dh ? j0 : i0) + dw * 16;
+  double va[VPT], vb[VPT];
+  // ---- IDENT decode: SPT consecutive samples of variant `dq` of tile `dh` (0: rows i0.., 1: rows j0..)
+  const int dh = tid / (NT / 2), tt = tid % (NT / 2);
+  const int dq = tt / (NT / 32), dw = (tt % (NT / 32)) / (16 / SPT), dpart = tt % (16 / SPT);
+  const int64_t rbase = (dh ? j0 : i0) + dw * 16;  // first sample of the thread's 32-bit word
   uint32_t word = 0;
   double t0 = 0, t1 = 0, t2 = 0;
   bool okw = false;
@@ -100,8 +109,8 @@ __global__ __launch_bounds__(256, 2) void k_tcross(const uint8_t *__restrict__ i
       t2 = T[4 * vc + 2];
     } else {
 #pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const int64_t v = v0 + dh * 8 + q;
+      for (int q = 0; q < VPT; q++) {
+        const int64_t v = v0 + dg * VPT + q;
         const bool okv = v < v_hi;
         const int64_t vc = okv ? v : v_hi - 1;
         const int64_t col = cols ? (int64_t)cols[vc] : col0 + vc;
@@ -115,30 +124,30 @@ __global__ __launch_bounds__(256, 2) void k_tcross(const uint8_t *__restrict__ i
   };
   auto stash = [&](int buf) {
     if constexpr (IDENT) {
-      double *dst = (dh ? sB[buf] : sA[buf]) + dq * kLdsRow + dw * 16;
-      const int rot = lane >> 1;
+      double *dst = (dh ? sB[buf] : sA[buf]) + dq * kLdsRow + dw * 16 + dpart * SPT;
+      const int rot = lane >> 1;  // every store of a wave then hits each 8-B bank exactly twice
 #pragma unroll
-      for (int e = 0; e < 16; e++) {
-        const int x = (e + rot) & 15;
-        const uint32_t code = (word >> (2 * x)) & 3u;
+      for (int e = 0; e < SPT; e++) {
+        const int x = (e + rot) & (SPT - 1), sx = dpart * SPT + x;
+        const uint32_t code = (word >> (2 * sx)) & 3u;
         double val = code == 0u ? t0 : (code == 1u ? t1 : (code == 2u ? t2 : 0.0));
-        if (!okw || rbase + x >= n) val = 0.0;
+        if (!okw || rbase + sx >= n) val = 0.0;
         dst[x] = val;
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 8; q++) {
-        sA[buf][(dh * 8 + q) * kLdsRow + dr] = va[q];
-        sB[buf][(dh * 8 + q) * kLdsRow + dr] = vb[q];
+      for (int q = 0; q < VPT; q++) {
+        sA[buf][(dg * VPT + q) * kLdsRow + dr] = va[q];
+        sB[buf][(dg * VPT + q) * kLdsRow + dr] = vb[q];
       }
     }
   };
 
-  v4d acc[4][4];
+  v4d acc[4][TB];
 #pragma unroll
   for (int a = 0; a < 4; a++)
 #pragma unroll
-    for (int b = 0; b < 4; b++) acc[a][b] = v4d{0, 0, 0, 0};
+    for (int b = 0; b < TB; b++) acc[a][b] = v4d{0, 0, 0, 0};
 
   fetch(v_lo);
   stash(0);
@@ -150,16 +159,15 @@ __global__ __launch_bounds__(256, 2) void k_tcross(const uint8_t *__restrict__ i
 #pragma unroll
     for (int ks = 0; ks < kChunk / 4; ks++) {
       const int k = ks * 4 + kq;
-      double a[4], b[4];
+      double a[4], b[TB];
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        a[t] = sA[buf][k * kLdsRow + wi * 64 + t * 16 + r16];
-        b[t] = sB[buf][k * kLdsRow + wj * 64 + t * 16 + r16];
-      }
+      for (int t = 0; t < 4; t++) a[t] = sA[buf][k * kLdsRow + wi * 64 + t * 16 + r16];
+#pragma unroll
+      for (int t = 0; t < TB; t++) b[t] = sB[buf][k * kLdsRow + wj * (16 * TB) + t * 16 + r16];
 #pragma unroll
       for (int ta = 0; ta < 4; ta++)
 #pragma unroll
-        for (int tb = 0; tb < 4; tb++)
+        for (int tb = 0; tb < TB; tb++)
           acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
     }
     if (more) stash(buf ^ 1);
@@ -172,10 +180,10 @@ __global__ __launch_bounds__(256, 2) void k_tcross(const uint8_t *__restrict__ i
 #pragma unroll
   for (int ta = 0; ta < 4; ta++)
 #pragma unroll
-    for (int tb = 0; tb < 4; tb++)
+    for (int tb = 0; tb < TB; tb++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int64_t i = i0 + wi * 64 + ta * 16 + kq + 4 * r, j = j0 + wj * 64 + tb * 16 + r16;
+        const int64_t i = i0 + wi * 64 + ta * 16 + kq + 4 * r, j = j0 + wj * (16 * TB) + tb * 16 + r16;
         if (i < n && j < n) {
           Kp[i + j * n] = acc[ta][tb][r];
           if (mirror) Kp[j + i * n] = acc[ta][tb][r];
@@ -230,12 +238,20 @@ extern "C" int bsn_bed_tcrossprod(bsn_bed *bed, const int64_t *ind_row, int64_t 
     if (nslab > 1) out = d_part.ensure((size_t)nslab * n * n);
     const dim3 grid((unsigned)pairs.size(), (unsigned)nslab);
     const int32_t *cols = op.cols_contig ? nullptr : op.d_cols.p;
-    if (op.rows_identity)
-      hipLaunchKernelGGL(k_tcross<true>, grid, dim3(256), 0, bed->stream, bed->d_img, bed->pitch, nullptr, cols,
-                         op.col0, n, m, m_slab, d_T.p, d_pairs.p, out);
-    else
-      hipLaunchKernelGGL(k_tcross<false>, grid, dim3(256), 0, bed->stream, bed->d_img, bed->pitch, op.d_rows.p, cols,
-                         op.col0, n, m, m_slab, d_T.p, d_pairs.p, out);
+    // BSN_TCROSS_WAVES=4 selects the 4-wave shape (A/B measurements)
+    const char *we = getenv("BSN_TCROSS_WAVES");
+    const bool w4 = we && atoi(we) == 4;
+#define BSN_TCROSS(IDENTV, WV, ROWS)                                                                              \
+  hipLaunchKernelGGL((k_tcross<IDENTV, WV>), grid, dim3(64 * WV), 0, bed->stream, bed->d_img, bed->pitch, ROWS, \
+                     cols, op.col0, n, m, m_slab, d_T.p, d_pairs.p, out)
+    if (op.rows_identity) {
+      if (w4) BSN_TCROSS(true, 4, nullptr);
+      else BSN_TCROSS(true, 8, nullptr);
+    } else {
+      if (w4) BSN_TCROSS(false, 4, op.d_rows.p);
+      else BSN_TCROSS(false, 8, op.d_rows.p);
+    }
+#undef BSN_TCROSS
     BSN_HIP(hipGetLastError());
     if (nslab > 1) {
       hipLaunchKernelGGL(k_tcross_reduce, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, bed->stream, d_part.p,
