@@ -164,8 +164,22 @@ def main():
         if uid[0] is not None:
             try:
                 comm = ba.Comm(uid[0], rank, world)
+                # first collective on a known vector: a communicator that initialises but cannot move data
+                # (IPC / topology trouble) must be found here, not inside the timed solves
+                import numpy as _np0
+                probe = ba.DeviceArray.from_numpy(_np0.full(1024, float(rank + 1)))
+                comm.allreduce(probe)
+                got = probe.to_numpy()
+                if not _np0.all(got == world * (world + 1) / 2.0):
+                    raise RuntimeError("RCCL all-reduce self-test returned %r" % got[:2])
             except Exception as e:
                 err = e
+                if comm is not None:
+                    try:
+                        comm.close()
+                    except Exception:
+                        pass
+                comm = None
         if world > 1:                   # all ranks take the same path
             import torch as _t
             ok = _t.tensor([1 if comm is not None else 0])
