@@ -167,7 +167,12 @@ static void stage_init(bsn_bed *b) {
 static void host_copy(void *dst, const void *src, size_t len) {
   constexpr size_t kPerThread = 4u << 20;
   const unsigned hw = std::thread::hardware_concurrency();
-  size_t nthr = std::min<size_t>({len / kPerThread, (size_t)8, (size_t)(hw ? hw : 1)});
+  static const size_t max_thr = [] {
+    const char *e = getenv("BSN_COPY_THREADS");  // threads per staged piece (default 8)
+    const int v = e ? atoi(e) : 8;
+    return (size_t)(v < 1 ? 1 : v > 64 ? 64 : v);
+  }();
+  size_t nthr = std::min<size_t>({len / kPerThread, max_thr, (size_t)(hw ? hw : 1)});
   if (nthr < 2) {
     std::memcpy(dst, src, len);
     return;
