@@ -581,6 +581,12 @@ int bsn_bed_release_workspace(bsn_bed *bed) {
     BSN_HIP(hipStreamSynchronize(bed->stream));
     bed->svd_op.reset();
     bed->svd_ws.reset();
+    if (bed->d_tiled) {  // the streaming-layout copy is rebuilt by the next solve if there is room again
+      BSN_HIP(hipFree(bed->d_tiled));
+      bed->d_tiled = nullptr;
+    }
+    bed->tiled_tried = false;
+    dev_cache_flush();
   });
 }
 

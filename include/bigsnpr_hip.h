@@ -281,7 +281,8 @@ int bsn_bed_tile(bsn_bed *bed, int *built);
 
 /* The device workspace of a solve (Krylov basis, panels, quantised operands: about
  * 8 (n + m) (8 k + 4 block) bytes, 4 GB at 400K x 1M, k = 20) stays on the handle for the next
- * solve (snp_autoSVD runs up to six in a row); this frees it early.  bsn_bed_close frees it too. */
+ * solve (snp_autoSVD runs up to six in a row); this frees it early, together with the streaming-layout copy
+ * of the image (bsn_bed_tile) and the cached work buffers of the device.  bsn_bed_close frees it too. */
 int bsn_bed_release_workspace(bsn_bed *bed);
 
 /* bed_tcrossprodSelf (R/bed-tcrossprodSelf.R:21-52): K[n x n] = A~ A~'; center / scale of length m as

@@ -65,3 +65,29 @@ def test_solve_bit_identical_with_and_without_the_tiled_copy(ba, monkeypatch, bl
     assert a["warm_launches"] == (2 if block == 0 else 0)
     for key in ("d", "u", "v", "center", "scale"):
         np.testing.assert_array_equal(a[key], b[key])
+
+
+def test_release_workspace_returns_the_memory(ba):
+    """bsn_bed_release_workspace gives back the solve's workspace, the tiled copy and the cached work buffers:
+    what stays allocated is the image itself; the next solve rebuilds everything and finds the same answer"""
+    import ctypes as C
+    from bigsnpr_amd import _lib
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    n, m = 20000, 40000
+    gb = ba.bed.synthetic(n, m, seed=2)
+    _lib.check(_lib.load().bsn_bed_release_workspace(gb.handle))
+    base = free_bytes()
+    r1 = ba.bed_randomSVD(gb, k=4)
+    assert r1["tiled"] == 1
+    used = base - free_bytes()
+    assert used >= gb.hbm_bytes()                      # at least the second copy of the image
+    _lib.check(_lib.load().bsn_bed_release_workspace(gb.handle))
+    assert base - free_bytes() <= 64 << 20             # allocator granularity only
+    r2 = ba.bed_randomSVD(gb, k=4)
+    np.testing.assert_array_equal(r1["d"], r2["d"])
