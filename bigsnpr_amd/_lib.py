@@ -72,6 +72,7 @@ SIGNATURES = {
     "bsn_bed_download": (C.c_int, [vp, u8p]),
     "bsn_bed_prodvec": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, f64p, f64p]),
     "bsn_bed_cprodvec": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, f64p, f64p]),
+    "bsn_bed_prodvec_sharded": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, f64p, vp, f64p]),
     "bsn_bed_col_counts": (C.c_int, [vp, i64p, i64, i64p, i64, i32p]),
     "bsn_bed_row_counts": (C.c_int, [vp, i64p, i64, i64p, i64, i32p]),
     "bsn_bed_colstats": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, i32p, i32p]),

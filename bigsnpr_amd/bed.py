@@ -242,13 +242,20 @@ def _center_scale(center, scale, ic):
     return center, scale
 
 
-def bed_prodVec(obj_bed, y_col, ind_row=None, ind_col=None, center=None, scale=None, ncores=1):
-    """R/bed-mult-vec.R:58-75 -> bed_pMatVec4.  ``ncores`` is accepted and ignored."""
+def bed_prodVec(obj_bed, y_col, ind_row=None, ind_col=None, center=None, scale=None, ncores=1, comm=None):
+    """R/bed-mult-vec.R:58-75 -> bed_pMatVec4.  ``ncores`` is accepted and ignored.  ``comm`` (a
+    bigsnpr_amd.Comm, not in the reference): this rank holds a shard of the columns; every rank gets the product
+    with the whole matrix (bsn_bed_prodvec_sharded)."""
     ir, ic = _args(obj_bed, ind_row, ind_col)
     y_col = as_f64(np.ravel(y_col))
     assert_lengths(y_col, ic)
     center, scale = _center_scale(center, scale, ic)
     out = np.empty(ir.size)
+    if comm is not None:
+        check(_lib.load().bsn_bed_prodvec_sharded(obj_bed.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p), ic.size,
+                                                  ptr(center, f64p), ptr(scale, f64p), ptr(y_col, f64p),
+                                                  comm.handle, ptr(out, f64p)))
+        return out
     check(_lib.load().bsn_bed_prodvec(obj_bed.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p),
                                       ic.size, ptr(center, f64p), ptr(scale, f64p),
                                       ptr(y_col, f64p), ptr(out, f64p)))

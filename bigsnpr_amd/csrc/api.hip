@@ -648,7 +648,7 @@ int bsn_op_sync(bsn_op *op) {
 // ---- .Call replacements ------------------------------------------------------------
 static void matvec_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
                         int64_t m, const double *center, const double *scale, const double *x,
-                        double *out, bool transpose) {
+                        double *out, bool transpose, bsn_comm *comm = nullptr) {
   bsn_op op;
   fill_op(&op, bed, ind_row, n, ind_col, m, center, scale);
   op.slices = 7;  // 56-bit fixed point: fp64-grade for a single vector, still one MFMA column block
@@ -660,6 +660,11 @@ static void matvec_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const i
     op_cprod(&op, d_in.p, nin, 1, d_out.p, nout);
   else
     op_prod(&op, d_in.p, nin, 1, d_out.p, nout);
+  if (comm) {  // column shards: sum of the partial products over the ranks, on the device
+    if (transpose) fail("internal: the crossproduct of a column shard needs no exchange");
+    if (comm->device != bed->device) fail("the communicator was created on another device");
+    comm_allreduce_sum(comm, d_out.p, nout, bed->stream);
+  }
   copy_d2h(bed, out, d_out.p, (size_t)nout * 8);
 }
 
@@ -667,6 +672,12 @@ int bsn_bed_prodvec(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64
                     int64_t m, const double *center, const double *scale, const double *x,
                     double *y) {
   return guarded([&] { matvec_host(bed, ind_row, n, ind_col, m, center, scale, x, y, false); });
+}
+
+int bsn_bed_prodvec_sharded(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                            int64_t m, const double *center, const double *scale, const double *x,
+                            bsn_comm *comm, double *y) {
+  return guarded([&] { matvec_host(bed, ind_row, n, ind_col, m, center, scale, x, y, false, comm); });
 }
 
 int bsn_bed_cprodvec(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,

@@ -26,8 +26,12 @@ def main():
     res = ba.bed_randomSVD(gb, k=k, tol=1e-9, comm=comm, m_total=m)
     d_all = [None] * world
     dist.all_gather_object(d_all, (res["d"].tolist(), res["niter"], float(np.abs(res["u"]).sum())))
+    # one-shot product of the column shards: x is the same seeded vector on every rank, each takes its slice
+    x = np.random.default_rng(7).normal(size=m)
+    y = ba.bed_prodVec(gb, x[j0:j1], center=res["center"], scale=res["scale"], comm=comm)
     if rank == 0:
-        json.dump(dict(d=res["d"].tolist(), niter=res["niter"], same=all(x == d_all[0] for x in d_all)), open(out, "w"))
+        json.dump(dict(d=res["d"].tolist(), niter=res["niter"], same=all(x_ == d_all[0] for x_ in d_all),
+                       y=y.tolist()), open(out, "w"))
     dist.barrier()
     comm.close()
     dist.destroy_process_group()

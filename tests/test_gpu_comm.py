@@ -38,6 +38,10 @@ def test_single_rank_communicator_is_the_identity(ba):
         assert viacomm["niter"] == plain["niter"]
         for key in ("d", "u", "v"):
             np.testing.assert_array_equal(viacomm[key], plain[key])
+        # the one-shot product of a column shard: partial vectors summed over the ranks on the device
+        xv = np.random.default_rng(1).normal(size=m)
+        np.testing.assert_array_equal(ba.bed_prodVec(gb, xv, center=plain["center"], scale=plain["scale"], comm=comm),
+                                      ba.bed_prodVec(gb, xv, center=plain["center"], scale=plain["scale"]))
     finally:
         comm.close()
 
@@ -62,3 +66,6 @@ def test_two_ranks_over_rccl(tmp_path, ba):
     gb = ba.bed.synthetic(n, m, seed=31)
     ref = ba.bed_randomSVD(gb, k=k, tol=1e-9)
     np.testing.assert_allclose(got["d"], ref["d"], rtol=1e-7)
+    x = np.random.default_rng(7).normal(size=m)
+    yref = ba.bed_prodVec(gb, x, center=ref["center"], scale=ref["scale"])
+    np.testing.assert_allclose(got["y"], yref, rtol=0, atol=1e-9 * np.abs(yref).max())
