@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "bsn_internal.hpp"
@@ -35,8 +36,16 @@ static Rccl &rccl() {
   if (r.h) return r;
   const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void *h = nullptr;
-  for (const char *nm : names)
-    if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+  // BSN_RCCL_LIBRARY: another library with RCCL's entry points (the tests load a shared-memory stand-in
+  // that lets two ranks share the one GPU of the test box, tests/native/mock_rccl.cpp)
+  if (const char *over = getenv("BSN_RCCL_LIBRARY")) {
+    h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+    if (!h) fail("cannot load BSN_RCCL_LIBRARY=%s: %s", over, dlerror());
+  }
+  for (const char *nm : names) {
+    if (h) break;
+    h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+  }
   if (!h) fail("cannot load RCCL (librccl.so.1): %s", dlerror());
 #define BSN_SYM(name)                                                      \
   r.name = (decltype(r.name))dlsym(h, "nccl" #name);                       \

@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_comm.py::test_two_ranks_over_rccl: one rank (= one GPU) of a column-sharded
+"""Worker of tests/test_gpu_comm.py::test_ranks_over_the_collective_calls: one rank (= one GPU) of a column-sharded
 bed_randomSVD whose exchange runs inside the library over RCCL.  torch.distributed (gloo) only carries
 the unique id.  Usage (via torch.distributed.run): rccl_svd_worker.py n m k out.json"""
 import json
@@ -17,7 +17,8 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import bigsnpr_amd as ba
     from bigsnpr_amd import _lib
-    _lib.check(_lib.load().bsn_set_device(int(os.environ.get("LOCAL_RANK", rank))))
+    # one GPU per rank; with BSN_RCCL_LIBRARY naming the shared-memory stand-in the ranks share what there is
+    _lib.check(_lib.load().bsn_set_device(int(os.environ.get("LOCAL_RANK", rank)) % ba.device_count()))
     uid = [ba.Comm.unique_id() if rank == 0 else None]
     dist.broadcast_object_list(uid, src=0)
     comm = ba.Comm(uid[0], rank, world)

@@ -13,3 +13,16 @@ def build():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall",
                                "-I", os.path.join(ROOT, "bigsnpr_amd", "csrc"), src, "-o", SO])
     return SO
+
+
+MOCK_RCCL = os.path.join(HERE, "libmock_rccl.so")
+
+
+def build_mock_rccl():
+    """the shared-memory stand-in for librccl.so used by the two-rank tests on a one-GPU box (mock_rccl.cpp)"""
+    src = os.path.join(HERE, "mock_rccl.cpp")
+    if not os.path.exists(MOCK_RCCL) or os.path.getmtime(src) > os.path.getmtime(MOCK_RCCL):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        subprocess.check_call([hipcc, "-x", "hip", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared",
+                               src, "-o", MOCK_RCCL, "-lpthread", "-lrt"])
+    return MOCK_RCCL

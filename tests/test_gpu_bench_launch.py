@@ -18,9 +18,9 @@ ARGS = ["--steps", "2", "--warmup", "1", "--samples", "20000", "--variants", "60
         "--no-cpu-baseline", "--no-ingest"]
 
 
-def _run(cmd):
+def _run(cmd, **extra_env):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
-                       env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1", **extra_env))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout[-2000:]          # the ONE line of the bench contract
@@ -46,3 +46,23 @@ def test_two_ranks_on_one_gpu_fall_back_and_agree():
         np.testing.assert_allclose(rec["value"],
                                    rec["config"]["m_total"] * rec["passes_per_solve"] / (rec["ms_per_step"] * 1e-3),
                                    rtol=1e-9)
+
+
+def test_two_ranks_through_the_in_library_collectives():
+    """the same launch with RCCL's entry points served by the shared-memory stand-in (tests/native/mock_rccl.cpp):
+    bench.py then takes its normal N > 1 route — communicator, self-test all-reduce, in-library panel exchange —
+    instead of the fallback, and must find the single-rank singular values with the same number of block steps"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "native"))
+    import build_native
+    mock = build_native.build_mock_rccl()
+    one, _ = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    two, err = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                     "--master-addr", "127.0.0.1", "--master-port", port, "bench.py", "--gpus", "2"] + ARGS,
+                    BSN_RCCL_LIBRARY=mock)
+    assert "falling back" not in err
+    assert two["n_gpus"] == 2 and "in-library RCCL" in two["config"]["parallelism"]
+    assert two["converged"] and two["niter"] == one["niter"]
+    np.testing.assert_allclose(two["sigma"], one["sigma"], rtol=1e-6)

@@ -46,20 +46,34 @@ def test_single_rank_communicator_is_the_identity(ba):
         comm.close()
 
 
-def test_two_ranks_over_rccl(tmp_path, ba):
-    if ba.device_count() < 2:
-        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
-    n, m, k = 3000, 4400, 6
+def _mock_rccl():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "native"))
+    import build_native
+    return build_native.build_mock_rccl()
+
+
+@pytest.mark.parametrize("transport,world,n", [("mock", 2, 3000), ("mock", 3, 3001), ("rccl", 2, 3000)])
+def test_ranks_over_the_collective_calls(tmp_path, ba, transport, world, n):
+    """several ranks through comm.hip's collective calls: reduce-scatter of the panel by sample blocks, Gram
+    all-reduces, all-gather of the basis block, and the sharded one-shot product.  `rccl` needs two GPUs; `mock`
+    runs the same library code on the one GPU of the test box with RCCL's entry points served by a shared-memory
+    stand-in (tests/native/mock_rccl.cpp, loaded through BSN_RCCL_LIBRARY)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    if transport == "rccl":
+        if ba.device_count() < 2:
+            pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    else:
+        env["BSN_RCCL_LIBRARY"] = _mock_rccl()
+    m, k = 4400, 6                      # 3 ranks x 3001 samples: the last sample block is padded
     out = str(tmp_path / "rccl.json")
     import socket
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = str(sock.getsockname()[1])
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", port,
            os.path.join(ROOT, "tests", "helpers", "rccl_svd_worker.py"), str(n), str(m), str(k), out]
-    r = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True,
-                       timeout=900)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     got = json.load(open(out))
     assert got["same"], "ranks diverged"

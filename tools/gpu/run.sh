@@ -6,4 +6,5 @@ cd "$(dirname "$0")/../.."
 python -m bigsnpr_amd.build > /dev/null
 python -m bigsnpr_amd.build --ablation > /dev/null
 (cd oracle && make -s)
+python -c "import sys; sys.path.insert(0, 'tests/native'); import build_native; build_native.build(); build_native.build_mock_rccl()"
 exec /usr/local/graft/bin/gpurun --timeout "$1" -- "bash $2"
