@@ -67,6 +67,10 @@ bool sync_ranks(Comm *c) {
 ncclResult_t collective(int kind, const void *send, void *recv, size_t count, Comm *c, hipStream_t st) {
   const size_t in = kind == 1 ? count * c->world : count;
   const size_t out = kind == 2 ? count * c->world : count;
+  static const bool trace = getenv("MOCK_RCCL_TRACE") != nullptr;  // rank 0: one line per collective
+  if (trace && c->rank == 0)
+    std::fprintf(stderr, "[mock rccl] %s count %zu (%zu bytes in, %zu out) stream %p\n",
+                 kind == 0 ? "all-reduce" : kind == 1 ? "reduce-scatter" : "all-gather", count, in * 8, out * 8, (void *)st);
   if (in * 8 > kSlot) return fail("message larger than the mock's slot");
   if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;
   if (hipMemcpy(c->slot(c->rank), send, in * 8, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
