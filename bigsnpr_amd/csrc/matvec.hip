@@ -530,8 +530,10 @@ __global__ void k_cprod_final(const int32_t *acc, int64_t m, int ncol, int S, co
 //   D        : lane l -> sample group (l&15), digit columns 4*(l>>4)+r
 // RAWP: the P plane is the device code itself (no look-up).
 // TILED: `img` is the streaming-layout copy; a step of the workgroup (64 variants x 256 B) is one tile.
+// XMAP: 1-D launch of wgx * ky workgroups (ky a multiple of 8) mapped so that all workgroups of a K slab run on
+// one XCD (workgroup i goes to XCD i mod 8): the slab's digit panel then lives in that XCD's L2.
 template <int NB, bool CONTIG, bool RAWP, bool HASQ = true, int WAVES = 4, int ABL = 0, int UG = 1, int SETS = 2,
-          int TAG = 0, bool TILED = false>
+          int TAG = 0, bool TILED = false, bool XMAP = false>
 __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__ img, int64_t pitch,
                                               const int32_t *__restrict__ cols, int64_t col0,
                                               int64_t m_pad, int64_t mc,
@@ -541,12 +543,18 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
   constexpr int NCOL = 16 * NB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int sg = lane & 15, g = lane >> 4;
-  int64_t wbase = ((int64_t)blockIdx.x * WAVES + wave) * 256;  // first sample of this wave
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  if constexpr (XMAP) {  // gridDim.x = wgx * ky
+    const unsigned wgx = (unsigned)(n_pad / (WAVES * 256)), i = blockIdx.x, xcd = i & 7u, t = i >> 3;
+    bx = t % wgx;
+    by = xcd + 8u * (t / wgx);
+  }
+  int64_t wbase = ((int64_t)bx * WAVES + wave) * 256;  // first sample of this wave
   const bool active = wbase < n_pad;  // WAVES = 8: the last workgroup may be half empty
   if (!active) wbase = 0;
   const int64_t wbyte = wbase / 4 + sg * 4;
   const uint32_t lane_off = (uint32_t)(g * 16 * pitch + wbyte);
-  const int64_t j0 = (int64_t)blockIdx.y * mc;
+  const int64_t j0 = (int64_t)by * mc;
   int64_t j1 = j0 + mc;
   if (j1 > m_pad) j1 = m_pad;
   const uint4 *wq4 = (const uint4 *)wq;
@@ -576,7 +584,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
       if constexpr (TILED) {
         // a wave owns 64 B of a 256-B column block: four waves per tile, WAVES / 4 tiles per workgroup and step
         static_assert(WAVES % 4 == 0, "streaming layout: whole 256-B column blocks per workgroup");
-        const int64_t sbw = __builtin_amdgcn_readfirstlane(active ? (int)((blockIdx.x * WAVES + wave) >> 2) : 0);
+        const int64_t sbw = __builtin_amdgcn_readfirstlane(active ? (int)((bx * WAVES + wave) >> 2) : 0);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(img + (((col0 + jb) >> 6) * (pitch >> 8) + sbw) * 16384), 0, 0x7fffffff, 0x00020000);
         const int toff = g * 4096 + (wave & 3) * 64 + sg * 4;
@@ -714,7 +722,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
       const int64_t i = wbase + sg * 16 + u;
 #pragma unroll
       for (int nb = 0; nb < NB; nb++)
-        *(v4i *)(acc_out + (((int64_t)blockIdx.y * n_pad + i) * NCOL + nb * 16 + 4 * g)) = acc[u][nb];
+        *(v4i *)(acc_out + (((int64_t)by * n_pad + i) * NCOL + nb * 16 + 4 * g)) = acc[u][nb];
     }
   }
 }
@@ -1343,6 +1351,14 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
       else if (tv == 62) BSN_LAUNCH_PROD(true, true, 2);
       else if (tv == 63) BSN_LAUNCH_PROD(true, true, 3);
       else BSN_LAUNCH_PROD(true, true, 32);
+      BSN_HIP(hipGetLastError());
+      return;
+    }
+    // BSN_TUNE = 77: XCD-aware slab placement on the tiled copy (needs a K split that is a multiple of 8: BSN_KY=16)
+    if (tv == 77 && lutP == kLutRaw && has_q && b->d_tiled && (op->col0 & 63) == 0 && grid.y % 8 == 0) {
+      hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 1, 2, 0, true, true>), dim3(grid.x * grid.y),
+                         dim3(256), 0, b->stream, b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP,
+                         lutQ);
       BSN_HIP(hipGetLastError());
       return;
     }
