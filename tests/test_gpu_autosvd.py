@@ -93,3 +93,45 @@ def test_mac_maf_thresholds(env):
                                    max_iter=0, verbose=False)):
             ind = res["subset"]
             assert np.all(info["maf"][ind] >= min_maf) and np.all(info["mac"][ind] >= min_mac)
+
+
+def test_subset_identical_to_the_loop_run_on_oracle_components(env, orc, example_bed):
+    """`attr(, "subset")` is an integer output.  Its host loop (MAF filter -> clumping -> SVD rounds with outlier
+    removal, R/autoSVD.R:95-186) is the same Python whatever computes the pieces, so the GPU pieces are pinned by
+    running the identical loop on the CPU oracle's pieces — dense SVD, oracle clumping, oracle MAF — and asking for
+    the same kept variants and long-range-LD table.  (The outlier statistics themselves restate bigutilsr and stay
+    unpinned against the reference; a tight solve keeps borderline variants from flipping on the last
+    digits of the singular vectors.)"""
+    ba, gb, G, CHR, POS, POS2 = env
+    from bigsnpr_amd import autosvd
+    Go = orc.fbm_from_bed(example_bed)
+    n, m, k = Go.n, Go.m, 10
+    for kw in (dict(), dict(roll_size=0, alpha_tukey=0.999), dict(infos_pos=POS, roll_size=0, alpha_tukey=0.9999,
+                                                                  int_min_size=0, max_iter=3)):
+        kw = dict(kw)
+        infos_pos = kw.pop("infos_pos", None)
+        thr_r2, size = 0.2, 500.0
+        st = orc.snp_colstats(Go)
+        maf = np.minimum(st["sumX"] / (2.0 * n), 1 - st["sumX"] / (2.0 * n))
+        maf_nok = (maf < max(0.02, 10 / (2.0 * n)), 10, 0.02, "MAF")
+
+        def svd_cpu(keep):
+            res = orc.dense_svd(example_bed, None, keep, k=k)
+            return dict(d=res["d"], u=res["u"], v=res["v"])
+
+        def clump_cpu(excl):
+            return orc.snp_clumping(Go, CHR, exclude=excl, thr_r2=thr_r2, size=size, infos_pos=infos_pos)
+
+        ref = autosvd._auto_svd(svd_cpu, clump_cpu, maf_nok, np.arange(m), CHR, infos_pos, thr_r2, k,
+                                kw.get("roll_size", 50), kw.get("int_min_size", 20), kw.get("alpha_tukey", 0.05),
+                                kw.get("max_iter", 5), False, m)
+        got = autosvd._auto_svd(lambda keep: ba.big_randomSVD(G, None, ind_col=keep, k=k, tol=1e-10, slices=7),
+                                lambda excl: ba.snp_clumping(G, CHR, exclude=excl, thr_r2=thr_r2, size=size,
+                                                             infos_pos=infos_pos),
+                                (ba.snp_MAF(G) < max(0.02, 10 / (2.0 * n)), 10, 0.02, "MAF"), np.arange(m), CHR,
+                                infos_pos, thr_r2, k, kw.get("roll_size", 50), kw.get("int_min_size", 20),
+                                kw.get("alpha_tukey", 0.05), kw.get("max_iter", 5), False, m)
+        np.testing.assert_array_equal(got["subset"], ref["subset"])
+        for key in ("Chr", "Start", "Stop", "Iter"):
+            np.testing.assert_array_equal(got["lrldr"][key], ref["lrldr"][key])
+        np.testing.assert_allclose(got["d"], ref["d"], rtol=1e-7)
