@@ -85,10 +85,46 @@ def prod_and_rowSumsSq(obj_bed, ind_row, ind_col, center, scale, V):
     return XV, rs
 
 
+def pca_OADP_proj2(XV, X_norm, sval):
+    """OADP_proj of R/bed-projectPCA.R:62-67 -> bigutilsr::pca_OADP_proj2 (external, not in the reference tree):
+    the Online Augmentation - Decomposition - Procrustes projection of Zhang, Dey & Lee (Bioinformatics 2020),
+    restated from the paper.  For one new sample with simple projection l = V'y (a row of XV) and squared norm
+    |y|^2, the reference X = U D V' augmented by y' has the factorisation
+        [X; y'] = [U 0; 0 1] [D 0; l' r] [V q]',      r^2 = |y|^2 - |l|^2,
+    so its PCA follows from the (K+1) x (K+1) matrix  M M' = [D^2, D l; (D l)', |y|^2]: eigenvectors A, eigenvalues
+    s^2.  The top-K scores of the augmented reference samples are U A[1:K, 1:K] diag(s), those of the new sample
+    A[K+1, 1:K] diag(s); the similarity transformation (rotation R, scale rho) that maps the former onto the
+    original scores U D only involves K x K matrices because U has orthonormal columns, and the projection is
+    rho * (A[K+1, 1:K] diag(s)) R.  Checked against the brute-force definition (SVD of the augmented matrix +
+    Procrustes on all reference samples) in tests/test_oadp_cpu.py; parity with bigutilsr itself is UNPINNED
+    (whether its Procrustes step also translates cannot be told from the reference tree; on PC scores, whose
+    columns sum to zero, a translation is zero up to rounding)."""
+    XV = np.asarray(XV, dtype=np.float64)
+    X_norm = np.asarray(X_norm, dtype=np.float64).ravel()
+    sval = np.asarray(sval, dtype=np.float64).ravel()
+    n, K = XV.shape
+    if sval.size != K or X_norm.size != n:
+        raise ValueError("Incompatibility between dimensions.")
+    idx = np.arange(K)
+    Q = np.zeros((n, K + 1, K + 1))
+    Q[:, idx, idx] = sval ** 2
+    Q[:, idx, K] = Q[:, K, idx] = sval * XV
+    Q[:, K, K] = X_norm
+    w, A = np.linalg.eigh(Q)                                   # ascending
+    w, A = w[:, ::-1][:, :K], A[:, :, ::-1][:, :, :K]          # the K largest
+    S = np.sqrt(np.maximum(w, 0.0))
+    ref_aug = A[:, :K, :] * S[:, None, :]                      # coordinates of the reference samples in U
+    new_aug = A[:, K, :] * S
+    M = np.einsum("nik,i->nki", ref_aug, sval)                 # ref_aug' D
+    Up, sp, Vtp = np.linalg.svd(M)
+    R = Up @ Vtp
+    rho = sp.sum(axis=1) / (ref_aug ** 2).sum(axis=(1, 2))
+    return rho[:, None] * np.einsum("nk,nkj->nj", new_aug, R)
+
+
 def bed_projectSelfPCA(obj_svd, obj_bed, ind_row, ind_col=None, ncores=1):
-    """R/bed-projectPCA.R:196-227: simple projection X V of new rows on the PCs of `obj_svd`
-    plus the squared row norms that the OADP correction needs.  The OADP step itself
-    (bigutilsr::pca_OADP_proj2, external) is not restated: `OADP_proj` is None."""
+    """R/bed-projectPCA.R:196-227: simple projection X V of new rows on the PCs of `obj_svd`, the squared
+    row norms, and the OADP projection computed from them (pca_OADP_proj2 above)."""
     ind_col = obj_svd["subset"] if ind_col is None and "subset" in obj_svd else ind_col
     if ind_col is None:
         raise ValueError("'ind.col' can't be `NULL`.")     # check_args(), test-2-pca-project.R:16-17
@@ -96,7 +132,8 @@ def bed_projectSelfPCA(obj_svd, obj_bed, ind_row, ind_col=None, ncores=1):
     if np.asarray(obj_svd["v"]).shape[0] != ic.size:
         raise ValueError("Incompatibility between dimensions.")
     XV, X_norm = prod_and_rowSumsSq(obj_bed, ir, ic, obj_svd["center"], obj_svd["scale"], obj_svd["v"])
-    return dict(obj_svd_ref=obj_svd, simple_proj=XV, X_norm=X_norm, OADP_proj=None)
+    return dict(obj_svd_ref=obj_svd, simple_proj=XV, X_norm=X_norm,
+                OADP_proj=pca_OADP_proj2(XV, X_norm, obj_svd["d"]))
 
 
 def prod_and_rowSumsSq2(G, ind_row, ind_col, center, scale, V):
@@ -120,12 +157,15 @@ def prod_and_rowSumsSq2(G, ind_row, ind_col, center, scale, V):
 
 
 def snp_projectSelfPCA(obj_svd, G, ind_row, ind_col=None, ncores=1):
-    """R/bed-projectPCA.R:252-281; `OADP_proj` is None for the same reason as in
-    bed_projectSelfPCA (bigutilsr::pca_OADP_proj2 is external)."""
+    """R/bed-projectPCA.R:252-281 (a row with a missing value is NaN in all three outputs, as in the reference)"""
     ind_col = obj_svd["subset"] if ind_col is None and "subset" in obj_svd else ind_col
     if ind_col is None:
         raise ValueError("'ind.col' can't be `NULL`.")
     im, ir, ic = _ind(G, ind_row, ind_col)
     assert_lengths(np.arange(np.asarray(obj_svd["v"]).shape[0]), ic)
-    XV, _ = prod_and_rowSumsSq2(im, ir, ic, obj_svd["center"], obj_svd["scale"], obj_svd["v"])
-    return dict(obj_svd_ref=obj_svd, simple_proj=XV, OADP_proj=None)
+    XV, X_norm = prod_and_rowSumsSq2(im, ir, ic, obj_svd["center"], obj_svd["scale"], obj_svd["v"])
+    ok = ~(np.isnan(X_norm) | np.isnan(XV).any(axis=1))
+    oadp = np.full(XV.shape, np.nan)
+    if ok.any():
+        oadp[ok] = pca_OADP_proj2(XV[ok], X_norm[ok], obj_svd["d"])
+    return dict(obj_svd_ref=obj_svd, simple_proj=XV, OADP_proj=oadp)

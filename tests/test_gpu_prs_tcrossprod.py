@@ -127,6 +127,15 @@ def test_fbm_twin_of_the_projection(ba, orc, golden_dir, example_bed, missing_be
     p_bed = ba.bed_projectSelfPCA(svd, ge, ind_row=np.arange(example_bed.n), ind_col=np.arange(example_bed.m))
     p_fbm = ba.snp_projectSelfPCA(svd, G, ind_row=test, ind_col=np.arange(example_bed.m))
     np.testing.assert_array_equal(p_fbm["simple_proj"], p_bed["simple_proj"][test])
+    # test-2-pca-project.R:49-57, 66: simple projections of left-out individuals are shrunk towards 0, the OADP
+    # projections sit closer to the population centres of the reference PCs; FBM and bed paths agree
+    np.testing.assert_allclose(p_fbm["OADP_proj"], p_bed["OADP_proj"][test], rtol=1e-9, atol=1e-9 * svd["d"][0])
+    pop = np.repeat([1, 2, 3], [143, 167, 207])
+    med = lambda X, who: np.array([np.median(X[pop[who] == c][:, 1:3], axis=0) for c in (1, 2, 3)])
+    refm = med(svd["u"] * svd["d"], ir)
+    pred1, pred2 = med(p_bed["simple_proj"][test], test), med(p_bed["OADP_proj"][test], test)
+    assert (refm ** 2).sum() > (pred1 ** 2).sum()
+    assert ((refm - pred2) ** 2).sum() < ((refm - pred1) ** 2).sum()
     ref, ref_rs = orc.prod_and_rowSumsSq2(Go, test, None, svd["center"], svd["scale"], svd["v"])
     np.testing.assert_allclose(p_fbm["simple_proj"], ref, rtol=0, atol=1e-9 * np.abs(ref).max())
     # missing codes: NA rows exactly where the reference's accessor would produce them
