@@ -126,7 +126,10 @@ out = [torch.empty_like(t) for _ in range(2)]
 dist.all_gather(out, t)
 assert torch.equal(out[0], out[1])
 dist.barrier()
-print("rank", rank, "ok", res["niter"])
+print("rank", rank, "ok", res["niter"], flush=True)
+dist.destroy_process_group()   # without it gloo's threads are torn down at interpreter exit and may abort
+sys.stdout.flush()
+os._exit(0)
 '''
 
 
