@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["svd", "ld"], default="svd")
+    ap.add_argument("--workload", choices=["svd", "ld", "matvec"], default="svd")
     ap.add_argument("--n", "--samples", type=int, default=400000)
     ap.add_argument("--m", "--variants", type=int, default=0, help="total SNP columns over all ranks (svd: 1e6, ld: 1e5)")
     ap.add_argument("--k", type=int, default=20)
@@ -141,8 +141,8 @@ def main():
         torch.cuda.set_device(device)
     ba.selftest()
     log("selftest ok")
-    if a.workload == "ld":
-        out = ld_bench(a, ba, L, rank, world, dist, torch)
+    if a.workload in ("ld", "matvec"):
+        out = (ld_bench if a.workload == "ld" else matvec_bench)(a, ba, L, rank, world, dist, torch)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -488,6 +488,57 @@ def ld_bench(a, ba, L, rank=0, world=1, dist=None, torch=None):
                          "tile_pairs": st["tile_pairs"], "products": st["products"],
                          "note": "achieved = useful int8 ops of the %d launches of one call / their summed HIP-event time"
                                  % st["launches"]}}
+
+
+def matvec_bench(a, ba, L, rank=0, world=1, dist=None, torch=None):
+    """config C2 (BASELINE.json configs[1]): bed_prodVec / bed_cprodVec of an FBM.code256 of calls, 50 000 x
+    200 000 by default, as ONE-SHOT calls — host vectors in, host vector out, everything the R function pays
+    except R itself.  A step = one prodVec + one cprodVec.  With N GPUs every rank holds its own matrix (weak
+    scaling, no collective).  roofline: 2-bit payload of the image / HIP-event time of the streaming kernel inside
+    the calls is not separable here, so `achieved` prices the whole call (transfers included) against HBM."""
+    import numpy as np
+    n, m = (a.n if a.n != 400000 else 50000), a.m or 200000
+    gb = ba.bed.synthetic(n, m, seed=9 + rank)
+    sc = ba.bed_scaleBinom(gb)
+    rng = np.random.default_rng(rank)
+    x, y = rng.normal(size=m), rng.normal(size=n)
+    step = lambda: (ba.bed_prodVec(gb, x, center=sc["center"], scale=sc["scale"]),
+                    ba.bed_cprodVec(gb, y, center=sc["center"], scale=sc["scale"]))
+    for _ in range(max(a.warmup, 3)):      # the first calls of an entry allocate its work buffers
+        step()
+    L.bsn_device_sync()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    L.bsn_device_sync()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    per_call = wall / a.steps / 2
+    nbytes = ((n + 3) // 4) * m
+    achieved = nbytes / per_call / 1e9
+    out = {"metric": "SNP-cols/sec for one-shot bed_prodVec / bed_cprodVec calls (m / time per call)",
+           "value": world * m / per_call, "unit": "SNP-cols/s", "n_gpus": world, "steps": a.steps, "warmup": max(a.warmup, 3),
+           "ms_per_step": 1e3 * wall / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "i8 (2-bit codes x 56-bit fixed-point image of the vector, 7 int8 slices, exact int32 MFMA accumulation)",
+           "data": "synthetic",
+           "config": {"workload": "bed_prodVec + bed_cprodVec, one-shot calls with host vectors, synthetic %dx%d 2-bit image "
+                                  "(config C2)" % (n, m), "n": n, "m": m,
+                      "parallelism": "one matrix per GPU, no collective" if world > 1 else "single GPU"},
+           "ms_per_call": 1e3 * per_call,
+           "roofline": {"bound": "hbm", "kernel": "whole call (vector upload, quantise, k_prod / k_cprod, finalize, download)",
+                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": None, "bytes_per_launch": nbytes}}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cb = cpu_baseline(ba, gb, n, min(m, a.cpu_sample_cols or m))
+        out["cpu_baseline"] = cb
+        out["gpu_over_cpu"] = out["value"] / cb["value"]
+    return out
 
 
 if __name__ == "__main__":

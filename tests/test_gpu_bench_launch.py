@@ -66,3 +66,16 @@ def test_two_ranks_through_the_in_library_collectives():
     assert two["n_gpus"] == 2 and "in-library RCCL" in two["config"]["parallelism"]
     assert two["converged"] and two["niter"] == one["niter"]
     np.testing.assert_allclose(two["sigma"], one["sigma"], rtol=1e-6)
+
+
+def test_other_workloads_print_one_line():
+    """`--workload matvec` (config C2) and `--workload ld` (config C5) at toy sizes: one JSON line each with the
+    contract's keys"""
+    for args in (["--workload", "matvec", "--samples", "3000", "--variants", "5000", "--steps", "3", "--no-cpu-baseline"],
+                 ["--workload", "ld", "--samples", "3000", "--variants", "4000", "--window", "200", "--steps", "1",
+                  "--warmup", "1"]):
+        rec, _ = _run([sys.executable, "bench.py"] + args)
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                    "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert key in rec, key
+        assert rec["value"] > 0 and rec["n_gpus"] == 1 and "workload" in rec["config"]
