@@ -128,8 +128,9 @@ struct bsn_op {
   // variant on the side and derives the binomial scaling from them (bsn_bed_randomsvd)
   bool stats_pending = false;
   bsn::DevBuf<int32_t> d_counts;  // 4 x m code counts of that pass
-  // total number of missing genotypes of that pass, copied to pinned host memory behind the pass
-  // (-1 until it has arrived): lets the solve switch to the complete-data kernels at its next
+  bsn::DevBuf<int32_t> d_na;      // m: their missing-value column (kept for the handle's completeness record)
+  // [0] total number of missing genotypes of that pass, [1] number of variants with > 50 % missing, copied
+  // to pinned host memory behind the pass (-1 until they have arrived): lets the solve switch to the complete-data kernels at its next
   // synchronisation point without one of its own
   long long *h_na_total = nullptr;
   bool na_poll = false;

@@ -81,8 +81,13 @@ __global__ void k_scatter_rows(const double *X, int64_t ldx, const int32_t *rows
 // vstep / voff / raw3: the value of a genotype is voff + vstep k (2-bit image: k = allele count, 1 / 0);
 // mode 1 quantises a = vstep X / scale and b = (c - voff) X / scale; raw3: the k plane holds 3 for a
 // missing value (raw 2-bit codes), so the second digit plane carries b - 3 a
+// Writes the maximum (and the number of non-finite inputs) of its slice to part[v][blockIdx.x][2]: k_quant
+// combines the slices itself, so the quantisation of a panel is two launches (round 2: five — clear, maximum
+// with atomics, scale, memset of the digits, digits).  Workgroup 0 of a vector also clears the sums that
+// k_quant accumulates.
 __global__ void k_absmax(const double *X, int64_t ldx, int64_t len, const double *center,
-                         const double *scale, int mode, VecMeta *meta, double vstep, double voff, int raw3) {
+                         const double *scale, int mode, VecMeta *meta, double *part, double vstep, double voff,
+                         int raw3) {
   int v = blockIdx.y;
   double mx = 0;
   unsigned long long bad = 0;
@@ -122,25 +127,12 @@ __global__ void k_absmax(const double *X, int64_t ldx, int64_t len, const double
       mx = fmax(mx, smx[w]);
       bad += sbad[w];
     }
-    atomicMax(&meta[v].absmax_bits, (unsigned long long)__double_as_longlong(mx));
-    if (bad) atomicAdd(&meta[v].nonfinite, bad);
+    double *pp = part + ((int64_t)v * gridDim.x + blockIdx.x) * 2;
+    pp[0] = mx;
+    pp[1] = (double)bad;
+    if (blockIdx.x == 0) meta[v].sum_hi = meta[v].sum_lo = meta[v].sum2_hi = meta[v].sum2_lo = 0;
   }
 }
-
-__global__ void k_set_qscale(VecMeta *meta, int nvec, int slices, int exact_int) {
-  int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= nvec) return;
-  double mx = __longlong_as_double((long long)meta[v].absmax_bits);
-  double lim = ldexp(0.99, 8 * slices - 1);
-  double qs = exact_int ? 1.0 : (mx > 0 ? lim / mx : 0.0);
-  if (!exact_int && mx > 0) {  // power-of-two scale: x*qs is then exact, only the rounding to integer errs
-    int e;
-    frexp(qs, &e);
-    qs = ldexp(1.0, e - 1);
-  }
-  meta[v].qscale = qs;
-}
-
 
 // One wave quantises 1024 consecutive k of one vector; a thread ends up with 16 of them as S
 // digit rows of 16 bytes.
@@ -154,12 +146,37 @@ __global__ __launch_bounds__(64) void k_quant(const double *__restrict__ X, int6
                                               int64_t len_pad, const double *__restrict__ center,
                                               const double *__restrict__ scale, int mode, int ncol,
                                               VecMeta *meta, int8_t *__restrict__ q, double vstep, double voff,
-                                              int raw3) {
+                                              int raw3, const double *__restrict__ part, int gx) {
   __shared__ double sa[64 * 17], sb[64 * 17];
   const int tid = threadIdx.x, v = blockIdx.y;
   const int64_t kb = (int64_t)blockIdx.x * 64 + tid;  // 16-block index of this thread
   const int nplanes = mode >= 1 ? 2 : 1;
-  const double qs = meta[v].qscale;
+  // fixed-point scale of the vector from the slice maxima of k_absmax (gx == 0: the values are
+  // integers already, scale 1): the largest power of two with absmax * qs <= 0.99 * 2^(8S-1), so that
+  // x * qs is exact and only the rounding to an integer errs
+  double qs = 1.0;
+  if (gx > 0) {
+    double mx = 0, bad = 0;
+    for (int t = tid; t < gx; t += 64) {
+      mx = fmax(mx, part[((int64_t)v * gx + t) * 2]);
+      bad += part[((int64_t)v * gx + t) * 2 + 1];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      mx = fmax(mx, __shfl_xor(mx, off));
+      bad += __shfl_xor(bad, off);
+    }
+    qs = 0.0;
+    if (mx > 0) {
+      int e;
+      frexp(ldexp(0.99, 8 * S - 1) / mx, &e);
+      qs = ldexp(1.0, e - 1);
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+      meta[v].absmax_bits = (unsigned long long)__double_as_longlong(mx);
+      meta[v].nonfinite = (unsigned long long)bad;
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0) meta[v].qscale = qs;
   // all 16 x (1..3) loads of a thread are issued before the first use
   double xa[16], xc[16], xs[16];
 #pragma unroll
@@ -1010,6 +1027,10 @@ void prof_collect(bsn_op *op, double ms[4], int count[4]) {
 }
 
 static int pick_nb(int ncols_needed) { return ncols_needed <= 16 ? 1 : 2; }
+constexpr int kMetaVecs = 32;   // vectors per launch at most (NB <= 2, one slice)
+static VecMeta *meta_buffer(bsn_op *op) {
+  return (VecMeta *)op->d_meta.ensure((size_t)kMetaVecs * 8 + (size_t)kMetaVecs * 256 * 2);
+}
 // samples a variant row is padded to (the digit panels and partial buffers are that long)
 static inline int64_t n_padded(const bsn_bed *b) { return b->bits == 8 ? b->pitch : b->pitch * 4; }
 
@@ -1021,17 +1042,21 @@ static void quantise(bsn_op *op, const double *d_X, int64_t ldx, int64_t len, in
   const double vstep = bytes ? op->bed->v_step : 1.0, voff = bytes ? op->bed->v_off : 0.0;
   const int raw3 = (!bytes && mode == 1) ? 1 : 0;
   if (bytes) permute = 0;  // the byte image holds the samples of a 16-block in natural order
-  hipLaunchKernelGGL(k_meta_clear, dim3(1), dim3(64), 0, st, meta, nvec);
-  if (!exact_int) {
-    int gx = (int)((len + 1023) / 1024);
+  // meta: kMetaVecs records, then the slice maxima of k_absmax (kMetaVecs x 256 x 2 doubles)
+  double *part = (double *)(meta + kMetaVecs);
+  int gx = 0;
+  if (exact_int) {
+    hipLaunchKernelGGL(k_meta_clear, dim3(1), dim3(64), 0, st, meta, nvec);
+  } else {
+    gx = (int)((len + 1023) / 1024);
     if (gx > 256) gx = 256;
     hipLaunchKernelGGL(k_absmax, dim3(gx, nvec), dim3(1024), 0, st, d_X, ldx, len,
                        mode == 1 ? op->d_center.p : mode == 2 ? d_W2 : nullptr,
-                       mode == 1 ? op->d_scale.p : nullptr, mode, meta, vstep, voff, raw3);
+                       mode == 1 ? op->d_scale.p : nullptr, mode, meta, part, vstep, voff, raw3);
   }
-  hipLaunchKernelGGL(k_set_qscale, dim3(1), dim3(64), 0, st, meta, nvec, S, exact_int);
-  int nplanes = mode >= 1 ? 2 : 1;
-  BSN_HIP(hipMemsetAsync(q, 0, (size_t)(len_pad / 16) * nplanes * ncol * 16, st));
+  // (no memset of q: k_quant writes every digit row of the columns in use, zeros past `len`; the columns
+  // of a column block that no vector uses keep stale bytes, which only reach accumulator columns that no
+  // finalize kernel reads)
   int64_t nblk = len_pad / 16;
   const double *qc = mode == 1 ? op->d_center.p : mode == 2 ? d_W2 : nullptr;
   const double *qsc = mode == 1 ? op->d_scale.p : nullptr;
@@ -1040,10 +1065,10 @@ static void quantise(bsn_op *op, const double *d_X, int64_t ldx, int64_t len, in
   case SV:                                                                                             \
     if (permute)                                                                                       \
       hipLaunchKernelGGL((k_quant<SV, 1>), qgrid, dim3(64), 0, st, d_X, ldx, len, len_pad, qc, qsc, mode, \
-                         ncol, meta, q, vstep, voff, raw3);                                            \
+                         ncol, meta, q, vstep, voff, raw3, part, gx);                                  \
     else                                                                                               \
       hipLaunchKernelGGL((k_quant<SV, 0>), qgrid, dim3(64), 0, st, d_X, ldx, len, len_pad, qc, qsc, mode, \
-                         ncol, meta, q, vstep, voff, raw3);                                            \
+                         ncol, meta, q, vstep, voff, raw3, part, gx);                                  \
     break;
   switch (S) {
     BSN_QUANT(1) BSN_QUANT(2) BSN_QUANT(3) BSN_QUANT(4) BSN_QUANT(5) BSN_QUANT(6) BSN_QUANT(7) BSN_QUANT(8)
@@ -1095,17 +1120,34 @@ __global__ void k_binom_scale(const int32_t *counts, int64_t m, double *center, 
 }
 #pragma clang fp contract(on)
 
-// total number of missing genotypes over the counted variants (one workgroup; exact)
-__global__ __launch_bounds__(1024) void k_na_total(const int32_t *counts, int64_t m, long long *out) {
-  long long s = 0;
-  for (int64_t j = threadIdx.x; j < m; j += 1024) s += counts[4 * j + 3];
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-  __shared__ long long sw[16];
-  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+// by-products of the counting pass, all on the device: the total number of missing genotypes (decides
+// whether the solve may drop the missing-value plane), the number of variants with more than 50 % missing
+// (the warning of bed_colstats, src/bed-fun.cpp:40-41) and the per-variant missing counts the handle keeps.
+// Integer atomics: exact and order-independent.  out[0] = total, out[1] = n_bad (both cleared by the caller).
+__global__ __launch_bounds__(256) void k_stats_summary(const int32_t *counts, int64_t m, int64_t n, int32_t *na,
+                                                       unsigned long long *out) {
+  long long s = 0, bad = 0;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < m; j += (int64_t)gridDim.x * 256) {
+    const int4 c = *(const int4 *)(counts + 4 * j);
+    s += c.w;
+    na[j] = c.w;
+    if (2 * ((int64_t)c.x + c.y + c.z) < n) bad++;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off);
+    bad += __shfl_down(bad, off);
+  }
+  __shared__ long long sw[4], sb[4];
+  if ((threadIdx.x & 63) == 0) {
+    sw[threadIdx.x >> 6] = s;
+    sb[threadIdx.x >> 6] = bad;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 16; w++) s += sw[w];
-    *out = s;
+    s = sw[0] + sw[1] + sw[2] + sw[3];
+    bad = sb[0] + sb[1] + sb[2] + sb[3];
+    if (s) atomicAdd(&out[0], (unsigned long long)s);
+    if (bad) atomicAdd(&out[1], (unsigned long long)bad);
   }
 }
 
@@ -1113,7 +1155,7 @@ __global__ __launch_bounds__(1024) void k_na_total(const int32_t *counts, int64_
 static bool use_tiled(const bsn_op *op) {
 #ifdef BSN_ABLATION
   // the ablation variants exist on the plain image only (41 - 46: workgroup shapes on the tiled copy)
-  if (tune_variant() != 0 && !(tune_variant() >= 41 && tune_variant() <= 48)) return false;
+  if (tune_variant() != 0 && !(tune_variant() >= 41 && tune_variant() <= 48) && !(tune_variant() >= 91 && tune_variant() <= 98)) return false;
 #endif
   return op->bed->d_tiled != nullptr && op->cols_contig && (op->col0 & 63) == 0;
 }
@@ -1164,6 +1206,25 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
       if (op->prof_kind_override == 3) BSN_LAUNCH_CPROD_T(1, TV, 8, 1);
       else BSN_LAUNCH_CPROD_T(1, TV, 8, 0);
     } else {
+#ifdef BSN_ABLATION
+      // BSN_TUNE = 91 .. 95: workgroup shapes of the two-column-block kernel on the tiled copy; correct results
+      if (tune_variant() >= 91 && tune_variant() <= 95) {
+#define BSN_SHAPE_T2(TILESV, WAVESV, KCV)                                                                 \
+  hipLaunchKernelGGL((k_cprod<2, NPLANE, KCV, RAW0, STATS, true, 0, TILESV, WAVESV, 1, 0, true>),         \
+                     dim3((unsigned)((op->m + 16 * TILESV * WAVESV - 1) / (16 * TILESV * WAVESV))),       \
+                     dim3(64 * WAVESV), 0, b->stream, b->d_tiled, b->pitch, nullptr, op->col0, op->m, q,  \
+                     acc, op->m, l0, l1, l2, counts, npad)
+        const int tv = tune_variant();
+        if (tv == 91) BSN_SHAPE_T2(2, 8, 512);
+        else if (tv == 92) BSN_SHAPE_T2(4, 8, 512);
+        else if (tv == 93) BSN_SHAPE_T2(4, 4, 512);
+        else if (tv == 94) BSN_SHAPE_T2(2, 16, 1024);
+        else BSN_SHAPE_T2(4, 16, 512);
+#undef BSN_SHAPE_T2
+        BSN_HIP(hipGetLastError());
+        return;
+      }
+#endif
       BSN_LAUNCH_CPROD_T(2, 2, 16, 0);
     }
 #undef BSN_LAUNCH_CPROD_T
@@ -1253,13 +1314,19 @@ static void finish_fused_stats(bsn_op *op) {
                      op->d_counts.p, op->m, op->d_center.p, op->d_scale.p);
   BSN_HIP(hipGetLastError());
   op->stats_pending = false;
-  // missing-value total -> pinned host word, picked up by op_poll_stats at the caller's next sync
-  if (!op->h_na_total) BSN_HIP(hipHostMalloc((void **)&op->h_na_total, sizeof(long long), hipHostMallocDefault));
-  *op->h_na_total = -1;
-  long long *d_tot = (long long *)(op->d_counts.p + 4 * op->m);  // two spare words behind the counts
-  hipLaunchKernelGGL(k_na_total, dim3(1), dim3(1024), 0, b->stream, op->d_counts.p, op->m, d_tot);
+  // missing-value total (and the > 50 % missing count) -> pinned host words, picked up by op_poll_stats at the
+  // caller's next sync
+  if (!op->h_na_total) BSN_HIP(hipHostMalloc((void **)&op->h_na_total, 2 * sizeof(long long), hipHostMallocDefault));
+  op->h_na_total[0] = -1;
+  op->h_na_total[1] = -1;
+  unsigned long long *d_tot = (unsigned long long *)(op->d_counts.p + 4 * op->m);  // four spare words behind the counts
+  BSN_HIP(hipMemsetAsync(d_tot, 0, 16, b->stream));
+  int gx = (int)((op->m + 1023) / 1024);
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(k_stats_summary, dim3(gx), dim3(256), 0, b->stream, op->d_counts.p, op->m, op->n,
+                     op->d_na.ensure((size_t)op->m), d_tot);
   BSN_HIP(hipGetLastError());
-  BSN_HIP(hipMemcpyAsync(op->h_na_total, d_tot, sizeof(long long), hipMemcpyDeviceToHost, b->stream));
+  BSN_HIP(hipMemcpyAsync(op->h_na_total, d_tot, 16, hipMemcpyDeviceToHost, b->stream));
   op->na_poll = true;
 }
 
@@ -1278,7 +1345,7 @@ void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z,
   if (nvec <= 0) return;
   const double *xsrc = scatter_rows_if_needed(op, d_X, &ldx, nvec);
   const int64_t npad = n_padded(b);
-  VecMeta *meta = (VecMeta *)op->d_meta.ensure(8 * 64);
+  VecMeta *meta = meta_buffer(op);
   for (int v0 = 0; v0 < nvec; v0 += vmax) {
     int nv = nvec - v0 < vmax ? nvec - v0 : vmax;
     int NB = pick_nb(nv * S), ncol = 16 * NB;
@@ -1311,7 +1378,7 @@ void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z,
     }
     if (op->stats_pending) {
       if (!op->rows_identity) fail("internal: fused scaling statistics need all samples");
-      launch_cprod<2, true, true>(op, NB, q, acc, kLutRaw, kLutNA, 0, op->d_counts.ensure((size_t)4 * op->m + 4));
+      launch_cprod<2, true, true>(op, NB, q, acc, kLutRaw, kLutNA, 0, op->d_counts.ensure((size_t)4 * op->m + 8));
     } else if (op->no_na) {
       launch_cprod<1, true, false>(op, NB, q, acc, kLutRaw, 0, 0);  // complete variants: code == genotype
     } else {
@@ -1397,6 +1464,25 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
     }
   }
 #endif
+#ifdef BSN_ABLATION
+  if constexpr (NB == 2 && CONTIG) {  // BSN_TUNE = 96 .. 98 on the tiled copy: 8-wave workgroups / 2 / 4 samples decoded together
+    const int tv = tune_variant();
+    if (tv >= 96 && tv <= 98 && lutP == kLutRaw && has_q && b->d_tiled && (op->col0 & 63) == 0) {
+      if (tv == 96)
+        hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 8, 0, 1, 2, 0, true>), dim3((grid.x + 1) / 2, grid.y),
+                           dim3(512), 0, b->stream, b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP,
+                           lutQ);
+      else if (tv == 97)
+        hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 2, 2, 0, true>), grid, dim3(256), 0, b->stream,
+                           b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
+      else
+        hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 4, 2, 0, true>), grid, dim3(256), 0, b->stream,
+                           b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
+      BSN_HIP(hipGetLastError());
+      return;
+    }
+  }
+#endif
   if constexpr (CONTIG) {
     if (use_tiled(op)) {  // streaming-layout copy: same arithmetic, contiguous 16-KB steps
 #define BSN_LAUNCH_PROD_T(RAWP, HASQ, TAGV)                                                                 \
@@ -1448,7 +1534,7 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
   if (b->pitch >= ((int64_t)1 << 24)) fail("more than 6.7e7 samples are not supported by the product kernel");
   const int64_t npad = n_padded(b);
   const int64_t m_pad = round_up(op->m, 64);
-  VecMeta *meta = (VecMeta *)op->d_meta.ensure(8 * 64);
+  VecMeta *meta = meta_buffer(op);
   // K split so that the grid has a few thousand workgroups
   int64_t wgx = b->bits == 8 ? npad / 256 : npad / 1024;  // workgroups along the samples
   int ky = (int)((4096 + wgx - 1) / wgx);
@@ -1541,7 +1627,7 @@ void op_cprod_raw(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *
   if (nvec <= 0) return;
   const double *xsrc = scatter_rows_if_needed(op, d_X, &ldx, nvec);
   const int64_t npad = n_padded(b);
-  VecMeta *meta = (VecMeta *)op->d_meta.ensure(8 * 64);
+  VecMeta *meta = meta_buffer(op);
   for (int v0 = 0; v0 < nvec; v0 += vmax) {
     int nv = nvec - v0 < vmax ? nvec - v0 : vmax;
     int NB = pick_nb(nv * S), ncol = 16 * NB;
@@ -1625,7 +1711,7 @@ void counts_weighted(bsn_op *op, const double *d_w, int64_t n_sub, int32_t *d_co
   bsn_bed *b = op->bed;
   const int S = 4;
   const int64_t npad = n_padded(b);
-  VecMeta *meta = (VecMeta *)op->d_meta.ensure(8 * 64);
+  VecMeta *meta = meta_buffer(op);
   int8_t *q = op->d_q.ensure((size_t)npad * 64);
   int32_t *acc = op->d_acc.ensure((size_t)3 * op->m * 16);
   quantise(op, d_w, b->n, b->n, npad, 1, 0, S, 16, 1, 1, meta, q);

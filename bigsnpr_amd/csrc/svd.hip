@@ -9,6 +9,7 @@
 #include <memory>
 
 #include "bsn_internal.hpp"
+#include "orth_small.hpp"
 #include "svd_driver.hpp"
 
 namespace bsn {
@@ -39,80 +40,97 @@ __global__ void k_random(double *W, int64_t ld, int64_t n, int b, uint32_t seed,
   W[il + j * ld] = 2.0 * x - 1.0;
 }
 
-// partial[rc][pt*4 + a][j] = sum over the row chunk of Q[i, pt*4+a] * W[i, j]; CB = number of
-// columns of W (compile-time, so that no register or FMA is spent on absent columns)
-template <int CB>
-__global__ __launch_bounds__(256) void k_gemm_tn_part(const double *__restrict__ Q, int64_t ldq,
-                                                      int p, const double *__restrict__ W,
-                                                      int64_t ldw, int64_t n, int64_t rows_per,
-                                                      double *partial) {
-  const int pt = blockIdx.x, rc = blockIdx.y, tid = threadIdx.x;
-  const int64_t r0 = (int64_t)rc * rows_per;
-  int64_t r1 = r0 + rows_per;
-  if (r1 > n) r1 = n;
-  double acc[4][CB];
+typedef double v4d __attribute__((ext_vector_type(4)));
+struct __attribute__((aligned(8))) d2 {
+  double x, y;
+};
+constexpr int64_t kGemmRows = 1024;   // rows per workgroup of k_gemm_tn (4 waves x 256)
+
+// C (p x cb, leading dimension ldc) = A[:, :p]' B[:, :cb]: the tall-skinny TN product of the panel algebra
+// on the fp64 matrix pipe.  v_mfma_f64_16x16x4 with the 16 columns of an A tile as M, the (<= 16) columns
+// of B as N and four rows as K: lane l supplies A[row, tile*16 + (l & 15)] and B[row, l & 15] for row slot
+// l >> 4; which row a slot stands for is free as long as A and B agree, so a lane takes TWO consecutive
+// rows per 16-byte load (rows r + 2 (l >> 4) + {0, 1} of an 8-row group, two MFMAs): every load
+// instruction then reads 64 contiguous bytes per column, straight from global memory — A is read exactly
+// once, B once per 16 columns of A (round 2's VALU kernel re-read B once per FOUR columns of A and was
+// the largest item of a solve outside the streaming passes).
+// Workgroup (tile, rc) covers rows [rc, rc + 1) * kGemmRows with four waves and writes the 16 x 16 sums to
+// partial[rc][tile]; k_gemm_tn_reduce adds the chunks up.
+__global__ __launch_bounds__(256) void k_gemm_tn(const double *__restrict__ A, int64_t lda, int p,
+                                                 const double *__restrict__ B, int64_t ldb, int cb, int64_t n,
+                                                 double *partial) {
+  const int tile = blockIdx.x, rc = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int a = lane & 15, kq = lane >> 4;
+  // columns past p (past cb) are read from a valid one and discarded (masked): no branch around the loads
+  const int ca = tile * 16 + a < p ? tile * 16 + a : p - 1;
+  const bool bval = a < cb;
+  const double *Ap = A + (int64_t)ca * lda, *Bp = B + (int64_t)(bval ? a : 0) * ldb;
+  const int64_t c0 = (int64_t)rc * kGemmRows, c1 = c0 + kGemmRows < n ? c0 + kGemmRows : n;
+  const int64_t r0 = c0 + wave * (kGemmRows / 4);
+  const int64_t r1 = r0 + kGemmRows / 4 < c1 ? r0 + kGemmRows / 4 : c1;
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+  // groups of 32 rows through two register sets: the loads of a group are in flight while the MFMAs of the
+  // previous one run (a wave that waited out every group's memory round trip left the kernel latency-bound
+  // at a quarter of the bandwidth).  No branch around the loads: past the end the last group is loaded again.
+  d2 av0[4], bv0[4], av1[4], bv1[4];
+  auto ld = [&](int64_t rr, d2 (&av)[4], d2 (&bv)[4]) {
 #pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int j = 0; j < CB; j++) acc[a][j] = 0;
-  const int pc = pt * 4;
-  // columns past p are read from the last valid one and discarded at the end (no branch in the loop)
-  const double *q0 = Q + (int64_t)(pc + 0 < p ? pc + 0 : p - 1) * ldq, *q1 = Q + (int64_t)(pc + 1 < p ? pc + 1 : p - 1) * ldq,
-               *q2 = Q + (int64_t)(pc + 2 < p ? pc + 2 : p - 1) * ldq, *q3 = Q + (int64_t)(pc + 3 < p ? pc + 3 : p - 1) * ldq;
-#pragma unroll 2
-  for (int64_t i = r0 + tid; i < r1; i += 256) {
-    double w[CB];
-#pragma unroll
-    for (int j = 0; j < CB; j++) w[j] = W[i + j * ldw];
-    const double q[4] = {q0[i], q1[i], q2[i], q3[i]};
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-      for (int j = 0; j < CB; j++) acc[a][j] += q[a] * w[j];
-  }
-  __shared__ double red[4][4 * CB];
-  const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int j = 0; j < CB; j++) {
-      double v = acc[a][j];
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-      if (lane == 0) red[wave][a * CB + j] = v;
+    for (int u = 0; u < 4; u++) {
+      av[u] = *(const d2 *)(Ap + rr + 8 * u + 2 * kq);
+      bv[u] = *(const d2 *)(Bp + rr + 8 * u + 2 * kq);
     }
+  };
+  auto mm = [&](const d2 (&av)[4], const d2 (&bv)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].x, bval ? bv[u].x : 0.0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].y, bval ? bv[u].y : 0.0, acc, 0, 0, 0);
+    }
+  };
+  const int64_t nfull = r1 > r0 ? (r1 - r0) / 32 : 0;
+  if (nfull > 0) {
+    ld(r0, av0, bv0);
+    for (int64_t g = 0; g < nfull; g += 2) {
+      ld(r0 + 32 * (g + 1 < nfull ? g + 1 : nfull - 1), av1, bv1);
+      mm(av0, bv0);
+      ld(r0 + 32 * (g + 2 < nfull ? g + 2 : nfull - 1), av0, bv0);
+      if (g + 1 < nfull) mm(av1, bv1);
+    }
+  }
+  int64_t r = r0 + 32 * nfull;
+  for (; r < r1; r += 8) {   // the ragged end of the last chunk
+    const int64_t i0 = r + 2 * kq, i1 = i0 + 1;
+    const double a0 = i0 < r1 ? Ap[i0] : 0.0, a1 = i1 < r1 ? Ap[i1] : 0.0;
+    const double b0 = (bval && i0 < r1) ? Bp[i0] : 0.0, b1 = (bval && i1 < r1) ? Bp[i1] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+  }
+  // D: column of B = lane & 15, column of the A tile = (lane >> 4) + 4 * reg
+  __shared__ double red[4][256];
+#pragma unroll
+  for (int g = 0; g < 4; g++) red[wave][(kq + 4 * g) * 16 + a] = acc[g];
   __syncthreads();
-  if (tid < 4 * CB) {
-    double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-    int a = tid / CB, j = tid % CB;
-    if (pc + a < p) partial[((int64_t)rc * p + pc + a) * kMaxB + j] = v;
-  }
+  partial[((int64_t)rc * gridDim.x + tile) * 256 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
-static void launch_gemm_tn_part(dim3 grid, hipStream_t st, const double *A, int64_t n, int p, const double *W,
-                                int cb, int64_t rows_per, double *partial) {
-#define BSN_TN(CBV)                                                                                     \
-  case CBV:                                                                                             \
-    hipLaunchKernelGGL((k_gemm_tn_part<CBV>), grid, dim3(256), 0, st, A, n, p, W, n, n, rows_per, partial); \
-    break;
-  switch (cb) {
-    BSN_TN(1) BSN_TN(2) BSN_TN(3) BSN_TN(4) BSN_TN(5) BSN_TN(6) BSN_TN(7) BSN_TN(8) BSN_TN(9) BSN_TN(10)
-    BSN_TN(11) BSN_TN(12) BSN_TN(13) BSN_TN(14) BSN_TN(15) BSN_TN(16)
-    default: fail("block size must be <= %d", kMaxB);
+// C[tile*16 + mrow, ncol] = sum over the row chunks, in a fixed order (four interleaved running sums, then
+// their sum): identical on every rank and in every run.  (A single launch with a "last workgroup adds up"
+// tail was tried in round 3: the device-scope fences it needs write back the L2 of every XCD, 0.15 us per
+// workgroup, several times the product itself.)
+__global__ __launch_bounds__(1024) void k_gemm_tn_reduce(const double *__restrict__ partial, int nrc, int ntile, int p,
+                                                         int cb, double *C, int ldc) {
+  const int tile = blockIdx.x, t = threadIdx.x & 255, part = threadIdx.x >> 8;
+  double sum = 0;
+#pragma unroll 4
+  for (int c = part; c < nrc; c += 4) sum += partial[((int64_t)c * ntile + tile) * 256 + t];
+  __shared__ double sp[4][256];
+  sp[part][t] = sum;
+  __syncthreads();
+  if (part == 0) {
+    sum = (sp[0][t] + sp[1][t]) + (sp[2][t] + sp[3][t]);
+    const int mrow = t >> 4, ncol = t & 15;
+    if (tile * 16 + mrow < p && ncol < cb) C[(tile * 16 + mrow) + (int64_t)ncol * ldc] = sum;
   }
-#undef BSN_TN
-}
-
-// one wave per output element, fixed summation order (lane-strided partial sums, then a
-// shuffle tree): the result is identical on every rank and in every run
-__global__ __launch_bounds__(256) void k_gemm_tn_reduce(const double *partial, int nrc, int p, int cb,
-                                                        double *C) {
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (t >= p * cb) return;
-  const int a = t % p, j = t / p;
-  double s = 0;
-  for (int rc = lane; rc < nrc; rc += 64) s += partial[((int64_t)rc * p + a) * kMaxB + j];
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-  if (lane == 0) C[a + (int64_t)j * p] = s;
 }
 
 // Out[i, j] = alpha * In[i, j] + beta * sum_a Q[i, a] S[a, j],  j < nc <= 8; S (p x nc) in global
@@ -175,84 +193,93 @@ __global__ void k_right_mult(double *W, int64_t ld, int64_t n, int cb, int r, co
     if (c < r) W[i + c * ld] = o[c];
 }
 
-// One normalisation pass of the block orthonormalisation on the device (single thread; b <= 12):
-// the arithmetic of chol_upper / inv_upper (dense_small.hpp) and of the rank tests of
-// svd_driver.hpp's orth().  G0 = W'W before the projections (scale of the deficiency test,
-// pass 0 only), G = W'W now.  Writes Ri = R^-1, Rout = R (pass 0) or R * Rout (pass 1), and
-// raises *flag when W is not numerically of full rank (the host then redoes the step on the
-// step-by-step path).
-__global__ __launch_bounds__(64) void k_orth_small(const double *G0, const double *G, int b, int pass,
-                                                    double *Ri, double *Rout, double *flag) {
-  // inputs are staged in LDS by the whole wave; thread 0 then works on LDS only (a chain of
-  // dependent global loads cost 30 us for a 5 x 5 block)
-  __shared__ double sG[kMaxB * kMaxB], sG0d[kMaxB], sR[kMaxB * kMaxB], sRi[kMaxB * kMaxB],
-      sRo[kMaxB * kMaxB], sRn[kMaxB * kMaxB];
-  __shared__ int sbad;
-  const int tid = threadIdx.x, bb = b * b;
-  for (int t = tid; t < bb; t += 64) {
-    sG[t] = G[t];
-    sR[t] = 0.0;
-    sRi[t] = 0.0;
-    sRo[t] = pass == 0 ? 0.0 : Rout[t];
+// The small-matrix half of one pass of the two-pass orthonormalisation (orth_small.hpp) on one
+// workgroup; the coefficient iterate lives in LDS.  mx_clear: the column maxima that the following
+// k_update accumulates (rounding of the finished block) start from zero.
+struct DevCtx {
+  int tid, nt;
+  __device__ void sync() { __syncthreads(); }
+};
+__global__ __launch_bounds__(512) void k_orth2(OrthSmall a, unsigned long long *mx_clear) {
+  __shared__ double sCs[kOrthMaxP * kOrthMaxB];
+  __shared__ double sG[kOrthMaxB * kOrthMaxB], sR[kOrthMaxB * kOrthMaxB], sRi[kOrthMaxB * kOrthMaxB],
+      sRo[kOrthMaxB * kOrthMaxB], sD[kOrthMaxB * kOrthMaxB], sT[2 * kOrthMaxB + 4];
+  a.Cs = sCs;
+  a.Gs = sG;
+  a.Rs = sR;
+  a.Ris = sRi;
+  a.Ro = sRo;
+  a.Dv = sD;
+  a.tmp = sT;
+  if (mx_clear && threadIdx.x < kOrthMaxB) mx_clear[threadIdx.x] = 0ull;
+  DevCtx cx{(int)threadIdx.x, (int)blockDim.x};
+  orth_small(cx, a);
+}
+
+// W[i, :cb] <- (W[i, :cb] - Q[i, :p] C) Ri   in place, one thread per row (the tall half of a pass);
+// mx != null: also the column maxima of the result (bits of a non-negative double order like u64)
+template <int CBT>
+__global__ __launch_bounds__(256) void k_update(const double *__restrict__ Q, int64_t ldq, int p,
+                                                const double *__restrict__ C, const double *__restrict__ Ri,
+                                                int cb, double *W, int64_t ldw, int64_t n,
+                                                unsigned long long *mx) {
+  constexpr int TP = 128, ROWS = 4;   // a workgroup covers 1024 rows: few atomics on the column maxima
+  __shared__ double sS[TP * CBT], sRi[CBT * CBT], smx[4][CBT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int t = tid; t < CBT * CBT; t += 256) {
+    const int j = t % CBT, c = t / CBT;
+    sRi[t] = (j < cb && c < cb) ? Ri[j + c * cb] : 0.0;
   }
-  if (tid < b) sG0d[tid] = G0[tid + tid * b];
-  __syncthreads();
-  if (tid == 0) {
-    bool bad = false;
-    if (pass == 0) {
-      double w0 = 0;
-      for (int i = 0; i < b; i++) w0 = fmax(w0, sG0d[i]);
-      for (int i = 0; i < b; i++)
-        if (!(sG[i + i * b] > 1e-22 * w0 && w0 > 0)) bad = true;
-    }
-    double dmax = 0;
-    for (int i = 0; i < b; i++) dmax = fmax(dmax, sG[i + i * b]);
-    for (int j = 0; j < b && !bad; j++) {
-      double s = sG[j + j * b];
-      for (int k = 0; k < j; k++) s -= sR[k + j * b] * sR[k + j * b];
-      if (!(s > 1e-22 * dmax) || !(dmax > 0)) {
-        bad = true;
-        break;
+  if (tid < 4 * CBT) smx[tid / CBT][tid % CBT] = 0.0;
+  const bool one_tile = p <= TP;
+  for (int it = 0; it < ROWS; it++) {
+    const int64_t i = ((int64_t)blockIdx.x * ROWS + it) * 256 + tid;
+    double acc[CBT];
+#pragma unroll
+    for (int j = 0; j < CBT; j++) acc[j] = 0;
+    for (int a0 = 0; a0 < p; a0 += TP) {
+      const int ta = p - a0 < TP ? p - a0 : TP;
+      if (!(one_tile && it > 0)) {   // (uniform) the coefficient tile stays in LDS when it is the only one
+        __syncthreads();
+        for (int t = tid; t < ta * CBT; t += 256) {
+          const int a = t / CBT, j = t % CBT;
+          sS[t] = j < cb ? C[(a0 + a) + (int64_t)j * p] : 0.0;
+        }
+        __syncthreads();
       }
-      const double rjj = sqrt(s);
-      sR[j + j * b] = rjj;
-      for (int i = j + 1; i < b; i++) {
-        double t = sG[j + i * b];
-        for (int k = 0; k < j; k++) t -= sR[k + j * b] * sR[k + i * b];
-        sR[j + i * b] = t / rjj;
-      }
-    }
-    if (bad) {
-      for (int t = 0; t < bb; t++) sRi[t] = 0.0;
-      for (int i = 0; i < b; i++) sRi[i + i * b] = 1.0;  // keep the following kernels finite
-    } else {
-      for (int j = 0; j < b; j++) {
-        sRi[j + j * b] = 1.0 / sR[j + j * b];
-        for (int i = j - 1; i >= 0; i--) {
-          double s = 0;
-          for (int k = i + 1; k <= j; k++) s += sR[i + k * b] * sRi[k + j * b];
-          sRi[i + j * b] = -s / sR[i + i * b];
+      if (i < n) {
+        for (int a = 0; a < ta; a++) {
+          const double q = Q[i + (int64_t)(a0 + a) * ldq];
+#pragma unroll
+          for (int j = 0; j < CBT; j++) acc[j] += q * sS[a * CBT + j];
         }
       }
-      if (pass == 0) {
-        for (int t = 0; t < bb; t++) sRn[t] = sR[t];
-      } else {
-        for (int j = 0; j < b; j++)
-          for (int i = 0; i < b; i++) {
-            double s = 0;
-            for (int t = i; t < b; t++) s += sR[i + t * b] * sRo[t + j * b];
-            sRn[i + j * b] = s;
-          }
+    }
+    if (p == 0 && it == 0) __syncthreads();   // sRi / smx are ready
+    double w[CBT];
+#pragma unroll
+    for (int j = 0; j < CBT; j++) w[j] = (i < n && j < cb) ? W[i + j * ldw] - acc[j] : 0.0;
+    // one output column at a time (the loop is kept rolled: 16 x 16 products unrolled need 300 registers)
+#pragma unroll 1
+    for (int c = 0; c < cb; c++) {
+      double s = 0;
+#pragma unroll
+      for (int j = 0; j < CBT; j++) s += w[j] * sRi[j + c * CBT];
+      if (i < n) W[i + c * ldw] = s;
+      if (mx) {
+        double m = fabs(s);
+        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off));
+        if (lane == 0) smx[wave][c] = fmax(smx[wave][c], m);
       }
     }
-    sbad = bad ? 1 : 0;
   }
-  __syncthreads();
-  for (int t = tid; t < bb; t += 64) {
-    Ri[t] = sRi[t];
-    if (!sbad) Rout[t] = sRn[t];
+  if (mx) {
+    __syncthreads();
+    if (tid < cb) {
+      const double m = fmax(fmax(smx[0][tid], smx[1][tid]), fmax(smx[2][tid], smx[3][tid]));
+      atomicMax(&mx[tid], (unsigned long long)__double_as_longlong(m));
+    }
   }
-  if (tid == 0 && sbad) *flag = 1.0;
 }
 
 // ---- rounding of a finished basis block to the fixed-point grid of the streaming products ----
@@ -317,17 +344,21 @@ __global__ void k_take_rows(const double *__restrict__ full, int64_t n, int cb, 
 // rows [r nr, (r+1) nr) of the basis Q and of the working panel W, orthogonalises them locally and
 // shares only the small coefficient matrices (p x b, b x b) — the n-side algebra is divided by the
 // number of ranks instead of being replicated.  The variants (columns of G, rows of Z) are sharded
-// as before.  Per block step:
+// as before.  Per block step (round 3: two small sums over the ranks instead of eight, every
+// collective on the solve's own stream):
 //   Z_g = A_g' Qfull           local crossproduct pass; Qfull = newest basis block, all n rows
 //   Wfull = A_g Z_g            local product pass, partial sums over this rank's variants
-//   W_r = reduce-scatter(Wfull) by sample blocks (own stream: overlaps the local Z'Z Gram kernels)
-//   orthonormalise W_r against Q_r (Gram blocks all-reduced, b x p doubles each)
+//   W_r = reduce-scatter(Wfull) by sample blocks
+//   all-reduce #1 of [Z'Z block | Q'Q block | Q'W | W'W], project + normalise W_r (orth_small.hpp)
+//   all-reduce #2 of [Q'W | W'W] of the new W_r, project + normalise again
 //   Qfull = round(all-gather(W_r)); Q_r gets its rows
 // Without a communicator (and without the test hook) nr = n and every collective is skipped: the
 // single-GPU path is the same code.
+// The working panel W is not a buffer of its own: it IS the next free columns of Q (W = Q[:, p : p+cb]),
+// so [Q W]' W is one tall product over contiguous columns and a finished block needs no copy.
 // device buffers of a solve; lives on the bed handle between solves (grow-only)
 struct SvdWorkspace {
-  DevBuf<double> Q, Z, W, partial, dsmall, Wsave, dorth, Wfull, Wblk, Qfull, dS, dU, dV, dUfull;
+  DevBuf<double> Q, Z, partial, dsmall, Wsave, dorth, Wfull, Wblk, Qfull, dS, dU, dV, dUfull, dM;
   // pinned host staging for the small matrices that cross the bus every block step (Gram blocks,
   // orthogonalisation coefficients): copies to pageable memory go through the runtime's own staging
   // and were measured to cost milliseconds each once a process has run a few solves
@@ -350,7 +381,7 @@ struct SvdWorkspace {
 struct HipSvdBackend : SvdBackend {
   SvdWorkspace &ws;
   explicit HipSvdBackend(SvdWorkspace &w)
-      : ws(w), Q(w.Q), Z(w.Z), W(w.W), partial(w.partial), dsmall(w.dsmall), Wsave(w.Wsave), dorth(w.dorth),
+      : ws(w), Q(w.Q), Z(w.Z), partial(w.partial), dsmall(w.dsmall), Wsave(w.Wsave), dorth(w.dorth),
         Wfull(w.Wfull), Wblk(w.Wblk), Qfull(w.Qfull) {}
   bsn_op *op = nullptr;
   hipStream_t st = nullptr;
@@ -360,13 +391,14 @@ struct HipSvdBackend : SvdBackend {
   int rank = 0, world = 1;
   bool dist = false;
   int64_t nr = 0, row0 = 0;  // rows of a sample block, first row of this rank's block
-  DevBuf<double> &Q, &Z, &W, &partial, &dsmall, &Wsave, &dorth, &Wfull, &Wblk, &Qfull;
+  DevBuf<double> &Q, &Z, &partial, &dsmall, &Wsave, &dorth, &Wfull, &Wblk, &Qfull;
+  double *Wc = nullptr;      // the working panel: columns wcol .. of Q
+  int wcol = 0;
   std::vector<double> horth;
   int cap = 0, b = 0;
-  int64_t rows_per = 0;
-  int nrc = 0;
-  bool rs_pending = false;
   int kmax = 0;
+  bool mx_valid = false;     // the column maxima of W (rounding) came out of the last k_update
+  int n_small_ar = 0;        // small all-reduces issued (diagnostics)
   // warm start on a leading subset of this rank's variants
   int64_t m_op_full = 0, m_sub = 0;
   bool fused_stats = false;
@@ -399,6 +431,7 @@ struct HipSvdBackend : SvdBackend {
   // host wall time per phase (BSN_TIMING=1): where a solve's time outside the streaming kernels goes
   bool timing = false;
   double t_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // alloc, At_Q, A_Z, grams, orth, round/copy, finalize, other
+  int n_sync = 0;  // host synchronisations with the solve's stream
   struct Tick {
     HipSvdBackend *b;
     int ph;
@@ -409,6 +442,10 @@ struct HipSvdBackend : SvdBackend {
         b->t_phase[ph] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
   };
+  void sync_stream() {
+    BSN_HIP(hipStreamSynchronize(st));
+    n_sync++;
+  }
 
   void setup_ranks() {
     if (comm) {
@@ -425,46 +462,37 @@ struct HipSvdBackend : SvdBackend {
     if (b_ > kMaxB) fail("block size must be <= %d", kMaxB);
     cap = cap_;
     b = b_;
-    auto t0 = std::chrono::steady_clock::now();
-    Q.ensure((size_t)nr * cap);
+    Q.ensure((size_t)nr * (cap + kMaxB));   // the working panel sits behind the basis
     Z.ensure((size_t)m_local * cap);
-    W.ensure((size_t)nr * kMaxB);
-    rows_per = 4096;
-    nrc = (int)((nr + rows_per - 1) / rows_per);
     {
       const int64_t rows_max = nr > m_local ? nr : m_local;
-      partial.ensure((size_t)((rows_max + rows_per - 1) / rows_per) * (cap + 4) * kMaxB);
+      partial.ensure((size_t)((rows_max + kGemmRows - 1) / kGemmRows) * ((cap + kMaxB + 15) / 16) * 256);
     }
     dsmall.ensure((size_t)(cap + 4) * 64);
     Wsave.ensure((size_t)nr * kMaxB);
-    dorth.ensure((size_t)8 * kMaxB * kMaxB + (size_t)3 * (cap + 4) * kMaxB);
+    dorth.ensure((size_t)16 + 3 * kMaxB * kMaxB + (size_t)6 * (cap + kMaxB + 4) * kMaxB);
+    ws.dM.ensure((size_t)kOrthMaxP * kOrthMaxP);
     if (dist) {
       const int wide = kmax > kMaxB ? kmax : kMaxB;
       Wfull.ensure((size_t)n * wide);
       Wblk.ensure((size_t)world * nr * wide);
       Qfull.ensure((size_t)n * kMaxB);
     }
-    (void)t0;
+    Wc = Q.p;
+    wcol = 0;
   }
 
-  // ---- collectives ------------------------------------------------------------------------
-  // sum of a small device matrix over the ranks, in place, ordered on the solve's stream
+  // ---- collectives (all on the solve's stream: one communicator, one stream, issue order = stream order) ----
+  // sum of a small device matrix over the ranks, in place
   void ar_small(double *d, int64_t count) {
     if (!dist) return;
-    wait_rs();
+    n_small_ar++;
     if (comm) {
       comm_allreduce_sum(comm, d, count, st);
     } else {
-      BSN_HIP(hipStreamSynchronize(st));
+      sync_stream();
       hook(d, count, ctx);
     }
-  }
-  // the reduce-scatter of the working panel runs on the communicator's stream; everything that
-  // reads W, and every later collective, waits for it here
-  void wait_rs() {
-    if (!rs_pending) return;
-    rs_pending = false;
-    if (comm) BSN_HIP(hipStreamWaitEvent(st, comm->ev_done, 0));
   }
   void reduce_scatter_W(int cb) {  // Wfull (n x cb partial sums) -> W (nr x cb, summed over ranks)
     const int64_t tot = (int64_t)world * cb * nr;
@@ -472,28 +500,23 @@ struct HipSvdBackend : SvdBackend {
                        Wblk.p);
     BSN_HIP(hipGetLastError());
     if (comm) {
-      BSN_HIP(hipEventRecord(comm->ev_ready, st));
-      BSN_HIP(hipStreamWaitEvent(comm->stream, comm->ev_ready, 0));
-      comm_reduce_scatter_sum(comm, Wblk.p, W.p, nr * cb, comm->stream);
-      BSN_HIP(hipEventRecord(comm->ev_done, comm->stream));
-      rs_pending = true;
+      comm_reduce_scatter_sum(comm, Wblk.p, Wc, nr * cb, st);
     } else {
-      BSN_HIP(hipStreamSynchronize(st));
+      sync_stream();
       hook(Wblk.p, tot, ctx);
-      BSN_HIP(hipMemcpyAsync(W.p, Wblk.p + (int64_t)rank * cb * nr, (size_t)nr * cb * 8,
+      BSN_HIP(hipMemcpyAsync(Wc, Wblk.p + (int64_t)rank * cb * nr, (size_t)nr * cb * 8,
                              hipMemcpyDeviceToDevice, st));
     }
   }
   // src (nr x cb local rows) -> dst (n x cb, all rows, column-major)
   void all_gather_rows(const double *src, int cb, double *dst) {
-    wait_rs();
     const int64_t tot = (int64_t)world * cb * nr;
     if (comm) {
       comm_all_gather(comm, src, Wblk.p, nr * cb, st);
     } else {
       BSN_HIP(hipMemsetAsync(Wblk.p, 0, (size_t)tot * 8, st));
       BSN_HIP(hipMemcpyAsync(Wblk.p + (int64_t)rank * cb * nr, src, (size_t)nr * cb * 8, hipMemcpyDeviceToDevice, st));
-      BSN_HIP(hipStreamSynchronize(st));
+      sync_stream();
       hook(Wblk.p, tot, ctx);
     }
     hipLaunchKernelGGL(k_unblock, dim3((unsigned)((n * cb + 255) / 256)), dim3(256), 0, st, Wblk.p, n, cb, nr, dst);
@@ -502,7 +525,10 @@ struct HipSvdBackend : SvdBackend {
 
   // ---- backend interface ------------------------------------------------------------------
   void random_W(int bb, uint32_t seed) override {
-    hipLaunchKernelGGL(k_random, dim3((unsigned)((nr + 255) / 256), bb), dim3(256), 0, st, W.p, nr, nr, bb, seed,
+    Wc = Q.p;
+    wcol = 0;
+    mx_valid = false;
+    hipLaunchKernelGGL(k_random, dim3((unsigned)((nr + 255) / 256), bb), dim3(256), 0, st, Wc, nr, nr, bb, seed,
                        row0, n);
     BSN_HIP(hipGetLastError());
   }
@@ -514,36 +540,34 @@ struct HipSvdBackend : SvdBackend {
   }
   void A_Zblock(int p0, int cb) override {
     Tick tk(this, 2);
-    op_prod(op, Z.p + (int64_t)p0 * m_local, m_local, cb, dist ? Wfull.p : W.p, n);
+    mx_valid = false;
+    op_prod(op, Z.p + (int64_t)p0 * m_local, m_local, cb, dist ? Wfull.p : Wc, n);
     if (dist) reduce_scatter_W(cb);
   }
+  // dC (p x cb, leading dimension ldc) = A[:, :p]' B[:, :cb] for operands with `rows` rows (leading
+  // dimension = rows); local rows only
+  void gemm_tn_any(const double *A, const double *B, int64_t rows, int p, int cb, double *dC, int ldc = 0) {
+    if (p <= 0 || cb <= 0) return;
+    dim3 grid((unsigned)((p + 15) / 16), (unsigned)((rows + kGemmRows - 1) / kGemmRows));
+    hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, st, A, rows, p, B, rows, cb, rows, partial.p);
+    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3(grid.x), dim3(1024), 0, st, partial.p, (int)grid.y, (int)grid.x, p, cb,
+                       dC, ldc > 0 ? ldc : p);
+  }
   void gemm_tn(const double *A, int p, int cb, double *C_host) {
-    wait_rs();
-    gemm_tn_any(A, W.p, nr, p, cb, dsmall.p);
+    gemm_tn_any(A, Wc, nr, p, cb, dsmall.p);
     BSN_HIP(hipGetLastError());
     ar_small(dsmall.p, (int64_t)p * cb);
-    double *hp = ws.pinned((size_t)(cap + 4) * kMaxB * 4 + 1024);
+    double *hp = ws.pinned((size_t)(cap + kMaxB + 4) * kMaxB * 4 + 1024);
     BSN_HIP(hipMemcpyAsync(hp, dsmall.p, (size_t)p * cb * 8, hipMemcpyDeviceToHost, st));
-    BSN_HIP(hipStreamSynchronize(st));
+    sync_stream();
     std::memcpy(C_host, hp, (size_t)p * cb * 8);
   }
-  // dC (p x cb) = sum over ranks of A[:, :p]' W[:, :cb] on the local sample block
-  void gemm_tn_dev(const double *A, int p, int cb, double *dC) {
-    gemm_tn_any(A, W.p, nr, p, cb, dC);
-    ar_small(dC, (int64_t)p * cb);
-  }
-  // dC (p x cb) = A[:, :p]' B[:, :cb] for operands with `rows` rows (leading dimension = rows)
-  void gemm_tn_any(const double *A, const double *B, int64_t rows, int p, int cb, double *dC) {
-    const int nrc_ = (int)((rows + rows_per - 1) / rows_per);
-    dim3 grid((unsigned)((p + 3) / 4), (unsigned)nrc_);
-    launch_gemm_tn_part(grid, st, A, rows, p, B, cb, rows_per, partial.p);
-    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((p * cb + 3) / 4)), dim3(256), 0, st,
-                       partial.p, nrc_, p, cb, dC);
-  }
-  void round_cols(double *X, int64_t rows, int cb) {
+  void round_cols(double *X, int64_t rows, int cb, bool have_mx) {
     unsigned long long *mx = (unsigned long long *)dorth.p;
-    BSN_HIP(hipMemsetAsync(mx, 0, (size_t)cb * 8, st));
-    hipLaunchKernelGGL(k_col_absmax, dim3(256, cb), dim3(1024), 0, st, X, rows, rows, mx);
+    if (!have_mx) {
+      BSN_HIP(hipMemsetAsync(mx, 0, (size_t)cb * 8, st));
+      hipLaunchKernelGGL(k_col_absmax, dim3(256, cb), dim3(1024), 0, st, X, rows, rows, mx);
+    }
     hipLaunchKernelGGL(k_round_cols, dim3((unsigned)((rows + 255) / 256), cb), dim3(256), 0, st, X, rows, rows, mx,
                        op->slices);
     BSN_HIP(hipGetLastError());
@@ -552,24 +576,25 @@ struct HipSvdBackend : SvdBackend {
     if (cb <= 0) return;
     Tick tk(this, 5);
     if (!dist) {
-      round_cols(W.p, n, cb);
+      round_cols(Wc, n, cb, mx_valid);
+      mx_valid = false;
       return;
     }
     // every rank rounds the same gathered block (column maxima over all n rows), then keeps its rows
-    all_gather_rows(W.p, cb, Qfull.p);
-    round_cols(Qfull.p, n, cb);
+    all_gather_rows(Wc, cb, Qfull.p);
+    round_cols(Qfull.p, n, cb, false);
     hipLaunchKernelGGL(k_take_rows, dim3((unsigned)((nr * cb + 255) / 256)), dim3(256), 0, st, Qfull.p, n, cb, nr,
-                       row0, W.p);
+                       row0, Wc);
     BSN_HIP(hipGetLastError());
   }
   void gram_to_host(const double *A, const double *B, int64_t rows, int p, int cb, double *out) {
     Tick tk(this, 3);
-    gemm_tn_any(A, B, rows, p, cb, dsmall.p);  // local part first: it overlaps the reduce-scatter of W
+    gemm_tn_any(A, B, rows, p, cb, dsmall.p);
     BSN_HIP(hipGetLastError());
     ar_small(dsmall.p, (int64_t)p * cb);
-    double *hp = ws.pinned((size_t)(cap + 4) * kMaxB * 4 + 1024);
+    double *hp = ws.pinned((size_t)(cap + kMaxB + 4) * kMaxB * 4 + 1024);
     BSN_HIP(hipMemcpyAsync(hp, dsmall.p, (size_t)p * cb * 8, hipMemcpyDeviceToHost, st));
-    BSN_HIP(hipStreamSynchronize(st));
+    sync_stream();
     std::memcpy(out, hp, (size_t)p * cb * 8);
     op_poll_stats(op);
   }
@@ -579,48 +604,75 @@ struct HipSvdBackend : SvdBackend {
   void QtQ(int p, int p0, int cb, double *M) override {
     gram_to_host(Q.p, Q.p + (int64_t)p0 * nr, nr, p, cb, M);
   }
-  // The whole orth() of svd_driver.hpp queued on the stream with the small matrices kept on
-  // the device: one host synchronisation per block step instead of eleven.
-  int orth_fused(int p, int cb, std::vector<double> &Cacc, std::vector<double> &Rout) override {
-    if (cb <= 0 || cb > kMaxB) return -1;
+
+  // ---- the fused block step (orth_small.hpp) -----------------------------------------------------
+  // arena (doubles): [mx 16] [flag 1 | Rout B2 | ZtZ p cb | QtQ p cb | HG1 (p+cb) cb] [HG2 (p+cb) cb] [C p cb]
+  // [Ct p cb] [Ri B2]; [flag .. QtQ] is downloaded in one piece, [ZtZ .. HG1] is one sum over the ranks
+  static constexpr int B2 = kMaxB * kMaxB;
+  void update_W(int p, int cb, const double *C, const double *Ri, unsigned long long *mx) {
+    const dim3 rows((unsigned)((nr + 1023) / 1024));
+    if (cb <= 8)
+      hipLaunchKernelGGL((k_update<8>), rows, dim3(256), 0, st, Q.p, nr, p, C, Ri, cb, Wc, nr, nr, mx);
+    else
+      hipLaunchKernelGGL((k_update<16>), rows, dim3(256), 0, st, Q.p, nr, p, C, Ri, cb, Wc, nr, nr, mx);
+  }
+  // Gram blocks of the newest basis block + orthonormalisation of W against Q[:, :p] and itself, queued
+  // without returning to the host; ONE synchronisation.  with_grams = false: orthonormalisation only
+  // (start block, p == 0).  Returns cb, -1 (not supported: the caller takes the step-by-step path
+  // for everything) or -2 (Gram blocks delivered, W restored: the panel needs the careful path).
+  int fused(int p, int p0, int cb, bool with_grams, double *blkZ, double *blkQ, std::vector<double> &Rout) {
+    if (cb <= 0 || cb > kMaxB || p + cb > kOrthMaxP || p + cb > cap + kMaxB) return -1;
+    if (p > 0 && Wc != Q.p + (int64_t)p * nr) return -1;
+    if (p > 0 && !with_grams) return -1;   // the device copy of Q'Q is only kept by the full step
+    const double *A0 = p > 0 ? Q.p : Wc;    // [Q W] (p + cb contiguous columns); the panel alone for p == 0
     Tick tk(this, 4);
-    wait_rs();
     hipEvent_t tev0 = nullptr, tev1 = nullptr;
     if (timing) {
       BSN_HIP(hipEventCreate(&tev0));
       BSN_HIP(hipEventCreate(&tev1));
       BSN_HIP(hipEventRecord(tev0, st));
     }
-    constexpr int B2 = kMaxB * kMaxB;
-    // arena: [flag | Rout | C1 | C2] is downloaded in one piece; then G0, G, Ri, C3
-    double *flag = dorth.p, *dRout = flag + 1, *C1 = dRout + B2, *C2 = C1 + (size_t)p * cb,
-           *G0 = C2 + (size_t)p * cb, *G = G0 + B2, *Ri = G + B2, *C3 = Ri + B2;
-    const size_t nsmall = 1 + B2 + (size_t)2 * p * cb;
-    BSN_HIP(hipMemsetAsync(flag, 0, nsmall * 8, st));
-    BSN_HIP(hipMemcpyAsync(Wsave.p, W.p, (size_t)nr * cb * 8, hipMemcpyDeviceToDevice, st));
-    const dim3 rows((unsigned)((nr + 255) / 256));
-    auto project = [&](double *C) {
-      gemm_tn_dev(Q.p, p, cb, C);
-      hipLaunchKernelGGL(k_gemm_nn, rows, dim3(256), kTP * kMaxB * 8, st, Q.p, nr, p, C, cb, W.p, nr, 1.0, -1.0,
-                         W.p, nr, nr);
-    };
-    gemm_tn_dev(W.p, cb, cb, G0);
-    if (p > 0) {
-      project(C1);
-      project(C2);
-    }
+    unsigned long long *mx = (unsigned long long *)dorth.p;
+    const size_t pc = (size_t)p * cb, hg = (size_t)(p + cb) * cb;
+    double *flag = dorth.p + 16, *dRout = flag + 1, *dZtZ = dRout + B2, *dQtQ = dZtZ + pc, *HG1 = dQtQ + pc,
+           *HG2 = HG1 + hg, *C = HG2 + hg, *Ct = C + pc, *Ri = Ct + pc;
+    BSN_HIP(hipMemsetAsync(flag, 0, (size_t)(1 + B2) * 8, st));
+    if (p > 0) gemm_tn_any(Z.p, Z.p + (int64_t)p0 * m_local, m_local, p, cb, dZtZ);
+    BSN_HIP(hipMemcpyAsync(Wsave.p, Wc, (size_t)nr * cb * 8, hipMemcpyDeviceToDevice, st));
+    if (p > 0) gemm_tn_any(Q.p, Q.p + (int64_t)p0 * nr, nr, p, cb, dQtQ);
+    OrthSmall a;
+    a.p = p;
+    a.cb = cb;
+    a.p0 = p0;
+    a.QtQ = p > 0 ? dQtQ : nullptr;
+    a.M = ws.dM.p;
+    a.ldm = kOrthMaxP;
+    a.C = C;
+    a.Ct = Ct;
+    a.Ri = Ri;
+    a.Rout = dRout;
+    a.flag = flag;
+    a.iters = 3;
+    a.Cs = a.Gs = a.Rs = a.Ris = a.Ro = a.Dv = a.tmp = nullptr;
     for (int pass = 0; pass < 2; pass++) {
-      gemm_tn_dev(W.p, cb, cb, G);
-      hipLaunchKernelGGL(k_orth_small, dim3(1), dim3(64), 0, st, G0, G, cb, pass, Ri, dRout, flag);
-      hipLaunchKernelGGL(k_right_mult, rows, dim3(256), 0, st, W.p, nr, nr, cb, cb, Ri);
-      if (pass == 0 && p > 0) project(C3);
+      double *HG = pass == 0 ? HG1 : HG2;
+      gemm_tn_any(A0, Wc, nr, p + cb, cb, HG, p + cb);   // [Q W]' W: W is columns p .. p+cb-1 of Q
+      if (pass == 0) ar_small(dZtZ, (int64_t)(2 * pc + hg));
+      else ar_small(HG, (int64_t)hg);
+      a.pass = pass;
+      a.HG = HG;
+      // the column maxima of the finished panel feed the rounding; with sample blocks they would have to be
+      // combined over the ranks, so the distributed solve takes them from the gathered block instead
+      unsigned long long *mxp = (pass == 1 && !dist) ? mx : nullptr;
+      hipLaunchKernelGGL(k_orth2, dim3(1), dim3(512), 0, st, a, mxp);
+      update_W(p, cb, C, Ri, mxp);
     }
     BSN_HIP(hipGetLastError());
-    horth.resize(nsmall);
-    double *hp = ws.pinned((size_t)(cap + 4) * kMaxB * 4 + 1024);
+    const size_t nsmall = 1 + B2 + 2 * pc;
+    double *hp = ws.pinned((size_t)(cap + kMaxB + 4) * kMaxB * 4 + 1024);
     BSN_HIP(hipMemcpyAsync(hp, flag, nsmall * 8, hipMemcpyDeviceToHost, st));
     if (timing) BSN_HIP(hipEventRecord(tev1, st));
-    BSN_HIP(hipStreamSynchronize(st));
+    sync_stream();
     if (timing) {
       float ms = 0;
       BSN_HIP(hipEventElapsedTime(&ms, tev0, tev1));
@@ -628,43 +680,55 @@ struct HipSvdBackend : SvdBackend {
       (void)hipEventDestroy(tev0);
       (void)hipEventDestroy(tev1);
     }
-    std::memcpy(horth.data(), hp, nsmall * 8);
     op_poll_stats(op);
-    if (horth[0] != 0.0) {  // rank deficient: undo and let the driver take the careful path
-      BSN_HIP(hipMemcpyAsync(W.p, Wsave.p, (size_t)nr * cb * 8, hipMemcpyDeviceToDevice, st));
-      return -1;
+    if (blkZ) std::memcpy(blkZ, hp + 1 + B2, pc * 8);
+    if (blkQ) std::memcpy(blkQ, hp + 1 + B2 + pc, pc * 8);
+    if (hp[0] != 0.0) {  // rank deficient or ill conditioned: undo, the driver takes the careful path
+      BSN_HIP(hipMemcpyAsync(Wc, Wsave.p, (size_t)nr * cb * 8, hipMemcpyDeviceToDevice, st));
+      mx_valid = false;
+      return -2;
     }
     Rout.assign((size_t)cb * cb, 0.0);
-    for (int t = 0; t < cb * cb; t++) Rout[(size_t)t] = horth[1 + (size_t)t];
-    Cacc.assign((size_t)p * cb, 0.0);
-    const double *h1 = horth.data() + 1 + B2, *h2 = h1 + (size_t)p * cb;
-    for (size_t t = 0; t < (size_t)p * cb; t++) Cacc[t] = h1[t] + h2[t];
+    for (int t = 0; t < cb * cb; t++) Rout[(size_t)t] = hp[1 + (size_t)t];
+    mx_valid = !dist;
     return cb;
   }
+  int step_fused(int p, int p0, int cb, double *blkZ, double *blkQ, std::vector<double> &Rout) override {
+    return fused(p, p0, cb, true, blkZ, blkQ, Rout);
+  }
+  int orth_fused(int p, int cb, std::vector<double> &Cacc, std::vector<double> &Rout) override {
+    if (p != 0) return -1;
+    Cacc.clear();
+    const int r = fused(0, 0, cb, false, nullptr, nullptr, Rout);
+    return r < 0 ? -1 : r;
+  }
   void QtW(int p, int cb, double *C) override { gemm_tn(Q.p, p, cb, C); }
-  void WtW(int cb, double *G) override { gemm_tn(W.p, cb, cb, G); }
+  void WtW(int cb, double *G) override { gemm_tn(Wc, cb, cb, G); }
   void W_minus_QC(int p, int cb, const double *C) override {
-    wait_rs();
+    mx_valid = false;
     copy_h2d(op->bed, dsmall.p, C, (size_t)p * cb * 8);
     hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((nr + 255) / 256)), dim3(256), kTP * kMaxB * 8, st,
-                       Q.p, nr, p, dsmall.p, cb, W.p, nr, 1.0, -1.0, W.p, nr, nr);
+                       Q.p, nr, p, dsmall.p, cb, Wc, nr, 1.0, -1.0, Wc, nr, nr);
     BSN_HIP(hipGetLastError());
-    BSN_HIP(hipStreamSynchronize(st));  // C is a host vector that may be reused
+    sync_stream();  // C is a host vector that may be reused
   }
   void W_times(int cb, int r, const double *M) override {
-    wait_rs();
+    mx_valid = false;
     copy_h2d(op->bed, dsmall.p, M, (size_t)cb * r * 8);
-    hipLaunchKernelGGL(k_right_mult, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, W.p, nr, nr,
+    hipLaunchKernelGGL(k_right_mult, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, Wc, nr, nr,
                        cb, r, dsmall.p);
     BSN_HIP(hipGetLastError());
-    BSN_HIP(hipStreamSynchronize(st));
+    sync_stream();
   }
   void W_to_Q(int p0, int r) override {
-    BSN_HIP(hipMemcpyAsync(Q.p + (int64_t)p0 * nr, W.p, (size_t)nr * r * 8, hipMemcpyDeviceToDevice, st));
+    double *dst = Q.p + (int64_t)p0 * nr;
+    if (dst != Wc)
+      BSN_HIP(hipMemcpyAsync(dst, Wc, (size_t)nr * r * 8, hipMemcpyDeviceToDevice, st));
+    wcol = p0 + r;
+    Wc = Q.p + (int64_t)wcol * nr;   // the next panel goes behind the block just stored
   }
   void finalize(int pp, int k, const double *S, const double *dinv, double *u, double *v) override {
     Tick tk(this, 6);
-    wait_rs();
     std::vector<double> Sv((size_t)pp * k);
     for (int t = 0; t < k; t++)
       for (int i = 0; i < pp; i++) Sv[(size_t)i + (size_t)t * pp] = S[(size_t)i + (size_t)t * pp] * dinv[t];
@@ -697,7 +761,7 @@ struct HipSvdBackend : SvdBackend {
     }
     if (u) copy_d2h(op->bed, u, ufull, (size_t)n * k * 8);
     if (v) copy_d2h(op->bed, v, dV.p, (size_t)m_local * k * 8);
-    BSN_HIP(hipStreamSynchronize(st));
+    sync_stream();
   }
 };
 
@@ -845,19 +909,20 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       // were measured to leave the runtime with ~4 ms wake-up latencies on every later stream
       // synchronisation of the process (tools/gpu/r02_h.sh).
       SvdWorkspace &ws = *bed->svd_ws;
-      const int64_t chunk = 1 << 20;  // elements per staged piece (8 MB of doubles)
-      double *hp = ws.pinned((size_t)chunk);
+      const int64_t chunk = 1 << 21;  // int32 per staged piece (8 MB)
+      int32_t *hp = (int32_t *)ws.pinned((size_t)chunk / 2);
       if ((int64_t)bed->na_cnt.size() != bed->m) bed->na_cnt.assign((size_t)bed->m, -1);
-      for (int64_t j0 = 0; j0 < m; j0 += chunk / 2) {   // 4 int32 per variant
-        const int64_t cnt = std::min<int64_t>(chunk / 2, m - j0);
-        BSN_HIP(hipMemcpyAsync(hp, op->d_counts.p + 4 * j0, (size_t)cnt * 16, hipMemcpyDeviceToHost, bed->stream));
+      for (int64_t j0 = 0; j0 < m; j0 += chunk) {
+        const int64_t cnt = std::min<int64_t>(chunk, m - j0);
+        BSN_HIP(hipMemcpyAsync(hp, op->d_na.p + j0, (size_t)cnt * 4, hipMemcpyDeviceToHost, bed->stream));
         BSN_HIP(hipStreamSynchronize(bed->stream));
-        const int32_t *c = (const int32_t *)hp;
-        for (int64_t j = 0; j < cnt; j++, c += 4) {
-          bed->na_cnt[(size_t)(ind_col ? ind_col[j0 + j] : j0 + j)] = c[3];
-          if (2 * (int64_t)(c[0] + c[1] + c[2]) < n) n_bad++;
+        if (ind_col) {
+          for (int64_t j = 0; j < cnt; j++) bed->na_cnt[(size_t)ind_col[j0 + j]] = hp[j];
+        } else {
+          std::memcpy(&bed->na_cnt[(size_t)j0], hp, (size_t)cnt * 4);
         }
       }
+      if (op->h_na_total && op->h_na_total[1] >= 0) n_bad += (int32_t)op->h_na_total[1];
       if (o->center_out) copy_d2h(bed, o->center_out, op->d_center.p, (size_t)m * 8);
       if (o->scale_out) copy_d2h(bed, o->scale_out, op->d_scale.p, (size_t)m * 8);
     }

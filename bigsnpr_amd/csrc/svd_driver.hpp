@@ -58,6 +58,15 @@ struct SvdBackend {
     (void)p; (void)cb; (void)Cacc; (void)Rout;
     return -1;
   }
+  // Optional fused form of a whole block step after the two products: the Gram blocks of the newest
+  // basis block (what ZtZ / QtQ deliver: blkZ, blkQ, p x cb each) AND the orthonormalisation of W,
+  // without returning to the host in between.  Returns the rank (== cb) on success; -1 if unsupported
+  // (nothing was done); -2 if the Gram blocks were delivered but W — left as on entry — needs the
+  // step-by-step orthonormalisation.
+  virtual int step_fused(int p, int p0, int cb, double *blkZ, double *blkQ, std::vector<double> &Rout) {
+    (void)p; (void)p0; (void)cb; (void)blkZ; (void)blkQ; (void)Rout;
+    return -1;
+  }
   // Warm start: restrict the two products to a leading subset of the variants (on) or restore all of
   // them (off).  Returns false if the backend has no cheap subset (then the start block stays random).
   virtual bool subset(bool on) {
@@ -122,13 +131,13 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
   std::vector<double> Gz((size_t)cap * cap, 0.0), Mq((size_t)cap * cap, 0.0);
   auto Gat = [&](int i, int j) -> double & { return Gz[(size_t)i + (size_t)j * cap]; };
   auto Mat = [&](int i, int j) -> double & { return Mq[(size_t)i + (size_t)j * cap]; };
-  std::vector<double> C, C2, G, R, Ri, R2, Rt, evec, eval, M, blk;
+  std::vector<double> C, C2, G, R, Ri, R2, Rt, evec, eval, M, blk, blk2;
   SvdResult res;
 
   // orthonormalise W (cb columns) against Q[:, :p] and itself; returns rank r and the
   // cb x cb upper factor Rt with W_in = Q C + W_out Rt  (first r rows of Rt meaningful)
-  auto orth = [&](int p, int cb, std::vector<double> &Cacc, std::vector<double> &Rout) -> int {
-    {
+  auto orth = [&](int p, int cb, std::vector<double> &Cacc, std::vector<double> &Rout, bool try_fused = true) -> int {
+    if (try_fused) {
       const int rf = bk.orth_fused(p, cb, Cacc, Rout);
       if (rf >= 0) return rf;
     }
@@ -220,13 +229,19 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
     res.nops += 2;
     res.niter++;
     // Gram blocks of the new columns p0 .. p-1 (Z of this step is complete now, Q was stored rounded)
+    // and the orthonormalisation of W: in one go when the backend can, else piece by piece
     blk.assign((size_t)p * cb, 0.0);
-    bk.ZtZ(p, p0, cb, blk.data());
+    blk2.assign((size_t)p * cb, 0.0);
+    int rn = bk.step_fused(p, p0, cb, blk.data(), blk2.data(), Rt);
+    const bool fused_failed = rn == -2;
+    if (rn == -1) {
+      bk.ZtZ(p, p0, cb, blk.data());
+      bk.QtQ(p, p0, cb, blk2.data());
+    }
     for (int j = 0; j < cb; j++)
       for (int i = 0; i < p; i++) Gat(i, p0 + j) = Gat(p0 + j, i) = blk[(size_t)i + (size_t)j * p];
-    bk.QtQ(p, p0, cb, blk.data());
     for (int j = 0; j < cb; j++)
-      for (int i = 0; i < p; i++) Mat(i, p0 + j) = Mat(p0 + j, i) = blk[(size_t)i + (size_t)j * p];
+      for (int i = 0; i < p; i++) Mat(i, p0 + j) = Mat(p0 + j, i) = blk2[(size_t)i + (size_t)j * p];
     for (int j = 0; j < cb; j++)  // symmetrise the diagonal blocks
       for (int i = 0; i < j; i++) {
         double a = 0.5 * (Gat(p0 + i, p0 + j) + Gat(p0 + j, p0 + i));
@@ -234,7 +249,8 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
         a = 0.5 * (Mat(p0 + i, p0 + j) + Mat(p0 + j, p0 + i));
         Mat(p0 + i, p0 + j) = Mat(p0 + j, p0 + i) = a;
       }
-    int rn = orth(p, cb, C2, Rt);  // Rt: cb x cb (rn rows used): W_in = Q C2 + W_out Rt
+    // Rt: cb x cb (rn rows used): W_in = Q C2 + W_out Rt
+    if (rn < 0) rn = orth(p, cb, C2, Rt, /*try_fused=*/!fused_failed);
     pp = p;
     const bool exhausted = (rn == 0) || (p >= dim);  // Krylov space is invariant: Ritz pairs exact
     // the coupling block of the FULL next block measures the residuals, whether or not the basis has
@@ -248,8 +264,9 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
     if (rn < 0) rn = 0;
 
     // Rayleigh-Ritz on span(Q[:, :pp]): (Gz) s = theta (Mq) s with Mq = R'R,
-    // i.e. the standard problem for R^-T Gz R^-1, s = R^-1 y
-    {
+    // i.e. the standard problem for R^-T Gz R^-1, s = R^-1 y.  Not needed while the basis is smaller
+    // than k and the iteration goes on (the device idles while the host works here).
+    if (pp >= k || rn == 0 || exhausted) {
       std::vector<double> Mp((size_t)pp * pp), Gp((size_t)pp * pp), Rm, Rmi, tmp((size_t)pp * pp);
       for (int j = 0; j < pp; j++)
         for (int i = 0; i < pp; i++) {

@@ -8,7 +8,7 @@ SO = os.path.join(HERE, "libnative_test.so")
 
 def build():
     src = os.path.join(HERE, "native_test.cpp")
-    deps = [src] + [os.path.join(ROOT, "bigsnpr_amd", "csrc", f) for f in ("svd_driver.hpp", "dense_small.hpp")]
+    deps = [src] + [os.path.join(ROOT, "bigsnpr_amd", "csrc", f) for f in ("svd_driver.hpp", "dense_small.hpp", "orth_small.hpp")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall",
                                "-I", os.path.join(ROOT, "bigsnpr_amd", "csrc"), src, "-o", SO])

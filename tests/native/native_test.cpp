@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 
+#include "orth_small.hpp"
 #include "svd_driver.hpp"
 
 using namespace bsn;
@@ -122,6 +123,84 @@ struct HostBackend : SvdBackend {
   void W_to_Q(int p0, int r) override {
     std::memcpy(&Q[(size_t)p0 * n], W.data(), sizeof(double) * (size_t)n * r);
   }
+  // ---- the fused block step of the product's HIP backend, with host loops for the tall products and the
+  // SAME small-matrix code (orth_small.hpp) the device runs in one workgroup ----
+  int fused_mode = 0;   // 0 = step-by-step path only; 1 = two-pass fused path (nt_set_fused)
+  int n_fused = 0, n_careful = 0;
+  std::vector<double> Mdev;   // the "device" copy of Q'Q, leading dimension kOrthMaxP
+  struct HostCtx {
+    int tid = 0, nt = 1;
+    void sync() {}
+  };
+  // HG ((p + cb) x cb) = [Q[:, :p] W]' W, summed over the ranks' rows (here: all rows are local)
+  void hg(int p, int cb, std::vector<double> &HG) {
+    HG.assign((size_t)(p + cb) * cb, 0.0);
+    for (int c = 0; c < cb; c++)
+      for (int a = 0; a < p + cb; a++) {
+        const double *col = a < p ? &Q[(size_t)a * n] : &W[(size_t)(a - p) * n];
+        double s = 0;
+        for (int64_t i = 0; i < n; i++) s += col[i] * W[i + (size_t)c * n];
+        HG[a + (size_t)c * (p + cb)] = s;
+      }
+  }
+  void update(int p, int cb, const double *C, const double *Ri) {
+    std::vector<double> row(cb), out(cb);
+    for (int64_t i = 0; i < n; i++) {
+      for (int j = 0; j < cb; j++) {
+        double acc = 0;
+        for (int a = 0; a < p; a++) acc += Q[i + (size_t)a * n] * C[a + (size_t)j * p];
+        row[j] = W[i + (size_t)j * n] - acc;
+      }
+      for (int c = 0; c < cb; c++) {
+        double s = 0;
+        for (int j = 0; j < cb; j++) s += row[j] * Ri[j + c * cb];
+        out[c] = s;
+      }
+      for (int c = 0; c < cb; c++) W[i + (size_t)c * n] = out[c];
+    }
+  }
+  int fused(int p, int p0, int cb, double *blkZ, double *blkQ, std::vector<double> &Rout) {
+    if (!fused_mode || cb <= 0 || cb > kOrthMaxB || p + cb > kOrthMaxP) return -1;
+    if (p > 0) {
+      ZtZ(p, p0, cb, blkZ);
+      QtQ(p, p0, cb, blkQ);
+    }
+    if (Mdev.empty()) Mdev.assign((size_t)kOrthMaxP * kOrthMaxP, 0.0);
+    std::vector<double> Wsave(W.begin(), W.begin() + (size_t)n * cb), HG, C((size_t)p * cb + 1), Ct((size_t)p * cb + 1),
+        Ri((size_t)cb * cb), Ro((size_t)cb * cb, 0.0), Cs((size_t)p * cb + 1), Gs((size_t)cb * cb), Rs((size_t)cb * cb),
+        Ris((size_t)cb * cb), Rob((size_t)cb * cb), Dv((size_t)cb * cb), tmp((size_t)2 * cb + 4);
+    double flag = 0.0;
+    OrthSmall a;
+    a.p = p; a.cb = cb; a.p0 = p0; a.QtQ = p > 0 ? blkQ : nullptr; a.M = Mdev.data(); a.ldm = kOrthMaxP;
+    a.C = C.data(); a.Ct = Ct.data(); a.Ri = Ri.data(); a.Rout = Ro.data(); a.flag = &flag; a.iters = 3;
+    a.Cs = Cs.data(); a.Gs = Gs.data(); a.Rs = Rs.data(); a.Ris = Ris.data(); a.Ro = Rob.data(); a.Dv = Dv.data(); a.tmp = tmp.data();
+    HostCtx cx;
+    for (int pass = 0; pass < 2; pass++) {
+      hg(p, cb, HG);
+      // (the column-sharded host test holds all n rows of Q and W on every rank: nothing to sum here)
+      a.pass = pass;
+      a.HG = HG.data();
+      orth_small(cx, a);
+      update(p, cb, C.data(), Ri.data());
+    }
+    if (flag != 0.0) {
+      std::copy(Wsave.begin(), Wsave.end(), W.begin());
+      n_careful++;
+      return -2;
+    }
+    Rout = Ro;
+    n_fused++;
+    return cb;
+  }
+  int step_fused(int p, int p0, int cb, double *blkZ, double *blkQ, std::vector<double> &Rout) override {
+    return fused(p, p0, cb, blkZ, blkQ, Rout);
+  }
+  int orth_fused(int p, int cb, std::vector<double> &Cacc, std::vector<double> &Rout) override {
+    if (p != 0) return -1;
+    Cacc.clear();
+    const int r = fused(0, 0, cb, nullptr, nullptr, Rout);
+    return r < 0 ? -1 : r;
+  }
   void finalize(int pp, int k, const double *S, const double *dinv, double *u, double *v) override {
     for (int t = 0; t < k; t++) {
       for (int64_t i = 0; i < n; i++) {
@@ -138,12 +217,17 @@ struct HostBackend : SvdBackend {
   }
 };
 
-static int g_slices = 0;
+static int g_slices = 0, g_fused = 0;
+static int g_counts[2] = {0, 0};
 
 extern "C" {
 
 // emulate the product's fixed-point products in the host backend (0 = exact)
 void nt_set_slices(int slices) { g_slices = slices; }
+// 1: the host backend takes the product's fused two-pass block step (orth_small.hpp)
+void nt_set_fused(int on) { g_fused = on; }
+// fused steps taken / steps handed to the careful path by the last solve
+void nt_fused_counts(int *out) { out[0] = g_counts[0]; out[1] = g_counts[1]; }
 
 void nt_eig_sym(int n, double *A, double *d) {
   std::vector<double> V(A, A + (size_t)n * n), w;
@@ -175,6 +259,7 @@ void nt_svd_host(const double *A, int64_t n, int64_t m_local, int64_t m_total, i
   bk.ar = ar;
   bk.ctx = ctx;
   bk.slices = g_slices;
+  bk.fused_mode = g_fused;
   SvdOptions o;
   o.k = k;
   o.tol = tol;
@@ -183,6 +268,8 @@ void nt_svd_host(const double *A, int64_t n, int64_t m_local, int64_t m_total, i
   o.seed = seed;
   o.resid_floor = g_slices > 0 ? 1.2 * std::ldexp(1.0, -8 * g_slices) : 0.0;
   SvdResult r = block_lanczos_svd(bk, o, d, u, v);
+  g_counts[0] = bk.n_fused;
+  g_counts[1] = bk.n_careful;
   info[0] = r.niter;
   info[1] = r.nops;
   info[2] = r.basis;

@@ -21,6 +21,16 @@ def nt():
     return lib
 
 
+@pytest.fixture(params=[0, 1], ids=["stepwise", "fused"], autouse=True)
+def fused(request, nt):
+    """every driver test runs twice: with the step-by-step orthonormalisation of svd_driver.hpp and with the
+    fused two-pass block step the HIP backend takes (same small-matrix code, orth_small.hpp, host loops for
+    the tall products)"""
+    nt.nt_set_fused(request.param)
+    yield request.param
+    nt.nt_set_fused(0)
+
+
 def host_svd(nt, A, k, tol=1e-10, block=8, m_total=None, ar=None, max_basis=0, seed=1):
     A = np.asfortranarray(A, dtype=np.float64)
     n, m = A.shape
@@ -104,6 +114,7 @@ import build_native
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=int(sys.argv[3]), world_size=2)
 rank = dist.get_rank()
 nt = C.CDLL(build_native.build())
+nt.nt_set_fused(int(sys.argv[4]))
 rng = np.random.default_rng(42)
 n, m, k = 180, 260, 10
 A = rng.normal(size=(n, 40)) @ np.diag(np.linspace(1, 20, 40)) @ rng.normal(size=(40, m)) + 0.01 * rng.normal(size=(n, m))
@@ -140,7 +151,7 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-def test_sharded_two_ranks_gloo(tmp_path, nt):
+def test_sharded_two_ranks_gloo(tmp_path, nt, fused):
     """N>1 path: columns sharded over 2 ranks, W all-reduced (gloo on CPU); both ranks must
     converge to the global SVD and hold identical u.  (`nt` builds the test library once in this
     process so that the two workers only load it.)"""
@@ -148,7 +159,7 @@ def test_sharded_two_ranks_gloo(tmp_path, nt):
     script.write_text(_WORKER)
     port = _free_port()
     env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "tests", "native"))
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], env=env,
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r), str(fused)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
@@ -197,3 +208,32 @@ def test_full_basis_is_not_mistaken_for_convergence(nt):
     # with room for the whole space the same call converges
     res = host_svd(nt, A, 10, tol=1e-12, block=4, max_basis=0)
     assert res["converged"]
+
+
+def test_fused_step_is_taken_and_hands_deficient_panels_to_the_careful_path(nt, fused):
+    """the fused two-pass step (orth_small.hpp) must carry a normal solve on its own — also with a basis that is
+    only orthonormal up to the rounding of its blocks (slices = 2: Q'Q = I + 1e-5) — and must give a panel that
+    lost its rank back to the step-by-step path instead of normalising noise"""
+    if not fused:
+        pytest.skip("fused mode only")
+    cnt = (C.c_int * 2)()
+    rng = np.random.default_rng(3)
+    A = rng.normal(size=(500, 60)) @ np.diag(np.linspace(1, 40, 60) ** 1.3) @ rng.normal(size=(60, 400)) / 8 \
+        + 0.3 * rng.normal(size=(500, 400))
+    d_true = np.linalg.svd(A, compute_uv=False)[:10]
+    try:
+        for S, tol in ((0, 1e-8), (2, 1e-4), (3, 1e-6)):
+            nt.nt_set_slices(S)
+            res = host_svd(nt, A, 10, tol=tol, block=8)
+            nt.nt_fused_counts(cnt)
+            assert res["converged"] and cnt[0] >= res["niter"] and cnt[1] == 0, (S, tol, cnt[0], cnt[1], res["niter"])
+            np.testing.assert_allclose(res["d"], d_true, rtol=max(1e-10, 10 * tol * tol))
+            np.testing.assert_allclose(res["u"].T @ res["u"], np.eye(10), atol=1e-9)
+    finally:
+        nt.nt_set_slices(0)
+    # exact rank 6 < block: the second panel is rank deficient -> careful path, same answer as before
+    A = rng.normal(size=(80, 6)) @ rng.normal(size=(6, 50))
+    res = host_svd(nt, A, 10, tol=1e-10)
+    nt.nt_fused_counts(cnt)
+    assert cnt[1] >= 1
+    np.testing.assert_allclose(res["d"][:6], np.linalg.svd(A, compute_uv=False)[:6], rtol=1e-8)
