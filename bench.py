@@ -53,9 +53,15 @@ def parse():
     ap.add_argument("--tol", type=float, default=1e-4)
     ap.add_argument("--slices", type=int, default=0)
     ap.add_argument("--window", type=int, default=2000, help="ld: variants per 3 cM window")
+    ap.add_argument("--no-uv", action="store_true",
+                    help="leave u and v on the device (diagnostic: the timed solve then ends before the 224-MB download "
+                         "of the result; the default times the whole function, result on the host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ingest", action="store_true")
     ap.add_argument("--ingest-gb", type=float, default=8.0, help="size of the .bed file written and re-opened")
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="N > 1 without a working RCCL communicator: take the host all-reduce hook over gloo (labelled in "
+                         "config.parallelism) instead of exiting with status 3")
     ap.add_argument("--force-dist", action="store_true",
                     help="go through the RCCL communicator even with one rank (self-test)")
     ap.add_argument("--cpu-sample-cols", type=int, default=0)
@@ -188,6 +194,13 @@ def main():
                 if comm is not None:
                     comm.close()
                 comm = None
+                if not a.allow_fallback:
+                    # a scaling number measured over gloo and the host would not be an RCCL / xGMI number
+                    log("in-library RCCL communicator unavailable (%s); not falling back (--allow-fallback to take "
+                        "the host all-reduce hook over gloo instead)" % err)
+                    dist.barrier()
+                    dist.destroy_process_group()
+                    sys.exit(3)
                 log("in-library RCCL communicator unavailable (%s): falling back to the host all-reduce hook (gloo)" % err)
                 import ctypes as _C
                 import numpy as _np
@@ -222,15 +235,23 @@ def main():
     def step():
         return ba.bed_randomSVD(gb, k=a.k, tol=a.tol, block=a.block, slices=a.slices, comm=comm,
                                 allreduce=hook, rank=rank, world=world,
-                                m_total=m_total, return_uv=False, verbose=a.verbose, warm_start=a.warm_start,
+                                m_total=m_total, return_uv=not a.no_uv, verbose=a.verbose, warm_start=a.warm_start,
                                 warm_denominator=a.warm_den)
 
+    wres = None
     for _ in range(a.warmup):
-        step()
+        wres = step()
+    del wres
     sync()
     log("warmup done")
     t0 = time.perf_counter()
-    infos = [step() for _ in range(a.steps)]
+    infos, last_uv = [], None
+    for _ in range(a.steps):
+        r = step()
+        # like `svd <- bed_randomSVD(...)` in a loop: the previous result is dropped when the new one is bound
+        # (its page-locked blocks go back to the library's result pool)
+        last_uv = (r.pop("u"), r.pop("v"))
+        infos.append(r)
     sync()
     wall = time.perf_counter() - t0
     log("timed solves done (%.1f ms per solve)" % (1e3 * wall / a.steps))
@@ -272,6 +293,10 @@ def main():
         "metric": "SNP-cols/sec for bed_randomSVD k=%d (m*passes/wall)" % a.k,
         "value": value, "unit": "SNP-cols/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        # what a caller pays for one bed_randomSVD: d, u, v, center, scale on the host (u / v are part of the
+        # timed region unless --no-uv)
+        "time_to_solution_ms": wall / a.steps * 1e3,
+        "result_on_host": ["d", "center", "scale"] + ([] if a.no_uv else ["u", "v"]),
         "vs_baseline": None,
         "dtype": "i8 (2-bit codes x %d-bit fixed-point image of the fp64 basis, %d int8 slices, exact int32 "
                  "MFMA accumulation; fp64 panel algebra and Rayleigh-Ritz)" % (8 * sl, sl),

@@ -28,7 +28,7 @@ class SvdOptions(C.Structure):
                 ("allreduce_ctx", C.c_void_p), ("hook_rank", C.c_int32), ("hook_world", C.c_int32),
                 ("comm", C.c_void_p), ("binom_scaling", C.c_int32),
                 ("center_out", C.POINTER(C.c_double)), ("scale_out", C.POINTER(C.c_double)),
-                ("warm_start", C.c_int32), ("warm_denominator", C.c_int32)]
+                ("warm_start", C.c_int32), ("warm_denominator", C.c_int32), ("max_restarts", C.c_int32)]
 
 
 class SvdInfo(C.Structure):
@@ -107,6 +107,8 @@ SIGNATURES = {
                                    C.c_int, f64p]),
     "bsn_malloc": (C.c_int, [C.POINTER(vp), i64]),
     "bsn_free": (C.c_int, [vp]),
+    "bsn_host_alloc": (C.c_int, [C.POINTER(vp), i64]),
+    "bsn_host_free": (C.c_int, [vp]),
     "bsn_memcpy_h2d": (C.c_int, [vp, vp, i64]),
     "bsn_memcpy_d2h": (C.c_int, [vp, vp, i64]),
     "bsn_device_sync": (C.c_int, []),
@@ -193,3 +195,57 @@ class DeviceArray:
             self.free()
         except Exception:
             pass
+
+
+class _PinnedBlock:
+    """a block of page-locked host memory (bsn_host_alloc); goes back to the pool when the last array
+    over it is collected"""
+
+    def __init__(self, pool, addr, size):
+        self.pool, self.addr, self.size = pool, addr, size
+        self.__array_interface__ = {"data": (addr, False), "shape": (size,), "typestr": "|u1", "version": 3}
+
+    def __del__(self):
+        try:
+            self.pool._give_back(self.addr, self.size)
+        except Exception:
+            pass
+
+
+class PinnedPool:
+    """Result buffers for the large outputs (u, v of bed_randomSVD): page-locked blocks that the DMA
+    engines write directly.  A block is reused once every numpy array over it has been collected, so
+    results stay valid for as long as the caller holds them; at most `keep` bytes of free blocks are kept."""
+
+    def __init__(self, keep=1 << 30):
+        self.free, self.keep = [], keep
+
+    def empty(self, shape, dtype=np.float64):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        size = max(4096, (n + 4095) // 4096 * 4096)
+        pick = None
+        for i, (addr, sz) in enumerate(self.free):
+            if sz >= size and (pick is None or sz < self.free[pick][1]):
+                pick = i
+        if pick is not None and self.free[pick][1] <= 2 * size:
+            addr, sz = self.free.pop(pick)
+        else:
+            p = vp()
+            check(load().bsn_host_alloc(C.byref(p), size))
+            addr, sz = p.value, size
+        blk = _PinnedBlock(self, addr, sz)
+        return np.asarray(blk)[:n].view(dtype).reshape(shape)
+
+    def _give_back(self, addr, size):
+        if sum(sz for _, sz in self.free) + size <= self.keep:
+            self.free.append((addr, size))
+        else:
+            load().bsn_host_free(vp(addr))
+
+    def drain(self):
+        for addr, _ in self.free:
+            load().bsn_host_free(vp(addr))
+        self.free = []
+
+
+result_pool = PinnedPool()

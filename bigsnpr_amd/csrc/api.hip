@@ -203,8 +203,24 @@ void copy_h2d(bsn_bed *b, void *d_dst, const void *src, size_t bytes) {
   }
 }
 
+// true when the runtime knows `p` as page-locked host memory (bsn_host_alloc, or registered by the
+// caller): the DMA engines can reach it directly, no staging
+static bool host_is_pinned(const void *p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();   // an ordinary pointer is reported as an error: not one
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+
 // Device -> host; complete when it returns.
 void copy_d2h(bsn_bed *b, void *dst, const void *d_src, size_t bytes) {
+  if (bytes >= (1u << 20) && host_is_pinned(dst)) {   // page-locked destination: one DMA, no host copy
+    BSN_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, b->stream));
+    BSN_HIP(hipStreamSynchronize(b->stream));
+    return;
+  }
   stage_init(b);
   const size_t npiece = (bytes + kStagePiece - 1) / kStagePiece;
   for (size_t k = 0; k <= npiece; k++) {
@@ -1005,6 +1021,15 @@ int bsn_malloc(void **d_ptr, int64_t bytes) {
 }
 int bsn_free(void *d_ptr) {
   return guarded([&] { BSN_HIP(hipFree(d_ptr)); });
+}
+int bsn_host_alloc(void **h_ptr, int64_t bytes) {
+  return guarded([&] {
+    require_gpu();
+    BSN_HIP(hipHostMalloc(h_ptr, (size_t)bytes, hipHostMallocDefault));
+  });
+}
+int bsn_host_free(void *h_ptr) {
+  return guarded([&] { BSN_HIP(hipHostFree(h_ptr)); });
 }
 int bsn_memcpy_h2d(void *d_dst, const void *src, int64_t bytes) {
   return guarded([&] { BSN_HIP(hipMemcpy(d_dst, src, (size_t)bytes, hipMemcpyHostToDevice)); });

@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__(256) void k_stats_summary(const int32_t *counts, in
 static bool use_tiled(const bsn_op *op) {
 #ifdef BSN_ABLATION
   // the ablation variants exist on the plain image only (41 - 46: workgroup shapes on the tiled copy)
-  if (tune_variant() != 0 && !(tune_variant() >= 41 && tune_variant() <= 48) && !(tune_variant() >= 91 && tune_variant() <= 98)) return false;
+  if (tune_variant() != 0 && !(tune_variant() >= 41 && tune_variant() <= 48) && !(tune_variant() >= 91 && tune_variant() <= 99)) return false;
 #endif
   return op->bed->d_tiled != nullptr && op->cols_contig && (op->col0 & 63) == 0;
 }
@@ -1467,6 +1467,12 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
 #ifdef BSN_ABLATION
   if constexpr (NB == 2 && CONTIG) {  // BSN_TUNE = 96 .. 98 on the tiled copy: 8-wave workgroups / 2 / 4 samples decoded together
     const int tv = tune_variant();
+    if (tv == 99 && lutP == kLutRaw && has_q && b->d_tiled && (op->col0 & 63) == 0) {  // three register sets
+      hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 1, 3, 0, true>), grid, dim3(256), 0, b->stream,
+                         b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
+      BSN_HIP(hipGetLastError());
+      return;
+    }
     if (tv >= 96 && tv <= 98 && lutP == kLutRaw && has_q && b->d_tiled && (op->col0 & 63) == 0) {
       if (tv == 96)
         hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 8, 0, 1, 2, 0, true>), dim3((grid.x + 1) / 2, grid.y),

@@ -170,6 +170,11 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const double *__restrict__ Q, i
   }
 }
 
+__global__ void k_set_identity(double *M, int ld, int r) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < r * r) M[(t % r) + (int64_t)(t / r) * ld] = (t % r) == (t / r) ? 1.0 : 0.0;
+}
+
 // in place W[:, :r] = W[:, :cb] * M (cb x r), one thread per row
 __global__ void k_right_mult(double *W, int64_t ld, int64_t n, int cb, int r, const double *M) {
   __shared__ double sM[kMaxB * kMaxB];
@@ -727,6 +732,36 @@ struct HipSvdBackend : SvdBackend {
     wcol = p0 + r;
     Wc = Q.p + (int64_t)wcol * nr;   // the next panel goes behind the block just stored
   }
+  // thick restart: Q[:, :keep] = Q[:, :pp] S and Z[:, :keep] = Z[:, :pp] S (local rows of both), the waiting
+  // panel moves behind column `keep`, the device copy of Q'Q becomes the identity on the kept part
+  bool restart(int pp, int keep, const double *S, int rn) override {
+    if (keep + rn > pp || keep <= 0) return false;   // the panel moves to the left of where it is
+    DevBuf<double> &dS = ws.dS, &tQ = ws.dU, &tZ = ws.dV;
+    dS.ensure((size_t)pp * keep + 16);
+    tQ.ensure((size_t)nr * keep);
+    tZ.ensure((size_t)m_local * keep);
+    copy_h2d(op->bed, dS.p, S, (size_t)pp * keep * 8);
+    for (int c0 = 0; c0 < keep; c0 += kMaxB) {
+      const int nc = keep - c0 < kMaxB ? keep - c0 : kMaxB;
+      hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((nr + 255) / 256)), dim3(256), kTP * kMaxB * 8, st, Q.p, nr, pp,
+                         dS.p + (size_t)c0 * pp, nc, (const double *)nullptr, (int64_t)0, 0.0, 1.0,
+                         tQ.p + (int64_t)c0 * nr, nr, nr);
+      hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((m_local + 255) / 256)), dim3(256), kTP * kMaxB * 8, st, Z.p,
+                         m_local, pp, dS.p + (size_t)c0 * pp, nc, (const double *)nullptr, (int64_t)0, 0.0, 1.0,
+                         tZ.p + (int64_t)c0 * m_local, m_local, m_local);
+    }
+    BSN_HIP(hipGetLastError());
+    BSN_HIP(hipMemcpyAsync(Q.p, tQ.p, (size_t)nr * keep * 8, hipMemcpyDeviceToDevice, st));
+    BSN_HIP(hipMemcpyAsync(Z.p, tZ.p, (size_t)m_local * keep * 8, hipMemcpyDeviceToDevice, st));
+    double *dst = Q.p + (int64_t)keep * nr;
+    BSN_HIP(hipMemcpyAsync(dst, Wc, (size_t)nr * rn * 8, hipMemcpyDeviceToDevice, st));
+    Wc = dst;
+    wcol = keep;
+    hipLaunchKernelGGL(k_set_identity, dim3((unsigned)((keep * keep + 255) / 256)), dim3(256), 0, st, ws.dM.p,
+                       kOrthMaxP, keep);
+    BSN_HIP(hipGetLastError());
+    return true;
+  }
   void finalize(int pp, int k, const double *S, const double *dinv, double *u, double *v) override {
     Tick tk(this, 6);
     std::vector<double> Sv((size_t)pp * k);
@@ -873,7 +908,14 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       int s_tol = 2;
       while (s_tol < 7 && 1.2 * std::ldexp(1.0, -8 * s_tol) > so.tol / 4) s_tol++;
       if (o->slices > 0) s_tol = o->slices;
-      int bb = o->block > 0 ? (o->block > kMaxB ? kMaxB : o->block) : std::max(1, std::min(8, 16 / s_tol));
+      // One column block (16 MFMA columns) holds b1 vectors, two hold b2.  A pass with two column blocks costs
+      // 1.3x a pass with one (the two-block kernels are bound by the matrix pipe and the VALU issue port, not by
+      // HBM), but the solve needs fewer block steps: measured at 400K x 1M, tol 1e-4 (profiles/r03_block_vs_k.txt):
+      // k = 20: 4 steps of 16 vectors = 8.1 passes, 204 ms, against 6 steps of 8 = 12.1 passes, 219 ms;
+      // k <= 10: 5 steps of 8 = 193 ms against 4 steps of 16 = 208 ms.  The default is chosen for the time to
+      // the solution, not for pass throughput.
+      const int b1 = std::max(1, std::min(8, 16 / s_tol)), b2 = std::max(b1, std::min(kMaxB, 32 / s_tol));
+      int bb = o->block > 0 ? (o->block > kMaxB ? kMaxB : o->block) : (4 * o->k >= 7 * b1 ? b2 : b1);
       int ss = s_tol;
       if (o->slices <= 0) {
         const int nb = (bb * s_tol + 15) / 16;
@@ -885,6 +927,7 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     so.resid_floor = 1.2 * std::ldexp(1.0, -8 * op->slices);
     so.warm = o->warm_start < 0 ? 0 : (o->warm_start == 0 ? 1 : o->warm_start);
     so.max_basis = o->max_basis;
+    so.max_restarts = o->max_restarts == 0 ? 100 : o->max_restarts;
     so.seed = o->seed ? o->seed : 1;
     so.verbose = o->verbose;
     BSN_HIP(hipEventRecord(bed->ev0, bed->stream));

@@ -67,6 +67,14 @@ struct SvdBackend {
     (void)p; (void)p0; (void)cb; (void)blkZ; (void)blkQ; (void)Rout;
     return -1;
   }
+  // Thick restart (the basis is full, the residuals are not there yet): the basis becomes
+  //   Q[:, :keep] = Q[:, :pp] S,  Z[:, :keep] = Z[:, :pp] S   (S: pp x keep, Ritz vectors to keep; Z stays A' Q),
+  // and the orthonormalised next block W (rn columns, waiting behind column pp) moves behind column `keep`.
+  // Returns false if the backend cannot (the driver then stops, unconverged, as before).
+  virtual bool restart(int pp, int keep, const double *S, int rn) {
+    (void)pp; (void)keep; (void)S; (void)rn;
+    return false;
+  }
   // Warm start: restrict the two products to a leading subset of the variants (on) or restore all of
   // them (off).  Returns false if the backend has no cheap subset (then the start block stays random).
   virtual bool subset(bool on) {
@@ -99,6 +107,10 @@ struct SvdOptions {
   // an estimate of 9.3e-5, but the TRUE residual of that solve is 1.23e-4 > tol — the estimate itself
   // carries first-order rounding effects.  tests/test_gpu_fullsize.py checks the true residuals.)
   double resid_floor = 0.0;
+  // A full basis is compressed to the k + block best Ritz vectors and the iteration continues (what the
+  // implicit restart of RSpectra::svds does for the reference, R/autoSVD.R:216-218); after max_restarts
+  // compressions the solve gives up (RSpectra: maxitr).  < 0: never restart (a full basis ends the solve).
+  int max_restarts = 100;
 };
 
 struct SvdResult {
@@ -107,6 +119,7 @@ struct SvdResult {
   int basis = 0;      // Krylov basis size at exit
   int converged = 0;  // 1 if all k residuals met tol
   int warm = 0;       // warm-start iterations on the variant subset actually run
+  int restarts = 0;   // thick restarts
   double max_rel_resid = 0;
 };
 
@@ -260,13 +273,16 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
       for (int i = 0; i < rn; i++) Rlast[(size_t)i + (size_t)j * rn] = Rt[(size_t)i + (size_t)j * cb];
     rl_rows = rn;
     rl_cols = cb;
+    const int rn_full = rn;
+    // no room for the next block: compress the basis first (below, once the Ritz vectors are known)
+    const bool want_restart = rn > cap - p && !exhausted && pp >= k && res.restarts < opt.max_restarts;
     if (rn > cap - p) rn = cap - p;
     if (rn < 0) rn = 0;
 
     // Rayleigh-Ritz on span(Q[:, :pp]): (Gz) s = theta (Mq) s with Mq = R'R,
     // i.e. the standard problem for R^-T Gz R^-1, s = R^-1 y.  Not needed while the basis is smaller
     // than k and the iteration goes on (the device idles while the host works here).
-    if (pp >= k || rn == 0 || exhausted) {
+    if (pp >= k || rn == 0 || exhausted || want_restart) {
       std::vector<double> Mp((size_t)pp * pp), Gp((size_t)pp * pp), Rm, Rmi, tmp((size_t)pp * pp);
       for (int j = 0; j < pp; j++)
         for (int i = 0; i < pp; i++) {
@@ -317,6 +333,36 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
       if (worst + opt.resid_floor <= opt.tol) {
         done = true;
         res.converged = 1;
+      }
+    }
+    if (!done && want_restart) {
+      // keep the k + b largest Ritz pairs (room for at least the next block must remain)
+      int keep = std::min(pp, k + b);
+      if (keep > cap - rn_full) keep = cap - rn_full;
+      if (keep >= k) {
+        std::vector<double> Sk((size_t)pp * keep);
+        for (int t = 0; t < keep; t++)
+          for (int i = 0; i < pp; i++) Sk[(size_t)i + (size_t)t * pp] = evec[(size_t)i + (size_t)(pp - 1 - t) * pp];
+        if (bk.restart(pp, keep, Sk.data(), rn_full)) {
+          // in the new basis Z'Z = diag(theta) and Q'Q = I on the kept part (s' M s = 1 by construction)
+          for (int j = 0; j < cap; j++)
+            for (int i = 0; i < cap; i++) Gat(i, j) = Mat(i, j) = 0.0;
+          for (int t = 0; t < keep; t++) {
+            Gat(t, t) = eval[pp - 1 - t];
+            Mat(t, t) = 1.0;
+          }
+          res.restarts++;
+          if (opt.verbose)
+            std::fprintf(stderr, "[bsn svd] basis full at %d: restart with %d Ritz vectors\n", pp, keep);
+          p = keep;
+          pp = keep;
+          rn = rn_full;
+          bk.round_W(rn);
+          bk.W_to_Q(p, rn);
+          p += rn;
+          cb = rn;
+          continue;
+        }
       }
     }
     if (done || rn == 0) {

@@ -18,7 +18,8 @@ from .bed import _args, assert_bed, bed_scaleBinom
 
 def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=None, k=10,
                   tol=1e-4, verbose=False, ncores=1, block=0, slices=0, max_basis=0, seed=1,
-                  comm=None, allreduce=None, rank=0, world=1, m_total=0, return_uv=True, warm_start=0, warm_denominator=0):
+                  comm=None, allreduce=None, rank=0, world=1, m_total=0, return_uv=True, warm_start=0, warm_denominator=0,
+                  max_restarts=0):
     """Partial SVD of the scaled matrix.  Extra (non-reference) arguments: ``block``
     (vectors per streaming pass), ``slices`` (int8 slices per fp64 value); column-sharded
     multi-GPU: ``comm`` (a bigsnpr_amd.Comm: the exchange runs inside the library over RCCL),
@@ -39,6 +40,7 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
         scale = np.ascontiguousarray(ms["scale"], dtype=np.float64)
     opts.k, opts.tol, opts.block, opts.slices = int(k), float(tol), int(block), int(slices)
     opts.warm_start, opts.warm_denominator = int(warm_start), int(warm_denominator)
+    opts.max_restarts = int(max_restarts)
     opts.max_basis, opts.seed, opts.verbose, opts.m_total = int(max_basis), int(seed), int(verbose), int(m_total)
     cb = None
     if comm is not None:
@@ -49,8 +51,13 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
         opts.hook_rank, opts.hook_world = int(rank), int(world)
     info = _lib.SvdInfo()
     d = np.empty(k)
-    u = np.empty((k, ir.size)) if return_uv else None
-    v = np.empty((k, ic.size)) if return_uv else None
+    # u and v go to page-locked memory of the library's result pool (bsn_host_alloc): written by the DMA
+    # engines directly, and — once an earlier result has been collected — without a first-touch page fault
+    # per 4 KB; a small result is not worth a pinned block
+    big = k * (ir.size + ic.size) * 8 >= (8 << 20)
+    alloc = _lib.result_pool.empty if big else np.empty
+    u = alloc((k, ir.size)) if return_uv else None
+    v = alloc((k, ic.size)) if return_uv else None
     L = _lib.load()
     rc = L.bsn_bed_randomsvd(obj_bed.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p), ic.size,
                              ptr(center, f64p), ptr(scale, f64p), C.byref(opts), ptr(d, f64p),

@@ -251,6 +251,11 @@ typedef struct bsn_svd_options {
    * skip it. */
   int32_t warm_start;
   int32_t warm_denominator; /* the subset is the leading 1 / warm_denominator of the variants (0 -> 16) */
+  /* A Krylov basis that fills up (max_basis) before the residuals meet tol is compressed to the k + block
+   * best Ritz vectors and the iteration goes on (thick restart; RSpectra::svds behind the reference restarts
+   * implicitly).  0 -> at most 100 restarts, n > 0 -> n, < 0 -> none: a full basis ends the solve with return
+   * code 2. */
+  int32_t max_restarts;
 } bsn_svd_options;
 typedef struct bsn_svd_info {
   int32_t niter;      /* block steps */
@@ -348,6 +353,13 @@ int bsn_clumping_chr_cached(bsn_bed *bed, const int64_t *ind_row, int64_t n, con
 /* ---- device memory + timing helpers for hosts without a HIP binding -------- */
 int bsn_malloc(void **d_ptr, int64_t bytes);
 int bsn_free(void *d_ptr);
+/* Page-locked host memory.  Every entry point accepts ordinary (pageable) caller memory and stages it
+ * through pinned buffers of its own; a result buffer obtained here is written by the DMA engines directly
+ * (bsn_bed_randomsvd: u and v, 224 MB at 400K x 1M, k = 20 — no staging copy, no first-touch page faults).
+ * The reference returns freshly allocated R vectors (R/autoSVD.R:216-218); an R shim has to copy into
+ * those, a host that controls its allocations (the Python mirror) does not. */
+int bsn_host_alloc(void **h_ptr, int64_t bytes);
+int bsn_host_free(void *h_ptr);
 int bsn_memcpy_h2d(void *d_dst, const void *src, int64_t bytes);
 int bsn_memcpy_d2h(void *dst, const void *d_src, int64_t bytes);
 int bsn_device_sync(void);

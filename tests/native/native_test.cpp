@@ -201,6 +201,25 @@ struct HostBackend : SvdBackend {
     const int r = fused(0, 0, cb, nullptr, nullptr, Rout);
     return r < 0 ? -1 : r;
   }
+  bool restart(int pp, int keep, const double *S, int rn) override {
+    (void)rn;   // W is a buffer of its own here
+    auto combine = [&](std::vector<double> &X, int64_t rows) {
+      std::vector<double> out((size_t)rows * keep, 0.0);
+      for (int t = 0; t < keep; t++)
+        for (int a = 0; a < pp; a++) {
+          const double f = S[a + (size_t)t * pp];
+          for (int64_t i = 0; i < rows; i++) out[i + (size_t)t * rows] += X[i + (size_t)a * rows] * f;
+        }
+      std::copy(out.begin(), out.end(), X.begin());
+    };
+    combine(Q, n);
+    combine(Z, m_local);
+    if (!Mdev.empty()) {
+      for (int j = 0; j < keep; j++)
+        for (int i = 0; i < keep; i++) Mdev[(size_t)i + (size_t)j * kOrthMaxP] = i == j ? 1.0 : 0.0;
+    }
+    return true;
+  }
   void finalize(int pp, int k, const double *S, const double *dinv, double *u, double *v) override {
     for (int t = 0; t < k; t++) {
       for (int64_t i = 0; i < n; i++) {
@@ -217,7 +236,7 @@ struct HostBackend : SvdBackend {
   }
 };
 
-static int g_slices = 0, g_fused = 0;
+static int g_slices = 0, g_fused = 0, g_max_restarts = 100;
 static int g_counts[2] = {0, 0};
 
 extern "C" {
@@ -226,6 +245,8 @@ extern "C" {
 void nt_set_slices(int slices) { g_slices = slices; }
 // 1: the host backend takes the product's fused two-pass block step (orth_small.hpp)
 void nt_set_fused(int on) { g_fused = on; }
+// thick restarts of a full basis (negative: none: a full basis ends the solve unconverged)
+void nt_set_max_restarts(int r) { g_max_restarts = r; }
 // fused steps taken / steps handed to the careful path by the last solve
 void nt_fused_counts(int *out) { out[0] = g_counts[0]; out[1] = g_counts[1]; }
 
@@ -266,6 +287,7 @@ void nt_svd_host(const double *A, int64_t n, int64_t m_local, int64_t m_total, i
   o.block = block;
   o.max_basis = max_basis;
   o.seed = seed;
+  o.max_restarts = g_max_restarts;
   o.resid_floor = g_slices > 0 ? 1.2 * std::ldexp(1.0, -8 * g_slices) : 0.0;
   SvdResult r = block_lanczos_svd(bk, o, d, u, v);
   g_counts[0] = bk.n_fused;
@@ -274,6 +296,7 @@ void nt_svd_host(const double *A, int64_t n, int64_t m_local, int64_t m_total, i
   info[1] = r.nops;
   info[2] = r.basis;
   info[3] = r.converged;
+  info[4] = r.restarts;
   *resid = r.max_rel_resid;
 }
 }

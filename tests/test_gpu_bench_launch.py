@@ -1,6 +1,7 @@
 """bench.py as the driver launches it for N > 1 (`python -m torch.distributed.run --nproc-per-node N bench.py
---gpus N ...`), on the one GPU of the test box: two ranks share device 0, RCCL refuses that, and the script
-must fall back — on every rank together — to the host all-reduce hook instead of dying.  What is checked is
+--gpus N ...`), on the one GPU of the test box: two ranks share device 0 and RCCL refuses that.  By default the
+script must then EXIT NON-ZERO on every rank (a scaling number produced over gloo is not an RCCL number); with
+`--allow-fallback` it takes — on every rank together — the host all-reduce hook.  What is checked is
 the launch path around the solver: rendezvous, column sharding, the one JSON line on rank 0's stdout, whole-job
 aggregation, and that the sharded solve finds the singular values of the single-rank one."""
 import json
@@ -27,13 +28,27 @@ def _run(cmd, **extra_env):
     return json.loads(lines[0]), r.stderr
 
 
-def test_two_ranks_on_one_gpu_fall_back_and_agree():
-    one, _ = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS)
+def _port():
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
-        port = str(sock.getsockname()[1])
+        return str(sock.getsockname()[1])
+
+
+def test_two_ranks_without_rccl_do_not_fall_back_silently():
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", _port(), "bench.py", "--gpus", "2"] + ARGS,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode != 0
+    assert "not falling back" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]   # no bench line
+
+
+def test_two_ranks_on_one_gpu_fall_back_and_agree():
+    one, _ = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS)
+    port = _port()
     two, err = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                     "--master-addr", "127.0.0.1", "--master-port", port, "bench.py", "--gpus", "2"] + ARGS)
+                     "--master-addr", "127.0.0.1", "--master-port", port, "bench.py", "--gpus", "2", "--allow-fallback"]
+                    + ARGS)
     assert "falling back to the host all-reduce hook" in err
     assert two["n_gpus"] == 2 and two["steps"] == 2 and two["warmup"] == 1
     assert two["config"]["m_total"] == 60000 and two["config"]["m_per_gpu"] == 30000

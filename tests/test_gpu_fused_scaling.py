@@ -91,7 +91,12 @@ def test_unconverged_solve_warns(ba, orc):
     gb = ba.bed.synthetic(n, m, seed=4)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
-        res = ba.bed_randomSVD(gb, k=10, tol=1e-12, slices=7, max_basis=16, block=4)
+        res = ba.bed_randomSVD(gb, k=10, tol=1e-12, slices=7, max_basis=16, block=4, max_restarts=-1)
     assert not res["converged"]
     assert any("did not converge" in str(x.message) for x in w)
     assert np.all(np.isfinite(res["d"]))
+    # with thick restarts (the default) the same small basis gets there
+    res = ba.bed_randomSVD(gb, k=10, tol=1e-8, slices=7, max_basis=48, block=4, verbose=1)
+    assert res["converged"] and res["basis"] <= 48
+    ref = orc.dense_svd(orc.fake_bed(n, m, seed=4), k=10)
+    np.testing.assert_allclose(res["d"], ref["d"], rtol=1e-8)

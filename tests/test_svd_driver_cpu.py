@@ -35,7 +35,7 @@ def host_svd(nt, A, k, tol=1e-10, block=8, m_total=None, ar=None, max_basis=0, s
     A = np.asfortranarray(A, dtype=np.float64)
     n, m = A.shape
     d = np.empty(k); u = np.empty((k, n)); v = np.empty((k, m))
-    info = np.zeros(4, dtype=np.int32); resid = C.c_double()
+    info = np.zeros(8, dtype=np.int32); resid = C.c_double()
     cb = AR_FN(ar) if ar is not None else AR_FN()
     nt.nt_svd_host(A.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(n), C.c_int64(m),
                    C.c_int64(m_total or m), k, C.c_double(tol), block, max_basis, C.c_uint32(seed),
@@ -43,7 +43,7 @@ def host_svd(nt, A, k, tol=1e-10, block=8, m_total=None, ar=None, max_basis=0, s
                    u.ctypes.data_as(C.POINTER(C.c_double)), v.ctypes.data_as(C.POINTER(C.c_double)),
                    info.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(resid))
     return dict(d=d, u=u.T, v=v.T, niter=info[0], nops=info[1], basis=info[2],
-                converged=bool(info[3]), resid=resid.value)
+                converged=bool(info[3]), resid=resid.value, restarts=int(info[4]))
 
 
 def test_eig_sym_matches_numpy(nt):
@@ -188,7 +188,9 @@ def test_ritz_values_do_not_see_the_product_precision(nt):
             np.testing.assert_allclose(A.T @ res["u"], res["v"] * res["d"], atol=1e-9 * d_true[0])
         # an unattainable tolerance (below the rounding floor of 16-bit products) is reported, not faked
         nt.nt_set_slices(2)
+        nt.nt_set_max_restarts(3)
         assert not host_svd(nt, A, k, tol=1e-7, block=8, max_basis=64)["converged"]
+        nt.nt_set_max_restarts(100)
     finally:
         nt.nt_set_slices(0)
     # the error of d is the convergence level (~tol^2) with or without rounded products
@@ -201,7 +203,11 @@ def test_full_basis_is_not_mistaken_for_convergence(nt):
     'not converged' (RSpectra warns in that case); the clipped next block must not zero the estimate"""
     rng = np.random.default_rng(5)
     A = rng.normal(size=(400, 300))
-    res = host_svd(nt, A, 10, tol=1e-12, block=4, max_basis=16)
+    nt.nt_set_max_restarts(-1)
+    try:
+        res = host_svd(nt, A, 10, tol=1e-12, block=4, max_basis=16)
+    finally:
+        nt.nt_set_max_restarts(100)
     assert not res["converged"] and res["basis"] == 16
     assert res["resid"] > 1e-6
     assert np.all(np.isfinite(res["d"])) and np.all(np.diff(res["d"]) <= 0)
@@ -237,3 +243,24 @@ def test_fused_step_is_taken_and_hands_deficient_panels_to_the_careful_path(nt, 
     nt.nt_fused_counts(cnt)
     assert cnt[1] >= 1
     np.testing.assert_allclose(res["d"][:6], np.linalg.svd(A, compute_uv=False)[:6], rtol=1e-8)
+
+
+def test_thick_restart_of_a_full_basis(nt):
+    """a basis that fills up before the residuals meet tol is compressed to the best Ritz vectors and the solve goes
+    on (what RSpectra's implicit restart does for the reference): a hard spectrum with a small basis cap must still
+    converge to the dense SVD, with exact products and with the rounded basis of the product (slices = 2)"""
+    rng = np.random.default_rng(11)
+    n, m, k = 500, 700, 12
+    A = rng.normal(size=(n, m)) + rng.normal(size=(n, 15)) @ np.diag(np.linspace(0.16, 0.09, 15)) @ rng.normal(size=(15, m))
+    U, d, Vt = np.linalg.svd(A, full_matrices=False)
+    try:
+        for S, tol, blk in ((0, 1e-8, 8), (2, 1e-4, 8), (2, 1e-4, 16), (3, 1e-6, 5)):
+            nt.nt_set_slices(S)
+            res = host_svd(nt, A, k, tol=tol, block=blk, max_basis=48)
+            assert res["converged"] and res["restarts"] >= 1, (S, tol, blk, res["restarts"], res["resid"])
+            assert res["basis"] <= 48
+            np.testing.assert_allclose(res["d"], d[:k], rtol=max(1e-10, 20 * tol * tol))
+            np.testing.assert_allclose(res["u"].T @ res["u"], np.eye(k), atol=1e-8)
+            np.testing.assert_allclose(A.T @ res["u"], res["v"] * res["d"], atol=1e-8 * d[0])
+    finally:
+        nt.nt_set_slices(0)
