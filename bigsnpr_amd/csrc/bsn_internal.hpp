@@ -137,6 +137,10 @@ struct bsn_op {
   int64_t col0 = 0;
   int slices = 4;
   int64_t passes = 0;         // streaming launches over the image issued so far
+  // op_cprod_prequant: the digits of this panel are already in d_q (quantised ahead of the call that uses them)
+  const double *preq_X = nullptr;
+  int64_t preq_ldx = 0;
+  int preq_nvec = 0;
   // per-launch HIP-event timing of the streaming kernels (kind 0 = k_cprod, 1 = k_prod, 2 = the k_cprod
   // launch that also counts the codes, first pass of a solve with fused scaling statistics)
   bool profile = false;
@@ -257,6 +261,10 @@ void comm_all_gather(bsn_comm *c, const double *d_send, double *d_recv, int64_t 
 void op_poll_stats(bsn_op *op);  // after a stream synchronisation: pick up the missing-value total
 void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy);
 void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z, int64_t ldz);
+// the quantisation half of op_cprod for a panel that fits one launch, queued ahead of time (the SVD driver
+// does it while the host still works on the previous step); op_cprod with the same panel then starts with
+// its streaming kernel.  Any other product on the operator forgets the digits.
+void op_cprod_prequant(bsn_op *op, const double *d_X, int64_t ldx, int nvec);
 void op_cprod_raw(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_P, double *d_Q,
                   int64_t ld);  // P = sum_i g0 x, Q = sum_i na x (m x nvec each)
 void require_bits(const bsn_bed *b, int bits, const char *what);  // fails with a clear message otherwise

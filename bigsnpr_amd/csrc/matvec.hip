@@ -514,25 +514,51 @@ __device__ __forceinline__ double horner_sub(const int32_t *a, const int32_t *q,
 }
 
 // z[j, v] = (P - c_j (Sx - Q)) / (s_j qs),  P = P' - 3 Q  (P' = plane sum of the raw codes)
-__global__ void k_cprod_final(const int32_t *acc, int64_t m, int ncol, int S, const VecMeta *meta,
-                              const double *center, const double *scale, double *Z, int64_t ldz,
-                              int has_q) {
-  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int v = blockIdx.y;
+// One thread per variant for ALL vectors of the launch: its 2 x NCOL raw sums are read once, as whole
+// 64 / 128-byte rows, and parked in the thread's own LDS row (stride NCOL 2 + 1 words: conflict free), from
+// where the digits of vector v are picked with run-time indices.  (Round 2 ran one thread per variant AND
+// vector, each reading 2 S of the row's 2 NCOL words: the rows were fetched once per vector — 1.5 ms per
+// pass of 16 vectors at 1M variants, as much as all the panel algebra of a solve.)
+template <int NCOL>
+__global__ __launch_bounds__(128) void k_cprod_final(const int32_t *__restrict__ acc, int64_t m, int S, int nv,
+                                                     const VecMeta *__restrict__ meta,
+                                                     const double *__restrict__ center,
+                                                     const double *__restrict__ scale, double *Z, int64_t ldz,
+                                                     int has_q) {
+  constexpr int ROW = 2 * NCOL + 1;
+  __shared__ int32_t srow[128 * ROW];
+  const int64_t j = (int64_t)blockIdx.x * 128 + threadIdx.x;
   if (j >= m) return;
-  // no missing plane: Q == 0 and P' == P
-  double P = has_q ? horner_sub(acc + j * ncol + v * S, acc + (m + j) * ncol + v * S, 3, S)
-                   : horner(acc + j * ncol + v * S, S);
-  double Q = has_q ? horner(acc + (m + j) * ncol + v * S, S) : 0.0;
-  double Sx = (double)meta[v].sum_hi * 16777216.0 + (double)meta[v].sum_lo;
-  double c = center ? center[j] : 0.0, s = scale ? scale[j] : 1.0;
-  double qs = meta[v].qscale;
-  double z = qs > 0 ? (P - c * (Sx - Q)) / (s * qs) : 0.0 / s;
-  // a variant with no non-missing genotype contributes only bedAccScaled's NA entry (0),
-  // whatever its centre / scale are (src/bed-acc.h:104); P and Sx - Q are exact integers
-  if (P == 0.0 && Sx - Q == 0.0 && qs > 0) z = 0.0;
-  if (meta[v].nonfinite) z = __longlong_as_double(0x7ff8000000000000LL);
-  Z[j + v * ldz] = z;
+  int32_t *my = srow + threadIdx.x * ROW;
+  {
+    const int4 *pa = (const int4 *)(acc + j * NCOL), *pq = (const int4 *)(acc + (m + j) * NCOL);
+#pragma unroll
+    for (int t = 0; t < NCOL / 4; t++) {
+      const int4 x = pa[t];
+      my[4 * t] = x.x; my[4 * t + 1] = x.y; my[4 * t + 2] = x.z; my[4 * t + 3] = x.w;
+    }
+    if (has_q) {
+#pragma unroll
+      for (int t = 0; t < NCOL / 4; t++) {
+        const int4 x = pq[t];
+        my[NCOL + 4 * t] = x.x; my[NCOL + 4 * t + 1] = x.y; my[NCOL + 4 * t + 2] = x.z; my[NCOL + 4 * t + 3] = x.w;
+      }
+    }
+  }
+  const double c = center ? center[j] : 0.0, s = scale ? scale[j] : 1.0;
+  for (int v = 0; v < nv; v++) {
+    // no missing plane: Q == 0 and P' == P
+    const double P = has_q ? horner_sub(my + v * S, my + NCOL + v * S, 3, S) : horner(my + v * S, S);
+    const double Q = has_q ? horner(my + NCOL + v * S, S) : 0.0;
+    const double Sx = (double)meta[v].sum_hi * 16777216.0 + (double)meta[v].sum_lo;
+    const double qs = meta[v].qscale;
+    double z = qs > 0 ? (P - c * (Sx - Q)) / (s * qs) : 0.0 / s;
+    // a variant with no non-missing genotype contributes only bedAccScaled's NA entry (0),
+    // whatever its centre / scale are (src/bed-acc.h:104); P and Sx - Q are exact integers
+    if (P == 0.0 && Sx - Q == 0.0 && qs > 0) z = 0.0;
+    if (meta[v].nonfinite) z = __longlong_as_double(0x7ff8000000000000LL);
+    Z[j + v * ldz] = z;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1338,11 +1364,26 @@ void op_poll_stats(bsn_op *op) {
   if (t == 0 && !getenv("BSN_FORCE_NA_PLANE")) op->no_na = true;  // complete data: skip the missing-value plane from now on
 }
 
+void op_cprod_prequant(bsn_op *op, const double *d_X, int64_t ldx, int nvec) {
+  bsn_bed *b = op->bed;
+  const int S = op->slices;
+  op->preq_X = nullptr;
+  if (nvec <= 0 || nvec > 32 / S || !op->rows_identity) return;
+  const int64_t npad = n_padded(b);
+  quantise(op, d_X, ldx, b->n, npad, nvec, 0, S, 16 * pick_nb(nvec * S), 1, 0, meta_buffer(op),
+           op->d_q.ensure((size_t)npad * 32 * 2));
+  op->preq_X = d_X;
+  op->preq_ldx = ldx;
+  op->preq_nvec = nvec;
+}
+
 void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z, int64_t ldz) {
   bsn_bed *b = op->bed;
   const int S = op->slices;
   const int vmax = 32 / S;  // vectors per launch (NB <= 2)
   if (nvec <= 0) return;
+  const bool have_digits = op->preq_X == d_X && op->preq_ldx == ldx && op->preq_nvec == nvec && d_X != nullptr;
+  op->preq_X = nullptr;
   const double *xsrc = scatter_rows_if_needed(op, d_X, &ldx, nvec);
   const int64_t npad = n_padded(b);
   VecMeta *meta = meta_buffer(op);
@@ -1351,7 +1392,7 @@ void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z,
     int NB = pick_nb(nv * S), ncol = 16 * NB;
     int8_t *q = op->d_q.ensure((size_t)npad * 32 * 2);
     int32_t *acc = op->d_acc.ensure((size_t)2 * op->m * 32);
-    quantise(op, xsrc + (int64_t)v0 * ldx, ldx, b->n, npad, nv, 0, S, ncol, 1, 0, meta, q);
+    if (!have_digits) quantise(op, xsrc + (int64_t)v0 * ldx, ldx, b->n, npad, nv, 0, S, ncol, 1, 0, meta, q);
     prof_begin(op, op->stats_pending ? 2 : 0);  // the pass that carries the code counts is timed apart
     if (b->bits == 8) {
       const dim3 grid8((unsigned)((op->m + 127) / 128));
@@ -1388,9 +1429,12 @@ void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z,
     op->passes++;
     const bool has_q = op->stats_pending || !op->no_na;
     if (op->stats_pending) finish_fused_stats(op);
-    hipLaunchKernelGGL(k_cprod_final, dim3((unsigned)((op->m + 255) / 256), nv), dim3(256), 0,
-                       b->stream, acc, op->m, ncol, S, meta, op->d_center.p, op->d_scale.p,
-                       d_Z + (int64_t)v0 * ldz, ldz, has_q ? 1 : 0);
+    if (NB == 1)
+      hipLaunchKernelGGL((k_cprod_final<16>), dim3((unsigned)((op->m + 127) / 128)), dim3(128), 0, b->stream, acc, op->m,
+                         S, nv, meta, op->d_center.p, op->d_scale.p, d_Z + (int64_t)v0 * ldz, ldz, has_q ? 1 : 0);
+    else
+      hipLaunchKernelGGL((k_cprod_final<32>), dim3((unsigned)((op->m + 127) / 128)), dim3(128), 0, b->stream, acc, op->m,
+                         S, nv, meta, op->d_center.p, op->d_scale.p, d_Z + (int64_t)v0 * ldz, ldz, has_q ? 1 : 0);
     BSN_HIP(hipGetLastError());
   }
 }
@@ -1536,6 +1580,7 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
   bsn_bed *b = op->bed;
   const int vmax = 32 / S;
   if (nvec <= 0) return;
+  op->preq_X = nullptr;
   // k_prod addresses a 64-variant step with 32-bit offsets from its first row
   if (b->pitch >= ((int64_t)1 << 24)) fail("more than 6.7e7 samples are not supported by the product kernel");
   const int64_t npad = n_padded(b);
@@ -1627,6 +1672,7 @@ __global__ void k_cprod_raw_final(const int32_t *acc, int64_t m, int ncol, int S
 void op_cprod_raw(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_P, double *d_Q,
                   int64_t ld) {
   require_bits(op->bed, 2, "the plane sums of multLinReg");
+  op->preq_X = nullptr;
   bsn_bed *b = op->bed;
   const int S = op->slices;
   const int vmax = 32 / S;
@@ -1714,6 +1760,7 @@ __global__ void k_counts_final(const int32_t *acc, int64_t m, int ncol, int S, i
 
 void counts_weighted(bsn_op *op, const double *d_w, int64_t n_sub, int32_t *d_counts) {
   require_bits(op->bed, 2, "bed_counts");
+  op->preq_X = nullptr;
   bsn_bed *b = op->bed;
   const int S = 4;
   const int64_t npad = n_padded(b);

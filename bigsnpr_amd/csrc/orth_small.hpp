@@ -38,7 +38,8 @@ constexpr int kOrthMaxP = 384;   // basis columns the fused step supports (devic
 struct OrthSmall {
   int p, cb, pass;      // basis size, panel width, pass 0 / 1
   int p0;               // pass 0: the Gram block `QtQ` (p x cb, columns p0 .. p0+cb-1 of M) is folded into M first
-  const double *QtQ;    // may be null (p == 0)
+  const double *QtQ;    // may be null (p == 0); leading dimension ldq
+  int ldq;
   const double *HG;     // (p + cb) x cb, leading dimension p + cb: rows < p = Q'W, rows >= p = W'W
   double *M;            // p x p Gram matrix of the stored basis, leading dimension ldm (updated in pass 0)
   int ldm;
@@ -61,9 +62,10 @@ BSN_HD inline void orth_small(Ctx &cx, const OrthSmall &a) {
   if (a.pass == 0 && a.QtQ && p > 0) {
     for (int t = tid; t < p * cb; t += nt) {
       const int i = t % p, j = t / p;
-      a.M[(long)i + (long)(a.p0 + j) * a.ldm] = a.QtQ[t];
+      const double g = a.QtQ[(long)i + (long)j * a.ldq];
+      a.M[(long)i + (long)(a.p0 + j) * a.ldm] = g;
       // the diagonal block is taken as computed (one writer per element: results stay run-to-run identical)
-      if (i < a.p0) a.M[(long)(a.p0 + j) + (long)i * a.ldm] = a.QtQ[t];
+      if (i < a.p0) a.M[(long)(a.p0 + j) + (long)i * a.ldm] = g;
     }
   }
   for (int t = tid; t < p * cb; t += nt) a.Cs[t] = H[(t % p) + (t / p) * ld];   // Cs: p x cb, ld p

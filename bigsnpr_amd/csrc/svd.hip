@@ -56,6 +56,8 @@ constexpr int64_t kGemmRows = 1024;   // rows per workgroup of k_gemm_tn (4 wave
 // the largest item of a solve outside the streaming passes).
 // Workgroup (tile, rc) covers rows [rc, rc + 1) * kGemmRows with four waves and writes the 16 x 16 sums to
 // partial[rc][tile]; k_gemm_tn_reduce adds the chunks up.
+// NT: 16-column tiles of B (cb <= 16 NT); an A tile is loaded once for all of them.
+template <int NT>
 __global__ __launch_bounds__(256) void k_gemm_tn(const double *__restrict__ A, int64_t lda, int p,
                                                  const double *__restrict__ B, int64_t ldb, int cb, int64_t n,
                                                  double *partial) {
@@ -63,29 +65,40 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const double *__restrict__ A, i
   const int a = lane & 15, kq = lane >> 4;
   // columns past p (past cb) are read from a valid one and discarded (masked): no branch around the loads
   const int ca = tile * 16 + a < p ? tile * 16 + a : p - 1;
-  const bool bval = a < cb;
-  const double *Ap = A + (int64_t)ca * lda, *Bp = B + (int64_t)(bval ? a : 0) * ldb;
+  const double *Ap = A + (int64_t)ca * lda;
+  bool bval[NT];
+  const double *Bp[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    bval[t] = t * 16 + a < cb;
+    Bp[t] = B + (int64_t)(bval[t] ? t * 16 + a : 0) * ldb;
+  }
   const int64_t c0 = (int64_t)rc * kGemmRows, c1 = c0 + kGemmRows < n ? c0 + kGemmRows : n;
   const int64_t r0 = c0 + wave * (kGemmRows / 4);
   const int64_t r1 = r0 + kGemmRows / 4 < c1 ? r0 + kGemmRows / 4 : c1;
-  v4d acc = {0.0, 0.0, 0.0, 0.0};
+  v4d acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
   // groups of 32 rows through two register sets: the loads of a group are in flight while the MFMAs of the
   // previous one run (a wave that waited out every group's memory round trip left the kernel latency-bound
   // at a quarter of the bandwidth).  No branch around the loads: past the end the last group is loaded again.
-  d2 av0[4], bv0[4], av1[4], bv1[4];
-  auto ld = [&](int64_t rr, d2 (&av)[4], d2 (&bv)[4]) {
+  d2 av0[4], bv0[NT][4], av1[4], bv1[NT][4];
+  auto ld = [&](int64_t rr, d2 (&av)[4], d2 (&bv)[NT][4]) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       av[u] = *(const d2 *)(Ap + rr + 8 * u + 2 * kq);
-      bv[u] = *(const d2 *)(Bp + rr + 8 * u + 2 * kq);
+#pragma unroll
+      for (int t = 0; t < NT; t++) bv[t][u] = *(const d2 *)(Bp[t] + rr + 8 * u + 2 * kq);
     }
   };
-  auto mm = [&](const d2 (&av)[4], const d2 (&bv)[4]) {
+  auto mm = [&](const d2 (&av)[4], const d2 (&bv)[NT][4]) {
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].x, bval ? bv[u].x : 0.0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].y, bval ? bv[u].y : 0.0, acc, 0, 0, 0);
-    }
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].x, bval[t] ? bv[t][u].x : 0.0, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].y, bval[t] ? bv[t][u].y : 0.0, acc[t], 0, 0, 0);
+      }
   };
   const int64_t nfull = r1 > r0 ? (r1 - r0) / 32 : 0;
   if (nfull > 0) {
@@ -101,16 +114,24 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const double *__restrict__ A, i
   for (; r < r1; r += 8) {   // the ragged end of the last chunk
     const int64_t i0 = r + 2 * kq, i1 = i0 + 1;
     const double a0 = i0 < r1 ? Ap[i0] : 0.0, a1 = i1 < r1 ? Ap[i1] : 0.0;
-    const double b0 = (bval && i0 < r1) ? Bp[i0] : 0.0, b1 = (bval && i1 < r1) ? Bp[i1] : 0.0;
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const double b0 = (bval[t] && i0 < r1) ? Bp[t][i0] : 0.0, b1 = (bval[t] && i1 < r1) ? Bp[t][i1] : 0.0;
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[t], 0, 0, 0);
+    }
   }
   // D: column of B = lane & 15, column of the A tile = (lane >> 4) + 4 * reg
   __shared__ double red[4][256];
 #pragma unroll
-  for (int g = 0; g < 4; g++) red[wave][(kq + 4 * g) * 16 + a] = acc[g];
-  __syncthreads();
-  partial[((int64_t)rc * gridDim.x + tile) * 256 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  for (int t = 0; t < NT; t++) {
+    if (t > 0) __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; g++) red[wave][(kq + 4 * g) * 16 + a] = acc[t][g];
+    __syncthreads();
+    partial[(((int64_t)rc * gridDim.x + tile) * NT + t) * 256 + tid] =
+        (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  }
 }
 
 // C[tile*16 + mrow, ncol] = sum over the row chunks, in a fixed order (four interleaved running sums, then
@@ -119,16 +140,16 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const double *__restrict__ A, i
 // workgroup, several times the product itself.)
 __global__ __launch_bounds__(1024) void k_gemm_tn_reduce(const double *__restrict__ partial, int nrc, int ntile, int p,
                                                          int cb, double *C, int ldc) {
-  const int tile = blockIdx.x, t = threadIdx.x & 255, part = threadIdx.x >> 8;
+  const int tile = blockIdx.x, bt = blockIdx.y, nt = gridDim.y, t = threadIdx.x & 255, part = threadIdx.x >> 8;
   double sum = 0;
 #pragma unroll 4
-  for (int c = part; c < nrc; c += 4) sum += partial[((int64_t)c * ntile + tile) * 256 + t];
+  for (int c = part; c < nrc; c += 4) sum += partial[(((int64_t)c * ntile + tile) * nt + bt) * 256 + t];
   __shared__ double sp[4][256];
   sp[part][t] = sum;
   __syncthreads();
   if (part == 0) {
     sum = (sp[0][t] + sp[1][t]) + (sp[2][t] + sp[3][t]);
-    const int mrow = t >> 4, ncol = t & 15;
+    const int mrow = t >> 4, ncol = bt * 16 + (t & 15);
     if (tile * 16 + mrow < p && ncol < cb) C[(tile * 16 + mrow) + (int64_t)ncol * ldc] = sum;
   }
 }
@@ -253,6 +274,8 @@ __global__ __launch_bounds__(256) void k_update(const double *__restrict__ Q, in
         __syncthreads();
       }
       if (i < n) {
+        // (unrolled by 8: the eight loads of Q go out together instead of one memory round trip per column)
+#pragma unroll 8
         for (int a = 0; a < ta; a++) {
           const double q = Q[i + (int64_t)(a0 + a) * ldq];
 #pragma unroll
@@ -369,6 +392,7 @@ struct SvdWorkspace {
   // and were measured to cost milliseconds each once a process has run a few solves
   double *h_pin = nullptr;
   size_t h_pin_n = 0;
+  hipEvent_t ev_small = nullptr;   // the small matrices of a block step have reached the host
   double *pinned(size_t count) {
     if (count > h_pin_n) {
       if (h_pin) (void)hipHostFree(h_pin);
@@ -379,6 +403,7 @@ struct SvdWorkspace {
     return h_pin;
   }
   ~SvdWorkspace() {
+    if (ev_small) (void)hipEventDestroy(ev_small);
     if (h_pin) (void)hipHostFree(h_pin);
   }
 };
@@ -403,6 +428,8 @@ struct HipSvdBackend : SvdBackend {
   int cap = 0, b = 0;
   int kmax = 0;
   bool mx_valid = false;     // the column maxima of W (rounding) came out of the last k_update
+  bool speculate = true;     // queue the start of the next step behind the orthonormalisation (BSN_NO_SPECULATION=1: off)
+  bool spec_rounded = false; // ... and it has been: the driver's next round_W is a no-op
   int n_small_ar = 0;        // small all-reduces issued (diagnostics)
   // warm start on a leading subset of this rank's variants
   int64_t m_op_full = 0, m_sub = 0;
@@ -471,11 +498,11 @@ struct HipSvdBackend : SvdBackend {
     Z.ensure((size_t)m_local * cap);
     {
       const int64_t rows_max = nr > m_local ? nr : m_local;
-      partial.ensure((size_t)((rows_max + kGemmRows - 1) / kGemmRows) * ((cap + kMaxB + 15) / 16) * 256);
+      partial.ensure((size_t)((rows_max + kGemmRows - 1) / kGemmRows) * ((cap + kMaxB + 15) / 16) * 2 * 256);
     }
     dsmall.ensure((size_t)(cap + 4) * 64);
     Wsave.ensure((size_t)nr * kMaxB);
-    dorth.ensure((size_t)16 + 3 * kMaxB * kMaxB + (size_t)6 * (cap + kMaxB + 4) * kMaxB);
+    dorth.ensure((size_t)16 + 3 * kMaxB * kMaxB + (size_t)7 * (cap + kMaxB + 4) * kMaxB);
     ws.dM.ensure((size_t)kOrthMaxP * kOrthMaxP);
     if (dist) {
       const int wide = kmax > kMaxB ? kmax : kMaxB;
@@ -533,6 +560,8 @@ struct HipSvdBackend : SvdBackend {
     Wc = Q.p;
     wcol = 0;
     mx_valid = false;
+    spec_rounded = false;
+    op->preq_X = nullptr;
     hipLaunchKernelGGL(k_random, dim3((unsigned)((nr + 255) / 256), bb), dim3(256), 0, st, Wc, nr, nr, bb, seed,
                        row0, n);
     BSN_HIP(hipGetLastError());
@@ -554,8 +583,14 @@ struct HipSvdBackend : SvdBackend {
   void gemm_tn_any(const double *A, const double *B, int64_t rows, int p, int cb, double *dC, int ldc = 0) {
     if (p <= 0 || cb <= 0) return;
     dim3 grid((unsigned)((p + 15) / 16), (unsigned)((rows + kGemmRows - 1) / kGemmRows));
-    hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, st, A, rows, p, B, rows, cb, rows, partial.p);
-    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3(grid.x), dim3(1024), 0, st, partial.p, (int)grid.y, (int)grid.x, p, cb,
+    const int nt = (cb + 15) / 16;
+    if (nt == 1)
+      hipLaunchKernelGGL((k_gemm_tn<1>), grid, dim3(256), 0, st, A, rows, p, B, rows, cb, rows, partial.p);
+    else if (nt == 2)
+      hipLaunchKernelGGL((k_gemm_tn<2>), grid, dim3(256), 0, st, A, rows, p, B, rows, cb, rows, partial.p);
+    else
+      fail("internal: panel product with %d columns", cb);
+    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3(grid.x, nt), dim3(1024), 0, st, partial.p, (int)grid.y, (int)grid.x, p, cb,
                        dC, ldc > 0 ? ldc : p);
   }
   void gemm_tn(const double *A, int p, int cb, double *C_host) {
@@ -579,6 +614,10 @@ struct HipSvdBackend : SvdBackend {
   }
   void round_W(int cb) override {
     if (cb <= 0) return;
+    if (spec_rounded) {   // already queued behind the orthonormalisation (column by column: a clipped block is fine)
+      spec_rounded = false;
+      return;
+    }
     Tick tk(this, 5);
     if (!dist) {
       round_cols(Wc, n, cb, mx_valid);
@@ -611,8 +650,9 @@ struct HipSvdBackend : SvdBackend {
   }
 
   // ---- the fused block step (orth_small.hpp) -----------------------------------------------------
-  // arena (doubles): [mx 16] [flag 1 | Rout B2 | ZtZ p cb | QtQ p cb | HG1 (p+cb) cb] [HG2 (p+cb) cb] [C p cb]
-  // [Ct p cb] [Ri B2]; [flag .. QtQ] is downloaded in one piece, [ZtZ .. HG1] is one sum over the ranks
+  // arena (doubles): [mx 16] [flag 1 | Rout B2 | ZtZ p cb | X = (Q'Qb over W'Qb | HG1) (p+cb) 2cb] [HG2 (p+cb) cb]
+  // [C p cb] [Ct p cb] [Ri B2]; [flag .. left half of X] is downloaded in one piece, [ZtZ .. X] is one sum over
+  // the ranks
   static constexpr int B2 = kMaxB * kMaxB;
   void update_W(int p, int cb, const double *C, const double *Ri, unsigned long long *mx) {
     const dim3 rows((unsigned)((nr + 1023) / 1024));
@@ -638,18 +678,21 @@ struct HipSvdBackend : SvdBackend {
       BSN_HIP(hipEventRecord(tev0, st));
     }
     unsigned long long *mx = (unsigned long long *)dorth.p;
+    // X = [Q W]' [Qb W] ((p + cb) x 2 cb, leading dimension p + cb; Qb = the newest basis block, columns
+    // p0 .. p-1 of Q, and W right behind it: contiguous columns): its left half holds the Gram block Q'Qb the
+    // Rayleigh-Ritz step needs, its right half [H; G] of pass 0 — ONE pass over Q for both
     const size_t pc = (size_t)p * cb, hg = (size_t)(p + cb) * cb;
-    double *flag = dorth.p + 16, *dRout = flag + 1, *dZtZ = dRout + B2, *dQtQ = dZtZ + pc, *HG1 = dQtQ + pc,
+    double *flag = dorth.p + 16, *dRout = flag + 1, *dZtZ = dRout + B2, *X = dZtZ + pc, *HG1 = X + (p > 0 ? hg : 0),
            *HG2 = HG1 + hg, *C = HG2 + hg, *Ct = C + pc, *Ri = Ct + pc;
     BSN_HIP(hipMemsetAsync(flag, 0, (size_t)(1 + B2) * 8, st));
     if (p > 0) gemm_tn_any(Z.p, Z.p + (int64_t)p0 * m_local, m_local, p, cb, dZtZ);
     BSN_HIP(hipMemcpyAsync(Wsave.p, Wc, (size_t)nr * cb * 8, hipMemcpyDeviceToDevice, st));
-    if (p > 0) gemm_tn_any(Q.p, Q.p + (int64_t)p0 * nr, nr, p, cb, dQtQ);
     OrthSmall a;
     a.p = p;
     a.cb = cb;
     a.p0 = p0;
-    a.QtQ = p > 0 ? dQtQ : nullptr;
+    a.QtQ = p > 0 ? X : nullptr;
+    a.ldq = p + cb;
     a.M = ws.dM.p;
     a.ldm = kOrthMaxP;
     a.C = C;
@@ -657,13 +700,17 @@ struct HipSvdBackend : SvdBackend {
     a.Ri = Ri;
     a.Rout = dRout;
     a.flag = flag;
-    a.iters = 3;
+    a.iters = op->slices >= 2 ? 2 : 4;   // |Q'Q - I| ~ 2^-8S: its cube (fifth power) is below rounding
     a.Cs = a.Gs = a.Rs = a.Ris = a.Ro = a.Dv = a.tmp = nullptr;
     for (int pass = 0; pass < 2; pass++) {
       double *HG = pass == 0 ? HG1 : HG2;
-      gemm_tn_any(A0, Wc, nr, p + cb, cb, HG, p + cb);   // [Q W]' W: W is columns p .. p+cb-1 of Q
-      if (pass == 0) ar_small(dZtZ, (int64_t)(2 * pc + hg));
-      else ar_small(HG, (int64_t)hg);
+      if (pass == 0 && p > 0) {
+        gemm_tn_any(Q.p, Q.p + (int64_t)p0 * nr, nr, p + cb, 2 * cb, X, p + cb);
+        ar_small(dZtZ, (int64_t)(pc + 2 * hg));
+      } else {
+        gemm_tn_any(A0, Wc, nr, p + cb, cb, HG, p + cb);   // [Q W]' W: W is columns p .. p+cb-1 of Q
+        ar_small(HG, (int64_t)hg);
+      }
       a.pass = pass;
       a.HG = HG;
       // the column maxima of the finished panel feed the rounding; with sample blocks they would have to be
@@ -673,11 +720,28 @@ struct HipSvdBackend : SvdBackend {
       update_W(p, cb, C, Ri, mxp);
     }
     BSN_HIP(hipGetLastError());
-    const size_t nsmall = 1 + B2 + 2 * pc;
+    const size_t nsmall = 1 + B2 + pc + (p > 0 ? hg : 0);
     double *hp = ws.pinned((size_t)(cap + kMaxB + 4) * kMaxB * 4 + 1024);
     BSN_HIP(hipMemcpyAsync(hp, flag, nsmall * 8, hipMemcpyDeviceToHost, st));
     if (timing) BSN_HIP(hipEventRecord(tev1, st));
-    sync_stream();
+    if (with_grams && speculate) {
+      // The host now waits for the small matrices and then runs the Rayleigh-Ritz step; the device would idle
+      // through both.  What the NEXT step starts with — rounding the new block and quantising it for the
+      // crossproduct pass — depends on neither (unless the solve ends here or the panel turns out rank
+      // deficient: then the two small kernels ran for nothing), so it is queued behind the copy and the host
+      // waits for the copy alone.
+      if (!ws.ev_small) BSN_HIP(hipEventCreateWithFlags(&ws.ev_small, hipEventDisableTiming));
+      BSN_HIP(hipEventRecord(ws.ev_small, st));
+      mx_valid = !dist;
+      spec_rounded = false;
+      round_W(cb);
+      op_cprod_prequant(op, dist ? Qfull.p : Wc, n, cb);
+      spec_rounded = true;
+      BSN_HIP(hipEventSynchronize(ws.ev_small));
+      n_sync++;
+    } else {
+      sync_stream();
+    }
     if (timing) {
       float ms = 0;
       BSN_HIP(hipEventElapsedTime(&ms, tev0, tev1));
@@ -687,15 +751,18 @@ struct HipSvdBackend : SvdBackend {
     }
     op_poll_stats(op);
     if (blkZ) std::memcpy(blkZ, hp + 1 + B2, pc * 8);
-    if (blkQ) std::memcpy(blkQ, hp + 1 + B2 + pc, pc * 8);
+    if (blkQ)   // the first p rows of the left half of X (leading dimension p + cb)
+      for (int j = 0; j < cb; j++) std::memcpy(blkQ + (size_t)j * p, hp + 1 + B2 + pc + (size_t)j * (p + cb), (size_t)p * 8);
     if (hp[0] != 0.0) {  // rank deficient or ill conditioned: undo, the driver takes the careful path
       BSN_HIP(hipMemcpyAsync(Wc, Wsave.p, (size_t)nr * cb * 8, hipMemcpyDeviceToDevice, st));
       mx_valid = false;
+      spec_rounded = false;
+      op->preq_X = nullptr;
       return -2;
     }
     Rout.assign((size_t)cb * cb, 0.0);
     for (int t = 0; t < cb * cb; t++) Rout[(size_t)t] = hp[1 + (size_t)t];
-    mx_valid = !dist;
+    mx_valid = spec_rounded ? false : !dist;
     return cb;
   }
   int step_fused(int p, int p0, int cb, double *blkZ, double *blkQ, std::vector<double> &Rout) override {
@@ -892,6 +959,7 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     if (bk.hook && (bk.rank < 0 || bk.rank >= bk.world)) fail("hook_rank %d of %d", bk.rank, bk.world);
     bk.setup_ranks();
     bk.timing = getenv("BSN_TIMING") != nullptr;
+    bk.speculate = getenv("BSN_NO_SPECULATION") == nullptr;
     bk.fused_stats = fused;
     bk.warm_den = o->warm_denominator >= 2 ? o->warm_denominator : 16;
     int64_t dim = bk.n < bk.m_total ? bk.n : bk.m_total;
@@ -915,7 +983,10 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       // k <= 10: 5 steps of 8 = 193 ms against 4 steps of 16 = 208 ms.  The default is chosen for the time to
       // the solution, not for pass throughput.
       const int b1 = std::max(1, std::min(8, 16 / s_tol)), b2 = std::max(b1, std::min(kMaxB, 32 / s_tol));
-      int bb = o->block > 0 ? (o->block > kMaxB ? kMaxB : o->block) : (4 * o->k >= 7 * b1 ? b2 : b1);
+      // (Without the warm start — fewer than 262 144 variants over all ranks — the wide block saves one step of
+      // seven instead of two of six and loses: 50 against 35 ms on a 125 000-variant matrix.)
+      const bool warm_on = o->warm_start >= 0 && bk.m_total / bk.warm_den >= 16384;
+      int bb = o->block > 0 ? (o->block > kMaxB ? kMaxB : o->block) : (4 * o->k >= 7 * b1 && warm_on ? b2 : b1);
       int ss = s_tol;
       if (o->slices <= 0) {
         const int nb = (bb * s_tol + 15) / 16;

@@ -171,7 +171,7 @@ struct HostBackend : SvdBackend {
         Ris((size_t)cb * cb), Rob((size_t)cb * cb), Dv((size_t)cb * cb), tmp((size_t)2 * cb + 4);
     double flag = 0.0;
     OrthSmall a;
-    a.p = p; a.cb = cb; a.p0 = p0; a.QtQ = p > 0 ? blkQ : nullptr; a.M = Mdev.data(); a.ldm = kOrthMaxP;
+    a.p = p; a.cb = cb; a.p0 = p0; a.QtQ = p > 0 ? blkQ : nullptr; a.ldq = p; a.M = Mdev.data(); a.ldm = kOrthMaxP;
     a.C = C.data(); a.Ct = Ct.data(); a.Ri = Ri.data(); a.Rout = Ro.data(); a.flag = &flag; a.iters = 3;
     a.Cs = Cs.data(); a.Gs = Gs.data(); a.Rs = Rs.data(); a.Ris = Ris.data(); a.Ro = Rob.data(); a.Dv = Dv.data(); a.tmp = tmp.data();
     HostCtx cx;
