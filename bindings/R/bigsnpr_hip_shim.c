@@ -2,8 +2,11 @@
  * bigsnpr_hip_shim.c — the `.Call` shim a bigsnpr maintainer adds to bind the reference's
  * R layer to libbigsnpr_hip.so (C ABI: include/bigsnpr_hip.h).
  *
- * NOT compiled in this repository's CI: the build image has no R (no Rinternals.h).  It is
- * deliberately thin — every function only converts SEXP arguments to plain pointers,
+ * The build image has no R.  tests/test_r_shim_cpu.py compiles this file (-Wall -Wextra -Werror) against
+ * declarations of the R API it uses (tests/rstub/include: test infrastructure written from "Writing R
+ * Extensions") and checks its registration table against the reference's; tests/test_gpu_r_shim.py runs
+ * its entry points on a GPU through a small stand-in runtime (tests/rstub/rstub.c) with R-like objects and
+ * compares with the oracle.  It is deliberately thin — every function only converts SEXP arguments to plain pointers,
  * subtracts 1 from R's 1-based indices where the reference does (src/bed-acc.h:64-65) and
  * turns a non-zero return code into Rf_error(bsn_last_error()) — so that all logic is
  * tested through the C ABI by tests/.
@@ -241,7 +244,9 @@ SEXP _bigsnpr_prod_and_rowSumsSq(SEXP obj_bed, SEXP ind_row, SEXP ind_col, SEXP 
  * with the file's size and modification time: an FBM written in place since (imputation,
  * snp_fastImpute) is uploaded again instead of serving stale genotypes. */
 typedef struct fbm_cache {
-  char *path; bsn_bed *img; off_t size; time_t mtime; long mtime_ns; struct fbm_cache *next;
+  char *path; bsn_bed *img; off_t size; time_t mtime; long mtime_ns;
+  double code[256];        /* the decode table the image was built with: G$copy(code = ...) shares the file */
+  struct fbm_cache *next;
 } fbm_cache;
 static fbm_cache *g_fbm = NULL;
 
@@ -258,34 +263,52 @@ static bsn_bed *upload_fbm(const char *bk, int64_t n, int64_t m, const double *c
   if (rc != 0) Rf_error("%s", bsn_last_error());
   return img;
 }
-static bsn_bed *get_image(SEXP obj) {
-  if (!has_field(obj, "code256")) return get_bed(obj);
-  const char *bk = CHAR(STRING_ELT(field(obj, "backingfile"), 0));
-  int64_t n = (int64_t) Rf_asReal(field(obj, "nrow")), m = (int64_t) Rf_asReal(field(obj, "ncol"));
-  SEXP code = PROTECT(field(obj, "code256"));
-  if (TYPEOF(code) != REALSXP || XLENGTH(code) != 256) Rf_error("'code256' must be 256 doubles");
-  const double *code256 = REAL(code);
-  UNPROTECT(1);   /* owned by the FBM object for the duration of the call */
+/* the device image of (backing file, decode table): one per pair — the reference routinely attaches the same
+ * file with several tables (CODE_012 -> CODE_IMPUTE_PRED / CODE_DOSAGE, R/impute.R:149-201; G.round of
+ * R/write-plink.R:35), and a table changes which bytes are missing, imputed or dosages.  A file written in
+ * place since (snp_fastImpute) is uploaded again for every table. */
+static bsn_bed *image_of(const char *bk, int64_t n, int64_t m, const double *code256) {
   struct stat st;
   if (stat(bk, &st) != 0) Rf_error("cannot stat backing file '%s'", bk);
   for (fbm_cache *c = g_fbm; c; c = c->next)
-    if (strcmp(c->path, bk) == 0) {
+    if (strcmp(c->path, bk) == 0 && memcmp(c->code, code256, sizeof(c->code)) == 0) {
       if (c->size == st.st_size && c->mtime == st.st_mtim.tv_sec && c->mtime_ns == st.st_mtim.tv_nsec)
         return c->img;
       bsn_bed_close(c->img);                       /* the file changed under the handle */
+      c->img = NULL;
       c->img = upload_fbm(bk, n, m, code256);
       c->size = st.st_size; c->mtime = st.st_mtim.tv_sec; c->mtime_ns = st.st_mtim.tv_nsec;
       return c->img;
     }
+  bsn_bed *img = upload_fbm(bk, n, m, code256);     /* (an R error here leaves the cache untouched) */
   fbm_cache *c = (fbm_cache *) malloc(sizeof(fbm_cache));
-  c->path = strdup(bk); c->img = upload_fbm(bk, n, m, code256);
+  if (!c) { bsn_bed_close(img); Rf_error("out of memory"); }
+  c->path = strdup(bk); c->img = img;
+  memcpy(c->code, code256, sizeof(c->code));
   c->size = st.st_size; c->mtime = st.st_mtim.tv_sec; c->mtime_ns = st.st_mtim.tv_nsec;
   c->next = g_fbm; g_fbm = c;
   return c->img;
 }
+/* the (n, m, backing file, decode table) of an FBM.code256 object */
+static const double *fbm_fields(SEXP obj, const char **bk, int64_t *n, int64_t *m) {
+  *bk = CHAR(STRING_ELT(field(obj, "backingfile"), 0));
+  *n = (int64_t) Rf_asReal(field(obj, "nrow"));
+  *m = (int64_t) Rf_asReal(field(obj, "ncol"));
+  SEXP code = PROTECT(field(obj, "code256"));
+  if (TYPEOF(code) != REALSXP || XLENGTH(code) != 256) Rf_error("'code256' must be 256 doubles");
+  const double *code256 = REAL(code);
+  UNPROTECT(1);   /* owned by the FBM object for the duration of the call */
+  return code256;
+}
+static bsn_bed *get_image(SEXP obj) {
+  if (!has_field(obj, "code256")) return get_bed(obj);
+  const char *bk; int64_t n, m;
+  const double *code256 = fbm_fields(obj, &bk, &n, &m);
+  return image_of(bk, n, m, code256);
+}
 /* drops every cached FBM image (R: .Call(`_bigsnpr_fbm_cache_clear_hip`)) */
 SEXP _bigsnpr_fbm_cache_clear_hip(void) {
-  while (g_fbm) { fbm_cache *c = g_fbm; g_fbm = c->next; bsn_bed_close(c->img); free(c->path); free(c); }
+  while (g_fbm) { fbm_cache *c = g_fbm; g_fbm = c->next; if (c->img) bsn_bed_close(c->img); free(c->path); free(c); }
   return R_NilValue;
 }
 
@@ -359,7 +382,24 @@ SEXP _bigsnpr_writebina(SEXP filename, SEXP BM, SEXP tab, SEXP rowInd, SEXP colI
   R_xlen_t n = XLENGTH(rowInd), m = XLENGTH(colInd);
   size_t n_byte = ((size_t) n + 3) / 4;
   uint8_t *payload = (uint8_t *) R_alloc(n_byte * (size_t) m, 1);
-  CHECK(bsn_bed_subset_payload(get_image(BM), ind0(rowInd), n, ind0(colInd), m, payload));
+  /* BM is G.round: code256 = replace(round(code), is.na(code), 3) (R/write-plink.R:35) — every entry in
+   * {0, 1, 2, 3} and 3 MEANS missing (`tab` maps it to the .bed code 01).  The library's table convention
+   * writes a missing value as NaN, so the table handed on is G.round's with 3 -> NaN: a 2-bit image. */
+  bsn_bed *img;
+  if (has_field(BM, "code256")) {
+    const char *bk; int64_t fn, fm;
+    const double *code256 = fbm_fields(BM, &bk, &fn, &fm);
+    double *code = (double *) R_alloc(256, sizeof(double));
+    for (int c = 0; c < 256; c++) {
+      if (!(code256[c] == 0 || code256[c] == 1 || code256[c] == 2 || code256[c] == 3))
+        Rf_error("snp_writeBed: the rounded code must hold 0, 1, 2 or 3 (missing) only");
+      code[c] = code256[c] == 3 ? NA_REAL : code256[c];
+    }
+    img = image_of(bk, fn, fm, code);
+  } else {
+    img = get_bed(BM);
+  }
+  CHECK(bsn_bed_subset_payload(img, ind0(rowInd), n, ind0(colInd), m, payload));
   FILE *f = fopen(CHAR(STRING_ELT(filename, 0)), "wb");
   if (!f) Rf_error("cannot open '%s' for writing", CHAR(STRING_ELT(filename, 0)));
   const unsigned char magic[3] = {108, 27, 1};
