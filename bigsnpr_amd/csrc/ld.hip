@@ -349,7 +349,7 @@ __global__ void k_band_fill8(const int32_t *__restrict__ stats, int nslice, cons
                              const double *__restrict__ thr, int mode, const double *__restrict__ v1,
                              const double *__restrict__ v2, double nrows, double *__restrict__ band,
                              const double *__restrict__ cx, const double *__restrict__ cxx, double vstep,
-                             double voff) {
+                             double voff, const double *__restrict__ nna) {
   const int pi = blockIdx.x;
   if (pi >= npairs) return;
   const int2 pr = pairs[pi];
@@ -361,8 +361,143 @@ __global__ void k_band_fill8(const int32_t *__restrict__ stats, int nslice, cons
     double xy = 0;
     for (int s = 0; s < nslice; s++) xy += (double)st[(s * TB + row) * TB + col];
     if (mode == 2) xy = vstep * vstep * xy + voff * (v1[j] + v1[j0]) - nrows * voff * voff;
-    band[j0 * W + (j0 - j - 1)] =
-        pair_value(mode, xy, cx[j0], cxx[j0], cx[j], cxx[j], (int)nrows, thr, v1, v2, j0, j, nrows);
+    double val = pair_value(mode, xy, cx[j0], cxx[j0], cx[j], cxx[j], (int)nrows, thr, v1, v2, j0, j, nrows);
+    // clumping_chr on an FBM with missing values: the reference's xySum is NA (a missing dosage decodes to
+    // NA_real, src/clumping.cpp:66-69), r2 is NA and `r2 > thr` is false
+    if (nna && (nna[j0] > 0 || nna[j] > 0)) val = __longlong_as_double(0x7ff8000000000000LL);
+    band[j0 * W + (j0 - j - 1)] = val;
+  }
+}
+
+// ---- byte image WITH missing values: the six pairwise-complete sums of corMat0 (src/corr.cpp:54-75) --------
+// The reference recodes a missing dosage to 3 and walks the same loop (src/corr.cpp:113-118); here the marker
+// -128 gives the mask plane M (1 = present) and leaves X = k with the marker zeroed; k^2 <= 16 129 does not fit
+// an int8 operand, so it enters as two digit planes k^2 = 128 H + L (0 <= H <= 126, 0 <= L <= 127).  Eight
+// exact int8 products per tile pair, in four groups of two (blockIdx.z) so that a wave's accumulators fit its
+// registers:   0: X.X', M.M'   1: X.M', M.X'   2: H.M', L.M'   3: M.H', M.L'
+// A workgroup's sample range never crosses a 131 072-sample slice (127^2 x 131 072 < 2^31); its int32 sums are
+// added to int64 statistics (exact, order-independent), stats64[pair][8][64][64].
+__device__ __forceinline__ uint32_t val8m_ld(uint32_t w, uint32_t &na) {
+  const uint32_t t = w ^ 0x80808080u;
+  const uint32_t y = (t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+  const uint32_t z = ~(y | t | 0x7F7F7F7Fu);  // 0x80 iff the byte of w is 0x80
+  na = z >> 7;
+  return w & ~(z | (z - na));
+}
+// per-byte k -> (k^2 >> 7, k^2 & 127)
+__device__ __forceinline__ void square8(uint32_t w, uint32_t &h, uint32_t &l) {
+  h = 0;
+  l = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const int k = (int)(int8_t)(w >> (8 * b));
+    const uint32_t sq = (uint32_t)(k * k);
+    h |= (sq >> 7) << (8 * b);
+    l |= (sq & 127u) << (8 * b);
+  }
+}
+struct Planes8 {
+  v4i x, m, h, l;
+};
+template <bool SQ>
+__device__ __forceinline__ Planes8 decode8(uint4 a, uint4 mk) {
+  Planes8 p;
+  uint32_t n0, n1, n2, n3;
+  // samples that are not selected (and the pad samples) count as missing
+  const uint32_t x0 = val8m_ld(a.x, n0) & mk.x, x1 = val8m_ld(a.y, n1) & mk.y, x2 = val8m_ld(a.z, n2) & mk.z,
+                 x3 = val8m_ld(a.w, n3) & mk.w;
+  p.x = v4i{(int)x0, (int)x1, (int)x2, (int)x3};
+  p.m = v4i{(int)((n0 ^ 0x01010101u) & mk.x), (int)((n1 ^ 0x01010101u) & mk.y), (int)((n2 ^ 0x01010101u) & mk.z),
+            (int)((n3 ^ 0x01010101u) & mk.w)};
+  if (SQ) {
+    uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+    square8(x0, h0, l0); square8(x1, h1, l1); square8(x2, h2, l2); square8(x3, h3, l3);
+    p.h = v4i{(int)h0, (int)h1, (int)h2, (int)h3};
+    p.l = v4i{(int)l0, (int)l1, (int)l2, (int)l3};
+  }
+  return p;
+}
+__global__ __launch_bounds__(64) void k_pair_stats8(const uint8_t *__restrict__ img, int64_t pitch,
+                                                    const int32_t *__restrict__ cols,
+                                                    const int2 *__restrict__ pairs,
+                                                    const uint8_t *__restrict__ rowmask, int64_t kbytes_per_split,
+                                                    long long *__restrict__ stats) {
+  const int lane = threadIdx.x, r16 = lane & 15, g = lane >> 4, grp = blockIdx.z;
+  const int2 pr = pairs[blockIdx.x];
+  const uint8_t *pa[4], *pb[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    pa[s] = img + (int64_t)cols[pr.x * TB + s * 16 + r16] * pitch + g * 16;
+    pb[s] = img + (int64_t)cols[pr.y * TB + s * 16 + r16] * pitch + g * 16;
+  }
+  const int64_t b0 = (int64_t)blockIdx.y * kbytes_per_split;
+  int64_t b1 = b0 + kbytes_per_split;
+  if (b1 > pitch) b1 = pitch;
+  if (b0 >= b1) return;
+  v4i acc[2][4][4];
+#pragma unroll
+  for (int q = 0; q < 2; q++)
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[q][i][j] = v4i{0, 0, 0, 0};
+  for (int64_t kb = b0; kb < b1; kb += 64) {  // 64 samples per step
+    const uint4 mk = *(const uint4 *)(rowmask + kb + g * 16);
+    v4i A0[4], A1[4], B0[4], B1[4];   // the two operand planes of this group, per 16-variant sub-tile
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const uint4 a = *(const uint4 *)(pa[s] + kb), b = *(const uint4 *)(pb[s] + kb);
+      if (grp == 0) {
+        const Planes8 A = decode8<false>(a, mk), B = decode8<false>(b, mk);
+        A0[s] = A.x; B0[s] = B.x; A1[s] = A.m; B1[s] = B.m;
+      } else if (grp == 1) {
+        const Planes8 A = decode8<false>(a, mk), B = decode8<false>(b, mk);
+        A0[s] = A.x; B0[s] = B.m; A1[s] = A.m; B1[s] = B.x;
+      } else if (grp == 2) {
+        const Planes8 A = decode8<true>(a, mk), B = decode8<false>(b, mk);
+        A0[s] = A.h; B0[s] = B.m; A1[s] = A.l; B1[s] = B.m;
+      } else {
+        const Planes8 A = decode8<false>(a, mk), B = decode8<true>(b, mk);
+        A0[s] = A.m; B0[s] = B.h; A1[s] = A.m; B1[s] = B.l;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc[0][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0[i], B0[j], acc[0][i][j], 0, 0, 0);
+        acc[1][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A1[i], B1[j], acc[1][i][j], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    unsigned long long *out = (unsigned long long *)stats + ((int64_t)blockIdx.x * 8 + grp * 2 + q) * TB * TB;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          atomicAdd(out + (i * 16 + 4 * g + r) * TB + j * 16 + r16, (unsigned long long)(long long)acc[q][i][j][r]);
+  }
+}
+// band entries from the eight exact sums (mode 0 / 1: Pearson's r is invariant under value = voff + vstep k)
+__global__ void k_band_fill8na(const long long *__restrict__ stats, const int2 *__restrict__ pairs, int npairs,
+                               int64_t m, const int64_t *__restrict__ lo, int64_t W, const double *__restrict__ thr,
+                               int mode, double nrows, double *__restrict__ band) {
+  const int pi = blockIdx.x;
+  if (pi >= npairs) return;
+  const int2 pr = pairs[pi];
+  const long long *st = stats + (int64_t)pi * 8 * TB * TB;
+  for (int e = threadIdx.x; e < TB * TB; e += blockDim.x) {
+    const int row = e / TB, col = e % TB;
+    const int64_t j0 = (int64_t)pr.x * TB + row, j = (int64_t)pr.y * TB + col;
+    if (j0 >= m || j >= j0 || j < lo[j0]) continue;
+    const double xy = (double)st[0 * TB * TB + e], nona = (double)st[1 * TB * TB + e], xs = (double)st[2 * TB * TB + e],
+                 ys = (double)st[3 * TB * TB + e],
+                 xx = 128.0 * (double)st[4 * TB * TB + e] + (double)st[5 * TB * TB + e],
+                 yy = 128.0 * (double)st[6 * TB * TB + e] + (double)st[7 * TB * TB + e];
+    band[j0 * W + (j0 - j - 1)] = pair_value(mode, xy, xs, xx, ys, yy, (int)nona, thr, nullptr, nullptr, j0, j, nrows);
   }
 }
 
@@ -485,7 +620,7 @@ __global__ void k_band_gt_upper(const double *__restrict__ band, const int64_t *
 // what bench.py --workload ld reports: set by every band_run
 struct LdStats {
   double pairs = 0, tile_pairs = 0, stats_ms = 0, launches = 0;
-  int kernel = 0;  // 0: six-product kernel with fused epilogue, 1: six-product + K split, 2: cross product only
+  int kernel = 0;  // 0: six-product kernel with fused epilogue, 1: six-product + K split, 2: cross product only, 3: byte image with missing values (eight products)
 };
 static LdStats g_ld_stats;
 
@@ -498,7 +633,8 @@ struct BandJob {
   DevBuf<int64_t> d_lo;
   DevBuf<uint32_t> d_mask;
   DevBuf<uint8_t> d_mask8;  // byte image: 0xFF per selected sample
-  DevBuf<double> d_band, d_thr, d_v1, d_v2, d_cx, d_cxx;
+  DevBuf<double> d_band, d_thr, d_v1, d_v2, d_cx, d_cxx, d_nna;   // d_nna: byte image, missing values per variant
+  DevBuf<long long> d_stats64;
   bool complete = false;  // no missing value among the selected samples of the selected variants
   bool use_mask = false;
   int64_t npairs = 0;
@@ -578,15 +714,16 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
     stats8(bed, ident ? nullptr : d_rows.p, n, J.d_cols.p, 0, m, d_st.ensure((size_t)3 * m));
     std::vector<long long> st((size_t)3 * m);
     copy_d2h(bed, st.data(), d_st.p, st.size() * 8);
-    std::vector<double> cx((size_t)m), cxx((size_t)m);
+    std::vector<double> cx((size_t)m), cxx((size_t)m), nna((size_t)m);
+    long long na_total = 0;
     for (int64_t j = 0; j < m; j++) {
-      if (st[(size_t)(3 * j + 2)] > 0)
-        fail("windowed LD on a dosage FBM needs data without missing values (variant %lld has %lld among the "
-             "selected samples); impute first", (long long)j, (long long)st[(size_t)(3 * j + 2)]);
+      na_total += st[(size_t)(3 * j + 2)];
+      nna[(size_t)j] = (double)st[(size_t)(3 * j + 2)];
       cx[(size_t)j] = (double)st[(size_t)(3 * j)];
       cxx[(size_t)j] = (double)st[(size_t)(3 * j + 1)];
     }
-    J.complete = true;
+    copy_h2d(bed, J.d_nna.ensure((size_t)m), nna.data(), (size_t)m * 8);
+    J.complete = na_total == 0;
     J.use_mask = true;
     copy_h2d(bed, J.d_cx.ensure((size_t)m), cx.data(), (size_t)m * 8);
     copy_h2d(bed, J.d_cxx.ensure((size_t)m), cxx.data(), (size_t)m * 8);
@@ -660,6 +797,39 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
     const int64_t slice_bytes = 131072;  // samples per int32 accumulator slice
     const int nslice = (int)((bed->pitch + slice_bytes - 1) / slice_bytes);
     if (nslice > 6) fail("windowed LD on a dosage FBM supports at most %lld samples", (long long)(6 * slice_bytes));
+    if (!J.complete && mode != 2) {
+      // missing values among the selected samples: the six pairwise-complete sums (eight int8 products)
+      const int64_t batch8 = 512;   // 512 x 8 x 64 x 64 x 8 B = 134 MB of int64 statistics
+      J.d_stats64.ensure((size_t)std::min(batch8, J.npairs) * 8 * TB * TB);
+      for (int64_t p0 = 0; p0 < J.npairs; p0 += batch8) {
+        const int64_t np = std::min(batch8, J.npairs - p0);
+        // enough workgroups to fill the chip; a split never crosses a 131 072-sample slice
+        int64_t ks = std::max<int64_t>(nslice, std::min<int64_t>(std::max<int64_t>(1, 4096 / (np * 4)), bed->pitch / 256));
+        int64_t kb = round_up((bed->pitch + ks - 1) / ks, 64);
+        if (kb > slice_bytes) kb = slice_bytes;
+        ks = (bed->pitch + kb - 1) / kb;
+        BSN_HIP(hipMemsetAsync(J.d_stats64.p, 0, (size_t)np * 8 * TB * TB * 8, bed->stream));
+        BSN_HIP(hipEventRecord(e0, bed->stream));
+        hipLaunchKernelGGL(k_pair_stats8, dim3((unsigned)np, (unsigned)ks, 4), dim3(64), 0, bed->stream, bed->d_img,
+                           bed->pitch, J.d_cols.p, J.d_pairs.p + p0, J.d_mask8.p, kb, J.d_stats64.p);
+        BSN_HIP(hipGetLastError());
+        BSN_HIP(hipEventRecord(e1, bed->stream));
+        hipLaunchKernelGGL(k_band_fill8na, dim3((unsigned)np), dim3(256), 0, bed->stream, J.d_stats64.p,
+                           J.d_pairs.p + p0, (int)np, J.m, J.d_lo.p, J.W, d_thr, mode, nrows, J.d_band.p);
+        BSN_HIP(hipGetLastError());
+        BSN_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        BSN_HIP(hipEventElapsedTime(&ms, e0, e1));
+        ms_total += ms;
+        ls.launches += 1;
+      }
+      ls.kernel = 3;   // byte image, eight products
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      ls.stats_ms = ms_total;
+      g_ld_stats = ls;
+      return;
+    }
     J.d_stats.ensure((size_t)std::min(batch, J.npairs) * 6 * TB * TB);
     for (int64_t p0 = 0; p0 < J.npairs; p0 += batch) {
       const int64_t np = std::min(batch, J.npairs - p0);
@@ -687,7 +857,7 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
       BSN_HIP(hipEventRecord(e1, bed->stream));
       hipLaunchKernelGGL(k_band_fill8, dim3((unsigned)np), dim3(256), 0, bed->stream, J.d_stats.p, nslice,
                          J.d_pairs.p + p0, (int)np, J.m, J.d_lo.p, J.W, d_thr, mode, d_v1, d_v2, nrows, J.d_band.p,
-                         J.d_cx.p, J.d_cxx.p, bed->v_step, bed->v_off);
+                         J.d_cx.p, J.d_cxx.p, bed->v_step, bed->v_off, J.complete ? (const double *)nullptr : J.d_nna.p);
       BSN_HIP(hipGetLastError());
       BSN_HIP(hipEventSynchronize(e1));
       float ms = 0;

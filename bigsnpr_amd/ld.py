@@ -24,7 +24,7 @@ class FBM_code256:
     (bsn_fbm_open): tables that decode to genotype calls (CODE_012, CODE_IMPUTE_PRED) become the 2-bit
     image and support every snp_* function; tables on a regular grid (CODE_DOSAGE) become a byte image
     that supports snp_colstats / snp_MAF / snp_scale*, big_prodVec / big_cprodVec / snp_PRS,
-    big_randomSVD and — for data without missing values — snp_cor / snp_ld_scores / snp_clumping;
+    big_randomSVD, snp_cor / snp_ld_scores (pairwise complete, like the reference) and snp_clumping;
     anything else is refused by the library."""
 
     def __init__(self, bytes_nm, code=CODE_012):
@@ -131,7 +131,11 @@ def _cor0(obj, ind_row, ind_col, size, alpha, thr_r2, fill_diag, infos_pos):
     # a pair of variants shares at least n - na_x - na_y samples
     from .bed import bed_counts
     if int(_lib.load().bsn_bed_bits(im.handle)) == 8:
-        na = np.zeros(ic.size, dtype=np.int64)    # a byte (dosage) image is only accepted without missing values
+        # a byte (dosage) image keeps no per-variant counts on the host: without missing values every pair has all
+        # n samples; with some, every threshold a pair could reach is evaluated
+        na = np.zeros(ic.size, dtype=np.int64)
+        if getattr(obj, "_has_na", False):
+            na[:] = ir.size // 2
     else:
         na = bed_counts(im, ir, ic)[3].astype(np.int64)
     top2 = np.sort(na)[-2:].sum() if na.size > 1 else int(na.sum())
@@ -346,6 +350,7 @@ def last_stats():
     out = np.zeros(5)
     check(_lib.load().bsn_ld_last_stats(ptr(out, f64p)))
     names = ("k_pair_stats<6 products, fused fp64 epilogue>", "k_pair_stats<6 products, K split> + k_band_fill",
-             "k_pair_xy64 (cross product only: no missing values) + k_band_fill")
+             "k_pair_xy64 (cross product only: no missing values) + k_band_fill",
+             "k_pair_stats8 (dosage bytes with missing values: 8 products) + k_band_fill8na")
     return dict(pairs=out[0], tile_pairs=out[1], stats_ms=out[2], launches=int(out[3]), kernel=names[int(out[4])],
-                products=1 if int(out[4]) == 2 else 6)
+                products={2: 1, 3: 8}.get(int(out[4]), 6))

@@ -215,11 +215,38 @@ def test_dosage_ld_matches_oracle(ba, orc):
     chrom = np.repeat([1, 2], [400, 300])
     for kw in (dict(thr_r2=0.2, infos_pos=pos), dict(thr_r2=0.05, size=20), dict(thr_r2=0.3, infos_pos=pos, ind_row=ir)):
         np.testing.assert_array_equal(ba.snp_clumping(G, chrom, **kw), orc.snp_clumping(Go, chrom, **kw))
-    # missing values: refused with a message (the six pairwise-complete sums need planes the byte image lacks)
-    raw2 = raw.copy()
-    raw2[5, 7] = 3
-    with pytest.raises(ba.BsnError, match="without missing values"):
-        ba.snp_cor(ba.FBM_code256(raw2, ba.CODE_DOSAGE), size=10)
+
+
+def test_dosage_ld_with_missing_values_matches_oracle(ba, orc):
+    """snp_cor / snp_ld_scores on a CODE_DOSAGE FBM WITH missing values: the reference recodes NA to 3 and runs
+    the pairwise-complete loop of corMat0 on any code256 (src/corr.cpp:113-118, src/ld-scores.cpp:92-97); the
+    byte image does it with eight exact int8 products (the marker -128 is the mask plane, k^2 two digit planes)
+    — identical sparsity pattern, x to 1e-9, LD scores to 1e-9.  snp_clumping: a pair with a missing dosage has
+    r2 = NA in the reference (clumping_chr has no missing-value handling) and never prunes."""
+    rng = np.random.default_rng(22)
+    n, m = 1100, 520
+    raw = _dosage_panel(rng, n, m)
+    miss = rng.random((n, m)) < 0.03
+    miss[:, 11] = rng.random(n) < 0.6          # a variant that is mostly missing
+    miss[:, 40] = False                         # and complete ones
+    miss[3, :] = True                           # a sample without data
+    raw[miss] = 3
+    Go, G = orc.FBM256(raw, ba.CODE_DOSAGE), ba.FBM_code256(raw, ba.CODE_DOSAGE)
+    assert G.bits == 8 and G._has_na
+    pos = np.cumsum(rng.integers(1, 3000, size=m)).astype(np.float64)
+    ir = np.sort(rng.choice(n, 700, replace=False))
+    for rows, kw in ((None, dict(size=40, infos_pos=pos)), (ir, dict(size=25, infos_pos=pos, alpha=0.05)),
+                     (None, dict(size=30, thr_r2=0.1))):
+        got = ba.snp_cor(G, ind_row=rows, **kw)
+        ri, rp, rx = orc.snp_cor(Go, ind_row=rows, **kw)
+        np.testing.assert_array_equal(got.p, rp)
+        np.testing.assert_array_equal(got.i, ri)
+        np.testing.assert_allclose(got.x, rx, rtol=0, atol=1e-9, equal_nan=True)
+    assert "8 products" in ba.ld.last_stats()["kernel"]
+    np.testing.assert_allclose(ba.snp_ld_scores(G, size=40, infos_pos=pos),
+                               orc.ld_scores(Go, size=40, infos_pos=pos), rtol=1e-9)
+    np.testing.assert_allclose(ba.snp_ld_scores(G, ind_row=ir, size=25, infos_pos=pos),
+                               orc.ld_scores(Go, ind_row=ir, size=25, infos_pos=pos), rtol=1e-9)
 
 
 def test_default_scaling_of_big_randomsvd_rides_along_the_first_pass(ba, orc, example_bed):
