@@ -246,6 +246,7 @@ static void free_bed(bsn_bed *b) {
   }
   if (b->d_img) (void)hipFree(b->d_img);
   if (b->d_tiled) (void)hipFree(b->d_tiled);
+  if (b->d_lut) (void)hipFree(b->d_lut);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -500,29 +501,50 @@ static void fbm_open(const uint8_t *bytes, int64_t n, int64_t m, int64_t ld, con
     std::vector<int32_t> cnt((size_t)4 * m);
     counts_host(b.get(), nullptr, n, nullptr, m, cnt.data());
   } else {
-    // smallest positive difference between two values as the step, mid-range as the offset
+    // smallest positive difference between two values as the step, mid-range as the offset; the grid is then
+    // SNAPPED to the range (step = range / number of steps): the raw difference of two rounded decimals, e.g.
+    // 0.00999999999999979 for CODE_DOSAGE, would bias every decoded value by up to 4e-14
     double step = 0;
     for (int a = 0; a < 256; a++)
       for (int c = 0; c < 256; c++) {
         const double d = code256[a] - code256[c];
         if (d > 1e-12 * (std::fabs(vmax) + std::fabs(vmin) + 1) && (step == 0 || d < step)) step = d;
       }
-    // values like 0.07 are not exactly k * 0.01 in binary: accept a relative deviation of 1e-9 of a step
-    const double half = std::round((vmax - vmin) / step / 2.0);
-    const double off = vmin + half * step;
+    double off = vmin;
     bool ok = step > 0 && (vmax - vmin) / step <= 254.5;
+    if (ok) {
+      const double nsteps = std::round((vmax - vmin) / step);
+      step = (vmax - vmin) / nsteps;
+      off = vmin + std::round(nsteps / 2.0) * step;
+    }
     for (int c = 0; c < 256 && ok; c++) {
       if (std::isnan(code256[c])) {
         lut[c] = 0x80;
         continue;
       }
-      const double kf = (code256[c] - off) / step, kr = std::round(kf);
-      if (std::fabs(kf - kr) > 1e-9 || kr < -127 || kr > 127) ok = false;
+      // values like 0.07 are not exactly k * 0.01 in binary: the decoded value must reproduce the table entry to
+      // a few units in the last place of the table's range
+      const double kr = std::round((code256[c] - off) / step);
+      if (kr < -127 || kr > 127 || std::fabs(off + step * kr - code256[c]) > 4e-16 * (std::fabs(vmax) + std::fabs(vmin) + step))
+        ok = false;
       lut[c] = (uint8_t)(int8_t)kr;
     }
-    if (!ok)
-      fail("this 'code256' table is not supported on the GPU: its values are neither genotype calls (0, 1, 2, NA) "
-           "nor on a regular grid of at most 255 steps (like CODE_DOSAGE)");
+    if (!ok) {
+      // any other table: the FBM's own bytes + the table, served by the fp64 look-up kernels only
+      for (int c = 0; c < 256; c++) lut[c] = (uint8_t)c;
+      image_alloc(b.get(), n, m, 8);
+      b->generic = true;
+      BSN_HIP(hipMalloc((void **)&b->d_lut, 256 * sizeof(double)));
+      BSN_HIP(hipMemcpy(b->d_lut, code256, 256 * sizeof(double), hipMemcpyHostToDevice));
+      image_from_fbm(b.get(), bytes, ld, lut);
+      // missing values: which codes are NaN, counted per variant on the host from the caller's bytes would
+      // cost a pass; the look-up kernels propagate NaN on their own, so only "some / none" is recorded
+      bool any_nan = false;
+      for (int c = 0; c < 256; c++) any_nan = any_nan || std::isnan(code256[c]);
+      if (!any_nan) b->na_cnt.assign((size_t)m, 0);
+      *out = b.release();
+      return;
+    }
     image_alloc(b.get(), n, m, 8);
     b->v_off = off;
     b->v_step = step;
@@ -672,6 +694,18 @@ static void matvec_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const i
   DevBuf<double> d_in, d_out;
   copy_h2d(bed, d_in.ensure((size_t)nin), x, (size_t)nin * 8);
   d_out.ensure((size_t)nout);
+  if (bed->generic) {   // arbitrary decode table: fp64 look-up kernels
+    const int32_t *rows = op.rows_identity ? nullptr : op.d_rows.p, *cols = op.cols_contig ? nullptr : op.d_cols.p;
+    if (comm) fail("sharded products are not available for a generic decode table");
+    if (transpose)
+      lut_cprod(bed, rows, n, cols, op.col0, m, center ? op.d_center.p : nullptr, scale ? op.d_scale.p : nullptr,
+                d_in.p, d_out.p);
+    else
+      lut_prod(bed, rows, n, cols, op.col0, m, center ? op.d_center.p : nullptr, scale ? op.d_scale.p : nullptr,
+               d_in.p, d_out.p);
+    copy_d2h(bed, out, d_out.p, (size_t)nout * 8);
+    return;
+  }
   if (transpose)
     op_cprod(&op, d_in.p, nin, 1, d_out.p, nout);
   else
@@ -755,6 +789,20 @@ int bsn_snp_colstats(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int6
     // src/colstats.cpp:22-32: no NA handling, denominator n.  The accessor decodes a missing code to
     // NA_real (code256 is passed as is, :14), which poisons the sums of its column: NaN here.
     const double qnan = std::numeric_limits<double>::quiet_NaN();
+    if (bed->generic) {   // arbitrary decode table: sum v and sum v^2 by look-up, src/colstats.cpp:22-32 in fp64
+      bsn_op op;
+      fill_op(&op, bed, ind_row, n, ind_col, m, nullptr, nullptr);
+      DevBuf<double> d_st;
+      lut_colstats(bed, op.rows_identity ? nullptr : op.d_rows.p, n, op.cols_contig ? nullptr : op.d_cols.p, op.col0, m,
+                   d_st.ensure((size_t)2 * m));
+      std::vector<double> st((size_t)2 * m);
+      copy_d2h(bed, st.data(), d_st.p, st.size() * 8);
+      for (int64_t j = 0; j < m; j++) {
+        sumX[j] = st[(size_t)(2 * j)];
+        denoX[j] = st[(size_t)(2 * j + 1)] - st[(size_t)(2 * j)] * st[(size_t)(2 * j)] / n;
+      }
+      return;
+    }
     if (bed->bits == 8) {
       bsn_op op;
       fill_op(&op, bed, ind_row, n, ind_col, m, nullptr, nullptr);

@@ -179,6 +179,12 @@ struct bsn_bed {
   // back to values is applied in fp64 at the end.
   int bits = 2;
   double v_off = 0.0, v_step = 1.0;
+  // bits = 8 and generic: an FBM.code256 whose decode table is neither calls nor a regular grid (any 256
+  // doubles, src/colstats.cpp:13-14).  The image holds the FBM's own bytes and d_lut the table; there is no
+  // exact integer image, so only the fp64 look-up kernels of image.hip serve it (snp_colstats, big_prodVec,
+  // big_cprodVec: VALU-bound, correct, slow) and every other entry point refuses it by name.
+  bool generic = false;
+  double *d_lut = nullptr;
   uint8_t *d_img = nullptr;
   // Second copy of a 2-bit image in the STREAMING layout (image.hip, image_tile): tiles of 64 variants x
   // 256 B (1024 samples), tile (vb, sb) at ((vb * pitch / 256) + sb) * 16 KB, variant v of the block at
@@ -221,6 +227,16 @@ void image_from_fbm(bsn_bed *b, const uint8_t *bytes, int64_t ld, const uint8_t 
 // NULL) or over a row list (with multiplicity); out: 3 x m int64 (S1, S2, nNA)
 void stats8(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t col0, int64_t m,
             long long *d_out);
+// generic decode table (bsn_bed::generic): fp64 look-up kernels.  d_rows / d_cols as above; center / scale may
+// be NULL (0 / 1).  lut_colstats: out 2 x m doubles (sum v, sum v^2 over the selected rows);
+// lut_cprod: z[j] = (sum_i v_ij x_i - c_j sum_i x_i) / s_j;  lut_prod: y[i] = sum_j (v_ij - c_j) x_j / s_j.
+void lut_colstats(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t col0, int64_t m,
+                  double *d_out);
+void lut_cprod(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t col0, int64_t m,
+               const double *d_center, const double *d_scale, const double *d_x, double *d_z);
+void lut_prod(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t col0, int64_t m,
+              const double *d_center, const double *d_scale, const double *d_x, double *d_y);
+void refuse_generic(const bsn_bed *b, const char *what);  // fails with a clear message on a generic image
 void image_generate(bsn_bed *b, uint32_t seed, uint32_t npop, uint32_t na16, int64_t j_begin);
 void image_download(bsn_bed *b, uint8_t *payload_out);
 // counts for variants cols[0..m) (device list or contiguous from col0) over all file rows;

@@ -374,6 +374,7 @@ __global__ __launch_bounds__(256) void k_stats8_rows(const uint8_t *img, int64_t
 }
 void stats8(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t col0, int64_t m,
             long long *d_out) {
+  refuse_generic(b, "this function");
   if (d_rows)
     hipLaunchKernelGGL(k_stats8_rows, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, b->stream, b->d_img, b->pitch,
                        d_rows, n, d_cols, col0, m, d_out);
@@ -381,6 +382,122 @@ void stats8(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols,
     hipLaunchKernelGGL(k_stats8, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, b->stream, b->d_img, b->pitch, d_cols,
                        col0, m, d_out);
   BSN_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// Generic decode table (bsn_bed::generic): value = lut[byte], any 256 doubles (src/colstats.cpp:13-14,
+// R/bigSNP-class.R:7-13).  No integer image exists, so these are plain fp64 kernels: one look-up (LDS), one FMA
+// per genotype — VALU-bound at a fraction of the streaming rate, but no table is refused.  A NaN entry
+// (missing code) propagates like NA_real does through the reference's accessor.
+void refuse_generic(const bsn_bed *b, const char *what) {
+  if (b->generic)
+    fail("%s is not available for this FBM.code256: its decode table is neither genotype calls (0, 1, 2, NA) nor a "
+         "regular grid (like CODE_DOSAGE); snp_colstats / snp_MAF / snp_scale*, big_prodVec and big_cprodVec are",
+         what);
+}
+// one wave per variant: out[2 j] = sum v, out[2 j + 1] = sum v^2 over the selected rows (fixed order)
+__global__ __launch_bounds__(256) void k_lut_colstats(const uint8_t *__restrict__ img, int64_t pitch,
+                                                      const double *__restrict__ lut, const int32_t *rows, int64_t n,
+                                                      const int32_t *cols, int64_t col0, int64_t m, double *out) {
+  __shared__ double sl[256];
+  sl[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= m) return;
+  const uint8_t *row = img + (cols ? (int64_t)cols[j] : col0 + j) * pitch;
+  double s1 = 0, s2 = 0;
+  for (int64_t i = lane; i < n; i += 64) {
+    const double v = sl[row[rows ? rows[i] : i]];
+    s1 += v;
+    s2 += v * v;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_down(s1, off);
+    s2 += __shfl_down(s2, off);
+  }
+  if (lane == 0) {
+    out[2 * j] = s1;
+    out[2 * j + 1] = s2;
+  }
+}
+void lut_colstats(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t col0, int64_t m,
+                  double *d_out) {
+  hipLaunchKernelGGL(k_lut_colstats, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, b->stream, b->d_img, b->pitch,
+                     b->d_lut, d_rows, n, d_cols, col0, m, d_out);
+  BSN_HIP(hipGetLastError());
+}
+// one wave per variant: z[j] = (sum_i v_ij x_i - c_j sum_i x_i) / s_j
+__global__ __launch_bounds__(256) void k_lut_cprod(const uint8_t *__restrict__ img, int64_t pitch,
+                                                   const double *__restrict__ lut, const int32_t *rows, int64_t n,
+                                                   const int32_t *cols, int64_t col0, int64_t m,
+                                                   const double *center, const double *scale,
+                                                   const double *__restrict__ x, double *z) {
+  __shared__ double sl[256];
+  sl[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= m) return;
+  const uint8_t *row = img + (cols ? (int64_t)cols[j] : col0 + j) * pitch;
+  double s = 0, sx = 0;
+  for (int64_t i = lane; i < n; i += 64) {
+    const double xi = x[i];
+    s += sl[row[rows ? rows[i] : i]] * xi;
+    sx += xi;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off);
+    sx += __shfl_down(sx, off);
+  }
+  if (lane == 0) z[j] = (s - (center ? center[j] : 0.0) * sx) / (scale ? scale[j] : 1.0);
+}
+void lut_cprod(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t col0, int64_t m,
+               const double *d_center, const double *d_scale, const double *d_x, double *d_z) {
+  hipLaunchKernelGGL(k_lut_cprod, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, b->stream, b->d_img, b->pitch,
+                     b->d_lut, d_rows, n, d_cols, col0, m, d_center, d_scale, d_x, d_z);
+  BSN_HIP(hipGetLastError());
+}
+// one thread per selected row and slab of variants: part[slab][i] = sum_j (v_ij - c_j) x_j / s_j over the slab
+__global__ __launch_bounds__(256) void k_lut_prod(const uint8_t *__restrict__ img, int64_t pitch,
+                                                  const double *__restrict__ lut, const int32_t *rows, int64_t n,
+                                                  const int32_t *cols, int64_t col0, int64_t m, int64_t per_slab,
+                                                  const double *center, const double *scale,
+                                                  const double *__restrict__ x, double *part) {
+  __shared__ double sl[256];
+  sl[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t ri = rows ? rows[i] : i;
+  const int64_t j0 = (int64_t)blockIdx.y * per_slab, j1 = j0 + per_slab < m ? j0 + per_slab : m;
+  double s = 0;
+  for (int64_t j = j0; j < j1; j++) {
+    const double w = x[j] / (scale ? scale[j] : 1.0);
+    s += (sl[img[(cols ? (int64_t)cols[j] : col0 + j) * pitch + ri]] - (center ? center[j] : 0.0)) * w;
+  }
+  part[(int64_t)blockIdx.y * n + i] = s;
+}
+__global__ void k_lut_prod_sum(const double *part, int nslab, int64_t n, double *y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0;
+  for (int k = 0; k < nslab; k++) s += part[(int64_t)k * n + i];   // slab order: deterministic
+  y[i] = s;
+}
+void lut_prod(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t col0, int64_t m,
+              const double *d_center, const double *d_scale, const double *d_x, double *d_y) {
+  const int64_t wg = (n + 255) / 256;
+  int64_t nslab = std::max<int64_t>(1, std::min<int64_t>(4096 / wg, (m + 63) / 64));
+  const int64_t per = (m + nslab - 1) / nslab;
+  nslab = (m + per - 1) / per;
+  DevBuf<double> part;
+  part.ensure((size_t)nslab * (size_t)n);
+  hipLaunchKernelGGL(k_lut_prod, dim3((unsigned)wg, (unsigned)nslab), dim3(256), 0, b->stream, b->d_img, b->pitch,
+                     b->d_lut, d_rows, n, d_cols, col0, m, per, d_center, d_scale, d_x, part.p);
+  hipLaunchKernelGGL(k_lut_prod_sum, dim3((unsigned)wg), dim3(256), 0, b->stream, part.p, (int)nslab, n, d_y);
+  BSN_HIP(hipGetLastError());
+  BSN_HIP(hipStreamSynchronize(b->stream));   // `part` is released on return
 }
 
 // ---------------------------------------------------------------------------

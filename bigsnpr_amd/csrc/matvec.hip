@@ -1379,6 +1379,7 @@ void op_cprod_prequant(bsn_op *op, const double *d_X, int64_t ldx, int nvec) {
 
 void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z, int64_t ldz) {
   bsn_bed *b = op->bed;
+  refuse_generic(b, "this function (it needs the streaming products)");
   const int S = op->slices;
   const int vmax = 32 / S;  // vectors per launch (NB <= 2)
   if (nvec <= 0) return;
@@ -1578,6 +1579,7 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
                         double *d_Y, int64_t ldy, int mode, uint32_t lutP, uint32_t lutQ, int sub_const,
                         double beta, int S) {
   bsn_bed *b = op->bed;
+  refuse_generic(b, "this function (it needs the streaming products)");
   const int vmax = 32 / S;
   if (nvec <= 0) return;
   op->preq_X = nullptr;

@@ -67,13 +67,18 @@ def snp_fake(n, m):
                          allele1=["A"] * m, allele2=["T"] * m))
 
 
-def _no_missing(G, what):
+def _no_missing(G, what, ind_row=None, ind_col=None):
     """bigstatsr's FBM products have no missing-value handling: a missing code decodes to NA_real and
     turns every result it touches into NA.  Rather than return such a vector (or, worse, a finite one
-    that silently took the value for 0), the GPU path refuses."""
-    if isinstance(G, FBM_code256) and G._has_na:
-        raise ValueError("%s: the FBM has missing values (bigstatsr would return NA); impute first "
-                         "(snp_fastImputeSimple)." % what)
+    that silently took the value for 0), the GPU path refuses — when the SELECTED rows and columns hold a
+    missing value: the reference returns finite results for a complete sub-matrix of an FBM that has missing
+    values elsewhere (callers exclude such columns through ind.col), and so does this."""
+    if not (isinstance(G, FBM_code256) and G._has_na):
+        return
+    # one statistics pass over the selection: a missing value poisons the sums of its column (src/colstats.cpp:14-27)
+    if np.isnan(snp_colstats(G, ind_row, ind_col)["sumX"]).any():
+        raise ValueError("%s: the selected rows and columns of the FBM hold missing values (bigstatsr would return "
+                         "NA); impute first (snp_fastImputeSimple) or exclude them." % what)
 
 
 def _image(obj):
@@ -312,16 +317,16 @@ def big_prodVec(X, y_col, ind_row=None, ind_col=None, center=None, scale=None, n
     """bigstatsr::big_prodVec for an FBM.code256 (external; callers R/PRS.R:5, R/autoSVD.R:129-134):
     ((X[ind.row, ind.col] - center) / scale) %*% y.col, centre / scale defaulting to 0 / 1."""
     from .bed import bed_prodVec
-    _no_missing(X, "big_prodVec")
     im, ir, ic = _ind(X, ind_row, ind_col)
+    _no_missing(X, "big_prodVec", ir, ic)
     return bed_prodVec(im, y_col, ir, ic, center, scale)
 
 
 def big_cprodVec(X, y_row, ind_row=None, ind_col=None, center=None, scale=None, ncores=1):
     """bigstatsr::big_cprodVec: crossprod((X[ind.row, ind.col] - center) / scale, y.row)"""
     from .bed import bed_cprodVec
-    _no_missing(X, "big_cprodVec")
     im, ir, ic = _ind(X, ind_row, ind_col)
+    _no_missing(X, "big_cprodVec", ir, ic)
     return bed_cprodVec(im, y_row, ir, ic, center, scale)
 
 
@@ -332,8 +337,8 @@ def big_randomSVD(X, fun_scaling=None, ind_row=None, ind_col=None, k=10, tol=1e-
     FBM's 2-bit image."""
     from .svd import bed_randomSVD
     from .bed import bed_scaleBinom
-    _no_missing(X, "big_randomSVD")
     im, ir, ic = _ind(X, ind_row, ind_col)
+    _no_missing(X, "big_randomSVD", ir, ic)
     if fun_scaling is None and int(_lib.load().bsn_bed_bits(im.handle)) == 2:
         # the default snp_scaleBinom() on data without missing values is bed_scaleBinom's formula with
         # nb_nona = n (R/binom-scaling.R:62-77 vs :133-142): evaluated inside the solve, its counts ride

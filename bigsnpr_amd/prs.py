@@ -11,8 +11,8 @@ def prodVecRev(G, betas_col, same_col, ind_row, ind_col):
     """R/PRS.R:3-7: big_prodVec(G, (2 * same - 1) * beta, ind.row, ind.col) + 2 * sum(beta[!same]).
     big_prodVec is bigstatsr's unscaled FBM product (external); here the same streaming
     kernel as bed_prodVec with center 0 / scale 1 on the FBM's 2-bit image."""
-    _no_missing(G, "snp_PRS")
     im, ir, ic = _ind(G, ind_row, ind_col)
+    _no_missing(G, "snp_PRS", ir, ic)
     betas_col = as_f64(betas_col)
     same_col = np.asarray(same_col, dtype=bool)
     if ic.size == 0:

@@ -127,8 +127,8 @@ def snp_grid_PRS(G, all_keep, betas, lpS, n_thr_lpS=50, grid_lpS_thr=None, ind_r
     """R/SCT.R:201-262.  Returns a MultiPRS (n x (number of sets * number of thresholds),
     float32 for type = "float", float64 for "double")."""
     from .ld import _no_missing
-    _no_missing(G, "snp_grid_PRS")
     im, ir, _ = _ind(G, ind_row, None)
+    _no_missing(G, "snp_grid_PRS", ir, None)
     betas, lpS = as_f64(np.ravel(betas)), as_f64(np.ravel(lpS))
     assert_lengths(np.arange(im.ncol), betas)
     assert_lengths(np.arange(im.ncol), lpS)

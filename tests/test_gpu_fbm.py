@@ -78,6 +78,18 @@ def test_dosage_with_missing_values(ba, orc):
     _close(st["denoX"][~bad], ref["denoX"][~bad], 1e-9)
     with pytest.raises(ValueError, match="missing values"):
         ba.big_prodVec(G, np.ones(m))
+    # ... for the SELECTION: a complete sub-matrix of an FBM with missing values elsewhere gives finite products,
+    # as bigstatsr does (callers exclude such columns through ind.col)
+    raw_c = raw.copy()
+    raw_c[:, :10][raw_c[:, :10] == 3] = 107          # ten complete variants (a dosage of 1.00) next to the others
+    Gc, Goc = ba.FBM_code256(raw_c, ba.CODE_DOSAGE), orc.FBM256(raw_c, ba.CODE_DOSAGE)
+    good = np.arange(10)
+    xg = rng.normal(size=good.size)
+    assert Gc._has_na
+    _close(ba.big_prodVec(Gc, xg, None, good), orc.fbm_prodVec(Goc, xg, None, good))
+    _close(ba.big_cprodVec(Gc, np.ones(n), None, good), orc.fbm_cprodVec(Goc, np.ones(n), None, good))
+    with pytest.raises(ValueError, match="missing values"):
+        ba.big_prodVec(Gc, np.ones(11), None, np.arange(11))
     # the library itself treats a missing value as "contributes nothing" (mean-imputed after centring),
     # like bedAccScaled (src/bed-acc.h:98-111): checked on every variant that has a value at all
     ok = np.nonzero(~(raw == 3).all(axis=0))[0]
@@ -117,8 +129,7 @@ def test_dosage_prs_and_svd(ba, orc):
 
 
 def test_code_tables(ba, orc, golden_dir, example_bed):
-    """CODE_IMPUTE_PRED (bytes 4-6 are imputed calls) shares the 2-bit image with CODE_012; a table that
-    is neither calls nor a grid is refused"""
+    """CODE_IMPUTE_PRED (bytes 4-6 are imputed calls) shares the 2-bit image with CODE_012"""
     G012 = orc.fbm_from_bed(example_bed)
     raw = G012.bytes.copy()
     flip = np.random.default_rng(0).random(raw.shape) < 0.3
@@ -129,14 +140,54 @@ def test_code_tables(ba, orc, golden_dir, example_bed):
     st = ba.snp_colstats(G)
     np.testing.assert_array_equal(st["sumX"], ref["sumX"])
     np.testing.assert_array_equal(st["denoX"], ref["denoX"])
-    bad = np.full(256, np.nan)
-    bad[:4] = [0.0, 1.0, np.pi, 2.0]
-    with pytest.raises(ba.BsnError, match="not supported on the GPU"):
-        ba.FBM_code256(raw[:50, :50] % 4, bad)
     # what the byte image cannot do says so
     Gd = ba.FBM_code256((raw[:60, :80] % 3 + 7).astype(np.uint8), ba.CODE_DOSAGE)
     with pytest.raises(ba.BsnError, match="2-bit genotype image"):
         ba.bed_counts(Gd._bed)
+
+
+def test_any_decode_table_is_served(ba, orc):
+    """SubBMCode256Acc decodes through ANY 256 doubles (src/colstats.cpp:13-14, R/bigSNP-class.R:7-13).  A table that
+    is neither calls nor a grid has no exact integer image: it takes the fp64 look-up kernels — snp_colstats,
+    big_prodVec, big_cprodVec within 1e-9 of the oracle, rows / columns with replacement, centre / scale — and
+    everything else says by name what it cannot do."""
+    rng = np.random.default_rng(31)
+    n, m = 700, 450
+    code = rng.normal(size=256) * np.exp(rng.normal(size=256))          # an arbitrary table, no missing code
+    raw = rng.integers(0, 256, size=(n, m)).astype(np.uint8)
+    Go, G = orc.FBM256(raw, code), ba.FBM_code256(raw, code)
+    assert G.bits == 8 and not G._has_na
+    st, ref = ba.snp_colstats(G), orc.snp_colstats(Go)
+    np.testing.assert_allclose(st["sumX"], ref["sumX"], rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(st["denoX"], ref["denoX"], rtol=1e-9)
+    ir, ic = rng.choice(n, 500, replace=True), rng.choice(m, 600, replace=True)
+    st, ref = ba.snp_colstats(G, ir, ic), orc.snp_colstats(Go, ir, ic)
+    np.testing.assert_allclose(st["sumX"], ref["sumX"], rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(st["denoX"], ref["denoX"], rtol=1e-9)
+    x, y = rng.normal(size=ic.size), rng.normal(size=ir.size)
+    _close(ba.big_prodVec(G, x, ir, ic), orc.fbm_prodVec(Go, x, ir, ic))
+    _close(ba.big_cprodVec(G, y, ir, ic), orc.fbm_cprodVec(Go, y, ir, ic))
+    xf, yf = rng.normal(size=m), rng.normal(size=n)
+    _close(ba.big_prodVec(G, xf), orc.fbm_prodVec(Go, xf))
+    _close(ba.big_cprodVec(G, yf), orc.fbm_cprodVec(Go, yf))
+    c, s_ = rng.normal(size=ic.size), rng.uniform(0.5, 2, size=ic.size)
+    _close(ba.big_prodVec(G, x, ir, ic, c, s_), orc.fbm_prodVec(Go, x / s_, ir, ic) - np.sum(c * x / s_))
+    _close(ba.big_cprodVec(G, y, ir, ic, c, s_), (orc.fbm_cprodVec(Go, y, ir, ic) - c * y.sum()) / s_)
+    # run-to-run identical (fixed summation order)
+    np.testing.assert_array_equal(ba.big_prodVec(G, xf), ba.big_prodVec(G, xf))
+    # a table with a missing code: NA_real poisons the sums of the columns that hold it, like the reference's accessor
+    code2 = code.copy()
+    code2[200:] = np.nan
+    G2, Go2 = ba.FBM_code256(raw, code2), orc.FBM256(raw, code2)
+    st, ref = ba.snp_colstats(G2), orc.snp_colstats(Go2)
+    assert np.array_equal(np.isnan(st["sumX"]), np.isnan(ref["sumX"])) and np.isnan(ref["sumX"]).any()
+    ok = ~np.isnan(ref["sumX"])
+    np.testing.assert_allclose(st["sumX"][ok], ref["sumX"][ok], rtol=1e-10, atol=1e-9)
+    # what the look-up image cannot do says so
+    for fn in (lambda: ba.snp_cor(G, size=10), lambda: ba.big_randomSVD(G, k=3),
+               lambda: ba.snp_ld_scores(G, size=10)):
+        with pytest.raises(ba.BsnError, match="neither genotype calls"):
+            fn()
 
 
 def test_fbm_products_on_calls_with_replacement(ba, orc, example_bed):
