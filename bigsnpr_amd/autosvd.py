@@ -119,8 +119,8 @@ def medcouple(x):
     med = np.median(x)
     up = x[x >= med] - med          # zi+ >= 0, ascending
     lo = (med - x[x <= med])[::-1]  # zj- >= 0 ... as positive distances, ascending
-    if up[-1] == 0 or lo[-1] == 0:
-        return 0.0 if up[-1] == lo[-1] else (1.0 if lo[-1] == 0 else -1.0)
+    if up[-1] == 0 and lo[-1] == 0:      # all values equal
+        return 0.0
     upp, lop = up[up > 0], lo[lo > 0]
     k0 = int(np.sum(up == 0))       # number of values tied at the median (the same on both sides)
     # kernel values of the pairs that involve a tie, as explicit lists (few):

@@ -687,3 +687,51 @@ def prod_and_rowSumsSq2(G, ind_row, ind_col, center, scale, V):
     X = G.code256[G.bytes[np.ix_(ir, ic)]]
     X = (X - _f64(center)[None, :]) / _f64(scale)[None, :]
     return X @ np.asarray(V, dtype=np.float64), (X * X).sum(1)
+
+
+# ---- GWAS step of the reference's PRS test (external to the path, needed to use its golden files) ----------
+def univ_logreg(G, y01, covar, ind_col=None, tol=1e-10, maxiter=50):
+    """bigstatsr::big_univLogReg (EXTERNAL to the reference tree; tests/testthat/test-6-PRS.R:19-22 calls it):
+    for every variant j the maximum-likelihood logistic regression y ~ 1 + covar + G[, j]; returns the
+    coefficient of the variant (`estim`), its standard error from the inverse Fisher information
+    (`std.err`), the Wald statistic `score` = estim / std.err and the two-sided normal p-value, which is what
+    predict(gwas, log10 = FALSE) reports.  The MLE is unique (Newton / IRLS from the covariates-only fit),
+    so this restatement of the published definition is pinned by the reference's own pval.rds."""
+    from scipy.stats import norm
+    ic = np.arange(G.m) if ind_col is None else np.asarray(ind_col)
+    dec = G.code256[G.bytes[:, ic]]                                   # n x m decoded genotypes
+    y = np.asarray(y01, dtype=np.float64)
+    n = y.size
+    X0 = np.column_stack([np.ones(n), np.asarray(covar, dtype=np.float64)])
+    p0 = X0.shape[1]
+    b0 = np.zeros(p0)                                                 # the null model: covariates only
+    for _ in range(100):
+        mu = 1.0 / (1.0 + np.exp(-(X0 @ b0)))
+        step = np.linalg.solve(X0.T @ (X0 * (mu * (1 - mu))[:, None]), X0.T @ (y - mu))
+        b0 += step
+        if np.abs(step).max() < 1e-12:
+            break
+    estim, se = np.empty(ic.size), np.empty(ic.size)
+    for j0 in range(0, ic.size, 256):
+        g = dec[:, j0:j0 + 256]                                       # n x B
+        B = g.shape[1]
+        X = np.concatenate([np.broadcast_to(X0[:, None, :], (n, B, p0)), g[:, :, None]], axis=2)   # n x B x p
+        beta = np.concatenate([np.broadcast_to(b0, (B, p0)), np.zeros((B, 1))], axis=1)            # B x p
+        for _ in range(maxiter):
+            eta = np.einsum("nbp,bp->nb", X, beta)
+            mu = 1.0 / (1.0 + np.exp(-eta))
+            w = mu * (1 - mu)
+            H = np.einsum("nbp,nb,nbq->bpq", X, w, X)
+            grad = np.einsum("nbp,nb->bp", X, y[:, None] - mu)
+            step = np.linalg.solve(H, grad[:, :, None])[:, :, 0]
+            beta = beta + step
+            if np.abs(step).max() < tol:
+                break
+        eta = np.einsum("nbp,bp->nb", X, beta)
+        mu = 1.0 / (1.0 + np.exp(-eta))
+        H = np.einsum("nbp,nb,nbq->bpq", X, mu * (1 - mu), X)
+        cov = np.linalg.inv(H)
+        estim[j0:j0 + B] = beta[:, -1]
+        se[j0:j0 + B] = np.sqrt(cov[:, -1, -1])
+    score = estim / se
+    return dict(estim=estim, std_err=se, score=score, pval=2.0 * norm.sf(np.abs(score)))

@@ -149,3 +149,31 @@ def test_rollmean_invariants():
         np.testing.assert_allclose(A.rollmean(np.full(100, 2.5), size), 2.5, rtol=1e-15)
     r = np.random.default_rng(0).normal(size=100)
     assert A.rollmean(r, 0) is r or np.array_equal(A.rollmean(r, 0), r)
+
+
+def test_two_independent_restatements_agree():
+    """bigutilsr is not in the reference tree: the product's restatements (bigsnpr_amd/autosvd.py: bisection medcouple,
+    convolution rolling mean, vectorised OGK) and the oracle's (oracle/autosvd_oracle.py: all-pairs medcouple, direct
+    sums, loop-by-loop OGK), written independently from the published definitions, must give the same numbers —
+    and the same intervals as the reference's getIntervals (R/autoSVD.R:4-12, which IS in the tree)."""
+    from bigsnpr_amd import autosvd as prod
+    from oracle import autosvd_oracle as orc_a
+    rng = np.random.default_rng(12)
+    for n in (3, 4, 7, 50, 301):
+        for x in (rng.normal(size=n), rng.exponential(size=n), np.round(rng.normal(size=n), 1),   # ties, also at the median
+                  np.r_[np.zeros(n // 2 + 1), rng.normal(size=n // 2)]):
+            assert abs(prod.medcouple(x) - orc_a.medcouple(x)) < 1e-12, (n, x[:5])
+    for n, size in ((40, 3), (200, 50), (200, 7.9), (30, 0), (12, 5)):
+        x = rng.normal(size=n)
+        np.testing.assert_allclose(prod.rollmean(x, size), orc_a.rollmean(x, size), rtol=1e-12, atol=1e-14)
+    for m, k in ((300, 3), (500, 10), (120, 1)):
+        U = rng.normal(size=(m, k)) * rng.uniform(0.5, 3, size=k)
+        U[:7] += 6.0                                              # a few outliers
+        np.testing.assert_allclose(prod.dist_ogk(U), orc_a.dist_ogk(U), rtol=1e-9)
+    for alpha in (0.05, 0.999, 1e-4):
+        x = rng.exponential(size=400)
+        assert abs(prod.tukey_mc_up(x, alpha=alpha) - orc_a.tukey_mc_up(x, alpha=alpha)) < 1e-10
+    for x, n in (([1, 2, 3, 7, 8, 12, 13, 14, 15], 2), ([1, 2, 3, 7, 8, 12, 13, 14, 15], 3), ([5], 2), ([4, 9], 1),
+                 (list(range(10, 40)) + [50, 51], 20), ([2, 3], 2)):
+        got = [tuple(r) for r in prod.getIntervals(np.asarray(x), n=n).tolist()]
+        assert got == orc_a.get_intervals(x, n=n), (x, n)

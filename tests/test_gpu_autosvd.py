@@ -95,25 +95,24 @@ def test_mac_maf_thresholds(env):
             assert np.all(info["maf"][ind] >= min_maf) and np.all(info["mac"][ind] >= min_mac)
 
 
-def test_subset_identical_to_the_loop_run_on_oracle_components(env, orc, example_bed):
-    """`attr(, "subset")` is an integer output.  Its host loop (MAF filter -> clumping -> SVD rounds with outlier
-    removal, R/autoSVD.R:95-186) is the same Python whatever computes the pieces, so the GPU pieces are pinned by
-    running the identical loop on the CPU oracle's pieces — dense SVD, oracle clumping, oracle MAF — and asking for
-    the same kept variants and long-range-LD table.  (The outlier statistics themselves restate bigutilsr and stay
-    unpinned against the reference; a tight solve keeps borderline variants from flipping on the last
-    digits of the singular vectors.)"""
+def test_subset_identical_to_the_oracle_loop_on_oracle_components(env, orc, example_bed):
+    """`attr(, "subset")` is an integer output.  The product's snp_autoSVD (its own loop, bigsnpr_amd/autosvd.py, on
+    GPU pieces) must keep the same variants and report the same long-range-LD table as the ORACLE's loop
+    (oracle/autosvd_oracle.py: R/autoSVD.R:95-186 restated independently, with its own plain restatements of the three
+    bigutilsr functions) run on the oracle's pieces — dense SVD, oracle clumping, oracle MAF.  Nothing is compared
+    with itself any more.  (bigutilsr itself is not in the reference tree: against it both stay unpinned, DESIGN.md §6;
+    a tight solve keeps borderline variants from flipping on the last digits of the singular vectors.)"""
     ba, gb, G, CHR, POS, POS2 = env
-    from bigsnpr_amd import autosvd
+    from oracle import autosvd_oracle as ao
     Go = orc.fbm_from_bed(example_bed)
     n, m, k = Go.n, Go.m, 10
     for kw in (dict(), dict(roll_size=0, alpha_tukey=0.999), dict(infos_pos=POS, roll_size=0, alpha_tukey=0.9999,
                                                                   int_min_size=0, max_iter=3)):
         kw = dict(kw)
-        infos_pos = kw.pop("infos_pos", None)
+        infos_pos = kw.get("infos_pos")
         thr_r2, size = 0.2, 500.0
         st = orc.snp_colstats(Go)
-        maf = np.minimum(st["sumX"] / (2.0 * n), 1 - st["sumX"] / (2.0 * n))
-        maf_nok = (maf < max(0.02, 10 / (2.0 * n)), 10, 0.02, "MAF")
+        maf = np.minimum(st["sumX"] / (2.0 * n), 1 - st["sumX"] / (2.0 * n))      # snp_MAF, R/binom-scaling.R:94-106
 
         def svd_cpu(keep):
             res = orc.dense_svd(example_bed, None, keep, k=k)
@@ -122,16 +121,21 @@ def test_subset_identical_to_the_loop_run_on_oracle_components(env, orc, example
         def clump_cpu(excl):
             return orc.snp_clumping(Go, CHR, exclude=excl, thr_r2=thr_r2, size=size, infos_pos=infos_pos)
 
-        ref = autosvd._auto_svd(svd_cpu, clump_cpu, maf_nok, np.arange(m), CHR, infos_pos, thr_r2, k,
-                                kw.get("roll_size", 50), kw.get("int_min_size", 20), kw.get("alpha_tukey", 0.05),
-                                kw.get("max_iter", 5), False, m)
-        got = autosvd._auto_svd(lambda keep: ba.big_randomSVD(G, None, ind_col=keep, k=k, tol=1e-10, slices=7),
-                                lambda excl: ba.snp_clumping(G, CHR, exclude=excl, thr_r2=thr_r2, size=size,
-                                                             infos_pos=infos_pos),
-                                (ba.snp_MAF(G) < max(0.02, 10 / (2.0 * n)), 10, 0.02, "MAF"), np.arange(m), CHR,
-                                infos_pos, thr_r2, k, kw.get("roll_size", 50), kw.get("int_min_size", 20),
-                                kw.get("alpha_tukey", 0.05), kw.get("max_iter", 5), False, m)
-        np.testing.assert_array_equal(got["subset"], ref["subset"])
-        for key in ("Chr", "Start", "Stop", "Iter"):
-            np.testing.assert_array_equal(got["lrldr"][key], ref["lrldr"][key])
-        np.testing.assert_allclose(got["d"], ref["d"], rtol=1e-7)
+        ref_svd, ref_subset, ref_lrldr = ao.auto_svd_loop(
+            svd_cpu, clump_cpu, maf, n, np.arange(m), CHR, infos_pos=infos_pos, thr_r2=thr_r2, k=k,
+            roll_size=kw.get("roll_size", 50), int_min_size=kw.get("int_min_size", 20),
+            alpha_tukey=kw.get("alpha_tukey", 0.05), max_iter=kw.get("max_iter", 5), n_all_cols=m)
+
+        import bigsnpr_amd.autosvd as prod
+        orig = prod.big_randomSVD
+        prod.big_randomSVD = lambda *a_, **k_: orig(*a_, tol=1e-10, slices=7, **k_)    # the tight solve
+        try:
+            got = ba.snp_autoSVD(G, CHR, infos_pos, thr_r2=thr_r2, size=size, k=k, verbose=False,
+                                 **{key: v for key, v in kw.items() if key != "infos_pos"})
+        finally:
+            prod.big_randomSVD = orig
+        np.testing.assert_array_equal(got["subset"], ref_subset)
+        assert len(got["lrldr"]["Chr"]) == len(ref_lrldr)
+        for r, row in enumerate(ref_lrldr):
+            assert (got["lrldr"]["Chr"][r], got["lrldr"]["Start"][r], got["lrldr"]["Stop"][r], got["lrldr"]["Iter"][r]) == row
+        np.testing.assert_allclose(got["d"], ref_svd["d"], rtol=1e-7)

@@ -1,0 +1,1 @@
+cd "$GRAFT_REPO_ROOT"; timeout 900 python -m pytest tests/test_gpu_autosvd.py -x -q 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -30
