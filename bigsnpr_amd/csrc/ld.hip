@@ -102,7 +102,10 @@ struct BandOut {
 // FUSE: the whole sample range is in this workgroup (no K split), so the six sums of a pair sit in
 // one lane's accumulators and the fp64 epilogue runs right here: the band entry is written, the
 // int32 statistics never leave the registers.
-template <bool ALL, bool FUSE>
+// CONTIG: the variants of a tile lie within 2 GB of its first one (a contiguous ind.col): the genotype loads are
+// buffer loads with one scalar descriptor per operand tile and a 32-bit lane offset instead of four 64-bit lane
+// addresses — the four registers that decide between two and three waves per SIMD (168 registers).
+template <bool ALL, bool FUSE, bool CONTIG = false>
 __global__ __launch_bounds__(256) void k_pair_stats(const uint8_t *__restrict__ img, int64_t pitch,
                                                     const int32_t *__restrict__ cols,
                                                     const int2 *__restrict__ pairs,
@@ -114,11 +117,19 @@ __global__ __launch_bounds__(256) void k_pair_stats(const uint8_t *__restrict__ 
   const int wr = wave >> 1, wc = wave & 1;
   const int2 pr = pairs[blockIdx.x];
   const uint8_t *pa[2], *pb[2];
+  uint32_t va[2], vb[2];
+  const int64_t ca0 = cols[pr.x * TB], cb0 = cols[pr.y * TB];
 #pragma unroll
   for (int s = 0; s < 2; s++) {
-    pa[s] = img + (int64_t)cols[pr.x * TB + wr * 32 + s * 16 + r16] * pitch + g * 16;
-    pb[s] = img + (int64_t)cols[pr.y * TB + wc * 32 + s * 16 + r16] * pitch + g * 16;
+    const int64_t ca = cols[pr.x * TB + wr * 32 + s * 16 + r16], cb = cols[pr.y * TB + wc * 32 + s * 16 + r16];
+    pa[s] = img + ca * pitch + g * 16;
+    pb[s] = img + cb * pitch + g * 16;
+    va[s] = (uint32_t)((ca - ca0) * pitch + g * 16);
+    vb[s] = (uint32_t)((cb - cb0) * pitch + g * 16);
   }
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(img + ca0 * pitch), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)(img + cb0 * pitch), 0, 0x7fffffff, 0x00020000);
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
   int64_t b0 = (int64_t)blockIdx.y * kbytes_per_split, b1 = b0 + kbytes_per_split;
   if (b1 > pitch) b1 = pitch;
 
@@ -135,8 +146,15 @@ __global__ __launch_bounds__(256) void k_pair_stats(const uint8_t *__restrict__ 
     uint4 a[2], b[2];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-      a[s] = *(const uint4 *)(pa[s] + kb);
-      b[s] = *(const uint4 *)(pb[s] + kb);
+      if constexpr (CONTIG) {
+        const v4u x = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)va[s], (int)kb, 0);
+        const v4u y = __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)vb[s], (int)kb, 0);
+        a[s] = uint4{x.x, x.y, x.z, x.w};
+        b[s] = uint4{y.x, y.y, y.z, y.w};
+      } else {
+        a[s] = *(const uint4 *)(pa[s] + kb);
+        b[s] = *(const uint4 *)(pb[s] + kb);
+      }
     }
     uint4 mk = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     if (rowmask) mk = *(const uint4 *)((const uint8_t *)rowmask + kb + g * 16);
@@ -169,20 +187,29 @@ __global__ __launch_bounds__(256) void k_pair_stats(const uint8_t *__restrict__ 
     }
   }
   if constexpr (FUSE && ALL) {
+    // The sixteen pairs of a lane go through the fp64 epilogue ONE AT A TIME in a rolled loop: their sums are
+    // parked in a run-time-indexed private array (scratch memory, written once, read once).  Unrolled, the
+    // sixteen inlined epilogues raised the register allocation of the WHOLE kernel from 168 to 224 — two waves
+    // per SIMD instead of three for the MFMA loop, which is where the time goes.
+    int32_t st[16][6];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
       for (int j = 0; j < 2; j++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int row = wr * 32 + i * 16 + 4 * g + r, col = wc * 32 + j * 16 + r16;
-          const int64_t j0 = (int64_t)pr.x * TB + row, jj = (int64_t)pr.y * TB + col;
-          if (j0 >= bo.m || jj >= j0 || jj < bo.lo[j0]) continue;
-          bo.band[j0 * bo.W + (j0 - jj - 1)] =
-              pair_value(bo.mode, (double)acc[i][j][0][r], (double)acc[i][j][1][r], (double)acc[i][j][2][r],
-                         (double)acc[i][j][3][r], (double)acc[i][j][4][r], acc[i][j][5][r], bo.thr, bo.v1, bo.v2,
-                         j0, jj, bo.nrows);
-        }
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int p = 0; p < 6; p++) st[(i * 2 + j) * 4 + r][p] = acc[i][j][p][r];
+#pragma unroll 1
+    for (int e = 0; e < 16; e++) {
+      const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
+      const int row = wr * 32 + i * 16 + 4 * g + r, col = wc * 32 + j * 16 + r16;
+      const int64_t j0 = (int64_t)pr.x * TB + row, jj = (int64_t)pr.y * TB + col;
+      if (j0 >= bo.m || jj >= j0 || jj < bo.lo[j0]) continue;
+      bo.band[j0 * bo.W + (j0 - jj - 1)] =
+          pair_value(bo.mode, (double)st[e][0], (double)st[e][1], (double)st[e][2], (double)st[e][3], (double)st[e][4],
+                     st[e][5], bo.thr, bo.v1, bo.v2, j0, jj, bo.nrows);
+    }
     return;
   }
   int32_t *out = stats + (int64_t)blockIdx.x * 6 * TB * TB;
@@ -637,6 +664,7 @@ struct BandJob {
   DevBuf<long long> d_stats64;
   bool complete = false;  // no missing value among the selected samples of the selected variants
   bool use_mask = false;
+  bool contig = false;    // every tile's variants lie within 2 GB of its first one, in ascending order
   int64_t npairs = 0;
 };
 
@@ -695,6 +723,12 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
     cols[(size_t)j] = (int32_t)c;
   }
   copy_h2d(bed, J.d_cols.ensure((size_t)m_pad), cols.data(), (size_t)m_pad * 4);
+  J.contig = true;
+  for (int64_t t = 0; t < mt && J.contig; t++)
+    for (int64_t j = t * TB; j < (t + 1) * TB; j++) {
+      const int64_t d = (int64_t)cols[(size_t)j] - cols[(size_t)(t * TB)];
+      if (d < 0 || (d + 1) * bed->pitch >= ((int64_t)1 << 31)) J.contig = false;
+    }
   if (bed->bits == 8) {
     // byte image: byte mask of the selected samples, per-variant totals of the grid indices over them
     std::vector<uint8_t> mask((size_t)bed->pitch, 0);
@@ -880,7 +914,7 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
     if (ksplit < 1) ksplit = 1;
     int64_t kbytes = round_up((bed->pitch + ksplit - 1) / ksplit, 64);
     ksplit = (int)((bed->pitch + kbytes - 1) / kbytes);
-    const bool fused = !xy_only && ksplit == 1;
+    const bool fused = !xy_only && ksplit == 1 && !getenv("BSN_LD_NOFUSE");   // (A/B switch: K split + k_band_fill)
     if (!fused) {
       J.d_stats.ensure((size_t)std::min(batch, J.npairs) * 6 * TB * TB);
       if (ksplit > 1 || xy_only) BSN_HIP(hipMemsetAsync(J.d_stats.p, 0, (size_t)np * 6 * TB * TB * 4, bed->stream));
@@ -896,9 +930,14 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
                          bed->pitch, J.d_cols.p, J.d_pairs.p + p0, J.d_mask.p, kb4, J.d_stats.p);
       ls.kernel = 2;
     } else if (fused) {
-      hipLaunchKernelGGL((k_pair_stats<true, true>), dim3((unsigned)np, 1), dim3(256), 0, bed->stream,
-                         bed->d_img, bed->pitch, J.d_cols.p, J.d_pairs.p + p0,
-                         J.use_mask ? J.d_mask.p : nullptr, kbytes, (int32_t *)nullptr, 0, bo);
+      if (J.contig)
+        hipLaunchKernelGGL((k_pair_stats<true, true, true>), dim3((unsigned)np, 1), dim3(256), 0, bed->stream,
+                           bed->d_img, bed->pitch, J.d_cols.p, J.d_pairs.p + p0,
+                           J.use_mask ? J.d_mask.p : nullptr, kbytes, (int32_t *)nullptr, 0, bo);
+      else
+        hipLaunchKernelGGL((k_pair_stats<true, true>), dim3((unsigned)np, 1), dim3(256), 0, bed->stream,
+                           bed->d_img, bed->pitch, J.d_cols.p, J.d_pairs.p + p0,
+                           J.use_mask ? J.d_mask.p : nullptr, kbytes, (int32_t *)nullptr, 0, bo);
       ls.kernel = 0;
     } else {
       hipLaunchKernelGGL((k_pair_stats<true, false>), dim3((unsigned)np, (unsigned)ksplit), dim3(256), 0, bed->stream,

@@ -13,7 +13,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "bigsnpr_amd", "csrc", "matvec.hip")
+SRC = os.path.join(ROOT, "bigsnpr_amd", "csrc", os.environ.get("ISA_SRC", "matvec.hip"))
 
 
 def main():
