@@ -234,6 +234,26 @@ def _args(obj_bed, ind_row, ind_col):
     return ir, ic
 
 
+def _lazy_ind(obj_bed, name, ind, limit):
+    """(pointer, length) of an index list for the C ABI; `None` (the R default rows_along / cols_along) goes down
+    as a NULL pointer, which every entry point reads as "the leading `length` ones": no 8 m-byte list is built,
+    uploaded or scanned for a call over the whole matrix"""
+    if ind is None:
+        return None, int(limit)
+    a = _check_ind(name, ind, limit)
+    return a, a.size
+
+
+def _center_scale_lazy(center, scale, m):
+    """centre / scale for the C ABI: `None` (R default rep(0, m) / rep(1, m)) goes down as NULL"""
+    c = None if center is None else as_f64(np.ravel(center))
+    s = None if scale is None else as_f64(np.ravel(scale))
+    for v in (c, s):
+        if v is not None and v.size != m:
+            raise ValueError(ERROR_DIM)
+    return c, s
+
+
 def _center_scale(center, scale, ic):
     center = np.zeros(ic.size) if center is None else as_f64(np.ravel(center))
     scale = np.ones(ic.size) if scale is None else as_f64(np.ravel(scale))
@@ -246,32 +266,36 @@ def bed_prodVec(obj_bed, y_col, ind_row=None, ind_col=None, center=None, scale=N
     """R/bed-mult-vec.R:58-75 -> bed_pMatVec4.  ``ncores`` is accepted and ignored.  ``comm`` (a
     bigsnpr_amd.Comm, not in the reference): this rank holds a shard of the columns; every rank gets the product
     with the whole matrix (bsn_bed_prodvec_sharded)."""
-    ir, ic = _args(obj_bed, ind_row, ind_col)
+    assert_bed(obj_bed)
+    ir, n = _lazy_ind(obj_bed, "ind.row", ind_row, obj_bed.nrow)
+    ic, m = _lazy_ind(obj_bed, "ind.col", ind_col, obj_bed.ncol)
     y_col = as_f64(np.ravel(y_col))
-    assert_lengths(y_col, ic)
-    center, scale = _center_scale(center, scale, ic)
-    out = np.empty(ir.size)
+    if y_col.size != m:
+        raise ValueError(ERROR_DIM)
+    center, scale = _center_scale_lazy(center, scale, m)
+    out = np.empty(n)
     if comm is not None:
-        check(_lib.load().bsn_bed_prodvec_sharded(obj_bed.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p), ic.size,
+        check(_lib.load().bsn_bed_prodvec_sharded(obj_bed.handle, ptr(ir, i64p), n, ptr(ic, i64p), m,
                                                   ptr(center, f64p), ptr(scale, f64p), ptr(y_col, f64p),
                                                   comm.handle, ptr(out, f64p)))
         return out
-    check(_lib.load().bsn_bed_prodvec(obj_bed.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p),
-                                      ic.size, ptr(center, f64p), ptr(scale, f64p),
-                                      ptr(y_col, f64p), ptr(out, f64p)))
+    check(_lib.load().bsn_bed_prodvec(obj_bed.handle, ptr(ir, i64p), n, ptr(ic, i64p), m, ptr(center, f64p),
+                                      ptr(scale, f64p), ptr(y_col, f64p), ptr(out, f64p)))
     return out
 
 
 def bed_cprodVec(obj_bed, y_row, ind_row=None, ind_col=None, center=None, scale=None, ncores=1):
     """R/bed-mult-vec.R:20-37 -> bed_cpMatVec4."""
-    ir, ic = _args(obj_bed, ind_row, ind_col)
+    assert_bed(obj_bed)
+    ir, n = _lazy_ind(obj_bed, "ind.row", ind_row, obj_bed.nrow)
+    ic, m = _lazy_ind(obj_bed, "ind.col", ind_col, obj_bed.ncol)
     y_row = as_f64(np.ravel(y_row))
-    assert_lengths(y_row, ir)
-    center, scale = _center_scale(center, scale, ic)
-    out = np.empty(ic.size)
-    check(_lib.load().bsn_bed_cprodvec(obj_bed.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p),
-                                       ic.size, ptr(center, f64p), ptr(scale, f64p),
-                                       ptr(y_row, f64p), ptr(out, f64p)))
+    if y_row.size != n:
+        raise ValueError(ERROR_DIM)
+    center, scale = _center_scale_lazy(center, scale, m)
+    out = np.empty(m)
+    check(_lib.load().bsn_bed_cprodvec(obj_bed.handle, ptr(ir, i64p), n, ptr(ic, i64p), m, ptr(center, f64p),
+                                       ptr(scale, f64p), ptr(y_row, f64p), ptr(out, f64p)))
     return out
 
 

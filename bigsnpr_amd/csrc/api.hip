@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cerrno>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -162,29 +163,85 @@ static void stage_init(bsn_bed *b) {
   }
 }
 
-// host copy between caller memory and a staging buffer; large pieces are split over a few threads
-// (one core moves ~10 GB/s, the PCIe link 50+)
+// Two helper threads that live as long as the process (created on first use, re-created in a forked child) take
+// their share of a host copy of 1 MB or more: the three m-vectors of a one-shot product at BASELINE config 2 —
+// x, centre, scale, 1.6 MB each — cost 0.12 ms apiece through one core, a third of the call's time outside its
+// streaming kernel; threads created per copy (round 2's way for pieces of 8 MB and more) cost more than they save
+// at this size.
+namespace {
+struct CopyJob {
+  void *dst = nullptr;
+  const void *src = nullptr;
+  size_t len = 0;
+};
+struct CopyPool {
+  static constexpr int kHelpers = 2;
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  CopyJob job[kHelpers];
+  unsigned long long seq = 0, done[kHelpers] = {0, 0};
+  pid_t owner = 0;
+  bool started = false;
+  void start() {
+    owner = getpid();
+    for (int h = 0; h < kHelpers; h++)
+      std::thread([this, h] {
+        unsigned long long seen = 0;
+        for (;;) {
+          CopyJob j;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_go.wait(lk, [&] { return seq != seen; });
+            seen = seq;
+            j = job[h];
+          }
+          if (j.len) std::memcpy(j.dst, j.src, j.len);
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            done[h] = seen;
+          }
+          cv_done.notify_one();
+        }
+      }).detach();
+    started = true;
+  }
+  void copy(void *dst, const void *src, size_t len) {
+    const size_t part = (len / (kHelpers + 1) + 63) & ~(size_t)63;
+    unsigned long long my;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (int h = 0; h < kHelpers; h++) {
+        const size_t lo = part * (size_t)(h + 1), hi = h + 1 == kHelpers ? len : std::min(len, lo + part);
+        job[h] = lo < hi ? CopyJob{(uint8_t *)dst + lo, (const uint8_t *)src + lo, hi - lo} : CopyJob{};
+      }
+      my = ++seq;
+    }
+    cv_go.notify_all();
+    std::memcpy(dst, src, std::min(part, len));
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return done[0] == my && done[1] == my; });
+  }
+};
+CopyPool *g_pool = nullptr;
+std::mutex g_pool_mu;   // one copy at a time goes through the pool (calls on different handles may be concurrent)
+}  // namespace
+
+// host copy between caller memory and a staging buffer
 static void host_copy(void *dst, const void *src, size_t len) {
-  constexpr size_t kPerThread = 4u << 20;
-  const unsigned hw = std::thread::hardware_concurrency();
-  static const size_t max_thr = [] {
-    const char *e = getenv("BSN_COPY_THREADS");  // threads per staged piece (default 8)
-    const int v = e ? atoi(e) : 8;
-    return (size_t)(v < 1 ? 1 : v > 64 ? 64 : v);
+  static const bool pool_off = [] {
+    const char *e = getenv("BSN_COPY_THREADS");  // 1: every copy on the calling thread
+    return e && atoi(e) <= 1;
   }();
-  size_t nthr = std::min<size_t>({len / kPerThread, max_thr, (size_t)(hw ? hw : 1)});
-  if (nthr < 2) {
+  if (len < (1u << 20) || pool_off) {
     std::memcpy(dst, src, len);
     return;
   }
-  std::vector<std::thread> th;
-  const size_t slice = (len + nthr - 1) / nthr;
-  for (size_t t = 0; t < nthr; t++) {
-    const size_t lo = t * slice, hi = std::min(len, lo + slice);
-    if (lo >= hi) break;
-    th.emplace_back([=] { std::memcpy((uint8_t *)dst + lo, (const uint8_t *)src + lo, hi - lo); });
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (!g_pool || g_pool->owner != getpid()) {   // first use, or a forked child (threads do not survive a fork)
+    g_pool = new CopyPool();                     // (the parent's pool object is abandoned in the child, not freed)
+    g_pool->start();
   }
-  for (auto &t : th) t.join();
+  g_pool->copy(dst, src, len);
 }
 
 // Host -> device through the two pinned staging buffers, ordered on the handle's stream.  Returns as

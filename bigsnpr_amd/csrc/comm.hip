@@ -1,5 +1,7 @@
 // comm.hip — the RCCL communicator of a column-sharded solve (one process per GPU, xGMI).
 //
+// (Round 3: every collective of a solve is issued on the SOLVE's stream — one communicator, one stream, issue
+// order = stream order on every rank; `stream` below only serves bsn_comm_allreduce, the stand-alone self-test.)
 // north_star: "SNP columns shard naturally across the 8 GPUs of one node, with the SVD's panel
 // all-reduced over RCCL/xGMI".  The collectives of bsn_bed_randomsvd run INSIDE the library, on
 // device buffers and HIP streams it owns (svd.hip); the host program only has to carry the 128-byte
@@ -103,9 +105,21 @@ int bsn_comm_init(const uint8_t *id, int rank, int world, bsn_comm **out) {
     ncclComm_t comm = nullptr;
     BSN_NCCL(rccl().CommInitRank(&comm, world, uid, rank));
     c->comm = comm;
+    // from here on a failure must give the communicator (and whatever else exists) back
+    struct Undo {
+      bsn_comm *c;
+      ~Undo() {
+        if (!c) return;
+        if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+        if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        if (c->comm) (void)rccl().CommDestroy((ncclComm_t)c->comm);
+      }
+    } undo{c.get()};
     BSN_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     BSN_HIP(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
     BSN_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    undo.c = nullptr;
     *out = c.release();
   });
 }
