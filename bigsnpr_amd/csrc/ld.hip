@@ -230,6 +230,133 @@ __global__ __launch_bounds__(256) void k_pair_stats(const uint8_t *__restrict__ 
         }
 }
 
+// The six-product kernel with the decode of one operand SHARED through LDS (round 3).  k_pair_stats decodes
+// three planes of four 16-variant sub-tiles per wave and K-step for 24 MFMAs: 3.5 VALU instructions per MFMA,
+// and VALU and MFMA share the issue port (16 of an MFMA's cycles against 4 per VALU instruction: at 3.5 the port,
+// not the matrix pipe, is the bound — counters: pipe 63 - 68 % busy).  Here a workgroup covers 128 x 32 variant
+// pairs (the area of a 64 x 64 tile pair): every wave owns 32 of the 128 "row" variants (decoded privately, as
+// before) and ALL four waves multiply them with the same 32 "column" variants, which are therefore decoded once
+// per workgroup — wave w decodes K-step w of the four K-steps of an iteration and parks the three planes in LDS
+// (double-buffered: one barrier per 256 samples).  2.1 VALU per MFMA; LDS moves 30 KB per wave and iteration,
+// 60 % of its bandwidth at three workgroups per CU.
+// pairs: (index of the 128-variant row block, index of the 32-variant column block); fused fp64 epilogue.
+constexpr int TR = 128, TC = 32;
+__global__ __launch_bounds__(256, 2) void k_pair_stats_b(const uint8_t *__restrict__ img, int64_t pitch,
+                                                      const int32_t *__restrict__ cols,
+                                                      const int2 *__restrict__ pairs,
+                                                      const uint32_t *__restrict__ rowmask, BandOut bo) {
+  __shared__ uint4 sB[2][4][2][3][64];   // [buffer][K-step][sub-tile][plane x, x2, m][lane]: 48 KB
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int2 pr = pairs[blockIdx.x];
+  const int64_t ca0 = cols[pr.x * TR], cb0 = cols[pr.y * TC];
+  uint32_t va[2], vb[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    va[s] = (uint32_t)(((int64_t)cols[pr.x * TR + wave * 32 + s * 16 + r16] - ca0) * pitch + g * 16);
+    vb[s] = (uint32_t)(((int64_t)cols[pr.y * TC + s * 16 + r16] - cb0) * pitch + g * 16);
+  }
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(img + ca0 * pitch), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)(img + cb0 * pitch), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void *)rowmask, 0, 0x7fffffff, 0x00020000);
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  v4i acc[2][2][6];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int p = 0; p < 6; p++) acc[i][j][p] = v4i{0, 0, 0, 0};
+  const int nit = (int)(pitch / 64);
+  // word `wave` of a 16-byte register (uniform per wave)
+  auto pick = [&](const v4u &x) -> uint32_t { return wave == 0 ? x.x : wave == 1 ? x.y : wave == 2 ? x.z : x.w; };
+  auto stash = [&](int buf, const uint32_t (&b)[2], const v4u &mk) {   // this wave's K-step of the column operand -> LDS
+    const uint32_t mw = pick(mk);
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const Planes P = decode3(b[s] | ~mw);
+      sB[buf][wave][s][0][lane] = uint4{(uint32_t)P.x[0], (uint32_t)P.x[1], (uint32_t)P.x[2], (uint32_t)P.x[3]};
+      sB[buf][wave][s][1][lane] = uint4{(uint32_t)P.x2[0], (uint32_t)P.x2[1], (uint32_t)P.x2[2], (uint32_t)P.x2[3]};
+      sB[buf][wave][s][2][lane] = uint4{(uint32_t)P.m[0], (uint32_t)P.m[1], (uint32_t)P.m[2], (uint32_t)P.m[3]};
+    }
+  };
+  // a wave needs only ITS K-step's word of the column operand: one dword per sub-tile and lane
+  v4u a[2], mk, an[2], mkn;
+  uint32_t b[2], bn[2];
+  const int wsel = __builtin_amdgcn_readfirstlane(wave) * 4;
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    a[s] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)va[s], 0, 0);
+    b[s] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsB, (int)vb[s], wsel, 0);
+  }
+  mk = __builtin_amdgcn_raw_buffer_load_b128(rsM, g * 16, 0, 0);
+  stash(0, b, mk);
+  __syncthreads();
+  for (int it = 0; it < nit; it++) {
+    // the next iteration's words (past the end the last one again: no branch around loads)
+    const int kbn = (it + 1 < nit ? it + 1 : it) * 64;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      an[s] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)va[s], kbn, 0);
+      bn[s] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsB, (int)vb[s], kbn + wsel, 0);
+    }
+    mkn = __builtin_amdgcn_raw_buffer_load_b128(rsM, g * 16, kbn, 0);
+    const int buf = it & 1;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const uint32_t mw = d == 0 ? mk.x : d == 1 ? mk.y : d == 2 ? mk.z : mk.w;
+      Planes A[2];
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const uint32_t wa = d == 0 ? a[s].x : d == 1 ? a[s].y : d == 2 ? a[s].z : a[s].w;
+        A[s] = decode3(wa | ~mw);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const uint4 bx = sB[buf][d][j][0][lane], bx2 = sB[buf][d][j][1][lane], bm = sB[buf][d][j][2][lane];
+        const v4i Bx = {(int)bx.x, (int)bx.y, (int)bx.z, (int)bx.w}, Bx2 = {(int)bx2.x, (int)bx2.y, (int)bx2.z, (int)bx2.w},
+                  Bm = {(int)bm.x, (int)bm.y, (int)bm.z, (int)bm.w};
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          acc[i][j][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].x, Bx, acc[i][j][0], 0, 0, 0);
+          acc[i][j][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].x, Bm, acc[i][j][1], 0, 0, 0);
+          acc[i][j][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].x2, Bm, acc[i][j][2], 0, 0, 0);
+          acc[i][j][3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].m, Bx, acc[i][j][3], 0, 0, 0);
+          acc[i][j][4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].m, Bx2, acc[i][j][4], 0, 0, 0);
+          acc[i][j][5] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].m, Bm, acc[i][j][5], 0, 0, 0);
+        }
+      }
+    }
+    // (Placing this decode between the K-steps above, where the matrix pipe is busy, costs 24 registers — two
+    // waves per SIMD instead of three — and 12 % of the time: measured.)
+    stash(buf ^ 1, bn, mkn);   // read by nobody until the barrier below; last read before the previous barrier
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; s++) a[s] = an[s];
+    mk = mkn;
+  }
+  // fp64 epilogue, one pair at a time (see k_pair_stats)
+  int32_t st[16][6];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int p = 0; p < 6; p++) st[(i * 2 + j) * 4 + r][p] = acc[i][j][p][r];
+#pragma unroll 1
+  for (int e = 0; e < 16; e++) {
+    const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
+    const int row = wave * 32 + i * 16 + 4 * g + r, col = j * 16 + r16;
+    const int64_t j0 = (int64_t)pr.x * TR + row, jj = (int64_t)pr.y * TC + col;
+    if (j0 >= bo.m || jj >= j0 || jj < bo.lo[j0]) continue;
+    bo.band[j0 * bo.W + (j0 - jj - 1)] =
+        pair_value(bo.mode, (double)st[e][0], (double)st[e][1], (double)st[e][2], (double)st[e][3], (double)st[e][4],
+                   st[e][5], bo.thr, bo.v1, bo.v2, j0, jj, bo.nrows);
+  }
+}
+
 // Cross product only (variants without missing values, FBM clumping): one wave owns the whole
 // 64 x 64 tile pair for its share of the samples (4 x 4 MFMA sub-tiles, so each decoded operand
 // feeds four MFMAs instead of two) and adds its int32 partial with atomics (K is split over
@@ -647,7 +774,7 @@ __global__ void k_band_gt_upper(const double *__restrict__ band, const int64_t *
 // what bench.py --workload ld reports: set by every band_run
 struct LdStats {
   double pairs = 0, tile_pairs = 0, stats_ms = 0, launches = 0;
-  int kernel = 0;  // 0: six-product kernel with fused epilogue, 1: six-product + K split, 2: cross product only, 3: byte image with missing values (eight products)
+  int kernel = 0;  // 0: six-product kernel with fused epilogue, 1: six-product + K split, 2: cross product only, 3: byte image with missing values (eight products), 4: six products, column operand decoded once per workgroup (LDS)
 };
 static LdStats g_ld_stats;
 
@@ -656,7 +783,7 @@ struct BandJob {
   int64_t n = 0, m = 0, W = 1;
   std::vector<int64_t> lo;
   DevBuf<int32_t> d_cols, d_stats;
-  DevBuf<int2> d_pairs;
+  DevBuf<int2> d_pairs, d_pairs_b;   // 64 x 64 tile pairs; 128 x 32 blocks of k_pair_stats_b
   DevBuf<int64_t> d_lo;
   DevBuf<uint32_t> d_mask;
   DevBuf<uint8_t> d_mask8;  // byte image: 0xFF per selected sample
@@ -665,7 +792,7 @@ struct BandJob {
   bool complete = false;  // no missing value among the selected samples of the selected variants
   bool use_mask = false;
   bool contig = false;    // every tile's variants lie within 2 GB of its first one, in ascending order
-  int64_t npairs = 0;
+  int64_t npairs = 0, npairs_b = 0;
 };
 
 // lo[j0] = first j with pos[j] >= pos[j0] - size (src/corr.cpp:52-53).  For clumping the
@@ -715,7 +842,7 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
     }
   }
   // columns (padded to the tile size with a valid column)
-  const int64_t mt = (m + TB - 1) / TB, m_pad = mt * TB;
+  const int64_t mt = (m + TB - 1) / TB, m_pad = (m + TR - 1) / TR * TR;   // (a multiple of 64 and of 128)
   std::vector<int32_t> cols((size_t)m_pad);
   for (int64_t j = 0; j < m_pad; j++) {
     int64_t c = ind_col ? ind_col[j < m ? j : m - 1] : (j < m ? j : m - 1);
@@ -723,11 +850,12 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
     cols[(size_t)j] = (int32_t)c;
   }
   copy_h2d(bed, J.d_cols.ensure((size_t)m_pad), cols.data(), (size_t)m_pad * 4);
-  J.contig = true;
-  for (int64_t t = 0; t < mt && J.contig; t++)
-    for (int64_t j = t * TB; j < (t + 1) * TB; j++) {
-      const int64_t d = (int64_t)cols[(size_t)j] - cols[(size_t)(t * TB)];
-      if (d < 0 || (d + 1) * bed->pitch >= ((int64_t)1 << 31)) J.contig = false;
+  J.contig = true;   // offsets from the first variant of every 128-block (hence of every 64- and 32-block) fit 31 bits
+  for (int64_t t = 0; t * TR < m_pad && J.contig; t++)
+    for (int64_t j = t * TR; j < (t + 1) * TR; j++) {
+      const int64_t d = (int64_t)cols[(size_t)j] - cols[(size_t)(t * TR)];
+      if (d < 0 || (d + 1) * bed->pitch >= ((int64_t)1 << 31) || (j > t * TR && cols[(size_t)j] < cols[(size_t)(j - 1)]))
+        J.contig = false;
     }
   if (bed->bits == 8) {
     // byte image: byte mask of the selected samples, per-variant totals of the grid indices over them
@@ -807,6 +935,16 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
   }
   J.npairs = (int64_t)pairs.size();
   copy_h2d(bed, J.d_pairs.ensure(pairs.size()), pairs.data(), pairs.size() * sizeof(int2));
+  {
+    // the same band in blocks of 128 row variants x 32 column variants (k_pair_stats_b)
+    std::vector<int2> pb;
+    for (int64_t I = 0; I * TR < m; I++) {
+      const int64_t last = std::min<int64_t>(m, (I + 1) * TR) - 1;
+      for (int64_t Jb = J.lo[(size_t)(I * TR)] / TC; Jb <= last / TC; Jb++) pb.push_back(int2{(int)I, (int)Jb});
+    }
+    J.npairs_b = (int64_t)pb.size();
+    copy_h2d(bed, J.d_pairs_b.ensure(pb.size()), pb.data(), pb.size() * sizeof(int2));
+  }
   copy_h2d(bed, J.d_lo.ensure((size_t)m), J.lo.data(), (size_t)m * 8);
   BSN_HIP(hipStreamSynchronize(bed->stream));  // host vectors go out of scope
   // statistics in batches of tile pairs (bounded scratch)
@@ -901,6 +1039,29 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
       ls.launches += 1;
     }
     ls.kernel = 2;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    ls.stats_ms = ms_total;
+    g_ld_stats = ls;
+    return;
+  }
+  if (!xy_only && J.contig && J.use_mask && J.npairs_b >= 1024 && !getenv("BSN_LD_NO_SHARED_DECODE")) {
+    // enough blocks to fill the chip without a K split: the kernel that shares the column operand's decode
+    for (int64_t p0 = 0; p0 < J.npairs_b; p0 += batch) {
+      const int64_t np = std::min(batch, J.npairs_b - p0);
+      BSN_HIP(hipEventRecord(e0, bed->stream));
+      hipLaunchKernelGGL(k_pair_stats_b, dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
+                         J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, bo);
+      BSN_HIP(hipGetLastError());
+      BSN_HIP(hipEventRecord(e1, bed->stream));
+      BSN_HIP(hipEventSynchronize(e1));
+      float ms = 0;
+      BSN_HIP(hipEventElapsedTime(&ms, e0, e1));
+      ms_total += ms;
+      ls.launches += 1;
+    }
+    ls.kernel = 4;
+    ls.tile_pairs = (double)J.npairs_b;   // blocks of 128 x 32 = the area of a 64 x 64 tile pair
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     ls.stats_ms = ms_total;
