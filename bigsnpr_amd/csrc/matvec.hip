@@ -575,8 +575,13 @@ __global__ __launch_bounds__(128) void k_cprod_final(const int32_t *__restrict__
 // TILED: `img` is the streaming-layout copy; a step of the workgroup (64 variants x 256 B) is one tile.
 // XMAP: 1-D launch of wgx * ky workgroups (ky a multiple of 8) mapped so that all workgroups of a K slab run on
 // one XCD (workgroup i goes to XCD i mod 8): the slab's digit panel then lives in that XCD's L2.
+// HALF (two column blocks): a PAIR of waves owns the 256 samples; both load the same 16 dwords per lane (the second
+// load hits L1) and each keeps the accumulators of 8 of the 16 sample positions — 64 instead of 128 accumulator
+// registers, three waves per SIMD instead of two (the two-block kernels are bound by the matrix pipe and the
+// instruction issue port, where a third wave to pick instructions from is what helps).  The 4 x 4 byte transposes
+// split cleanly: the half that owns sample quads q = 0, 1 needs only the low halves of the first-level permutes.
 template <int NB, bool CONTIG, bool RAWP, bool HASQ = true, int WAVES = 4, int ABL = 0, int UG = 1, int SETS = 2,
-          int TAG = 0, bool TILED = false, bool XMAP = false>
+          int TAG = 0, bool TILED = false, bool XMAP = false, bool HALF = false>
 __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__ img, int64_t pitch,
                                               const int32_t *__restrict__ cols, int64_t col0,
                                               int64_t m_pad, int64_t mc,
@@ -592,7 +597,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
     bx = t % wgx;
     by = xcd + 8u * (t / wgx);
   }
-  int64_t wbase = ((int64_t)bx * WAVES + wave) * 256;  // first sample of this wave
+  static_assert(!HALF || (TILED && WAVES == 8 && UG == 1 && SETS == 2 && !XMAP), "wave pairs: tiled copy, 8 waves");
+  const int swave = HALF ? (wave >> 1) : wave;       // which 256-sample block of the workgroup
+  const int qh = HALF ? (wave & 1) : 0;               // HALF: this wave keeps sample quads 2 qh, 2 qh + 1
+  constexpr int SW = HALF ? WAVES / 2 : WAVES;        // 256-sample blocks per workgroup
+  int64_t wbase = ((int64_t)bx * SW + swave) * 256;  // first sample of this wave
   const bool active = wbase < n_pad;  // WAVES = 8: the last workgroup may be half empty
   if (!active) wbase = 0;
   const int64_t wbyte = wbase / 4 + sg * 4;
@@ -602,9 +611,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
   if (j1 > m_pad) j1 = m_pad;
   const uint4 *wq4 = (const uint4 *)wq;
 
-  v4i acc[16][NB];
+  constexpr int NU = HALF ? 8 : 16, NQ = HALF ? 2 : 4;
+  v4i acc[NU][NB];
 #pragma unroll
-  for (int u = 0; u < 16; u++)
+  for (int u = 0; u < NU; u++)
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) acc[u][nb] = v4i{0, 0, 0, 0};
 
@@ -627,10 +637,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
       if constexpr (TILED) {
         // a wave owns 64 B of a 256-B column block: four waves per tile, WAVES / 4 tiles per workgroup and step
         static_assert(WAVES % 4 == 0, "streaming layout: whole 256-B column blocks per workgroup");
-        const int64_t sbw = __builtin_amdgcn_readfirstlane(active ? (int)((bx * WAVES + wave) >> 2) : 0);
+        const int64_t sbw = __builtin_amdgcn_readfirstlane(active ? (int)((bx * SW + swave) >> 2) : 0);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(img + (((col0 + jb) >> 6) * (pitch >> 8) + sbw) * 16384), 0, 0x7fffffff, 0x00020000);
-        const int toff = g * 4096 + (wave & 3) * 64 + sg * 4;
+        const int toff = g * 4096 + (swave & 3) * 64 + sg * 4;
 #pragma unroll
         for (int r = 0; r < 16; r++) dst[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, toff, r * 256, 0);
       } else {
@@ -678,21 +688,28 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
       aw[nb] = v4i{(int)t0.x, (int)t0.y, (int)t0.z, (int)t0.w};
       awc[nb] = v4i{(int)t1.x, (int)t1.y, (int)t1.z, (int)t1.w};
     }
-    // T[q][r4]: byte b = byte q of X[4*r4 + b]
-    uint32_t T[4][4];
+    // T[q][r4]: byte b = byte q of X[4*r4 + b]   (HALF: q counts from 2 qh)
+    uint32_t T[NQ][4];
 #pragma unroll
     for (int r4 = 0; r4 < 4; r4++) {
       constexpr int XS_ = SETS >= 2 ? SET : 0;
       const uint32_t x0 = X[XS_][4 * r4], x1 = X[XS_][4 * r4 + 1], x2 = X[XS_][4 * r4 + 2],
                      x3 = X[XS_][4 * r4 + 3];
-      const uint32_t lo01 = perm8(x1, x0, 0x05010400u);  // x0.b0 x1.b0 x0.b1 x1.b1
-      const uint32_t hi01 = perm8(x1, x0, 0x07030602u);  // x0.b2 x1.b2 x0.b3 x1.b3
-      const uint32_t lo23 = perm8(x3, x2, 0x05010400u);
-      const uint32_t hi23 = perm8(x3, x2, 0x07030602u);
-      T[0][r4] = perm8(lo23, lo01, 0x05040100u);  // lo01.b0 lo01.b1 lo23.b0 lo23.b1
-      T[1][r4] = perm8(lo23, lo01, 0x07060302u);
-      T[2][r4] = perm8(hi23, hi01, 0x05040100u);
-      T[3][r4] = perm8(hi23, hi01, 0x07060302u);
+      if constexpr (HALF) {
+        const uint32_t sel = qh ? 0x07030602u : 0x05010400u;   // (uniform per wave)
+        const uint32_t h01 = perm8(x1, x0, sel), h23 = perm8(x3, x2, sel);
+        T[0][r4] = perm8(h23, h01, 0x05040100u);
+        T[1][r4] = perm8(h23, h01, 0x07060302u);
+      } else {
+        const uint32_t lo01 = perm8(x1, x0, 0x05010400u);  // x0.b0 x1.b0 x0.b1 x1.b1
+        const uint32_t hi01 = perm8(x1, x0, 0x07030602u);  // x0.b2 x1.b2 x0.b3 x1.b3
+        const uint32_t lo23 = perm8(x3, x2, 0x05010400u);
+        const uint32_t hi23 = perm8(x3, x2, 0x07030602u);
+        T[0][r4] = perm8(lo23, lo01, 0x05040100u);  // lo01.b0 lo01.b1 lo23.b0 lo23.b1
+        T[1][r4] = perm8(lo23, lo01, 0x07060302u);
+        T[NQ - 2][r4] = perm8(hi23, hi01, 0x05040100u);
+        T[NQ - 1][r4] = perm8(hi23, hi01, 0x07060302u);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     if (ABL & 32) {  // ablation: no genotype loads after the prologue
@@ -706,7 +723,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
     // G = 1, 2, 4 time the same (profiles/r01_ablation.txt), so the smallest is used
     constexpr int G = UG;
 #pragma unroll
-    for (int q = 0; q < 4; q++)
+    for (int q = 0; q < NQ; q++)
 #pragma unroll
       for (int u0 = 0; u0 < 4; u0 += G) {
         v4i g0[G], na[G];
@@ -761,8 +778,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
   // raw accumulators: acc_out[ky][sample][NCOL], lane holds columns nb*16 + 4g .. +3
   if (active) {
 #pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const int64_t i = wbase + sg * 16 + u;
+    for (int u = 0; u < NU; u++) {
+      const int64_t i = wbase + sg * 16 + (HALF ? 8 * qh : 0) + u;
 #pragma unroll
       for (int nb = 0; nb < NB; nb++)
         *(v4i *)(acc_out + (((int64_t)by * n_pad + i) * NCOL + nb * 16 + 4 * g)) = acc[u][nb];
@@ -1181,7 +1198,7 @@ __global__ __launch_bounds__(256) void k_stats_summary(const int32_t *counts, in
 static bool use_tiled(const bsn_op *op) {
 #ifdef BSN_ABLATION
   // the ablation variants exist on the plain image only (41 - 46: workgroup shapes on the tiled copy)
-  if (tune_variant() != 0 && !(tune_variant() >= 41 && tune_variant() <= 48) && !(tune_variant() >= 91 && tune_variant() <= 99)) return false;
+  if (tune_variant() != 0 && !(tune_variant() >= 41 && tune_variant() <= 48) && !(tune_variant() >= 90 && tune_variant() <= 99)) return false;
 #endif
   return op->bed->d_tiled != nullptr && op->cols_contig && (op->col0 & 63) == 0;
 }
@@ -1536,9 +1553,25 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
 #endif
   if constexpr (CONTIG) {
     if (use_tiled(op)) {  // streaming-layout copy: same arithmetic, contiguous 16-KB steps
-#define BSN_LAUNCH_PROD_T(RAWP, HASQ, TAGV)                                                                 \
-  hipLaunchKernelGGL((k_prod<NB, true, RAWP, HASQ, 4, 0, 1, 2, TAGV, true>), grid, dim3(256), 0, b->stream, \
-                     b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ)
+      // (BSN_TUNE = 90, ablation build: wave pairs that split the 16 sample positions (HALF): three waves per SIMD
+      // instead of two, but every wave still loads and shifts all 16 dwords — 30.9 ms against 24.2)
+#ifdef BSN_ABLATION
+      const bool half = NB == 2 && tune_variant() == 90;
+#define BSN_LAUNCH_PROD_TH(RAWP, HASQ, TAGV)                                                                           \
+  hipLaunchKernelGGL((k_prod<NB, true, RAWP, HASQ, 8, 0, 1, 2, TAGV, true, false, (NB == 2)>), grid, dim3(512), 0,     \
+                     b->stream, b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ)
+#else
+      constexpr bool half = false;
+#define BSN_LAUNCH_PROD_TH(RAWP, HASQ, TAGV) ((void)0)
+#endif
+#define BSN_LAUNCH_PROD_T(RAWP, HASQ, TAGV)                                                                     \
+  do {                                                                                                          \
+    if (half)                                                                                                   \
+      BSN_LAUNCH_PROD_TH(RAWP, HASQ, TAGV);                                                                     \
+    else                                                                                                        \
+      hipLaunchKernelGGL((k_prod<NB, true, RAWP, HASQ, 4, 0, 1, 2, TAGV, true>), grid, dim3(256), 0, b->stream, \
+                         b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);             \
+  } while (0)
       const bool warm = op->prof_kind_override == 3;
       if (lutP == kLutRaw) {
         if (has_q) { if (warm) BSN_LAUNCH_PROD_T(true, true, 1); else BSN_LAUNCH_PROD_T(true, true, 0); }
@@ -1548,6 +1581,7 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
         else BSN_LAUNCH_PROD_T(false, false, 0);
       }
 #undef BSN_LAUNCH_PROD_T
+#undef BSN_LAUNCH_PROD_TH
       BSN_HIP(hipGetLastError());
       return;
     }
