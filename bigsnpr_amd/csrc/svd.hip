@@ -191,9 +191,9 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const double *__restrict__ Q, i
   }
 }
 
-__global__ void k_set_identity(double *M, int ld, int r) {
+__global__ void k_put_block(double *M, int ld, int r, const double *src) {   // M[:r, :r] (leading dimension ld) = src (r x r)
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < r * r) M[(t % r) + (int64_t)(t / r) * ld] = (t % r) == (t / r) ? 1.0 : 0.0;
+  if (t < r * r) M[(t % r) + (int64_t)(t / r) * ld] = src[t];
 }
 
 // in place W[:, :r] = W[:, :cb] * M (cb x r), one thread per row
@@ -428,6 +428,7 @@ struct HipSvdBackend : SvdBackend {
   int cap = 0, b = 0;
   int kmax = 0;
   bool mx_valid = false;     // the column maxima of W (rounding) came out of the last k_update
+  bool no_fused = false;     // BSN_NO_FUSED_STEP=1: the step-by-step path only (A/B, debugging)
   bool speculate = true;     // queue the start of the next step behind the orthonormalisation (BSN_NO_SPECULATION=1: off)
   bool spec_rounded = false; // ... and it has been: the driver's next round_W is a no-op
   int n_small_ar = 0;        // small all-reduces issued (diagnostics)
@@ -666,7 +667,7 @@ struct HipSvdBackend : SvdBackend {
   // (start block, p == 0).  Returns cb, -1 (not supported: the caller takes the step-by-step path
   // for everything) or -2 (Gram blocks delivered, W restored: the panel needs the careful path).
   int fused(int p, int p0, int cb, bool with_grams, double *blkZ, double *blkQ, std::vector<double> &Rout) {
-    if (cb <= 0 || cb > kMaxB || p + cb > kOrthMaxP || p + cb > cap + kMaxB) return -1;
+    if (cb <= 0 || cb > kMaxB || p + cb > kOrthMaxP || p + cb > cap + kMaxB || no_fused) return -1;
     if (p > 0 && Wc != Q.p + (int64_t)p * nr) return -1;
     if (p > 0 && !with_grams) return -1;   // the device copy of Q'Q is only kept by the full step
     const double *A0 = p > 0 ? Q.p : Wc;    // [Q W] (p + cb contiguous columns); the panel alone for p == 0
@@ -801,7 +802,7 @@ struct HipSvdBackend : SvdBackend {
   }
   // thick restart: Q[:, :keep] = Q[:, :pp] S and Z[:, :keep] = Z[:, :pp] S (local rows of both), the waiting
   // panel moves behind column `keep`, the device copy of Q'Q becomes the identity on the kept part
-  bool restart(int pp, int keep, const double *S, int rn) override {
+  bool restart(int pp, int keep, const double *S, int rn, const double *Mk) override {
     if (keep + rn > pp || keep <= 0) return false;   // the panel moves to the left of where it is
     DevBuf<double> &dS = ws.dS, &tQ = ws.dU, &tZ = ws.dV;
     dS.ensure((size_t)pp * keep + 16);
@@ -824,8 +825,11 @@ struct HipSvdBackend : SvdBackend {
     BSN_HIP(hipMemcpyAsync(dst, Wc, (size_t)nr * rn * 8, hipMemcpyDeviceToDevice, st));
     Wc = dst;
     wcol = keep;
-    hipLaunchKernelGGL(k_set_identity, dim3((unsigned)((keep * keep + 255) / 256)), dim3(256), 0, st, ws.dM.p,
-                       kOrthMaxP, keep);
+    // the device copy of Q'Q on the kept part: S'(Q'Q)S as the driver computed it (the identity up to rounding
+    // unless the old basis was ill conditioned)
+    copy_h2d(op->bed, dS.p, Mk, (size_t)keep * keep * 8);
+    hipLaunchKernelGGL(k_put_block, dim3((unsigned)((keep * keep + 255) / 256)), dim3(256), 0, st, ws.dM.p,
+                       kOrthMaxP, keep, dS.p);
     BSN_HIP(hipGetLastError());
     return true;
   }
@@ -960,6 +964,7 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     bk.setup_ranks();
     bk.timing = getenv("BSN_TIMING") != nullptr;
     bk.speculate = getenv("BSN_NO_SPECULATION") == nullptr;
+    bk.no_fused = getenv("BSN_NO_FUSED_STEP") != nullptr;
     bk.fused_stats = fused;
     bk.warm_den = o->warm_denominator >= 2 ? o->warm_denominator : 16;
     int64_t dim = bk.n < bk.m_total ? bk.n : bk.m_total;

@@ -71,8 +71,10 @@ struct SvdBackend {
   //   Q[:, :keep] = Q[:, :pp] S,  Z[:, :keep] = Z[:, :pp] S   (S: pp x keep, Ritz vectors to keep; Z stays A' Q),
   // and the orthonormalised next block W (rn columns, waiting behind column pp) moves behind column `keep`.
   // Returns false if the backend cannot (the driver then stops, unconverged, as before).
-  virtual bool restart(int pp, int keep, const double *S, int rn) {
-    (void)pp; (void)keep; (void)S; (void)rn;
+  // Mk (keep x keep) = S' (Q'Q) S, the Gram matrix of the kept vectors (the identity up to rounding unless the old
+  // basis was ill conditioned): for backends that keep their own copy of Q'Q.
+  virtual bool restart(int pp, int keep, const double *S, int rn, const double *Mk) {
+    (void)pp; (void)keep; (void)S; (void)rn; (void)Mk;
     return false;
   }
   // Warm start: restrict the two products to a leading subset of the variants (on) or restore all of
@@ -233,6 +235,7 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
   int cb = r;     // size of the newest block
   int pp = 0;     // number of leading columns whose T columns are complete
   std::vector<double> Rlast;  // coupling block (r_next x cb) of the newest complete block
+  int rr_rank = 0;            // independent directions the last Rayleigh-Ritz step worked with (== pp normally)
   int rl_rows = 0, rl_cols = 0;
 
   while (cb > 0) {
@@ -290,25 +293,68 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
           Gp[(size_t)i + (size_t)j * pp] = Gat(i, j);
         }
       int rk = chol_upper(pp, Mp, Rm, 1e-14);
-      if (rk < pp) {  // cannot happen for an orthonormalised, then rounded, basis; be safe
-        Rm.assign((size_t)pp * pp, 0.0);
-        for (int i = 0; i < pp; i++) Rm[(size_t)i + (size_t)i * pp] = 1.0;
+      if (opt.verbose > 1) {
+        double dev = 0;
+        for (int j = 0; j < pp; j++)
+          for (int i = 0; i < pp; i++) dev = std::max(dev, std::fabs(Mat(i, j) - (i == j ? 1.0 : 0.0)));
+        std::fprintf(stderr, "[bsn svd]   Q'Q: max |M - I| = %.3e, Cholesky rank %d of %d\n", dev, rk, pp);
       }
-      inv_upper(pp, Rm, Rmi);
-      // tmp = Gp * Rmi ; evec = Rmi' * tmp
-      small_mm(pp, pp, pp, Gp.data(), Rmi.data(), tmp.data());
-      evec.assign((size_t)pp * pp, 0.0);
-      for (int j = 0; j < pp; j++)
-        for (int i = 0; i <= j; i++) {
-          double a = 0;
-          for (int t = 0; t <= i; t++) a += Rmi[(size_t)t + (size_t)i * pp] * tmp[(size_t)t + (size_t)j * pp];
-          evec[(size_t)i + (size_t)j * pp] = a;
-          evec[(size_t)j + (size_t)i * pp] = a;
+      rr_rank = pp;
+      if (rk == pp) {
+        inv_upper(pp, Rm, Rmi);
+        // tmp = Gp * Rmi ; evec = Rmi' * tmp
+        small_mm(pp, pp, pp, Gp.data(), Rmi.data(), tmp.data());
+        evec.assign((size_t)pp * pp, 0.0);
+        for (int j = 0; j < pp; j++)
+          for (int i = 0; i <= j; i++) {
+            double a = 0;
+            for (int t = 0; t <= i; t++) a += Rmi[(size_t)t + (size_t)i * pp] * tmp[(size_t)t + (size_t)j * pp];
+            evec[(size_t)i + (size_t)j * pp] = a;
+            evec[(size_t)j + (size_t)i * pp] = a;
+          }
+        eig_sym(pp, evec, eval);
+        // back-transform: s = Rmi * y (upper triangular)
+        small_mm(pp, pp, pp, Rmi.data(), evec.data(), tmp.data());
+        evec.swap(tmp);
+      } else {
+        // The stored basis is numerically DEPENDENT (Q'Q singular to 1e-14).  It happens when the Krylov space
+        // is exhausted but rounded products keep handing over "new" directions that are amplified noise — a
+        // request for more singular values than the matrix has rank, k > rank(A).  Canonical orthogonalisation:
+        // Q'Q = V L V', keep the r directions with L > 1e-8 max L, T = V L^(-1/2) (pp x r); the Ritz pairs of
+        // span(Q) are those of T' (Z'Z) T, s = T y; the pp - r dropped directions get Ritz value 0.
+        std::vector<double> V(Mp), lam;
+        eig_sym(pp, V, lam);
+        const double lmax = lam[pp - 1];
+        int r = 0;
+        while (r < pp && lam[pp - 1 - r] > 1e-8 * lmax && lmax > 0) r++;
+        std::vector<double> T((size_t)pp * std::max(r, 1), 0.0), GT((size_t)pp * std::max(r, 1)), B((size_t)r * r), bl;
+        for (int c = 0; c < r; c++) {
+          const double f = 1.0 / std::sqrt(lam[pp - 1 - c]);
+          for (int i = 0; i < pp; i++) T[(size_t)i + (size_t)c * pp] = V[(size_t)i + (size_t)(pp - 1 - c) * pp] * f;
         }
-      eig_sym(pp, evec, eval);
-      // back-transform: s = Rmi * y (upper triangular)
-      small_mm(pp, pp, pp, Rmi.data(), evec.data(), tmp.data());
-      evec.swap(tmp);
+        small_mm(pp, pp, r, Gp.data(), T.data(), GT.data());
+        for (int j = 0; j < r; j++)
+          for (int i = 0; i <= j; i++) {
+            double a = 0;
+            for (int t = 0; t < pp; t++) a += T[(size_t)t + (size_t)i * pp] * GT[(size_t)t + (size_t)j * pp];
+            B[(size_t)i + (size_t)j * r] = B[(size_t)j + (size_t)i * r] = a;
+          }
+        eig_sym(r, B, bl);
+        rr_rank = r;
+        eval.assign((size_t)pp, 0.0);
+        evec.assign((size_t)pp * pp, 0.0);
+        for (int c = 0; c < r; c++) {   // ascending order, the r computed pairs at the top end
+          const int col = pp - r + c;
+          eval[(size_t)col] = bl[(size_t)c];
+          for (int i = 0; i < pp; i++) {
+            double a = 0;
+            for (int t = 0; t < r; t++) a += T[(size_t)i + (size_t)t * pp] * B[(size_t)t + (size_t)c * r];
+            evec[(size_t)i + (size_t)col * pp] = a;
+          }
+        }
+        if (opt.verbose)
+          std::fprintf(stderr, "[bsn svd]   dependent basis: %d of %d directions kept for the Rayleigh-Ritz step\n", r, pp);
+      }
     }
     bool done = false;
     if (pp >= k) {
@@ -337,20 +383,45 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
     }
     if (!done && want_restart) {
       // keep the k + b largest Ritz pairs (room for at least the next block must remain)
-      int keep = std::min(pp, k + b);
+      int keep = std::min(std::min(pp, rr_rank), k + b);
       if (keep > cap - rn_full) keep = cap - rn_full;
       if (keep >= k) {
         std::vector<double> Sk((size_t)pp * keep);
         for (int t = 0; t < keep; t++)
           for (int i = 0; i < pp; i++) Sk[(size_t)i + (size_t)t * pp] = evec[(size_t)i + (size_t)(pp - 1 - t) * pp];
-        if (bk.restart(pp, keep, Sk.data(), rn_full)) {
-          // in the new basis Z'Z = diag(theta) and Q'Q = I on the kept part (s' M s = 1 by construction)
+        // Gram matrices of the kept vectors from the exact Gram matrices of the old basis: S'(Z'Z)S and S'(Q'Q)S.
+        // In exact arithmetic they are diag(theta) and I; with an ill-conditioned old basis (Krylov exhaustion)
+        // the computed S is only (Q'Q)-orthonormal to eps * cond, and assuming I would make Z'Z and Q'Q
+        // inconsistent — Ritz values above the largest singular value were the symptom.
+        std::vector<double> Gk((size_t)keep * keep), Mk((size_t)keep * keep), tG((size_t)pp * keep), tM((size_t)pp * keep);
+        {
+          std::vector<double> Mp((size_t)pp * pp), Gp((size_t)pp * pp);
+          for (int j = 0; j < pp; j++)
+            for (int i = 0; i < pp; i++) {
+              Mp[(size_t)i + (size_t)j * pp] = Mat(i, j);
+              Gp[(size_t)i + (size_t)j * pp] = Gat(i, j);
+            }
+          small_mm(pp, pp, keep, Gp.data(), Sk.data(), tG.data());
+          small_mm(pp, pp, keep, Mp.data(), Sk.data(), tM.data());
+          for (int j = 0; j < keep; j++)
+            for (int i = 0; i <= j; i++) {
+              double g = 0, mm = 0;
+              for (int t = 0; t < pp; t++) {
+                g += Sk[(size_t)t + (size_t)i * pp] * tG[(size_t)t + (size_t)j * pp];
+                mm += Sk[(size_t)t + (size_t)i * pp] * tM[(size_t)t + (size_t)j * pp];
+              }
+              Gk[(size_t)i + (size_t)j * keep] = Gk[(size_t)j + (size_t)i * keep] = g;
+              Mk[(size_t)i + (size_t)j * keep] = Mk[(size_t)j + (size_t)i * keep] = mm;
+            }
+        }
+        if (bk.restart(pp, keep, Sk.data(), rn_full, Mk.data())) {
           for (int j = 0; j < cap; j++)
             for (int i = 0; i < cap; i++) Gat(i, j) = Mat(i, j) = 0.0;
-          for (int t = 0; t < keep; t++) {
-            Gat(t, t) = eval[pp - 1 - t];
-            Mat(t, t) = 1.0;
-          }
+          for (int j = 0; j < keep; j++)
+            for (int i = 0; i < keep; i++) {
+              Gat(i, j) = Gk[(size_t)i + (size_t)j * keep];
+              Mat(i, j) = Mk[(size_t)i + (size_t)j * keep];
+            }
           res.restarts++;
           if (opt.verbose)
             std::fprintf(stderr, "[bsn svd] basis full at %d: restart with %d Ritz vectors\n", pp, keep);

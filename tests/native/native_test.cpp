@@ -201,7 +201,7 @@ struct HostBackend : SvdBackend {
     const int r = fused(0, 0, cb, nullptr, nullptr, Rout);
     return r < 0 ? -1 : r;
   }
-  bool restart(int pp, int keep, const double *S, int rn) override {
+  bool restart(int pp, int keep, const double *S, int rn, const double *Mk) override {
     (void)rn;   // W is a buffer of its own here
     auto combine = [&](std::vector<double> &X, int64_t rows) {
       std::vector<double> out((size_t)rows * keep, 0.0);
@@ -216,7 +216,7 @@ struct HostBackend : SvdBackend {
     combine(Z, m_local);
     if (!Mdev.empty()) {
       for (int j = 0; j < keep; j++)
-        for (int i = 0; i < keep; i++) Mdev[(size_t)i + (size_t)j * kOrthMaxP] = i == j ? 1.0 : 0.0;
+        for (int i = 0; i < keep; i++) Mdev[(size_t)i + (size_t)j * kOrthMaxP] = Mk[(size_t)i + (size_t)j * keep];
     }
     return true;
   }

@@ -121,3 +121,31 @@ def test_warm_start_on_a_variant_subset(ba):
     np.testing.assert_allclose(warm["d"], tight["d"], rtol=1e-6)
     small = ba.bed_randomSVD(ba.bed.synthetic(1000, 5000, seed=1), k=5)
     assert small["warm_launches"] == 0
+
+
+def test_rank_deficient_panels_take_the_careful_path(ba, orc):
+    """a matrix of rank 12 (12 distinct variants, each repeated five times): the Krylov space is exhausted inside the
+    second block, the fused block step must notice (its downdated Gram matrix has no digits left), hand the panel to the
+    step-by-step orthonormalisation — which works on the same in-place panel behind the basis — and the solve must end
+    with the exact singular values; the ones beyond the rank come out as zero up to the noise of the 16-bit products
+    amplified by the dependent basis (absolute, relative to the largest: 1e-3; 1e-6 with 56-bit products)"""
+    n, m0, rep = 300, 12, 5
+    base = orc.fake_bed(n, m0, seed=9, na16=0)
+    payload = np.tile(base.payload.reshape(m0, -1), (rep, 1)).reshape(-1)
+    ob = orc.BedFile.from_payload(payload, n, m0 * rep)
+    gb = ba.bed.from_payload(payload, n, m0 * rep)
+    ref = orc.dense_svd(ob, k=20)
+    for kw in (dict(), dict(block=4), dict(tol=1e-10, slices=7)):
+        res = ba.bed_randomSVD(gb, k=20, **kw)
+        assert res["converged"]
+        np.testing.assert_allclose(res["d"][:m0 - 1], ref["d"][:m0 - 1], rtol=1e-6)
+        assert np.all(res["d"][m0:] < (1e-6 if kw.get("slices") == 7 else 1e-3) * ref["d"][0]), res["d"][m0:]
+    # and a thick restart on the GPU: a small basis cap on a hard spectrum
+    ob2 = orc.fake_bed(1500, 4000, seed=21)
+    gb2 = ba.bed.synthetic(1500, 4000, seed=21)
+    sc = orc.bed_scaleBinom(ob2)
+    ic = np.nonzero(sc["scale"] > 0)[0]
+    ref2 = orc.dense_svd(ob2, None, ic, k=20)
+    res = ba.bed_randomSVD(gb2, ind_col=ic, k=20, block=16, max_basis=96, verbose=False)
+    assert res["converged"] and res["basis"] <= 96
+    np.testing.assert_allclose(res["d"], ref2["d"], rtol=1e-6)
