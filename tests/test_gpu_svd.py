@@ -149,3 +149,16 @@ def test_rank_deficient_panels_take_the_careful_path(ba, orc):
     res = ba.bed_randomSVD(gb2, ind_col=ic, k=20, block=16, max_basis=96, verbose=False)
     assert res["converged"] and res["basis"] <= 96
     np.testing.assert_allclose(res["d"], ref2["d"], rtol=1e-6)
+
+
+def test_basis_beyond_the_fused_step_limit(ba, orc):
+    """the fused block step serves bases of up to 384 columns (the coefficient iterate of its small-matrix half lives
+    in LDS); a caller who asks for a larger basis gets the step-by-step path from there on — same answer"""
+    ob = orc.fake_bed(1500, 4000, seed=21)
+    gb = ba.bed.synthetic(1500, 4000, seed=21)
+    sc = orc.bed_scaleBinom(ob)
+    ic = np.nonzero(sc["scale"] > 0)[0]
+    ref = orc.dense_svd(ob, None, ic, k=30)
+    res = ba.bed_randomSVD(gb, ind_col=ic, k=30, block=8, max_basis=440, max_restarts=-1, tol=1e-9, slices=7)
+    assert res["basis"] > 384, res["basis"]
+    np.testing.assert_allclose(res["d"], ref["d"], rtol=1e-7)
