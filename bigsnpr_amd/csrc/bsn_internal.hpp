@@ -114,8 +114,7 @@ struct SvdWorkspace;  // svd.hip
 struct bsn_comm {
   void *comm = nullptr;
   int rank = 0, world = 1, device = 0;
-  hipStream_t stream = nullptr;           // collectives that overlap compute of the solve's stream
-  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  hipStream_t stream = nullptr;           // bsn_comm_allreduce (stand-alone self-test); a solve's collectives run on the solve's stream
 };
 
 struct bsn_op {

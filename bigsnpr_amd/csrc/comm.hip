@@ -110,15 +110,11 @@ int bsn_comm_init(const uint8_t *id, int rank, int world, bsn_comm **out) {
       bsn_comm *c;
       ~Undo() {
         if (!c) return;
-        if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-        if (c->ev_done) (void)hipEventDestroy(c->ev_done);
         if (c->stream) (void)hipStreamDestroy(c->stream);
         if (c->comm) (void)rccl().CommDestroy((ncclComm_t)c->comm);
       }
     } undo{c.get()};
     BSN_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    BSN_HIP(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
-    BSN_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
     undo.c = nullptr;
     *out = c.release();
   });
@@ -140,8 +136,6 @@ int bsn_comm_destroy(bsn_comm *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->comm) (void)rccl().CommDestroy((ncclComm_t)c->comm);
-    if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
   });

@@ -17,6 +17,12 @@
 // block of the orthonormalisation) see first-order rounding effects only, which perturb the
 // subspace, not the Ritz values computed on it.
 //
+// Round 3: a block step asks the backend for its fused form first (step_fused: Gram blocks + two-pass
+// orthonormalisation without returning to the host, orth_small.hpp) and keeps the step-by-step
+// orthonormalisation below as the careful path for rank-deficient panels; a basis that fills up is compressed to
+// the best Ritz vectors and the iteration continues (thick restart); a numerically dependent basis (Krylov
+// exhaustion under rounded products, k > rank) is handled by canonical orthogonalisation in the Rayleigh-Ritz step.
+//
 // Columns (variants) may be sharded over ranks: Z = A' Q is local to the shard,
 // W = A Z is summed over ranks by the backend (one all-reduce of n x b doubles per
 // step); everything else is replicated and deterministic, so all ranks take identical
