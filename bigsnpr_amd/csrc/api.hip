@@ -295,7 +295,8 @@ void copy_d2h(bsn_bed *b, void *dst, const void *d_src, size_t bytes) {
   b->stage_busy[0] = b->stage_busy[1] = false;  // every event recorded so far has completed
 }
 
-static void free_bed(bsn_bed *b) {
+static void free_bed(bsn_bed *b) { bed_free(b); }
+void bed_free(bsn_bed *b) {
   if (!b) return;
   for (int i = 0; i < 2; i++) {
     if (b->h_stage[i]) (void)hipHostFree(b->h_stage[i]);

@@ -216,6 +216,9 @@ namespace bsn {
 
 // image.hip
 void image_alloc(bsn_bed *b, int64_t n, int64_t m, int bits = 2);
+void bed_free(bsn_bed *b);  // api.hip: everything a handle owns
+// a new handle holding the sub-matrix [ind_row, ind_col] (rows in list order, repeats allowed), same coding
+bsn_bed *image_gather(bsn_bed *src, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m);
 bool image_tile(bsn_bed *b);  // true when the streaming-layout copy exists (builds it if memory allows)
 void image_from_host(bsn_bed *b, const uint8_t *payload, int64_t n_byte_src);
 void image_from_file(bsn_bed *b, int fd, int64_t offset, int64_t n_byte_src);

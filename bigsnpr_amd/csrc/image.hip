@@ -701,6 +701,62 @@ __global__ void k_subset_pack(const uint8_t *img, int64_t pitch, const int32_t *
   out[j * n_byte_out + b] = (uint8_t)(plink_from_dev(v) & keep);
 }
 
+// ---------------------------------------------------------------------------
+// A gathered copy of the image: sample i of the copy is sample rows[i] of the source (any order, repeats
+// allowed), variant j is variant cols[j]; same coding, pad samples 0.  One thread per output byte.
+__global__ void k_gather_image(const uint8_t *img, int64_t pitch, int bits, const int32_t *rows, int64_t n,
+                               const int32_t *cols, int64_t m, uint8_t *out, int64_t pitch_out) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t j = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (b >= pitch_out || j >= m) return;
+  const uint8_t *col = img + (int64_t)cols[j] * pitch;
+  uint32_t v = 0;
+  if (bits == 8) {
+    if (b < n) v = col[rows[b]];
+  } else {
+    for (int e = 0; e < 4; e++) {
+      const int64_t i = b * 4 + e;
+      if (i < n) {
+        const int64_t i2 = rows[i];
+        v |= ((col[i2 >> 2] >> (2 * (i2 & 3))) & 3u) << (2 * e);
+      }
+    }
+  }
+  out[j * pitch_out + b] = (uint8_t)v;
+}
+
+bsn_bed *image_gather(bsn_bed *src, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m) {
+  if (n <= 0 || m <= 0) fail("'ind.row' and 'ind.col' can't be empty.");
+  if (src->generic) fail("internal: image_gather on a look-up image");
+  BSN_HIP(hipSetDevice(src->device));
+  std::vector<int32_t> rows((size_t)n), cols((size_t)m);
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t r = ind_row ? ind_row[i] : i;
+    if (r < 0 || r >= src->n) fail("Tested %lld < %lld. Subscript out of bounds (ind.row).", (long long)r, (long long)src->n);
+    rows[(size_t)i] = (int32_t)r;
+  }
+  for (int64_t j = 0; j < m; j++) {
+    const int64_t c = ind_col ? ind_col[j] : j;
+    if (c < 0 || c >= src->m) fail("Tested %lld < %lld. Subscript out of bounds (ind.col).", (long long)c, (long long)src->m);
+    cols[(size_t)j] = (int32_t)c;
+  }
+  std::unique_ptr<bsn_bed, void (*)(bsn_bed *)> b(new bsn_bed(), bed_free);
+  image_alloc(b.get(), n, m, src->bits);
+  b->v_off = src->v_off;
+  b->v_step = src->v_step;
+  DevBuf<int32_t> d_rows, d_cols;
+  BSN_HIP(hipStreamSynchronize(src->stream));   // whatever still writes the source image
+  BSN_HIP(hipMemcpy(d_rows.ensure((size_t)n), rows.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  BSN_HIP(hipMemcpy(d_cols.ensure((size_t)m), cols.data(), (size_t)m * 4, hipMemcpyHostToDevice));
+  BSN_HIP(hipMemsetAsync(b->d_img + b->m * b->pitch, 0, (size_t)(kPadRows * b->pitch), b->stream));
+  const int64_t gy = m < 65535 ? m : 65535, gz = (m + 65534) / 65535;
+  hipLaunchKernelGGL(k_gather_image, dim3((unsigned)((b->pitch + 255) / 256), (unsigned)gy, (unsigned)gz), dim3(256), 0,
+                     b->stream, src->d_img, src->pitch, src->bits, d_rows.p, n, d_cols.p, m, b->d_img, b->pitch);
+  BSN_HIP(hipGetLastError());
+  BSN_HIP(hipStreamSynchronize(b->stream));
+  return b.release();
+}
+
 void to_bytes(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t m,
               uint8_t *d_out) {
   require_bits(b, 2, "readbina2");

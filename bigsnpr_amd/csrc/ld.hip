@@ -865,7 +865,7 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
     for (int64_t i = 0; i < n; i++) {
       int64_t r = ind_row ? ind_row[i] : i;
       if (r < 0 || r >= bed->n) fail("Tested %lld < %lld. Subscript out of bounds (ind.row).", (long long)r, (long long)bed->n);
-      if (mask[(size_t)r]) fail("duplicated 'ind.row' are not supported by the GPU LD path");
+      if (mask[(size_t)r]) fail("internal: repeated samples reached the keep-mask (row_view)");
       mask[(size_t)r] = 0xFF;
       rows32[(size_t)i] = (int32_t)r;
       ident = ident && r == i;
@@ -892,7 +892,7 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
     copy_h2d(bed, J.d_cxx.ensure((size_t)m), cxx.data(), (size_t)m * 8);
   } else {
     // rows: keep-mask, 2 bits per sample (also removes the pad samples, which are coded as
-    // non-missing genotype 0 in the image).  Duplicated rows are not supported on this path.
+    // non-missing genotype 0 in the image).  Lists with repeated samples never get here (row_view).
     J.use_mask = true;
     {
       std::vector<uint32_t> mask((size_t)(bed->pitch / 4), 0u);
@@ -900,7 +900,7 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
         int64_t r = ind_row ? ind_row[i] : i;
         if (r < 0 || r >= bed->n) fail("Tested %lld < %lld. Subscript out of bounds (ind.row).", (long long)r, (long long)bed->n);
         uint32_t bit = 3u << (2 * (r & 15));
-        if (mask[(size_t)(r >> 4)] & bit) fail("duplicated 'ind.row' are not supported by the GPU LD path");
+        if (mask[(size_t)(r >> 4)] & bit) fail("internal: repeated samples reached the keep-mask (row_view)");
         mask[(size_t)(r >> 4)] |= bit;
       }
       copy_h2d(bed, J.d_mask.ensure(mask.size()), mask.data(), mask.size() * 4);
@@ -1131,7 +1131,35 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
 
 using namespace bsn;
 
+// ind.row with repeated samples (a bootstrap draw; the reference's accessors take any list, src/bed-acc.h:64-65): the
+// band kernels select samples through a keep-mask, which cannot count a sample twice, so the selected sub-matrix is
+// materialised once (rows in list order, the selected variants only) and the job runs on that image with identity
+// lists.  Every statistic is an integer sum over samples: the order of the rows changes nothing.
+struct RowView {
+  bsn_bed *bed;
+  const int64_t *ind_row, *ind_col;
+  std::shared_ptr<bsn_bed> owned;
+};
+static RowView row_view(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m) {
+  RowView v{bed, ind_row, ind_col, nullptr};
+  if (!ind_row || n <= 1 || m <= 0 || bed->generic) return v;
+  std::vector<uint64_t> seen((size_t)(bed->n + 63) / 64, 0ull);
+  bool dup = false;
+  for (int64_t i = 0; i < n && !dup; i++) {
+    const int64_t r = ind_row[i];
+    if (r < 0 || r >= bed->n) return v;   // reported by the job, with the reference's message
+    dup = (seen[(size_t)(r >> 6)] >> (r & 63)) & 1ull;
+    seen[(size_t)(r >> 6)] |= 1ull << (r & 63);
+  }
+  if (!dup) return v;
+  v.owned.reset(image_gather(bed, ind_row, n, ind_col, m), bed_free);
+  v.bed = v.owned.get();
+  v.ind_row = v.ind_col = nullptr;
+  return v;
+}
+
 struct bsn_cor {
+  std::shared_ptr<bsn_bed> owned;   // declared first: the buffers below are released before the image's stream goes
   BandJob job;
   DevBuf<int32_t> d_p, d_i;
   DevBuf<double> d_x;
@@ -1140,12 +1168,16 @@ struct bsn_cor {
 
 extern "C" {
 
-int bsn_cormat(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+int bsn_cormat(bsn_bed *bed_in, const int64_t *ind_row_in, int64_t n, const int64_t *ind_col_in, int64_t m,
                double size, const double *thr, const double *pos, int fill_diag, int32_t *p_out,
                int64_t *nnz_out, bsn_cor **out) {
   return guarded([&] {
     std::unique_ptr<bsn_cor> C(new bsn_cor());
     BandJob &J = C->job;
+    const RowView rv = row_view(bed_in, ind_row_in, n, ind_col_in, m);
+    bsn_bed *bed = rv.bed;
+    const int64_t *ind_row = rv.ind_row, *ind_col = rv.ind_col;
+    C->owned = rv.owned;
     band_stats(J, bed, ind_row, n, ind_col, m, pos, size);
     copy_h2d(bed, J.d_thr.ensure((size_t)n), thr, (size_t)n * 8);
     band_run(J, 0, J.d_thr.p, nullptr, nullptr, (double)n);
@@ -1203,9 +1235,12 @@ int bsn_cormat_free(bsn_cor *c) {
   return guarded([&] { delete c; });
 }
 
-int bsn_ld_scores(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+int bsn_ld_scores(bsn_bed *bed_in, const int64_t *ind_row_in, int64_t n, const int64_t *ind_col_in, int64_t m,
                   double size, const double *pos, double *out) {
   return guarded([&] {
+    const RowView rv = row_view(bed_in, ind_row_in, n, ind_col_in, m);
+    bsn_bed *bed = rv.bed;
+    const int64_t *ind_row = rv.ind_row, *ind_col = rv.ind_col;
     BandJob J;
     band_stats(J, bed, ind_row, n, ind_col, m, pos, size);
     band_run(J, 1, nullptr, nullptr, nullptr, (double)n);
@@ -1455,7 +1490,8 @@ int bsn_clumping_chr(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int6
                      const int32_t *ordInd, const int32_t *rankInd, const double *pos, double size,
                      double thr, int32_t *keep) {
   return guarded([&] {
-    clumping_grid(bed, ind_row, n, ind_col, m, mode, aux1, aux2, ordInd, rankInd, pos, 1, &size, &thr, keep);
+    const RowView rv = row_view(bed, ind_row, n, ind_col, m);
+    clumping_grid(rv.bed, rv.ind_row, n, rv.ind_col, m, mode, aux1, aux2, ordInd, rankInd, pos, 1, &size, &thr, keep);
   });
 }
 
@@ -1464,7 +1500,8 @@ int bsn_clumping_chr_cached(bsn_bed *bed, const int64_t *ind_row, int64_t n, con
                             const int32_t *ordInd, const int32_t *rankInd, const double *pos,
                             int64_t n_grid, const double *sizes, const double *thrs, int32_t *keep) {
   return guarded([&] {
-    clumping_grid(bed, ind_row, n, ind_col, m, mode, aux1, aux2, ordInd, rankInd, pos, n_grid, sizes, thrs,
+    const RowView rv = row_view(bed, ind_row, n, ind_col, m);
+    clumping_grid(rv.bed, rv.ind_row, n, rv.ind_col, m, mode, aux1, aux2, ordInd, rankInd, pos, n_grid, sizes, thrs,
                   keep);
   });
 }

@@ -312,8 +312,8 @@ int bsn_bed_tcrossprod(bsn_bed *bed, const int64_t *ind_row, int64_t n, const in
 /* ---- windowed LD (replaces corMat, ld_scores, clumping_chr, bed_clumping_chr) -----------
  * The handle may come from bsn_bed_open (.bed) or bsn_bed_from_fbm (FBM.code256 with NA),
  * which is the dispatch of src/corr.cpp:113-125.  `pos` has length m and must be sorted;
- * `size` is already in position units (R multiplies by 1000, R/corr.R:29).  Rows must not be
- * duplicated on this path. */
+ * `size` is already in position units (R multiplies by 1000, R/corr.R:29).  A row list with repeated
+ * samples is served from a gathered copy of the selected sub-matrix. */
 typedef struct bsn_cor bsn_cor;
 /* _bigsnpr_corMat (8 args) src/corr.cpp:102-126.  Two-phase: this call computes everything
  * on the device, fills p_out[m+1] (CSC column pointers exactly as R/corr.R:43-47 builds

@@ -1,0 +1,137 @@
+"""Seeded random shapes through the C ABI against the oracle: the fixed-size tests pin the reference's own cases, these
+sweep what lies between them — ragged sizes around every tile boundary (4 samples per byte, 16 / 64 / 128-row MFMA tiles,
+256-variant panels), index lists with repeats and in any order, missing-value rates from none to heavy, every block
+size and digit count the solver accepts.  Same tolerances as the fixed tests: integer and index outputs bit-exact,
+products 1e-9, correlations 1e-12, singular values 1e-6."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ba():
+    import bigsnpr_amd
+    return bigsnpr_amd
+
+
+def _pair(ba, orc, n, m, seed, na16):
+    return ba.bed.synthetic(n, m, seed=seed, na16=na16), orc.fake_bed(n, m, seed=seed, na16=na16)
+
+
+def _indices(rng, limit, style):
+    if style == 0:
+        return None
+    if style == 1:                                    # sorted subset
+        return np.sort(rng.choice(limit, max(1, int(limit * rng.uniform(0.2, 0.9))), replace=False))
+    if style == 2:                                    # any order, with repeats
+        return rng.integers(0, limit, size=max(1, int(limit * rng.uniform(0.3, 1.4))))
+    return np.arange(limit)[::-1].copy()              # reversed
+
+
+_SIZES = [1, 3, 4, 5, 15, 16, 17, 63, 64, 65, 127, 129, 255, 257, 511, 1023, 1025, 2049]
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_products_and_statistics(ba, orc, case):
+    rng = np.random.default_rng(1000 + case)
+    n = int(rng.choice(_SIZES)) + int(rng.integers(0, 3))
+    m = int(rng.choice(_SIZES)) + int(rng.integers(0, 3))
+    na16 = int(rng.choice([0, 0, 655, 6000, 30000]))
+    gb, ob = _pair(ba, orc, n, m, 77 + case, na16)
+    ir = _indices(rng, n, case % 4)
+    ic = _indices(rng, m, (case // 4) % 4)
+    nr = n if ir is None else ir.size
+    nc = m if ic is None else ic.size
+    # counts and column statistics: bit-exact
+    np.testing.assert_array_equal(ba.bed_counts(gb, ir, ic), orc.bed_col_counts(ob, ir, ic))
+    st, st_o = ba.bed_colstats(gb, ir, ic), orc.bed_colstats(ob, ir, ic)
+    for f in ("sumX", "denoX", "nb_nona_col"):
+        np.testing.assert_array_equal(st[f], st_o[f])
+    np.testing.assert_array_equal(ba.read_bed(gb, np.arange(n) if ir is None else ir,
+                                              np.arange(m) if ic is None else ic),
+                                  orc.read_bed(ob, ir, ic))
+    center = rng.normal(size=nc) if case % 3 else None
+    scale = rng.uniform(0.5, 2.0, size=nc) if case % 3 else None
+    x = rng.normal(size=nc) * 10.0 ** rng.integers(-6, 6)
+    y = rng.normal(size=nr) * 10.0 ** rng.integers(-6, 6)
+    got, want = ba.bed_prodVec(gb, x, ir, ic, center, scale), orc.bed_prodVec(ob, x, ir, ic, center, scale)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()))
+    got, want = ba.bed_cprodVec(gb, y, ir, ic, center, scale), orc.bed_cprodVec(ob, y, ir, ic, center, scale)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()))
+
+
+@pytest.mark.parametrize("case", range(20))
+def test_partial_svd(ba, orc, case):
+    rng = np.random.default_rng(2000 + case)
+    n = int(rng.integers(30, 2200))
+    m = int(rng.integers(40, 4200))
+    na16 = int(rng.choice([0, 655, 6000]))
+    gb, ob = _pair(ba, orc, n, m, 177 + case, na16)
+    ir = _indices(rng, n, 1) if case % 2 else None
+    nr = n if ir is None else ir.size
+    sc = orc.bed_scaleBinom(ob, ir, None)
+    ic = np.nonzero(sc["scale"] > 0)[0]
+    if case % 3 == 0 and ic.size > 60:
+        ic = np.sort(rng.choice(ic, int(ic.size * 0.7), replace=False))
+    k = int(rng.integers(1, max(2, min(25, min(nr, ic.size) // 3))))
+    block = int(rng.choice([0, 0, 1, 3, 4, 8, 16]))
+    slices = int(rng.choice([0, 0, 2, 3, 4, 7]))
+    if block * max(slices, 2) > 32:                   # the library's limit on digit columns per pass
+        block = 4
+    ref = orc.dense_svd(ob, ir, ic, k=k)
+    res = ba.bed_randomSVD(gb, ind_row=ir, ind_col=ic, k=k, block=block, slices=slices, seed=case + 1)
+    assert res["converged"], (n, m, k, block, slices)
+    np.testing.assert_allclose(res["d"], ref["d"], rtol=1e-6)
+    np.testing.assert_array_equal(res["center"], ref["center"])
+    np.testing.assert_array_equal(res["scale"], ref["scale"])
+    # the triplets are consistent with the matrix itself: A~ v = u d through the oracle's products
+    j = int(rng.integers(0, k))
+    av = orc.bed_prodVec(ob, res["v"][:, j].copy(), ir, ic, ref["center"], ref["scale"])
+    assert np.abs(av - res["u"][:, j] * res["d"][j]).max() <= 2e-4 * res["d"][0]
+    np.testing.assert_allclose(res["u"].T @ res["u"], np.eye(k), atol=1e-6)
+    np.testing.assert_allclose(res["v"].T @ res["v"], np.eye(k), atol=1e-6)
+
+
+def _same_cor(res, ref, tol=1e-12):
+    i, p, x = ref
+    np.testing.assert_array_equal(res.p, p)
+    np.testing.assert_array_equal(res.i, i)
+    assert np.all(np.isnan(res.x) == np.isnan(x))
+    ok = ~np.isnan(x)
+    np.testing.assert_allclose(res.x[ok], x[ok], rtol=0, atol=tol)
+
+
+@pytest.mark.filterwarnings("ignore:.*NA or NaN values.*")
+@pytest.mark.parametrize("case", range(16))
+def test_correlations_scores_clumping(ba, orc, case):
+    rng = np.random.default_rng(3000 + case)
+    n = int(rng.integers(20, 1500))
+    m = int(rng.integers(2, 900))
+    na16 = int(rng.choice([0, 655, 12000]))
+    gb, ob = _pair(ba, orc, n, m, 277 + case, na16)
+    ir = _indices(rng, n, case % 3)
+    ic = _indices(rng, m, 1) if case % 2 else None
+    mc = m if ic is None else ic.size
+    size = float(rng.choice([1, 7, 33, 150, 1e4]))
+    kw = dict(size=size, alpha=float(rng.choice([1.0, 0.2])), thr_r2=float(rng.choice([0.0, 0.1])),
+              fill_diag=bool(case % 2))
+    pos = None
+    if case % 4 == 3:
+        pos = np.cumsum(rng.integers(1, 3000, size=mc)).astype(np.float64)
+        kw["size"] = float(rng.choice([2.0, 20.0]))
+    _same_cor(ba.bed_cor(gb, ir, ic, infos_pos=pos, **kw), orc.snp_cor(ob, ir, ic, infos_pos=pos, ncores=8, **kw))
+    got = ba.bed_ld_scores(gb, ir, ic, size=kw["size"], infos_pos=pos)
+    want = orc.ld_scores(ob, ir, ic, size=kw["size"], infos_pos=pos)
+    assert np.all(np.isnan(got) == np.isnan(want))
+    np.testing.assert_allclose(got[~np.isnan(want)], want[~np.isnan(want)], rtol=1e-12)
+    # clumping over the whole matrix in two "chromosomes": kept indices identical
+    chrom = np.r_[np.ones(m // 2, dtype=np.int64), np.full(m - m // 2, 2, dtype=np.int64)]
+    bp = np.cumsum(rng.integers(1, 5000, size=m))
+    S = rng.uniform(size=m) if case % 2 else None
+    thr = float(rng.choice([0.05, 0.2, 0.5]))
+    win = float(rng.choice([50, 500]))
+    with np.errstate(all="ignore"):
+        want = orc.bed_clumping(ob, chrom, bp, ind_row=ir, S=S, thr_r2=thr, size=win)
+        got = ba.bed_clumping(gb, ind_row=ir, S=S, thr_r2=thr, size=win, infos_chr=chrom, infos_pos=bp)
+    np.testing.assert_array_equal(got, want)
