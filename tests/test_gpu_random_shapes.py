@@ -135,3 +135,89 @@ def test_correlations_scores_clumping(ba, orc, case):
         want = orc.bed_clumping(ob, chrom, bp, ind_row=ir, S=S, thr_r2=thr, size=win)
         got = ba.bed_clumping(gb, ind_row=ir, S=S, thr_r2=thr, size=win, infos_chr=chrom, infos_pos=bp)
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_kinship_projection_regression_prs(ba, orc, case):
+    rng = np.random.default_rng(4000 + case)
+    n = int(rng.choice([9, 31, 130, 257, 640, 1001]))
+    m = int(rng.integers(20, 1800))
+    na16 = int(rng.choice([0, 655, 9000]))
+    gb, ob = _pair(ba, orc, n, m, 377 + case, na16)
+    ir = _indices(rng, n, (case % 3))
+    nr = n if ir is None else ir.size
+    sc = orc.bed_scaleBinom(ob, ir, None)
+    ic = np.nonzero(sc["scale"] > 0)[0]
+    if case % 2:
+        ic = ic[rng.permutation(ic.size)[:max(1, ic.size // 2)]]
+    # bed_tcrossprodSelf
+    fs = lambda obj, ind_row, ind_col, ncores=1: dict(center=sc["center"][ind_col], scale=sc["scale"][ind_col])
+    K, _ = ba.bed_tcrossprodSelf(gb, fun_scaling=fs, ind_row=ir, ind_col=ic)
+    A = orc.read_bed_scaled(ob, ob.rows() if ir is None else ir, ic, sc["center"][ic], sc["scale"][ic])
+    Kref = A @ A.T
+    np.testing.assert_allclose(K, Kref, rtol=0, atol=1e-10 * max(1.0, np.abs(Kref).max()))
+    np.testing.assert_array_equal(K, K.T)
+    # prod_and_rowSumsSq
+    kk = int(rng.integers(1, 12))
+    V = rng.normal(size=(ic.size, kk))
+    XV, rs = ba.prod_and_rowSumsSq(gb, np.arange(n) if ir is None else ir, ic, sc["center"][ic], sc["scale"][ic], V)
+    np.testing.assert_allclose(XV, A @ V, rtol=0, atol=1e-9 * max(1.0, np.abs(A @ V).max()))
+    np.testing.assert_allclose(rs, (A * A).sum(1), rtol=1e-9, atol=1e-9)
+    # multLinReg
+    if nr > 8:
+        ku = int(rng.integers(1, min(6, nr - 3)))
+        U = rng.normal(size=(nr, ku))
+        ref = orc.multLinReg(ob, ir, ic, U)
+        got = ba.multLinReg(gb, ir, ic, U)
+        ok = ~np.isnan(ref)
+        assert np.array_equal(np.isnan(got), ~ok)
+        np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-7, atol=1e-7)
+    # snp_PRS on the FBM image of the same calls (complete data only, as the reference requires)
+    if na16 == 0:
+        Go = orc.fbm_from_bed(ob)
+        G = ba.FBM_code256(Go.bytes)
+        keep = np.sort(rng.choice(m, max(1, m // 2), replace=False))
+        betas = rng.normal(size=keep.size)
+        lp = rng.uniform(0, 6, size=keep.size)
+        same = rng.random(keep.size) < 0.7
+        thr = np.sort(rng.uniform(0, 6, size=int(rng.integers(1, 9))))
+        got = ba.snp_PRS(G, betas, ir, keep, same, lp, thr)
+        ref = orc.snp_PRS(Go, betas, ir, keep, same, lp, thr)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()))
+
+
+@pytest.mark.filterwarnings("ignore:.*NA or NaN values.*")
+@pytest.mark.parametrize("case", range(10))
+def test_dosage_matrices(ba, orc, case):
+    rng = np.random.default_rng(5000 + case)
+    n = int(rng.integers(10, 1300))
+    m = int(rng.integers(3, 700))
+    f = rng.uniform(0.05, 0.95, size=m)
+    dos = np.clip(np.round((2 * f + 0.4 * rng.normal(size=(n, m))) * 100), 0, 200).astype(np.int64)
+    raw = (dos + 7).astype(np.uint8)
+    with_na = case % 2 == 1
+    if with_na:
+        raw[rng.random(raw.shape) < rng.choice([0.002, 0.05])] = 3
+    Go, G = orc.FBM256(raw, ba.CODE_DOSAGE), ba.FBM_code256(raw, ba.CODE_DOSAGE)
+    ir = _indices(rng, n, case % 3)
+    ic = _indices(rng, m, 1) if case % 4 >= 2 else None
+    st, ref = ba.snp_colstats(G, ir, ic), orc.snp_colstats(Go, ir, ic)
+    assert np.array_equal(np.isnan(st["sumX"]), np.isnan(ref["sumX"]))
+    ok = ~np.isnan(ref["sumX"])
+    np.testing.assert_allclose(st["sumX"][ok], ref["sumX"][ok], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(st["denoX"][ok], ref["denoX"][ok], rtol=1e-9, atol=1e-9)
+    if not with_na:
+        nr = n if ir is None else ir.size
+        nc = m if ic is None else ic.size
+        x, y = rng.normal(size=nc), rng.normal(size=nr)
+        want = orc.fbm_prodVec(Go, x, ir, ic)
+        np.testing.assert_allclose(ba.big_prodVec(G, x, ir, ic), want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()))
+        want = orc.fbm_cprodVec(Go, y, ir, ic)
+        np.testing.assert_allclose(ba.big_cprodVec(G, y, ir, ic), want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()))
+    # windowed correlations on dosages, with and without missing values (src/corr.cpp:113-118)
+    kw = dict(size=float(rng.choice([3, 40, 1e4])), thr_r2=float(rng.choice([0.0, 0.05])), fill_diag=bool(case % 2))
+    _same_cor(ba.snp_cor(G, ir, ic, **kw), orc.snp_cor(Go, ir, ic, **kw), tol=1e-9)
+    got = ba.snp_ld_scores(G, ir, ic, size=kw["size"])
+    want = orc.ld_scores(Go, ir, ic, size=kw["size"])
+    assert np.all(np.isnan(got) == np.isnan(want))
+    np.testing.assert_allclose(got[~np.isnan(want)], want[~np.isnan(want)], rtol=1e-9)
