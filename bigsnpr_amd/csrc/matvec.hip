@@ -1625,13 +1625,34 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
   // K split so that the grid has a few thousand workgroups
   int64_t wgx = b->bits == 8 ? npad / 256 : npad / 1024;  // workgroups along the samples
   int ky = (int)((4096 + wgx - 1) / wgx);
-#ifdef BSN_ABLATION
-  if (const char *e = getenv("BSN_KY")) ky = atoi(e);  // grid-shape sweep (correct results)
-#endif
   int64_t steps = m_pad / 64;
   if (ky > steps) ky = (int)steps;
   if (ky > 64) ky = 64;
   if (ky < 1) ky = 1;
+  if (b->bits == 2) {
+    // ... but every slab writes (and the finalize kernel reads back) its own n x 16 NB accumulators: on a matrix with
+    // few samples per variant that is real traffic (50 000 x 200 000: 64 slabs = 16 % of the image), so the split is
+    // capped at 4 % of the image bytes; and two workgroups per CU are resident, so among the splits left the one
+    // whose grid fills whole rounds of 512 best wins (same matrix: 10 slabs = 490 workgroups, 0.72 - 0.75 ms per
+    // call against 0.80 - 0.84 with 64 and 0.86 with 11 = 539; profiles/r03_c2_grid_sweep.txt)
+    const int ncol_max = 16 * pick_nb((nvec < vmax ? nvec : vmax) * S);
+    int64_t cap = (int64_t)(0.04 * (double)m_pad / (32.0 * ncol_max));
+    if (cap < 1) cap = 1;
+    if (ky > cap) ky = (int)cap;
+    int best = ky;
+    double best_fill = 0.0;
+    for (int c = ky; c >= 1 && 2 * c >= ky; c--) {
+      const int64_t W = wgx * c;
+      const double fill = (double)W / (512.0 * (double)((W + 511) / 512));
+      if (fill > best_fill + 1e-9) best_fill = fill, best = c;
+    }
+    ky = best;
+  }
+#ifdef BSN_ABLATION
+  if (const char *e = getenv("BSN_KY")) ky = atoi(e);  // grid-shape sweep (correct results)
+  if (ky > steps) ky = (int)steps;
+  if (ky < 1) ky = 1;
+#endif
   // int32 accumulators: a slab adds at most 768 per variant (planes up to 4, digits up to 128)
   const int64_t ky_min = (m_pad + 2499999) / 2500000;
   if (ky < ky_min) ky = (int)ky_min;
