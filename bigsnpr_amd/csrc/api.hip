@@ -13,6 +13,8 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <sched.h>
+#include <atomic>
 #include <thread>
 
 #include <cstdlib>
@@ -163,63 +165,71 @@ static void stage_init(bsn_bed *b) {
   }
 }
 
-// Two helper threads that live as long as the process (created on first use, re-created in a forked child) take
-// their share of a host copy of 1 MB or more: the three m-vectors of a one-shot product at BASELINE config 2 —
-// x, centre, scale, 1.6 MB each — cost 0.12 ms apiece through one core, a third of the call's time outside its
-// streaming kernel; threads created per copy (round 2's way for pieces of 8 MB and more) cost more than they save
-// at this size.
+// Helper threads that live as long as the process (created on first use, re-created in a forked child) take their
+// share of a host copy of 256 KB or more: the three m-vectors of a one-shot product at BASELINE config 2 — x, centre,
+// scale, 1.6 MB each — cost 0.12 ms apiece through one core, a third of the call's time outside its streaming kernel;
+// threads created per copy (round 2's way for pieces of 8 MB and more) cost more than they save at this size.  A
+// helper that has just finished a share polls for the next one for some tens of microseconds before it goes to
+// sleep: the copies of one call follow each other within that time, so only the first pays a wake-up.
 namespace {
 struct CopyJob {
   void *dst = nullptr;
   const void *src = nullptr;
   size_t len = 0;
 };
+static inline void cpu_relax() { __builtin_ia32_pause(); }
 struct CopyPool {
-  static constexpr int kHelpers = 2;
+  static constexpr int kMaxHelpers = 6;
+  int nh = 2;
   std::mutex mu;
-  std::condition_variable cv_go, cv_done;
-  CopyJob job[kHelpers];
-  unsigned long long seq = 0, done[kHelpers] = {0, 0};
+  std::condition_variable cv_go;
+  CopyJob job[kMaxHelpers];
+  std::atomic<unsigned long long> seq{0};
+  std::atomic<int> pending{0}, sleepers{0};
   pid_t owner = 0;
-  bool started = false;
   void start() {
     owner = getpid();
-    for (int h = 0; h < kHelpers; h++)
+    cpu_set_t set;
+    int cpus = (int)std::thread::hardware_concurrency();
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = std::min(cpus > 0 ? cpus : 1, CPU_COUNT(&set));
+    nh = std::max(1, std::min(kMaxHelpers, cpus / 2 - 1));
+    if (const char *e = getenv("BSN_COPY_THREADS")) nh = std::max(1, std::min(kMaxHelpers, atoi(e) - 1));
+    for (int h = 0; h < nh; h++)
       std::thread([this, h] {
         unsigned long long seen = 0;
         for (;;) {
-          CopyJob j;
-          {
+          int spins = 0;
+          while (seq.load(std::memory_order_acquire) == seen) {
+            if (++spins < 4000) {
+              cpu_relax();
+              continue;
+            }
             std::unique_lock<std::mutex> lk(mu);
-            cv_go.wait(lk, [&] { return seq != seen; });
-            seen = seq;
-            j = job[h];
+            sleepers.fetch_add(1);
+            cv_go.wait(lk, [&] { return seq.load() != seen; });
+            sleepers.fetch_sub(1);
           }
+          seen = seq.load(std::memory_order_acquire);   // (the caller waits for every share before the next copy)
+          const CopyJob j = job[h];
           if (j.len) std::memcpy(j.dst, j.src, j.len);
-          {
-            std::lock_guard<std::mutex> lk(mu);
-            done[h] = seen;
-          }
-          cv_done.notify_one();
+          pending.fetch_sub(1, std::memory_order_release);
         }
       }).detach();
-    started = true;
   }
   void copy(void *dst, const void *src, size_t len) {
-    const size_t part = (len / (kHelpers + 1) + 63) & ~(size_t)63;
-    unsigned long long my;
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      for (int h = 0; h < kHelpers; h++) {
-        const size_t lo = part * (size_t)(h + 1), hi = h + 1 == kHelpers ? len : std::min(len, lo + part);
-        job[h] = lo < hi ? CopyJob{(uint8_t *)dst + lo, (const uint8_t *)src + lo, hi - lo} : CopyJob{};
-      }
-      my = ++seq;
+    const size_t part = (len / (size_t)(nh + 1) + 63) & ~(size_t)63;
+    for (int h = 0; h < nh; h++) {
+      const size_t lo = part * (size_t)(h + 1), hi = h + 1 == nh ? len : std::min(len, lo + part);
+      job[h] = lo < hi ? CopyJob{(uint8_t *)dst + lo, (const uint8_t *)src + lo, hi - lo} : CopyJob{};
     }
-    cv_go.notify_all();
+    pending.store(nh, std::memory_order_relaxed);
+    seq.fetch_add(1);
+    if (sleepers.load() > 0) {
+      { std::lock_guard<std::mutex> lk(mu); }
+      cv_go.notify_all();
+    }
     std::memcpy(dst, src, std::min(part, len));
-    std::unique_lock<std::mutex> lk(mu);
-    cv_done.wait(lk, [&] { return done[0] == my && done[1] == my; });
+    while (pending.load(std::memory_order_acquire) != 0) cpu_relax();
   }
 };
 CopyPool *g_pool = nullptr;
@@ -232,7 +242,7 @@ static void host_copy(void *dst, const void *src, size_t len) {
     const char *e = getenv("BSN_COPY_THREADS");  // 1: every copy on the calling thread
     return e && atoi(e) <= 1;
   }();
-  if (len < (1u << 20) || pool_off) {
+  if (len < (256u << 10) || pool_off) {
     std::memcpy(dst, src, len);
     return;
   }
@@ -247,17 +257,27 @@ static void host_copy(void *dst, const void *src, size_t len) {
 // Host -> device through the two pinned staging buffers, ordered on the handle's stream.  Returns as
 // soon as the caller's memory has been read (the last pieces may still be on their way: whatever uses
 // d_dst is queued behind them on the same stream).
-void copy_h2d(bsn_bed *b, void *d_dst, const void *src, size_t bytes) {
+void copy_h2d(bsn_bed *b, void *d_dst, const void *src, size_t bytes, hipStream_t stream) {
+  if (!stream) stream = b->stream;
   stage_init(b);
   for (size_t off = 0; off < bytes; off += kStagePiece) {
     const size_t len = std::min(kStagePiece, bytes - off);
     const int s = (int)(b->stage_next++ & 1);
     if (b->stage_busy[s]) BSN_HIP(hipEventSynchronize(b->ev_stage[s]));  // its previous piece has left the buffer
     host_copy(b->h_stage[s], (const uint8_t *)src + off, len);
-    BSN_HIP(hipMemcpyAsync((uint8_t *)d_dst + off, b->h_stage[s], len, hipMemcpyHostToDevice, b->stream));
-    BSN_HIP(hipEventRecord(b->ev_stage[s], b->stream));
+    BSN_HIP(hipMemcpyAsync((uint8_t *)d_dst + off, b->h_stage[s], len, hipMemcpyHostToDevice, stream));
+    BSN_HIP(hipEventRecord(b->ev_stage[s], stream));
     b->stage_busy[s] = true;
   }
+}
+
+// the handle's second stream: uploads that may run beside the kernels of the main one (op_cprod's centre / scale)
+hipStream_t upload_stream(bsn_bed *b) {
+  if (!b->stream_up) {
+    BSN_HIP(hipStreamCreateWithFlags(&b->stream_up, hipStreamNonBlocking));
+    BSN_HIP(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
+  }
+  return b->stream_up;
 }
 
 // true when the runtime knows `p` as page-locked host memory (bsn_host_alloc, or registered by the
@@ -279,6 +299,9 @@ void copy_d2h(bsn_bed *b, void *dst, const void *d_src, size_t bytes) {
     return;
   }
   stage_init(b);
+  if (b->stream_up)   // an upload on the second stream may still be reading a staging buffer
+    for (int i = 0; i < 2; i++)
+      if (b->stage_busy[i]) BSN_HIP(hipEventSynchronize(b->ev_stage[i]));
   const size_t npiece = (bytes + kStagePiece - 1) / kStagePiece;
   for (size_t k = 0; k <= npiece; k++) {
     if (k < npiece) {  // launch piece k (stream order puts it behind any upload still reading the buffer)
@@ -307,6 +330,8 @@ void bed_free(bsn_bed *b) {
   if (b->d_lut) (void)hipFree(b->d_lut);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->ev_up) (void)hipEventDestroy(b->ev_up);
+  if (b->stream_up) (void)hipStreamDestroy(b->stream_up);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
 }
@@ -746,7 +771,19 @@ static void matvec_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const i
                         int64_t m, const double *center, const double *scale, const double *x,
                         double *out, bool transpose, bsn_comm *comm = nullptr) {
   bsn_op op;
-  fill_op(&op, bed, ind_row, n, ind_col, m, center, scale);
+  // A~' x needs centre / scale only in its finalize kernel: their upload is queued on the second stream and runs
+  // beside the streaming kernel (2-bit image; the byte and look-up kernels read them earlier)
+  const bool late = transpose && bed->bits == 2 && !bed->generic && (center || scale);
+  fill_op(&op, bed, ind_row, n, ind_col, m, center, scale, late);
+  if (late) {   // (fill_op has only allocated centre / scale; a default is written here, on the main stream)
+    op.late_center = center;
+    op.late_scale = scale;
+    if (!center) BSN_HIP(hipMemsetAsync(op.d_center.p, 0, (size_t)m * 8, bed->stream));
+    if (!scale) {
+      hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, bed->stream, op.d_scale.p, m, 1.0);
+      BSN_HIP(hipGetLastError());
+    }
+  }
   op.slices = 7;  // 56-bit fixed point: fp64-grade for a single vector, still one MFMA column block
   int64_t nin = transpose ? n : m, nout = transpose ? m : n;
   DevBuf<double> d_in, d_out;

@@ -136,6 +136,9 @@ struct bsn_op {
   int64_t col0 = 0;
   int slices = 4;
   int64_t passes = 0;         // streaming launches over the image issued so far
+  // one-shot crossproduct (api.hip): centre / scale (host pointers, m doubles each, may be null = default) are only needed
+  // by the finalize kernel; the next op_cprod uploads them on the handle's second stream beside its streaming kernel
+  const double *late_center = nullptr, *late_scale = nullptr;
   // op_cprod_prequant: the digits of this panel are already in d_q (quantised ahead of the call that uses them)
   const double *preq_X = nullptr;
   int64_t preq_ldx = 0;
@@ -194,6 +197,8 @@ struct bsn_bed {
   bool tiled_tried = false;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream_up = nullptr;   // second stream (created on first use): uploads beside the kernels of `stream`
+  hipEvent_t ev_up = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // number of missing genotypes per variant over ALL samples, -1 = not known yet; filled as a
   // by-product of every full-row count (and at creation for FBM / NA-free synthetic images).
@@ -262,7 +267,8 @@ void subset_pack(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_
 // The runtime's own handling of pageable buffers was measured to leave every later stream
 // synchronisation of the process with a ~4 ms wake-up latency (tools/gpu/r02_h.sh), which costs a
 // solve 10 % — so no hot entry point hands pageable memory to hipMemcpy.
-void copy_h2d(bsn_bed *b, void *d_dst, const void *src, size_t bytes);
+void copy_h2d(bsn_bed *b, void *d_dst, const void *src, size_t bytes, hipStream_t stream = nullptr);  // default: the handle's stream
+hipStream_t upload_stream(bsn_bed *b);
 void copy_d2h(bsn_bed *b, void *dst, const void *d_src, size_t bytes);
 
 // api.hip: operator over a sub-view; defer_scale leaves centre / scale unset (stats_pending path)

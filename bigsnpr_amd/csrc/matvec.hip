@@ -1445,6 +1445,15 @@ void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z,
     }
     prof_end(op);
     op->passes++;
+    if (op->late_center || op->late_scale) {
+      // staged and sent while the streaming kernel runs; the finalize kernel waits for them
+      hipStream_t up = upload_stream(b);
+      if (op->late_center) copy_h2d(b, op->d_center.p, op->late_center, (size_t)op->m * 8, up);
+      if (op->late_scale) copy_h2d(b, op->d_scale.p, op->late_scale, (size_t)op->m * 8, up);
+      BSN_HIP(hipEventRecord(b->ev_up, up));
+      BSN_HIP(hipStreamWaitEvent(b->stream, b->ev_up, 0));
+      op->late_center = op->late_scale = nullptr;
+    }
     const bool has_q = op->stats_pending || !op->no_na;
     if (op->stats_pending) finish_fused_stats(op);
     if (NB == 1)
