@@ -170,12 +170,18 @@ def test_clumping_with_missing_values(ba, orc, golden_dir, missing_bed):
                                   orc.bed_clumping(missing_bed, chrom, pos, thr_r2=0.1))
 
 
-def test_ld_errors(ba, golden_dir):
+def test_ld_errors_and_repeated_samples(ba, orc, golden_dir, missing_bed):
     gb = ba.bed(os.path.join(golden_dir, "example-missing.bed"))
     with pytest.raises(ValueError, match="not sorted"):
         ba.bed_cor(gb, infos_pos=np.arange(gb.ncol)[::-1])
-    with pytest.raises(ba.BsnError, match="duplicated"):
-        ba.bed_cor(gb, ind_row=np.array([0, 1, 1, 2]))
+    # a row list with repeats (a bootstrap draw): the reference's accessor takes any list (src/bed-acc.h:64-65); here
+    # the sub-matrix is gathered once and the band runs on the copy
+    rng = np.random.default_rng(4)
+    ir = rng.integers(0, missing_bed.n, size=300)
+    ic = np.arange(100, 700)
+    with np.errstate(all="ignore"):
+        _same_cor(ba.bed_cor(gb, ir, ic, size=40), orc.snp_cor(missing_bed, ir, ic, size=40))
+    np.testing.assert_allclose(ba.bed_ld_scores(gb, ir, ic, size=40), orc.ld_scores(missing_bed, ir, ic, size=40), rtol=1e-12)
 
 
 def test_clumping_at_a_threshold_that_sits_on_a_pair(ba, orc, golden_dir, missing_bed):
