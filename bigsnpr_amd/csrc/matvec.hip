@@ -1638,7 +1638,9 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
   if (ky > steps) ky = (int)steps;
   if (ky > 64) ky = 64;
   if (ky < 1) ky = 1;
-  if (b->bits == 2) {
+  if (b->bits == 2 && pick_nb((nvec < vmax ? nvec : vmax) * S) == 1) {
+    // (one column block: the kernel is bound by HBM; with two it is bound by instruction issue, more slabs only help
+    // there — 400 000 x 125 000, 16 vectors: 4 slabs 3.45 ms, 5: 3.19, 9: 3.13, 11: 3.12 — and the rule above stays)
     // ... but every slab writes (and the finalize kernel reads back) its own n x 16 NB accumulators: on a matrix with
     // few samples per variant that is real traffic (50 000 x 200 000: 64 slabs = 16 % of the image), so the split is
     // capped at 4 % of the image bytes; and two workgroups per CU are resident, so among the splits left the one
