@@ -221,3 +221,46 @@ def test_dosage_matrices(ba, orc, case):
     want = orc.ld_scores(Go, ir, ic, size=kw["size"])
     assert np.all(np.isnan(got) == np.isnan(want))
     np.testing.assert_allclose(got[~np.isnan(want)], want[~np.isnan(want)], rtol=1e-9)
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_partial_svd_of_tiny_matrices(ba, orc, case):
+    """dimensions below one tile, k up to the smaller dimension minus one: the Krylov space is exhausted on the way
+    (the centred matrix has rank <= n - 1), singular values beyond the rank come out as (numerical) zeros"""
+    rng = np.random.default_rng(6000 + case)
+    n = int(rng.integers(5, 48))
+    m = int(rng.integers(6, 70))
+    gb, ob = _pair(ba, orc, n, m, 477 + case, int(rng.choice([0, 3000])))
+    sc = orc.bed_scaleBinom(ob)
+    ic = np.nonzero(sc["scale"] > 0)[0]
+    if ic.size < 3:
+        pytest.skip("degenerate draw")
+    kmax = min(n, ic.size) - 1
+    k = int(rng.integers(1, kmax + 1))
+    block = int(rng.choice([0, 1, 2, 8, 16]))
+    ref = orc.dense_svd(ob, None, ic, k=k)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)      # an exhausted space may be reported as not converged
+        res = ba.bed_randomSVD(gb, ind_col=ic, k=k, block=block, seed=case + 1)
+    np.testing.assert_allclose(res["d"], ref["d"], rtol=1e-6, atol=2e-4 * ref["d"][0])
+    big = ref["d"] > 1e-3 * ref["d"][0]
+    np.testing.assert_allclose(res["d"][big], ref["d"][big], rtol=1e-6)
+    kk = int(big.sum())
+    np.testing.assert_allclose((res["u"].T @ res["u"])[:kk, :kk], np.eye(kk), atol=1e-6)
+
+
+@pytest.mark.parametrize("n,m,k,block", [(1500, 2500, 40, 0), (1200, 5000, 80, 8), (900, 1400, 120, 16), (2500, 1800, 64, 4)])
+def test_many_triplets(ba, orc, n, m, k, block):
+    """k well beyond one block: many block steps, thick restarts when the basis fills up, same singular values"""
+    gb, ob = _pair(ba, orc, n, m, 577 + k, 655)
+    sc = orc.bed_scaleBinom(ob)
+    ic = np.nonzero(sc["scale"] > 0)[0]
+    ref = orc.dense_svd(ob, None, ic, k=k)
+    res = ba.bed_randomSVD(gb, ind_col=ic, k=k, block=block)
+    assert res["converged"]
+    np.testing.assert_allclose(res["d"], ref["d"], rtol=1e-6)
+    np.testing.assert_allclose(res["u"].T @ res["u"], np.eye(k), atol=1e-6)
+    j = k - 1
+    av = orc.bed_prodVec(ob, res["v"][:, j].copy(), None, ic, ref["center"], ref["scale"])
+    assert np.abs(av - res["u"][:, j] * res["d"][j]).max() <= 2e-4 * res["d"][0]
