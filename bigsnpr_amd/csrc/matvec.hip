@@ -581,7 +581,7 @@ __global__ __launch_bounds__(128) void k_cprod_final(const int32_t *__restrict__
 // instruction issue port, where a third wave to pick instructions from is what helps).  The 4 x 4 byte transposes
 // split cleanly: the half that owns sample quads q = 0, 1 needs only the low halves of the first-level permutes.
 template <int NB, bool CONTIG, bool RAWP, bool HASQ = true, int WAVES = 4, int ABL = 0, int UG = 1, int SETS = 2,
-          int TAG = 0, bool TILED = false, bool XMAP = false, bool HALF = false>
+          int TAG = 0, bool TILED = false, bool XMAP = false, bool HALF = false, bool LH = false>
 __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__ img, int64_t pitch,
                                               const int32_t *__restrict__ cols, int64_t col0,
                                               int64_t m_pad, int64_t mc,
@@ -598,20 +598,26 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
     by = xcd + 8u * (t / wgx);
   }
   static_assert(!HALF || (TILED && WAVES == 8 && UG == 1 && SETS == 2 && !XMAP), "wave pairs: tiled copy, 8 waves");
+  static_assert(!LH || (TILED && !HALF && UG == 1 && SETS == 2 && !XMAP), "lane halves: tiled copy");
+  // LH (two column blocks): a wave owns 128 samples — 8 dwords per variant row, lanes 2 d and 2 d + 1 of a k-group load
+  // the same dword (one address, coalesced) and keep one half of its 16 samples each: 64 accumulator registers
+  // instead of 128, and — unlike HALF — in four-wave workgroups, so that a third workgroup fits on a CU.
   const int swave = HALF ? (wave >> 1) : wave;       // which 256-sample block of the workgroup
-  const int qh = HALF ? (wave & 1) : 0;               // HALF: this wave keeps sample quads 2 qh, 2 qh + 1
-  constexpr int SW = HALF ? WAVES / 2 : WAVES;        // 256-sample blocks per workgroup
-  int64_t wbase = ((int64_t)bx * SW + swave) * 256;  // first sample of this wave
+  const int qh = LH ? (sg & 1) : HALF ? (wave & 1) : 0;   // this wave (HALF) / lane (LH) keeps sample quads 2 qh, 2 qh + 1
+  const int dw = LH ? (sg >> 1) : sg;                 // which dword of the wave's sample range
+  constexpr int SW = HALF ? WAVES / 2 : WAVES;        // sample blocks per workgroup
+  constexpr int WSAMP = LH ? 128 : 256;               // samples per wave
+  int64_t wbase = ((int64_t)bx * SW + swave) * WSAMP;  // first sample of this wave
   const bool active = wbase < n_pad;  // WAVES = 8: the last workgroup may be half empty
   if (!active) wbase = 0;
-  const int64_t wbyte = wbase / 4 + sg * 4;
+  const int64_t wbyte = wbase / 4 + dw * 4;
   const uint32_t lane_off = (uint32_t)(g * 16 * pitch + wbyte);
   const int64_t j0 = (int64_t)by * mc;
   int64_t j1 = j0 + mc;
   if (j1 > m_pad) j1 = m_pad;
   const uint4 *wq4 = (const uint4 *)wq;
 
-  constexpr int NU = HALF ? 8 : 16, NQ = HALF ? 2 : 4;
+  constexpr int NU = (HALF || LH) ? 8 : 16, NQ = (HALF || LH) ? 2 : 4;
   v4i acc[NU][NB];
 #pragma unroll
   for (int u = 0; u < NU; u++)
@@ -637,10 +643,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
       if constexpr (TILED) {
         // a wave owns 64 B of a 256-B column block: four waves per tile, WAVES / 4 tiles per workgroup and step
         static_assert(WAVES % 4 == 0, "streaming layout: whole 256-B column blocks per workgroup");
-        const int64_t sbw = __builtin_amdgcn_readfirstlane(active ? (int)((bx * SW + swave) >> 2) : 0);
+        const int64_t sbw = __builtin_amdgcn_readfirstlane(active ? (int)((bx * SW + swave) >> (LH ? 3 : 2)) : 0);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(img + (((col0 + jb) >> 6) * (pitch >> 8) + sbw) * 16384), 0, 0x7fffffff, 0x00020000);
-        const int toff = g * 4096 + (swave & 3) * 64 + sg * 4;
+        const int toff = LH ? g * 4096 + (int)((bx * SW + swave) & 7) * 32 + dw * 4 : g * 4096 + (swave & 3) * 64 + sg * 4;
 #pragma unroll
         for (int r = 0; r < 16; r++) dst[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, toff, r * 256, 0);
       } else {
@@ -695,8 +701,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
       constexpr int XS_ = SETS >= 2 ? SET : 0;
       const uint32_t x0 = X[XS_][4 * r4], x1 = X[XS_][4 * r4 + 1], x2 = X[XS_][4 * r4 + 2],
                      x3 = X[XS_][4 * r4 + 3];
-      if constexpr (HALF) {
-        const uint32_t sel = qh ? 0x07030602u : 0x05010400u;   // (uniform per wave)
+      if constexpr (HALF || LH) {
+        const uint32_t sel = qh ? 0x07030602u : 0x05010400u;   // (HALF: uniform per wave; LH: per lane)
         const uint32_t h01 = perm8(x1, x0, sel), h23 = perm8(x3, x2, sel);
         T[0][r4] = perm8(h23, h01, 0x05040100u);
         T[1][r4] = perm8(h23, h01, 0x07060302u);
@@ -779,7 +785,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
   if (active) {
 #pragma unroll
     for (int u = 0; u < NU; u++) {
-      const int64_t i = wbase + sg * 16 + (HALF ? 8 * qh : 0) + u;
+      const int64_t i = wbase + dw * 16 + ((HALF || LH) ? 8 * qh : 0) + u;
 #pragma unroll
       for (int nb = 0; nb < NB; nb++)
         *(v4i *)(acc_out + (((int64_t)by * n_pad + i) * NCOL + nb * 16 + 4 * g)) = acc[u][nb];
@@ -1198,7 +1204,7 @@ __global__ __launch_bounds__(256) void k_stats_summary(const int32_t *counts, in
 static bool use_tiled(const bsn_op *op) {
 #ifdef BSN_ABLATION
   // the ablation variants exist on the plain image only (41 - 46: workgroup shapes on the tiled copy)
-  if (tune_variant() != 0 && !(tune_variant() >= 41 && tune_variant() <= 48) && !(tune_variant() >= 90 && tune_variant() <= 99)) return false;
+  if (tune_variant() != 0 && !(tune_variant() >= 41 && tune_variant() <= 48) && !(tune_variant() >= 89 && tune_variant() <= 99)) return false;
 #endif
   return op->bed->d_tiled != nullptr && op->cols_contig && (op->col0 & 63) == 0;
 }
@@ -1565,6 +1571,17 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
       // (BSN_TUNE = 90, ablation build: wave pairs that split the 16 sample positions (HALF): three waves per SIMD
       // instead of two, but every wave still loads and shifts all 16 dwords — 30.9 ms against 24.2)
 #ifdef BSN_ABLATION
+      if (NB == 2 && tune_variant() == 89 && lutP == kLutRaw && op->prof_kind_override != 3) {  // lane halves, 4-wave workgroups
+        const dim3 g2(grid.x * 2, grid.y);
+        if (has_q)
+          hipLaunchKernelGGL((k_prod<NB, true, true, true, 4, 0, 1, 2, 0, true, false, false, (NB == 2)>), g2, dim3(256), 0,
+                             b->stream, b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
+        else
+          hipLaunchKernelGGL((k_prod<NB, true, true, false, 4, 0, 1, 2, 0, true, false, false, (NB == 2)>), g2, dim3(256), 0,
+                             b->stream, b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
+        BSN_HIP(hipGetLastError());
+        return;
+      }
       const bool half = NB == 2 && tune_variant() == 90;
 #define BSN_LAUNCH_PROD_TH(RAWP, HASQ, TAGV)                                                                           \
   hipLaunchKernelGGL((k_prod<NB, true, RAWP, HASQ, 8, 0, 1, 2, TAGV, true, false, (NB == 2)>), grid, dim3(512), 0,     \
