@@ -97,6 +97,7 @@ SIGNATURES = {
     "bsn_cormat": (C.c_int, [vp, i64p, i64, i64p, i64, C.c_double, f64p, f64p, C.c_int, i32p,
                              C.POINTER(C.c_int64), C.POINTER(vp)]),
     "bsn_cormat_fetch": (C.c_int, [vp, i32p, f64p]),
+    "bsn_cormat_has_nan": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "bsn_cormat_free": (C.c_int, [vp]),
     "bsn_ld_scores": (C.c_int, [vp, i64p, i64, i64p, i64, C.c_double, f64p, f64p]),
     "bsn_clumping_chr": (C.c_int, [vp, i64p, i64, i64p, i64, C.c_int, f64p, f64p, i32p, i32p, f64p,
@@ -217,7 +218,7 @@ class PinnedPool:
     engines write directly.  A block is reused once every numpy array over it has been collected, so
     results stay valid for as long as the caller holds them; at most `keep` bytes of free blocks are kept."""
 
-    def __init__(self, keep=1 << 30):
+    def __init__(self, keep=4 << 30):
         self.free, self.keep = [], keep
 
     def empty(self, shape, dtype=np.float64):

@@ -696,7 +696,7 @@ __global__ void k_cor_count(const double *__restrict__ band, const int64_t *__re
 
 __global__ void k_cor_fill(const double *__restrict__ band, const int64_t *__restrict__ lo, int64_t W,
                            int64_t m, int fill_diag, const int32_t *__restrict__ p,
-                           int32_t *__restrict__ oi, double *__restrict__ ox) {
+                           int32_t *__restrict__ oi, double *__restrict__ ox, int *__restrict__ nan_seen) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t j0 = (int64_t)blockIdx.x * 4 + wave;
   if (j0 >= m) return;
@@ -713,6 +713,7 @@ __global__ void k_cor_fill(const double *__restrict__ band, const int64_t *__res
       const int off = __popcll(mask & ((1ull << lane) - 1ull));
       oi[base + off] = (int32_t)(lo[j0] + t);
       ox[base + off] = v;
+      if (v != v) *nan_seen = 1;   // (every writer stores the same value)
     }
     base += __popcll(mask);
   }
@@ -1164,6 +1165,7 @@ struct bsn_cor {
   DevBuf<int32_t> d_p, d_i;
   DevBuf<double> d_x;
   int64_t nnz = 0;
+  int has_nan = 0;   // an NaN among the stored correlations (a variant without variation, R/corr.R:53-54)
 };
 
 extern "C" {
@@ -1200,9 +1202,12 @@ int bsn_cormat(bsn_bed *bed_in, const int64_t *ind_row_in, int64_t n, const int6
     copy_h2d(bed, C->d_p.ensure((size_t)m + 1), p_out, (size_t)(m + 1) * 4);
     C->d_i.ensure((size_t)std::max<int64_t>(nnz, 1));
     C->d_x.ensure((size_t)std::max<int64_t>(nnz, 1));
+    DevBuf<int> d_nan;
+    BSN_HIP(hipMemsetAsync(d_nan.ensure(1), 0, sizeof(int), bed->stream));
     hipLaunchKernelGGL(k_cor_fill, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, bed->stream, J.d_band.p,
-                       J.d_lo.p, J.W, m, fill_diag, C->d_p.p, C->d_i.p, C->d_x.p);
+                       J.d_lo.p, J.W, m, fill_diag, C->d_p.p, C->d_i.p, C->d_x.p, d_nan.p);
     BSN_HIP(hipGetLastError());
+    BSN_HIP(hipMemcpyAsync(&C->has_nan, d_nan.p, sizeof(int), hipMemcpyDeviceToHost, bed->stream));
     BSN_HIP(hipStreamSynchronize(bed->stream));
     J.d_band.release();
     J.d_stats.release();
@@ -1229,6 +1234,10 @@ int bsn_cormat_fetch(bsn_cor *c, int32_t *i_out, double *x_out) {
       copy_d2h(c->job.bed, x_out, c->d_x.p, (size_t)c->nnz * 8);
     }
   });
+}
+
+int bsn_cormat_has_nan(const bsn_cor *c, int *out) {
+  return guarded([&] { *out = c->has_nan; });
 }
 
 int bsn_cormat_free(bsn_cor *c) {

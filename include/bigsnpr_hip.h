@@ -323,6 +323,10 @@ int bsn_cormat(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *i
                double size, const double *thr, const double *pos, int fill_diag, int32_t *p_out,
                int64_t *nnz_out, bsn_cor **out);
 int bsn_cormat_fetch(bsn_cor *cor, int32_t *i_out, double *x_out);
+/* *out = 1 when a stored correlation is NaN (a variant without variation among the selected samples): what
+ * R/corr.R:53-54 finds with anyNA(corr@x), here noted by the kernel that writes @x instead of a pass over the
+ * 12 bytes per pair on the host. */
+int bsn_cormat_has_nan(const bsn_cor *cor, int *out);
 int bsn_cormat_free(bsn_cor *cor);
 /* measurement hook (bench.py --workload ld): figures of the last bsn_cormat / bsn_ld_scores /
  * bsn_clumping_* call of this process: out[0] = variant pairs in the band, out[1] = 64 x 64 tile

@@ -178,7 +178,7 @@ def test_ld_errors_and_repeated_samples(ba, orc, golden_dir, missing_bed):
     # the sub-matrix is gathered once and the band runs on the copy
     rng = np.random.default_rng(4)
     ir = rng.integers(0, missing_bed.n, size=300)
-    ic = np.arange(100, 700)
+    ic = np.arange(50, min(missing_bed.m, 450))
     with np.errstate(all="ignore"):
         _same_cor(ba.bed_cor(gb, ir, ic, size=40), orc.snp_cor(missing_bed, ir, ic, size=40))
     np.testing.assert_allclose(ba.bed_ld_scores(gb, ir, ic, size=40), orc.ld_scores(missing_bed, ir, ic, size=40), rtol=1e-12)
