@@ -59,7 +59,10 @@ def bed_tcrossprodSelf(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_co
     ir, ic = _args(obj_bed, ind_row, ind_col)
     ms = fun_scaling(obj_bed, ind_row=ir, ind_col=ic)
     center, scale = as_f64(ms["center"]), as_f64(ms["scale"])
-    K = np.empty((ir.size, ir.size), dtype=np.float64, order="F")
+    if ir.size * ir.size * 8 >= (8 << 20):   # a large K lands in a page-locked block of the result pool (direct DMA)
+        K = _lib.result_pool.empty((ir.size, ir.size)).T      # (symmetric: the orientation of the block is immaterial)
+    else:
+        K = np.empty((ir.size, ir.size), dtype=np.float64, order="F")
     check(_lib.load().bsn_bed_tcrossprod(obj_bed.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p),
                                          ic.size, ptr(center, f64p), ptr(scale, f64p),
                                          int(block_size), K.ctypes.data_as(f64p)))
