@@ -45,6 +45,18 @@ def scale_tau2(x, c1=4.5, c2=3.0, mu_too=False):
     return (mu, s) if mu_too else s
 
 
+def _map_threads(f, items):
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    items = list(items)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    with ThreadPoolExecutor(max_workers=max(1, min(16, ncpu, len(items)))) as ex:
+        return list(ex.map(f, items))
+
+
 def covrob_ogk(U, niter=2, beta=0.9):
     """Orthogonalised Gnanadesikan-Kettenring estimate with reweighting (hard rejection)."""
     from scipy.stats import chi2
@@ -52,20 +64,25 @@ def covrob_ogk(U, niter=2, beta=0.9):
     n, p = U.shape
     Z = U.copy()
     A = []
+    # the p + p (p - 1) robust scales of a round are independent of each other and each is a few passes over n
+    # values (two medians, two weighted sums): on a million variants they are the whole cost of the outlier step, so
+    # they are spread over a few threads (numpy releases the interpreter lock inside them; same values, any order)
+    run = _map_threads if n * p >= 200000 else (lambda f, items: [f(t) for t in items])
     for _ in range(niter):
-        d = np.array([scale_tau2(Z[:, j]) for j in range(p)])
+        d = np.array(run(lambda j: scale_tau2(Z[:, j]), range(p)))
         d[d <= 0] = 1.0
         Z = Z / d
         R = np.eye(p)
-        for i in range(p):
-            for j in range(i):
-                R[i, j] = R[j, i] = (scale_tau2(Z[:, i] + Z[:, j]) ** 2 -
-                                     scale_tau2(Z[:, i] - Z[:, j]) ** 2) / 4
+        pairs = [(i, j) for i in range(p) for j in range(i)]
+        vals = run(lambda ij: (scale_tau2(Z[:, ij[0]] + Z[:, ij[1]]) ** 2 -
+                               scale_tau2(Z[:, ij[0]] - Z[:, ij[1]]) ** 2) / 4, pairs)
+        for (i, j), v in zip(pairs, vals):
+            R[i, j] = R[j, i] = v
         _, E = np.linalg.eigh(R)
         E = E[:, ::-1]
         A.append(d[:, None] * E)
         Z = Z @ E
-    ms = [scale_tau2(Z[:, j], mu_too=True) for j in range(p)]
+    ms = run(lambda j: scale_tau2(Z[:, j], mu_too=True), range(p))
     mu = np.array([t[0] for t in ms]); sig = np.array([t[1] for t in ms])
     sig[sig <= 0] = 1.0
     wdist = np.sum(((Z - mu) / sig) ** 2, axis=1)
