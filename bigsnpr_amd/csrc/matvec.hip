@@ -1318,7 +1318,7 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
       return;
     }
     // BSN_TUNE = 21 .. 27: workgroup shapes (tiles per wave, waves, samples per chunk); correct results
-    if (NB == 1 && abl >= 21 && abl <= 27 && op->cols_contig) {
+    if (NB == 1 && abl >= 21 && abl <= 29 && op->cols_contig) {
 #define BSN_SHAPE(TILESV, WAVESV, KCV)                                                                    \
   hipLaunchKernelGGL((k_cprod<1, NPLANE, KCV, RAW0, STATS, true, 0, TILESV, WAVESV, 1>),                  \
                      dim3((unsigned)((op->m + 16 * TILESV * WAVESV - 1) / (16 * TILESV * WAVESV))),       \
@@ -1330,6 +1330,8 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
       else if (abl == 24) BSN_SHAPE(1, 16, 512);
       else if (abl == 25) BSN_SHAPE(2, 4, 512);
       else if (abl == 26) BSN_SHAPE(2, 16, 512);
+      else if (abl == 28) BSN_SHAPE(4, 8, 512);
+      else if (abl == 29) BSN_SHAPE(4, 4, 512);
       else BSN_SHAPE(1, 16, 1024);
 #undef BSN_SHAPE
       BSN_HIP(hipGetLastError());

@@ -23,7 +23,6 @@ p = t(lambda: ba.bed_prodVec(gb, x, center=sc["center"], scale=sc["scale"]))
 c = t(lambda: ba.bed_cprodVec(gb, y, center=sc["center"], scale=sc["scale"]))
 print("%s prodVec %.3f ms  cprodVec %.3f ms" % (sys.argv[1], p, c))
 P
-for rep in 1 2; do
-python /tmp/c2probe.py base 2>/dev/null | tee -a $O/sweep.txt
-for ky in 4 5 6 8 10 11 12 14 16 20; do BSN_KY=$ky python /tmp/c2probe.py ky$ky 2>/dev/null | tee -a $O/sweep.txt; done
+for rep in 1 2 3; do
+for tv in 0 28 29 25; do BSN_TUNE=$tv python /tmp/c2probe.py tune$tv 2>/dev/null | tee -a $O/sweep2.txt; done
 done
