@@ -160,16 +160,35 @@ def medcouple(x):
             c = int(np.sum(lop.size - np.searchsorted(lop, thr, side="left")))
         return c + n_minus + int(np.sum(tie <= t))       # the +1 pairs only at t >= 1
 
-    def kth(k):  # k-th smallest kernel value (1-based) by bisection, then snapped to an attained value
+    def window(a, b):  # every kernel value in (a, b], -1 < a < b < 1 (regular pairs and the ties among themselves)
+        lo_i = np.searchsorted(lop, upp * (1 - b) / (1 + b), side="left")     # h <= b  <=>  l >= this
+        hi_i = np.searchsorted(lop, upp * (1 - a) / (1 + a), side="left")     # h >  a  <=>  l <  this
+        cnt = np.maximum(hi_i - lo_i, 0)
+        tot = int(cnt.sum())
+        u_rep = np.repeat(upp, cnt)
+        first = np.repeat(lo_i - (np.cumsum(cnt) - cnt), cnt)                 # l index = first + running position
+        l = lop[first + np.arange(tot)]
+        return np.concatenate([(u_rep - l) / (u_rep + l), tie[(tie > a) & (tie <= b)]])
+
+    def kth(k):  # k-th smallest kernel value (1-based)
         a, b = -1.0, 1.0
-        if count_le(-1.0) >= k:
+        ca = count_le(-1.0)
+        if ca >= k:
             return -1.0
+        cb = total
+        # bisection on t until few kernel values are left between the bounds; those are then written out and the
+        # wanted one picked by its rank (exact, and a fifth of the count evaluations of a bisection down to 1e-15)
         for _ in range(200):
+            if -1.0 < a and b < 1.0 and cb - ca <= 400000:
+                vals = window(a, b)
+                if vals.size == cb - ca:                                      # (always, unless rounding moved a pair across a bound)
+                    return float(np.partition(vals, k - ca - 1)[k - ca - 1])
             mid = 0.5 * (a + b)
-            if count_le(mid) >= k:
-                b = mid
+            cm = count_le(mid)
+            if cm >= k:
+                b, cb = mid, cm
             else:
-                a = mid
+                a, ca = mid, cm
             if b - a < 1e-15:
                 break
         # attained values near b: ties give exactly -1, 0, +1; regular pairs (u - l) / (u + l)
