@@ -177,3 +177,23 @@ def test_two_independent_restatements_agree():
                  (list(range(10, 40)) + [50, 51], 20), ([2, 3], 2)):
         got = [tuple(r) for r in prod.getIntervals(np.asarray(x), n=n).tolist()]
         assert got == orc_a.get_intervals(x, n=n), (x, n)
+
+
+def test_scaled_up_paths_give_the_same_numbers():
+    """what only large inputs reach: the robust scales of dist_ogk on several threads (same values as one after the
+    other), and the medcouple's windowed rank selection deep into a bisection (against the all-pairs definition)"""
+    from bigsnpr_amd import autosvd as prod
+    from oracle import autosvd_oracle as orc_a
+    rng = np.random.default_rng(77)
+    U = rng.normal(size=(25000, 8)) * rng.uniform(0.5, 3, size=8)
+    U[:40] += 5.0
+    threaded = prod.dist_ogk(U)                                   # 25 000 x 8 >= the threshold of the threaded path
+    keep = prod._map_threads
+    try:
+        prod._map_threads = lambda f, items: [f(t) for t in items]
+        serial = prod.dist_ogk(U)
+    finally:
+        prod._map_threads = keep
+    np.testing.assert_array_equal(threaded, serial)
+    for x in (rng.normal(size=1500) ** 2, np.round(rng.gamma(2.0, size=1201), 1)):
+        assert abs(prod.medcouple(x) - orc_a.medcouple(x)) < 1e-12
