@@ -1008,6 +1008,22 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     so.verbose = o->verbose;
     BSN_HIP(hipEventRecord(bed->ev0, bed->stream));
     SvdResult r = block_lanczos_svd(bk, so, d, u, v);
+    if (r.exhausted && r.exhausted_resid > 1e-9 && o->slices <= 0 && op->slices < 7) {
+      // a Krylov space exhausted on rounded products (svd_driver.hpp): only matrices whose rank fits the basis get
+      // here, so the second solve — 56-bit digits, at most four vectors per pass — is cheap, and it is run whenever
+      // the coupling block is not negligible, met tolerance or not: a matrix this small deserves its exact values
+      if (o->verbose)
+        std::fprintf(stderr, "[bsn svd] Krylov space exhausted with a relative residual of %.3g on %d-bit products: "
+                             "again with 56-bit products\n", r.max_rel_resid, 8 * op->slices);
+      op->slices = 7;
+      so.block = std::min(so.block, 32 / 7);
+      so.resid_floor = 1.2 * std::ldexp(1.0, -8 * op->slices);
+      const SvdResult r1 = r;
+      r = block_lanczos_svd(bk, so, d, u, v);
+      r.niter += r1.niter;
+      r.nops += r1.nops;
+      r.restarts += r1.restarts;
+    }
     const double t_solve = since() - t_create;
     if (o->verbose > 1 || bk.timing)
       std::fprintf(stderr,

@@ -3,8 +3,13 @@ sweep what lies between them — ragged sizes around every tile boundary (4 samp
 256-variant panels), index lists with repeats and in any order, missing-value rates from none to heavy, every block
 size and digit count the solver accepts.  Same tolerances as the fixed tests: integer and index outputs bit-exact,
 products 1e-9, correlations 1e-12, singular values 1e-6."""
+import os
+
 import numpy as np
 import pytest
+
+# BSN_TEST_SEED_OFFSET=<k> moves every case to another draw (exploration runs; the committed suite runs offset 0)
+_OFF = 100000 * int(os.environ.get("BSN_TEST_SEED_OFFSET", "0"))
 
 pytestmark = pytest.mark.gpu
 
@@ -34,7 +39,7 @@ _SIZES = [1, 3, 4, 5, 15, 16, 17, 63, 64, 65, 127, 129, 255, 257, 511, 1023, 102
 
 @pytest.mark.parametrize("case", range(24))
 def test_products_and_statistics(ba, orc, case):
-    rng = np.random.default_rng(1000 + case)
+    rng = np.random.default_rng(_OFF + 1000 + case)
     n = int(rng.choice(_SIZES)) + int(rng.integers(0, 3))
     m = int(rng.choice(_SIZES)) + int(rng.integers(0, 3))
     na16 = int(rng.choice([0, 0, 655, 6000, 30000]))
@@ -63,7 +68,7 @@ def test_products_and_statistics(ba, orc, case):
 
 @pytest.mark.parametrize("case", range(20))
 def test_partial_svd(ba, orc, case):
-    rng = np.random.default_rng(2000 + case)
+    rng = np.random.default_rng(_OFF + 2000 + case)
     n = int(rng.integers(30, 2200))
     m = int(rng.integers(40, 4200))
     na16 = int(rng.choice([0, 655, 6000]))
@@ -105,7 +110,7 @@ def _same_cor(res, ref, tol=1e-12):
 @pytest.mark.filterwarnings("ignore:.*NA or NaN values.*")
 @pytest.mark.parametrize("case", range(16))
 def test_correlations_scores_clumping(ba, orc, case):
-    rng = np.random.default_rng(3000 + case)
+    rng = np.random.default_rng(_OFF + 3000 + case)
     n = int(rng.integers(20, 1500))
     m = int(rng.integers(2, 900))
     na16 = int(rng.choice([0, 655, 12000]))
@@ -129,7 +134,10 @@ def test_correlations_scores_clumping(ba, orc, case):
     chrom = np.r_[np.ones(m // 2, dtype=np.int64), np.full(m - m // 2, 2, dtype=np.int64)]
     bp = np.cumsum(rng.integers(1, 5000, size=m))
     S = rng.uniform(size=m) if case % 2 else None
-    thr = float(rng.choice([0.05, 0.2, 0.5]))
+    # (thresholds that no r2 can hit: bed_clumping_chr sums scaled products in fp64, src/clumping-bed.cpp:62-76, while the
+    # GPU works from exact integer sums — with a few dozen samples r2 = 1 / 5 EXACTLY happens, the reference then sees
+    # 0.20000000000000004 > 0.2 and the two sides of the tie differ legitimately; tests/test_gpu_ld.py treats that case)
+    thr = float(rng.choice([0.0517, 0.2013, 0.4989]))
     win = float(rng.choice([50, 500]))
     with np.errstate(all="ignore"):
         want = orc.bed_clumping(ob, chrom, bp, ind_row=ir, S=S, thr_r2=thr, size=win)
@@ -139,7 +147,7 @@ def test_correlations_scores_clumping(ba, orc, case):
 
 @pytest.mark.parametrize("case", range(10))
 def test_kinship_projection_regression_prs(ba, orc, case):
-    rng = np.random.default_rng(4000 + case)
+    rng = np.random.default_rng(_OFF + 4000 + case)
     n = int(rng.choice([9, 31, 130, 257, 640, 1001]))
     m = int(rng.integers(20, 1800))
     na16 = int(rng.choice([0, 655, 9000]))
@@ -189,7 +197,7 @@ def test_kinship_projection_regression_prs(ba, orc, case):
 @pytest.mark.filterwarnings("ignore:.*NA or NaN values.*")
 @pytest.mark.parametrize("case", range(10))
 def test_dosage_matrices(ba, orc, case):
-    rng = np.random.default_rng(5000 + case)
+    rng = np.random.default_rng(_OFF + 5000 + case)
     n = int(rng.integers(10, 1300))
     m = int(rng.integers(3, 700))
     f = rng.uniform(0.05, 0.95, size=m)
@@ -227,7 +235,7 @@ def test_dosage_matrices(ba, orc, case):
 def test_partial_svd_of_tiny_matrices(ba, orc, case):
     """dimensions below one tile, k up to the smaller dimension minus one: the Krylov space is exhausted on the way
     (the centred matrix has rank <= n - 1), singular values beyond the rank come out as (numerical) zeros"""
-    rng = np.random.default_rng(6000 + case)
+    rng = np.random.default_rng(_OFF + 6000 + case)
     n = int(rng.integers(5, 48))
     m = int(rng.integers(6, 70))
     gb, ob = _pair(ba, orc, n, m, 477 + case, int(rng.choice([0, 3000])))
@@ -239,11 +247,11 @@ def test_partial_svd_of_tiny_matrices(ba, orc, case):
     k = int(rng.integers(1, kmax + 1))
     block = int(rng.choice([0, 1, 2, 8, 16]))
     ref = orc.dense_svd(ob, None, ic, k=k)
-    import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore", RuntimeWarning)      # an exhausted space may be reported as not converged
-        res = ba.bed_randomSVD(gb, ind_col=ic, k=k, block=block, seed=case + 1)
-    np.testing.assert_allclose(res["d"], ref["d"], rtol=1e-6, atol=2e-4 * ref["d"][0])
+    res = ba.bed_randomSVD(gb, ind_col=ic, k=k, block=block, seed=case + 1)
+    # an exhausted space whose last directions carry the noise of the 16-bit products is solved again on 56-bit
+    # products (svd_driver.hpp): converged, and the values of a dense solver
+    assert res["converged"]
+    np.testing.assert_allclose(res["d"], ref["d"], rtol=1e-6, atol=1e-6 * ref["d"][0])
     big = ref["d"] > 1e-3 * ref["d"][0]
     np.testing.assert_allclose(res["d"][big], ref["d"][big], rtol=1e-6)
     kk = int(big.sum())
