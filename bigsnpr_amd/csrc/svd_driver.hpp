@@ -447,6 +447,10 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
       }
     }
     if (done || rn == 0) {
+      if (exhausted) {
+        res.exhausted = 1;
+        res.exhausted_resid = worst_sig;
+      }
       if (exhausted && !done) {
         // An invariant Krylov space gives exact Ritz pairs — in exact arithmetic.  The products here are exact for a
         // ROUNDED basis: the last directions of a nearly exhausted space are what is left of a panel after projecting
@@ -454,8 +458,6 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
         // digits: the 25th of 25 directions is 98.5 % right, the singular values 1.5e-3 off), and the coupling block of
         // the step says so.  Triplets beyond the rank (theta ~ 0) are exempt: any null vector serves.  The caller
         // (svd.hip) answers an inexact exhaustion with a second solve on 56-bit products.
-        res.exhausted = 1;
-        res.exhausted_resid = worst_sig;
         res.converged = (worst_sig + opt.resid_floor <= opt.tol) ? 1 : 0;
       }
       break;
