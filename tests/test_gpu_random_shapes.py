@@ -272,3 +272,39 @@ def test_many_triplets(ba, orc, n, m, k, block):
     j = k - 1
     av = orc.bed_prodVec(ob, res["v"][:, j].copy(), None, ic, ref["center"], ref["scale"])
     assert np.abs(av - res["u"][:, j] * res["d"][j]).max() <= 2e-4 * res["d"][0]
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_grid_clumping_and_scores(ba, orc, case):
+    """snp_grid_clumping / snp_grid_PRS (R/SCT.R) on random shapes: kept indices identical, scores 1e-9"""
+    rng = np.random.default_rng(_OFF + 7000 + case)
+    n = int(rng.integers(30, 900))
+    m = int(rng.integers(20, 700))
+    gb, ob = _pair(ba, orc, n, m, 677 + case, 0)
+    Go = orc.fbm_from_bed(ob)
+    G = ba.FBM_code256(Go.bytes)
+    nchr = int(rng.integers(1, 4))
+    chrom = np.sort(rng.integers(1, nchr + 1, size=m))
+    pos = np.zeros(m, dtype=np.int64)
+    for c in np.unique(chrom):
+        idx = np.nonzero(chrom == c)[0]
+        pos[idx] = np.cumsum(rng.integers(1, 4000, size=idx.size))
+    lpval = -np.log10(rng.uniform(size=m))
+    ir = _indices(rng, n, case % 2)                      # all rows / a sorted subset
+    kw = dict(grid_thr_r2=tuple(sorted(rng.choice([0.0513, 0.1007, 0.2011, 0.5003, 0.8009], size=2, replace=False))),
+              grid_base_size=tuple(sorted(rng.choice([37, 50, 100, 211], size=2, replace=False).tolist())))
+    if case % 3 == 0:
+        kw["exclude"] = rng.choice(m, size=max(1, m // 10), replace=False)
+    with np.errstate(all="ignore"):
+        got = ba.snp_grid_clumping(G, chrom, pos, lpval, ind_row=ir, **kw)
+        want, grid, _ = orc.snp_grid_clumping(Go, chrom, pos, lpval, ind_row=ir, **kw)
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert len(a) == len(b)
+        for u, v in zip(a, b):
+            np.testing.assert_array_equal(u, v)
+    betas = rng.normal(0, 0.1, m)
+    thr = orc.seq_log(0.1, 0.9999 * lpval.max(), 6)
+    S = ba.snp_grid_PRS(G, got, betas, lpval, ind_row=ir, grid_lpS_thr=thr, type="double")
+    Sref = orc.snp_grid_PRS(Go, want, betas, lpval, thr, ind_row=ir)
+    np.testing.assert_allclose(np.asarray(S), Sref, rtol=0, atol=1e-9 * max(1.0, np.abs(Sref).max()))
