@@ -308,3 +308,31 @@ def test_grid_clumping_and_scores(ba, orc, case):
     S = ba.snp_grid_PRS(G, got, betas, lpval, ind_row=ir, grid_lpS_thr=thr, type="double")
     Sref = orc.snp_grid_PRS(Go, want, betas, lpval, thr, ind_row=ir)
     np.testing.assert_allclose(np.asarray(S), Sref, rtol=0, atol=1e-9 * max(1.0, np.abs(Sref).max()))
+
+
+@pytest.mark.filterwarnings("ignore:.*NA or NaN values.*")
+@pytest.mark.parametrize("case", range(6))
+def test_correlations_on_longer_chromosomes(ba, orc, case):
+    """several thousand variants: many 128 x 32 blocks per launch, windows that cut blocks anywhere, the lazy clumping
+    path, rows as a subset / with repeats"""
+    rng = np.random.default_rng(_OFF + 8000 + case)
+    n = int(rng.integers(150, 1600))
+    m = int(rng.integers(2500, 7000))
+    gb, ob = _pair(ba, orc, n, m, 777 + case, int(rng.choice([0, 655, 9000])))
+    ir = _indices(rng, n, case % 3)
+    ic = _indices(rng, m, 1) if case % 2 else None
+    mc = m if ic is None else ic.size
+    pos = np.cumsum(rng.integers(1, 2000, size=mc)).astype(np.float64)
+    size = float(rng.choice([15.0, 90.0, 400.0]))           # kb: windows of a few to a few hundred variants
+    _same_cor(ba.bed_cor(gb, ir, ic, size=size, infos_pos=pos, thr_r2=0.0507), orc.snp_cor(ob, ir, ic, size=size, infos_pos=pos, thr_r2=0.0507, ncores=8))
+    got = ba.bed_ld_scores(gb, ir, ic, size=size, infos_pos=pos)
+    want = orc.ld_scores(ob, ir, ic, size=size, infos_pos=pos)
+    assert np.all(np.isnan(got) == np.isnan(want))
+    np.testing.assert_allclose(got[~np.isnan(want)], want[~np.isnan(want)], rtol=1e-11)
+    chrom = np.ones(m, dtype=np.int64)
+    bp = np.cumsum(rng.integers(1, 3000, size=m))
+    win = float(rng.choice([100, 1000]))
+    with np.errstate(all="ignore"):
+        want = orc.bed_clumping(ob, chrom, bp, ind_row=ir, thr_r2=0.2013, size=win)
+        got = ba.bed_clumping(gb, ind_row=ir, thr_r2=0.2013, size=win, infos_chr=chrom, infos_pos=bp)
+    np.testing.assert_array_equal(got, want)
