@@ -52,7 +52,7 @@ def _mock_rccl():
     return build_native.build_mock_rccl()
 
 
-@pytest.mark.parametrize("transport,world,n", [("mock", 2, 3000), ("mock", 3, 3001), ("mock", 8, 3005), ("rccl", 2, 3000)])
+@pytest.mark.parametrize("transport,world,n", [("mock", 2, 3000), ("mock", 3, 3001), ("mock", 4, 1234), ("mock", 7, 2050), ("mock", 8, 3005), ("rccl", 2, 3000)])
 def test_ranks_over_the_collective_calls(tmp_path, ba, transport, world, n):
     """several ranks through comm.hip's collective calls: reduce-scatter of the panel by sample blocks, Gram
     all-reduces, all-gather of the basis block, and the sharded one-shot product.  `rccl` needs two GPUs; `mock`
