@@ -941,9 +941,6 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     } else {
       fill_op(op, bed, ind_row, n, ind_col, m, center, scale);
     }
-    // a solve streams the image a dozen times: give the two streaming kernels their layout (a second copy in
-    // 64-variant x 256-B tiles, one extra pass of copying, kept on the handle) when the device has the room
-    if (op->cols_contig && (op->col0 & 63) == 0 && m >= 4096) image_tile(bed);
     const double t_create = since();
     op->profile = true;
     if (o->slices > 7) fail("slices must be in 1..7");
@@ -1000,6 +997,12 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       so.block = bb;
       op->slices = ss;
     }
+    // a solve streams the image a dozen times: the ONE-block kernels, which are bound by HBM, get their layout (a
+    // second copy in 64-variant x 256-B tiles, one extra pass of copying, kept on the handle) when the device has the
+    // room: 2 - 4 % per pass.  The two-block kernels are bound by instruction issue and gain nothing from it (k_prod<2>
+    // 23.65 ms on the plain image against 23.75 on the copy, k_cprod<2> 21.65 against 21.52: profiles/r03_shape_sweeps.txt),
+    // so the default solve at k >= 14 leaves the other half of the HBM alone; a copy that exists is used either way.
+    if (so.block * op->slices <= 16 && op->cols_contig && (op->col0 & 63) == 0 && m >= 4096) image_tile(bed);
     so.resid_floor = 1.2 * std::ldexp(1.0, -8 * op->slices);
     so.warm = o->warm_start < 0 ? 0 : (o->warm_start == 0 ? 1 : o->warm_start);
     so.max_basis = o->max_basis;
