@@ -57,6 +57,8 @@ def parse():
                     help="leave u and v on the device (diagnostic: the timed solve then ends before the 224-MB download "
                          "of the result; the default times the whole function, result on the host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-wide", action="store_true",
+                    help="skip the two extra solves on 32- and 56-bit panels that fill `fp64_equivalent`")
     ap.add_argument("--no-ingest", action="store_true")
     ap.add_argument("--ingest-gb", type=float, default=8.0, help="size of the .bed file written and re-opened")
     ap.add_argument("--allow-fallback", action="store_true",
@@ -279,16 +281,26 @@ def main():
     dom = kern[dom_key]
     # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside
     # the process, so this is the committed rocprofv3 measurement of the same workload
-    traffic = None
+    traffic, traffic_note = None, None
     blk, sl = infos[-1]["block"], infos[-1]["slices"]
     nb = 1 if blk * sl <= 16 else 2          # MFMA column blocks of the streaming kernels
+    running = streaming_kernel_names(L, gb)  # what this build launched in the last solve, by kind
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        # the counters are per kernel variant: one column block (block x slices <= 16) or two
-        if pm["workload"] == {"n": n, "m_per_gpu": m_local}:
-            traffic = pm["kernels" if nb == 1 else "kernels_nb2"][dom_key]["hbm_read_bytes"]
-    except Exception:
-        traffic = None
+        # the counters are per kernel variant: one column block (block x slices <= 16) or two.  The record is only
+        # quoted when it was taken on the SAME kernel instantiation built from the SAME source as the running library
+        rec = pm["kernels" if nb == 1 else "kernels_nb2"][dom_key]
+        if pm["workload"] != {"n": n, "m_per_gpu": m_local}:
+            traffic_note = "profiles/pmc_traffic.json was taken on another workload"
+        elif pm.get("matvec_sha256") != source_sha256("matvec.hip"):
+            traffic_note = "profiles/pmc_traffic.json was taken on another build of matvec.hip"
+        elif norm_kernel(rec["name"]) != norm_kernel(running.get(dom_key, "")):
+            traffic_note = ("profiles/pmc_traffic.json holds %s, this build launched %s"
+                            % (rec["name"], running.get(dom_key)))
+        else:
+            traffic = rec["hbm_read_bytes"]
+    except Exception as e:
+        traffic, traffic_note = None, "no usable profiles/pmc_traffic.json (%s)" % e
     achieved = bytes_per_launch / (dom["avg_ms"] * 1e-3) / 1e9
     # the same launch priced against the matrix pipe: per 16 variants x 64 samples one v_mfma_i32_16x16x64_i8
     # (32 768 int8 ops) per plane (genotype, missing-value) and column block
@@ -329,7 +341,9 @@ def main():
         "generate_s": gen_s,
         "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2, bytes per launch)" if traffic else None,
+                     "traffic_source": ("profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2, bytes per launch; same kernel "
+                                        "instantiation and matvec.hip hash as this build)") if traffic else traffic_note,
+                     "kernels_launched": running,
                      "bytes_per_launch": bytes_per_launch, "avg_launch_ms": dom["avg_ms"],
                      "launches": dom["launches"],
                      # the two-column-block kernels (16 vectors per pass) are bound by the matrix pipe / the VALU issue
@@ -342,6 +356,9 @@ def main():
     }
 
     if rank == 0 and world == 1:
+        if not a.no_wide:
+            out["fp64_equivalent"] = wide_solves(ba, gb, a, infos[-1], sync)
+            log("wide-arithmetic solves done")
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ba, gb, n, a.cpu_sample_cols)
             log("cpu baseline done")
@@ -358,6 +375,55 @@ def main():
     if rank == 0:
         real_stdout.write(json.dumps(out) + "\n")   # the ONE stdout line
         real_stdout.flush()
+
+
+def norm_kernel(name):
+    """kernel name as rocprofv3 / the demangler print it -> comparable form"""
+    name = name.split("(")[0]
+    for junk in ("void ", "bsn::", " "):
+        name = name.replace(junk, "")
+    return name
+
+
+def source_sha256(fname):
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, "bigsnpr_amd", "csrc", fname), "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
+def streaming_kernel_names(L, gb):
+    import ctypes as C
+    buf = C.create_string_buffer(4096)
+    if L.bsn_bed_streaming_kernels(gb.handle, buf, 4096) != 0:
+        return {}
+    return dict(line.split("=", 1) for line in buf.value.decode().splitlines() if "=" in line)
+
+
+def wide_solves(ba, gb, a, default_info, sync):
+    """What the 16-bit panels of the default solve buy: the SAME solve with the panels carried at 32 and
+    56 bits (--slices 4 / 7; 56 bits is the width at which the products are as exact as the reference's own fp64
+    summation), one timed solve each after one untimed, with the relative difference of d to the default solve."""
+    import numpy as np
+    res = {"default": {"slices": default_info["slices"], "block": default_info["block"]}}
+    d0 = np.asarray(default_info["d"])
+    for sl in (4, 7):
+        def one():
+            return ba.bed_randomSVD(gb, k=a.k, tol=a.tol, block=a.block, slices=sl, return_uv=not a.no_uv,
+                                    warm_start=a.warm_start, warm_denominator=a.warm_den)
+        one()
+        sync()
+        t0 = time.perf_counter()
+        r = one()
+        sync()
+        ms = (time.perf_counter() - t0) * 1e3
+        passes = r["nops"] - r["warm_launches"] * (1.0 - r["warm_fraction"]) + (0 if r["fused_stats"] else 1)
+        res["slices_%d" % sl] = {"panel_bits": 8 * sl, "ms": ms, "block": r["block"], "niter": r["niter"],
+                                 "passes": passes, "converged": r["converged"],
+                                 "max_rel_diff_d_vs_default": float(np.max(np.abs(np.asarray(r["d"]) / d0 - 1.0)))}
+        del r
+    return res
 
 
 def cpu_baseline(ba, gb, n, sample_cols):

@@ -1,4 +1,5 @@
 // api.hip — the extern "C" surface declared in include/bigsnpr_hip.h.
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -20,8 +21,37 @@
 #include <cstdlib>
 
 #include "bsn_internal.hpp"
+#include <cxxabi.h>
 
 namespace bsn {
+
+// ---- roctx (optional) ------------------------------------------------------------------------------------------
+namespace {
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    if (!getenv("BSN_ROCTX")) return;
+    void *h = nullptr;
+    for (const char *name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"})
+      if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return;
+    push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+    pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+Roctx &roctx() {
+  static Roctx r;
+  return r;
+}
+}  // namespace
+void roctx_push(const char *name) {
+  if (roctx().push) roctx().push(name);
+}
+void roctx_pop() {
+  if (roctx().pop) roctx().pop();
+}
 
 static thread_local std::string g_err;
 void set_error(const char *msg) { g_err = msg ? msg : ""; }
@@ -696,6 +726,33 @@ int bsn_bed_tile(bsn_bed *bed, int *built) {
   });
 }
 
+// Names (demangled, without the argument list: rocprofv3's Kernel_Name up to the parenthesis) of the streaming
+// kernels the LAST profiled solve on this handle launched, one "kind=name" per line for the kinds cprod / prod /
+// cprod_stats / warm.  Lets a measurement record be tied to the kernels of the running build.
+int bsn_bed_streaming_kernels(bsn_bed *bed, char *buf, int64_t len) {
+  return guarded([&] {
+    if (!buf || len < 1) fail("bsn_bed_streaming_kernels: no buffer");
+    buf[0] = 0;
+    if (!bed->svd_op) return;
+    static const char *kinds[4] = {"cprod", "prod", "cprod_stats", "warm"};
+    std::string out;
+    for (int k = 0; k < 4; k++) {
+      const void *fn = bed->svd_op->prof_kernel[k];
+      if (!fn) continue;
+      const char *mangled = hipKernelNameRefByPtr(fn, bed->stream);
+      if (!mangled) continue;
+      int status = 1;
+      char *dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+      std::string name = (status == 0 && dem) ? dem : mangled;
+      free(dem);
+      const size_t par = name.find('(');
+      if (par != std::string::npos) name.resize(par);
+      out += std::string(kinds[k]) + "=" + name + "\n";
+    }
+    snprintf(buf, (size_t)len, "%s", out.c_str());
+  });
+}
+
 int bsn_bed_release_workspace(bsn_bed *bed) {
   return guarded([&] {
     BSN_HIP(hipSetDevice(bed->device));
@@ -1148,6 +1205,19 @@ static void convert_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const 
 int bsn_bed_to_fbm(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
                    uint8_t *out) {
   return guarded([&] { convert_host(bed, ind_row, n, ind_col, m, out, false); });
+}
+
+int bsn_bed_readbina(bsn_bed *bed, const uint8_t *tab, uint8_t *out) {
+  return guarded([&] {
+    if (!tab || !out) fail("readbina: 'tab' and the output must not be NULL");
+    BSN_HIP(hipSetDevice(bed->device));
+    DevBuf<uint8_t> d_tab, d_o;
+    copy_h2d(bed, d_tab.ensure(1024), tab, 1024);
+    const size_t bytes = (size_t)bed->n * (size_t)bed->m;
+    readbina_bytes(bed, d_tab.p, d_o.ensure(bytes));
+    copy_d2h(bed, out, d_o.p, bytes);
+    BSN_HIP(hipStreamSynchronize(bed->stream));
+  });
 }
 
 int bsn_bed_subset_payload(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,

@@ -149,6 +149,7 @@ struct bsn_op {
   int prof_kind_override = -1;  // >= 0: every launch is filed under this kind (3 = warm-start launches on a subset)
   std::vector<hipEvent_t> ev_begin, ev_end;
   std::vector<int> ev_kind;
+  const void *prof_kernel[4] = {nullptr, nullptr, nullptr, nullptr};  // host stub of the last kernel launched under each kind
   ~bsn_op() {
     for (auto e : ev_begin) (void)hipEventDestroy(e);
     for (auto e : ev_end) (void)hipEventDestroy(e);
@@ -258,6 +259,7 @@ void read_dense(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_c
 
 void to_bytes(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t m,
               uint8_t *d_out);
+void readbina_bytes(bsn_bed *b, const uint8_t *d_tab, uint8_t *d_out);
 void subset_pack(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t m,
                  uint8_t *d_out);
 
@@ -298,6 +300,17 @@ void op_row_counts(bsn_op *op, double *d_out);  // n doubles: sum_j A~[i, j]^2
 void counts_weighted(bsn_op *op, const double *d_w, int64_t n_sub, int32_t *d_counts);
 void selftest();
 // event helpers around a streaming launch (no-ops unless op->profile)
+// roctx ranges (BSN_ROCTX=1: the roctx library is dlopen'ed on first use; otherwise, or when it is absent, no-ops):
+// rocprofv3 --marker-trace --kernel-trace then cuts the timeline of a solve by itself — warm start, every block step's
+// phases, the formation of u / v (tools/README.md)
+void roctx_push(const char *name);
+void roctx_pop();
+struct RoctxRange {
+  explicit RoctxRange(const char *name) { roctx_push(name); }
+  ~RoctxRange() { roctx_pop(); }
+  RoctxRange(const RoctxRange &) = delete;
+  RoctxRange &operator=(const RoctxRange &) = delete;
+};
 void prof_begin(bsn_op *op, int kind);
 void prof_end(bsn_op *op);
 // sums the recorded launches: ms[kind], count[kind]; clears the records

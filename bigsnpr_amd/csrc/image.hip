@@ -682,6 +682,28 @@ __global__ void k_to_bytes(const uint8_t *img, int64_t pitch, const int32_t *row
   out[i + j * n] = (uint8_t)code;  // the device code is the CODE_012 byte
 }
 
+// readbina (src/read-plink.cpp:13-56): every byte of the .bed payload goes through the caller's 4 x 256 table
+// (tab[4 * byte + e] = FBM byte of genotype e of that .bed byte; getCode() in R/utils.R:21-31), whole matrix, no
+// subsets.  One thread per payload byte: device code -> PLINK byte -> four table bytes.
+__global__ __launch_bounds__(256) void k_readbina(const uint8_t *__restrict__ img, int64_t pitch, int64_t n,
+                                                  int64_t m, const uint8_t *__restrict__ tab,
+                                                  uint8_t *__restrict__ out) {
+  __shared__ uint32_t stab[256];
+  stab[threadIdx.x] = ((const uint32_t *)tab)[threadIdx.x];
+  __syncthreads();
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t j = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (4 * b >= n || j >= m) return;
+  const uint32_t t = stab[plink_from_dev(img[j * pitch + b]) & 0xFFu];
+  uint8_t *o = out + j * n + 4 * b;
+  const int64_t left = n - 4 * b;
+  if (left >= 4 && (((uintptr_t)o) & 3) == 0) {
+    *(uint32_t *)o = t;
+  } else {
+    for (int e = 0; e < 4 && e < left; e++) o[e] = (uint8_t)(t >> (8 * e));
+  }
+}
+
 // packed .bed payload of the sub-matrix [rows, cols]: ceil(n/4) bytes per variant, pad bits 0
 __global__ void k_subset_pack(const uint8_t *img, int64_t pitch, const int32_t *rows, int64_t n,
                               const int32_t *cols, int64_t m, int64_t n_byte_out, uint8_t *out) {
@@ -763,6 +785,15 @@ void to_bytes(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_col
   int64_t gy = m < 65535 ? m : 65535, gz = (m + 65534) / 65535;
   hipLaunchKernelGGL(k_to_bytes, dim3((unsigned)((n + 255) / 256), (unsigned)gy, (unsigned)gz), dim3(256),
                      0, b->stream, b->d_img, b->pitch, d_rows, n, d_cols, m, d_out);
+  BSN_HIP(hipGetLastError());
+}
+
+void readbina_bytes(bsn_bed *b, const uint8_t *d_tab, uint8_t *d_out) {
+  require_bits(b, 2, "readbina");
+  const int64_t nb = (b->n + 3) / 4;
+  int64_t gy = b->m < 65535 ? b->m : 65535, gz = (b->m + 65534) / 65535;
+  hipLaunchKernelGGL(k_readbina, dim3((unsigned)((nb + 255) / 256), (unsigned)gy, (unsigned)gz), dim3(256), 0,
+                     b->stream, b->d_img, b->pitch, b->n, b->m, d_tab, d_out);
   BSN_HIP(hipGetLastError());
 }
 

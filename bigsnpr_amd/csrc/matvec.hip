@@ -29,6 +29,16 @@ namespace bsn {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
+// Every launch of a streaming kernel notes WHICH instantiation it was: prof_end files it under the launch's kind and
+// bsn_bed_streaming_kernels reports the names, so that a committed counter record (profiles/pmc_traffic.json) can be
+// matched against the kernels the running build really launches (bench.py: roofline.traffic).
+static thread_local const void *g_last_kernel = nullptr;
+#define BSN_KLAUNCH(kern, ...)                 \
+  do {                                         \
+    g_last_kernel = (const void *)(kern);      \
+    hipLaunchKernelGGL(kern, __VA_ARGS__);     \
+  } while (0)
+
 // byte look-up: result byte k = lut byte (sel byte k), sel bytes in 0..3.  The LUT is
 // given as both sources so the result does not depend on the S0/S1 order of v_perm_b32.
 __device__ __forceinline__ uint32_t lut4(uint32_t lut, uint32_t sel) {
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(64) void k_quant(const double *__restrict__ X, int6
 // TILED (with CONTIG, col0 a multiple of 64): `img` is the streaming-layout copy (bsn_internal.hpp): variant
 // a, byte o of its row at ((a >> 6) * (pitch >> 8) + (o >> 8)) * 16384 + (a & 63) * 256 + (o & 255).
 template <int NB, int NPLANE, int KC, bool RAW0, bool STATS, bool CONTIG, int ABL = 0, int TILES = 2,
-          int WAVES = 8, int MINW = 1, int TAG = 0, bool TILED = false>
+          int WAVES = 8, int MINW = 1, int TAG = 0, bool TILED = false, int SGB = 0, bool SWAP = false>
 __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__restrict__ img, int64_t pitch,
                                                const int32_t *__restrict__ cols, int64_t col0,
                                                int64_t m, const int8_t *__restrict__ xq,
@@ -378,6 +388,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
       if constexpr (NX > 3) xr3 = src[tid + 3 * NT];
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the digit loads up here, a chunk ahead of their use
+    if constexpr (SGB & 2) __builtin_amdgcn_s_setprio(2);  // experiment: the MFMA phase outranks waves that are loading
     const int off2 = ch2 * (KC / 4);
     // one K-step of one tile: 16 samples x 16 variants per lane-quad, decode + MFMAs
     auto kstep = [&](const int t, const uint32_t w, const uint4 (&bv)[NB]) {
@@ -406,7 +417,8 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
           if (ABL & 1) {  // ablation: no MFMA, keep the operands alive
             asm volatile("" ::"v"(a), "v"(b));
           } else {
-            acc[t][p][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[t][p][nb], 0, 0, 0);
+            acc[t][p][nb] = SWAP ? __builtin_amdgcn_mfma_i32_16x16x64_i8(b, a, acc[t][p][nb], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[t][p][nb], 0, 0, 0);
           }
         }
       }
@@ -455,7 +467,38 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
           ga[SET][t][it] = gload(t, off2 + it * 64);
         }
       }
+    if constexpr (SGB & 1) {
+      // Explicit software pipeline (profiles/r04_sched.txt: 2 % on the two-block kernel): the decode of the following
+      // K-steps is slotted into the shadows of the MFMAs — the VALU instructions of a K-step spread evenly behind its
+      // MFMAs —, the digit reads one K-step ahead, the refill loads last.  The compiler's own order issues the MFMAs
+      // in back-to-back pairs, the second of which stalls its wave for the 12 remaining cycles of the first.
+      // masks: 0x008 MFMA, 0x002 VALU, 0x100 DS read, 0x020 VMEM read
+      constexpr int VSTEP = TILES * (7 + (NPLANE - (RAW0 ? 1 : 0)) * 4 + (STATS ? 7 : 0));  // VALU per K-step
+      constexpr int MSTEP = TILES * NPLANE * NB;                                             // MFMA per K-step
+      __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+      auto slot = [&](auto IC) {
+        constexpr int i = decltype(IC)::value;
+        constexpr int nv = VSTEP * (i + 1) / MSTEP - VSTEP * i / MSTEP;
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (nv > 0) __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);
+      };
+      auto slots = [&](auto self, auto IC) {
+        constexpr int i = decltype(IC)::value;
+        if constexpr (i < MSTEP) {
+          slot(IC);
+          self(self, std::integral_constant<int, i + 1>{});
+        }
+      };
+#pragma unroll
+      for (int stp = 0; stp < LD * 4; stp++) {
+        __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);
+        slots(slots, std::integral_constant<int, 0>{});
+      }
+      __builtin_amdgcn_sched_group_barrier(0x020, TILES * LD, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SGB & 2) __builtin_amdgcn_s_setprio(0);
     {
       if (XFULL || tid < XS) xs[SET ^ 1][tid] = xr0;
       if constexpr (NX > 1) xs[SET ^ 1][tid + NT] = xr1;
@@ -470,6 +513,20 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
   }
 
   // raw accumulators: acc_out[plane][variant][NCOL]
+  if constexpr (SWAP) {
+    // digits were the A operand: D is transposed — lane -> variant (l & 15), digit columns 4 * (l >> 4) .. + 3
+#pragma unroll
+    for (int t = 0; t < TILES; t++) {
+      const int64_t j = snp_base + t * 16 + c;
+      if (j < m) {
+#pragma unroll
+        for (int p = 0; p < NPLANE; p++)
+#pragma unroll
+          for (int nb = 0; nb < NB; nb++)
+            *(v4i *)(acc_out + ((int64_t)p * m_out + j) * NCOL + nb * 16 + 4 * g) = acc[t][p][nb];
+      }
+    }
+  } else
 #pragma unroll
   for (int t = 0; t < TILES; t++)
 #pragma unroll
@@ -496,6 +553,166 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
         *(int4 *)(counts + 4 * j) =
             int4{(int32_t)(pitch * 4) - n1 - n2 - (int32_t)na - n_pad_samples, n1, n2, (int32_t)na};
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_cprod32: the crossproduct with TWO column blocks (32 digit columns = 16 vectors x 2 slices) on
+// v_mfma_i32_32x32x32_i8.  Same memory pipeline, same integer arithmetic and the same output as
+// k_cprod<2, ...> (bit-identical), different tile: one wave owns 32 variants as ONE 32-row tile and multiplies
+// them with all 32 digit columns in one instruction.  Why (profiles/r04_mfma32.txt): per 256 B of genotypes the
+// 16 x 16 x 64 shape issues four MFMAs of 16 cycles next to 11 decode instructions — 15 of the 16 issue slots of
+// the matrix pipe's busy time, which no schedule fills (the pipe ran 61-65 % busy); the 32 x 32 x 32 shape issues
+// two MFMAs of 32 cycles: 13 of 32 slots.
+//   A operand: lane l -> variant row (l & 31), K half (l >> 5): 16 samples of that variant (one decoded dword)
+//   B operand: lane l -> digit column (l & 31), the same 16 samples (one ds_read_b128)
+//   D        : lane l -> digit column (l & 31), variant rows 8 * (r / 4) + 4 * (l >> 5) + (r % 4), r = 0 .. 15
+// A lane loads 16 B (64 samples: four K-steps) at byte it * 32 + (l >> 5) * 16 of its row's 128-B chunk, so K-step
+// (it, d) covers the sample blocks it * 8 + h * 4 + d (h = 0, 1) of the chunk's 32 blocks of 16.
+// SWAP (experiment): the digits as the A operand and the codes as B (D transposed).
+typedef int v16i __attribute__((ext_vector_type(16)));
+template <int NPLANE, bool STATS, int WAVES = 16, int TAG = 0, int SGB = 0, bool SWAP = false>
+__global__ __launch_bounds__(64 * WAVES) void k_cprod32(const uint8_t *__restrict__ img, int64_t pitch, int64_t col0,
+                                                        int64_t m, const int8_t *__restrict__ xq,
+                                                        int32_t *__restrict__ acc_out, int64_t m_out, uint32_t lutB,
+                                                        int32_t *__restrict__ counts, int32_t n_pad_samples) {
+  constexpr int KC = 512, NCOL = 32, LD = 4, XS = KC / 16 * NCOL;  // 1024 digit entries of 16 B per chunk
+  constexpr int NT = 64 * WAVES, NX = XS / NT;
+  static_assert(XS % NT == 0 && NX >= 1 && NX <= 4, "digit staging");
+  __shared__ uint4 xs[2][XS];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t wg_base = (int64_t)blockIdx.x * (WAVES * 32);
+  const int64_t snp_base = wg_base + wave * 32;
+  int64_t jr = snp_base + r;
+  if (jr > m - 1) jr = m - 1;
+  const uint32_t voff = (uint32_t)((jr - wg_base) * pitch + h * 16);
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(img + (col0 + wg_base) * pitch), 0, 0x7fffffff, 0x00020000);
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  auto gload = [&](const int off) -> uint4 {
+    const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, off, 0);
+    return uint4{t.x, t.y, t.z, t.w};
+  };
+  const int nchunks = (int)(pitch * 4 / KC);
+  const uint4 *xq4 = (const uint4 *)xq;
+
+  v16i acc[NPLANE];
+#pragma unroll
+  for (int p = 0; p < NPLANE; p++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[p][e] = 0;
+  uint32_t st_lo = 0, st_hi = 0, st_na = 0;
+
+  uint4 ga[2][LD];
+  uint4 xr[NX];
+#pragma unroll
+  for (int it = 0; it < LD; it++) ga[0][it] = gload(it * 32);
+#pragma unroll
+  for (int x = 0; x < NX; x++) xs[0][tid + x * NT] = xq4[tid + x * NT];
+#pragma unroll
+  for (int it = 0; it < LD; it++) ga[1][it] = gload((nchunks > 1 ? KC / 4 : 0) + it * 32);
+  __syncthreads();
+
+  auto chunk = [&](auto SETC, const int ch) {
+    constexpr int SET = decltype(SETC)::value;
+    // branch-free prefetch, as in k_cprod: past the end the last chunk is loaded again
+    const int ch1 = ch + 1 < nchunks ? ch + 1 : nchunks - 1;
+    const int ch2 = ch + 2 < nchunks ? ch + 2 : nchunks - 1;
+#pragma unroll
+    for (int x = 0; x < NX; x++) xr[x] = xq4[(int64_t)ch1 * XS + tid + x * NT];
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SGB & 2) __builtin_amdgcn_s_setprio(2);
+    const int off2 = ch2 * (KC / 4);
+    uint4 bv = xs[SET][(h * 4) * NCOL + r], bn = bv;
+#pragma unroll
+    for (int it = 0; it < LD; it++) {
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        if (it * 4 + d + 1 < LD * 4) {
+          const int itn = (it * 4 + d + 1) / 4, dn = (it * 4 + d + 1) % 4;
+          bn = xs[SET][(itn * 8 + h * 4 + dn) * NCOL + r];
+        }
+        const uint32_t w = d == 0 ? ga[SET][it].x : d == 1 ? ga[SET][it].y : d == 2 ? ga[SET][it].z : ga[SET][it].w;
+        const uint32_t s0 = w & 0x03030303u, s1 = (w >> 2) & 0x03030303u, s2 = (w >> 4) & 0x03030303u,
+                       s3 = (w >> 6) & 0x03030303u;
+        if constexpr (STATS) {
+          const uint32_t lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;
+          st_lo += __popc(lo);
+          st_hi += __popc(hi);
+          st_na += __popc(lo & hi);
+        }
+        const v4i b = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
+        const v4i a0 = {(int)s0, (int)s1, (int)s2, (int)s3};
+        acc[0] = SWAP ? __builtin_amdgcn_mfma_i32_32x32x32_i8(b, a0, acc[0], 0, 0, 0)
+                      : __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b, acc[0], 0, 0, 0);
+        if constexpr (NPLANE == 2) {
+          const v4i a1 = {(int)lut4(lutB, s0), (int)lut4(lutB, s1), (int)lut4(lutB, s2), (int)lut4(lutB, s3)};
+          acc[1] = SWAP ? __builtin_amdgcn_mfma_i32_32x32x32_i8(b, a1, acc[1], 0, 0, 0)
+                        : __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b, acc[1], 0, 0, 0);
+        }
+        bv = bn;
+      }
+    }
+    // the set is consumed: refill it with the chunk two ahead, the four quarters of a 128-B line back to back
+#pragma unroll
+    for (int it = 0; it < LD; it++) ga[SET][it] = gload(off2 + it * 32);
+    if constexpr (SGB & 1) {
+      // the decode of the following K-step in the shadow of the MFMAs: 1 MFMA : 6 / 5 VALU (0x008 MFMA, 0x002 VALU,
+      // 0x100 DS read, 0x020 VMEM read)
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+#pragma unroll
+      for (int stp = 0; stp < LD * 4; stp++) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NPLANE == 2 ? 6 : 7, 0);
+        if constexpr (NPLANE == 2) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        }
+      }
+      __builtin_amdgcn_sched_group_barrier(0x020, LD, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SGB & 2) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int x = 0; x < NX; x++) xs[SET ^ 1][tid + x * NT] = xr[x];
+    __syncthreads();
+  };
+  for (int ch = 0; ch < nchunks; ch += 2) {
+    chunk(std::integral_constant<int, 0>{}, ch);
+    if (ch + 1 < nchunks) chunk(std::integral_constant<int, 1>{}, ch + 1);
+  }
+
+  // raw accumulators: acc_out[plane][variant][32], the layout of k_cprod<2>
+#pragma unroll
+  for (int e = 0; e < 16; e++) {
+    if constexpr (SWAP) {
+      // D transposed: lane -> variant (l & 31), digit columns 8 * (e / 4) + 4 * h + (e % 4)
+      const int64_t j = snp_base + r;
+      const int c = 8 * (e >> 2) + 4 * h + (e & 3);
+      if (j < m) {
+#pragma unroll
+        for (int p = 0; p < NPLANE; p++) acc_out[((int64_t)p * m_out + j) * NCOL + c] = acc[p][e];
+      }
+    } else {
+      const int64_t j = snp_base + 8 * (e >> 2) + 4 * h + (e & 3);
+      if (j < m) {
+#pragma unroll
+        for (int p = 0; p < NPLANE; p++) acc_out[((int64_t)p * m_out + j) * NCOL + r] = acc[p][e];
+      }
+    }
+  }
+  if constexpr (STATS) {
+    uint32_t lo = st_lo, hi = st_hi, na = st_na;  // a variant row is spread over the wave's two K halves
+    lo += __shfl_xor(lo, 32); hi += __shfl_xor(hi, 32); na += __shfl_xor(na, 32);
+    const int64_t j = snp_base + r;
+    if (h == 0 && j < m) {
+      const int32_t n1 = (int32_t)(lo - na), n2 = (int32_t)(hi - na);
+      *(int4 *)(counts + 4 * j) =
+          int4{(int32_t)(pitch * 4) - n1 - n2 - (int32_t)na - n_pad_samples, n1, n2, (int32_t)na};
     }
   }
 }
@@ -581,7 +798,7 @@ __global__ __launch_bounds__(128) void k_cprod_final(const int32_t *__restrict__
 // instruction issue port, where a third wave to pick instructions from is what helps).  The 4 x 4 byte transposes
 // split cleanly: the half that owns sample quads q = 0, 1 needs only the low halves of the first-level permutes.
 template <int NB, bool CONTIG, bool RAWP, bool HASQ = true, int WAVES = 4, int ABL = 0, int UG = 1, int SETS = 2,
-          int TAG = 0, bool TILED = false, bool XMAP = false, bool HALF = false, bool LH = false>
+          int TAG = 0, bool TILED = false, bool XMAP = false, bool HALF = false, bool LH = false, int SGB = 0>
 __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__ img, int64_t pitch,
                                               const int32_t *__restrict__ cols, int64_t col0,
                                               int64_t m_pad, int64_t mc,
@@ -725,6 +942,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
       load(SETS == 3 ? jn3 : (SETS == 2 ? jn2 : jn1), X[SETS >= 2 ? SET : 0]);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SGB & 2) __builtin_amdgcn_s_setprio(2);
     // G samples are decoded together and their MFMAs interleaved (g0 of all, then na of all);
     // G = 1, 2, 4 time the same (profiles/r01_ablation.txt), so the smallest is used
     constexpr int G = UG;
@@ -755,16 +973,28 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
 #pragma unroll
             for (int k = 0; k < G; k++)
               acc[q * 4 + u0 + k][nb] =
-                  __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[nb], g0[k], acc[q * 4 + u0 + k][nb], 0, 0, 0);
+                  (SGB & 4) ? __builtin_amdgcn_mfma_i32_16x16x64_i8(g0[k], aw[nb], acc[q * 4 + u0 + k][nb], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[nb], g0[k], acc[q * 4 + u0 + k][nb], 0, 0, 0);
             if (HASQ) {
 #pragma unroll
               for (int k = 0; k < G; k++)
                 acc[q * 4 + u0 + k][nb] =
-                    __builtin_amdgcn_mfma_i32_16x16x64_i8(awc[nb], na[k], acc[q * 4 + u0 + k][nb], 0, 0, 0);
+                    (SGB & 4) ? __builtin_amdgcn_mfma_i32_16x16x64_i8(na[k], awc[nb], acc[q * 4 + u0 + k][nb], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_i32_16x16x64_i8(awc[nb], na[k], acc[q * 4 + u0 + k][nb], 0, 0, 0);
             }
           }
         }
       }
+    if constexpr (SGB & 1) {
+      // experiment (profiles/r04_sched.txt): 1 MFMA : 3 VALU through the decode + MFMA phase of a step
+#pragma unroll
+      for (int i = 0; i < NU * NB * (HASQ ? 2 : 1); i++) {
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (SGB & 2) __builtin_amdgcn_s_setprio(0);
     ws[WB ^ 1][wtid] = wreg;
     wpar ^= 1;
     __syncthreads();
@@ -782,6 +1012,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
     }
   }
   // raw accumulators: acc_out[ky][sample][NCOL], lane holds columns nb*16 + 4g .. +3
+  if constexpr ((SGB & 4) != 0) {
+    // experiment: codes as the A operand -> D transposed: lane holds digit column (l & 15), sample groups 4 g + r
+    static_assert(!(SGB & 4) || (!HALF && !LH), "operand swap: plain shape only");
+    if (active) {
+#pragma unroll
+      for (int u = 0; u < NU; u++)
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++)
+            acc_out[((int64_t)by * n_pad + wbase + (4 * g + rr) * 16 + u) * NCOL + nb * 16 + sg] = acc[u][nb][rr];
+    }
+  } else
   if (active) {
 #pragma unroll
     for (int u = 0; u < NU; u++) {
@@ -1057,6 +1300,7 @@ void prof_begin(bsn_op *op, int kind) {
 void prof_end(bsn_op *op) {
   if (!op->profile) return;
   BSN_HIP(hipEventRecord(op->ev_end.back(), op->bed->stream));
+  op->prof_kernel[op->ev_kind.back() & 3] = g_last_kernel;
 }
 void prof_collect(bsn_op *op, double ms[4], int count[4]) {
   ms[0] = ms[1] = ms[2] = ms[3] = 0;
@@ -1223,7 +1467,7 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
     // 4 tiles per wave on the tiled copy (a wave = one 64-variant block, 512 variants share a digit panel): 2 %
     // faster than the 2-tile shape there, and slower on the plain image (profiles/r02_ablation.txt)
 #define BSN_LAUNCH_CPROD_T(NBV, TV, WV, TAGV)                                                                    \
-  hipLaunchKernelGGL((k_cprod<NBV, NPLANE, KC, RAW0, STATS, true, 0, TV, WV, 1, TAGV, true>),                    \
+  BSN_KLAUNCH((k_cprod<NBV, NPLANE, KC, RAW0, STATS, true, 0, TV, WV, 1, TAGV, true, (NBV == 2 ? 3 : 0)>), \
                      dim3((unsigned)((op->m + 16 * TV * WV - 1) / (16 * TV * WV))), dim3(64 * WV), 0, b->stream, \
                      b->d_tiled, b->pitch, nullptr, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad)
 #ifdef BSN_ABLATION
@@ -1231,7 +1475,7 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
     // (48 = 2 x 8 x 512, the shape used on the plain image)
     if (NB == 1 && tune_variant() >= 41 && tune_variant() <= 48 && op->prof_kind_override != 3) {
 #define BSN_SHAPE_T(TILESV, WAVESV, KCV)                                                                  \
-  hipLaunchKernelGGL((k_cprod<1, NPLANE, KCV, RAW0, STATS, true, 0, TILESV, WAVESV, 1, 0, true>),         \
+  BSN_KLAUNCH((k_cprod<1, NPLANE, KCV, RAW0, STATS, true, 0, TILESV, WAVESV, 1, 0, true>),         \
                      dim3((unsigned)((op->m + 16 * TILESV * WAVESV - 1) / (16 * TILESV * WAVESV))),       \
                      dim3(64 * WAVESV), 0, b->stream, b->d_tiled, b->pitch, nullptr, op->col0, op->m, q,  \
                      acc, op->m, l0, l1, l2, counts, npad)
@@ -1259,7 +1503,7 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
       // BSN_TUNE = 91 .. 95: workgroup shapes of the two-column-block kernel on the tiled copy; correct results
       if (tune_variant() >= 91 && tune_variant() <= 95) {
 #define BSN_SHAPE_T2(TILESV, WAVESV, KCV)                                                                 \
-  hipLaunchKernelGGL((k_cprod<2, NPLANE, KCV, RAW0, STATS, true, 0, TILESV, WAVESV, 1, 0, true>),         \
+  BSN_KLAUNCH((k_cprod<2, NPLANE, KCV, RAW0, STATS, true, 0, TILESV, WAVESV, 1, 0, true>),         \
                      dim3((unsigned)((op->m + 16 * TILESV * WAVESV - 1) / (16 * TILESV * WAVESV))),       \
                      dim3(64 * WAVESV), 0, b->stream, b->d_tiled, b->pitch, nullptr, op->col0, op->m, q,  \
                      acc, op->m, l0, l1, l2, counts, npad)
@@ -1281,12 +1525,12 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
     return;
   }
 #define BSN_LAUNCH_CPROD_C(NBV, ABLV, CONTIGV)                                                          \
-  hipLaunchKernelGGL((k_cprod<NBV, NPLANE, KC, RAW0, STATS, CONTIGV, ABLV, 2, 8, 1>), grid, dim3(512), 0, \
+  BSN_KLAUNCH((k_cprod<NBV, NPLANE, KC, RAW0, STATS, CONTIGV, ABLV, 2, 8, 1>), grid, dim3(512), 0, \
                      b->stream, b->d_img, b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad)
 #define BSN_LAUNCH_CPROD(NBV, ABLV)                                                                       \
   do {                                                                                                    \
     if (op->cols_contig && op->prof_kind_override == 3)                                                   \
-      hipLaunchKernelGGL((k_cprod<NBV, NPLANE, KC, RAW0, STATS, true, 0, 2, 8, 1, 1>), grid, dim3(512), 0, \
+      BSN_KLAUNCH((k_cprod<NBV, NPLANE, KC, RAW0, STATS, true, 0, 2, 8, 1, 1>), grid, dim3(512), 0, \
                          b->stream, b->d_img, b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2, \
                          counts, npad);                                                                   \
     else if (op->cols_contig) BSN_LAUNCH_CPROD_C(NBV, ABLV, true);                                        \
@@ -1317,10 +1561,68 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
       BSN_HIP(hipGetLastError());
       return;
     }
+    // BSN_TUNE = 131 .. 137: k_cprod32 (32 x 32 x 32 MFMA) plain / pipelined / + s_setprio / operands swapped /
+    // 8-wave workgroups / s_setprio alone / swapped + pipelined (correct results, bit-identical)
+    if (NB == 2 && op->cols_contig && abl >= 131 && abl <= 137) {
+#define BSN_C32(WV, SGBV, SWAPV)                                                                                \
+  BSN_KLAUNCH((k_cprod32<NPLANE, STATS, WV, 0, SGBV, SWAPV>), dim3((unsigned)((op->m + 32 * WV - 1) / (32 * WV))), \
+                     dim3(64 * WV), 0, b->stream, b->d_img, b->pitch, op->col0, op->m, q, acc, op->m, l1, counts, npad)
+      if (abl == 131) BSN_C32(16, 0, false);
+      else if (abl == 132) BSN_C32(16, 1, false);
+      else if (abl == 133) BSN_C32(16, 3, false);
+      else if (abl == 134) BSN_C32(16, 0, true);
+      else if (abl == 135) BSN_C32(8, 0, false);
+      else if (abl == 136) BSN_C32(16, 2, false);
+      else BSN_C32(16, 1, true);
+#undef BSN_C32
+      BSN_HIP(hipGetLastError());
+      return;
+    }
+    // BSN_TUNE = 111 / 112 / 113 / 117 / 119: the same ablations of the two-column-block kernel;
+    // 121 / 122 / 123: its sched_group_barrier pipeline / + s_setprio / s_setprio alone (correct results)
+    if (NB == 2 && op->cols_contig && ((abl >= 111 && abl <= 119) || (abl >= 121 && abl <= 126))) {
+#define BSN_C2(ABLV, SGBV) BSN_C2S(ABLV, SGBV, false)
+#define BSN_C2S(ABLV, SGBV, SWAPV)                                                                           \
+  BSN_KLAUNCH((k_cprod<2, NPLANE, KC, RAW0, STATS, true, ABLV, 2, 16, 1, 0, false, SGBV, SWAPV>),     \
+                     dim3((unsigned)((op->m + 511) / 512)), dim3(1024), 0, b->stream, b->d_img, b->pitch,    \
+                     cols, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad)
+      if (abl == 111) BSN_C2(1, 0);
+      else if (abl == 112) BSN_C2(2, 0);
+      else if (abl == 113) BSN_C2(3, 0);
+      else if (abl == 117) BSN_C2(32, 0);
+      else if (abl == 119) BSN_C2(56, 0);
+      else if (abl == 121) BSN_C2(0, 1);
+      else if (abl == 122) BSN_C2(0, 3);
+      else if (abl == 123) BSN_C2(0, 2);
+      else if (abl == 124) BSN_C2S(0, 0, true);   // digits as the A operand
+      else if (abl == 125) BSN_C2S(0, 1, true);
+      else if (abl == 126) BSN_C2S(0, 3, true);
+      else BSN_C2(0, 0);
+#undef BSN_C2
+#undef BSN_C2S
+      BSN_HIP(hipGetLastError());
+      return;
+    }
+    if (NB == 1 && op->cols_contig && abl == 143) {   // one column block with the explicit pipeline + priority
+      BSN_KLAUNCH((k_cprod<1, NPLANE, KC, RAW0, STATS, true, 0, 2, 8, 1, 0, false, 3>), grid, dim3(512), 0,
+                         b->stream, b->d_img, b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad);
+      BSN_HIP(hipGetLastError());
+      return;
+    }
+    if (NB == 1 && op->cols_contig && (abl == 141 || abl == 142)) {   // one column block with the digits as the A operand
+      if (abl == 141)
+        BSN_KLAUNCH((k_cprod<1, NPLANE, KC, RAW0, STATS, true, 0, 2, 8, 1, 0, false, 0, true>), grid, dim3(512), 0,
+                           b->stream, b->d_img, b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad);
+      else
+        BSN_KLAUNCH((k_cprod<1, NPLANE, KC, RAW0, STATS, true, 0, 2, 8, 1, 0, false, 1, true>), grid, dim3(512), 0,
+                           b->stream, b->d_img, b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad);
+      BSN_HIP(hipGetLastError());
+      return;
+    }
     // BSN_TUNE = 21 .. 27: workgroup shapes (tiles per wave, waves, samples per chunk); correct results
     if (NB == 1 && abl >= 21 && abl <= 29 && op->cols_contig) {
 #define BSN_SHAPE(TILESV, WAVESV, KCV)                                                                    \
-  hipLaunchKernelGGL((k_cprod<1, NPLANE, KCV, RAW0, STATS, true, 0, TILESV, WAVESV, 1>),                  \
+  BSN_KLAUNCH((k_cprod<1, NPLANE, KCV, RAW0, STATS, true, 0, TILESV, WAVESV, 1>),                  \
                      dim3((unsigned)((op->m + 16 * TILESV * WAVESV - 1) / (16 * TILESV * WAVESV))),       \
                      dim3(64 * WAVESV), 0, b->stream, b->d_img, b->pitch, cols, op->col0, op->m, q, acc, \
                      op->m, l0, l1, l2, counts, npad)
@@ -1342,13 +1644,14 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
   if (NB == 1) {
     BSN_LAUNCH_CPROD(1, 0);
   } else {
-    // 16 waves share one digit panel: half the L2 reads of it (12.4 vs 12.8 ms on a 50 GB shard)
+    // 16 waves share one digit panel: half the L2 reads of it (12.4 vs 12.8 ms on a 50 GB shard); explicit
+    // MFMA / decode interleave + raised priority through the MFMA phase (SGB = 3: 2 %, profiles/r04_sched.txt)
     if (op->cols_contig)
-      hipLaunchKernelGGL((k_cprod<2, NPLANE, KC, RAW0, STATS, true, 0, 2, 16, 1>),
+      BSN_KLAUNCH((k_cprod<2, NPLANE, KC, RAW0, STATS, true, 0, 2, 16, 1, 0, false, 3>),
                          dim3((unsigned)((op->m + 511) / 512)), dim3(1024), 0, b->stream, b->d_img, b->pitch, cols,
                          op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad);
     else
-      hipLaunchKernelGGL((k_cprod<2, NPLANE, KC, RAW0, STATS, false, 0, 2, 16, 1>),
+      BSN_KLAUNCH((k_cprod<2, NPLANE, KC, RAW0, STATS, false, 0, 2, 16, 1>),
                          dim3((unsigned)((op->m + 511) / 512)), dim3(1024), 0, b->stream, b->d_img, b->pitch, cols,
                          op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad);
   }
@@ -1424,7 +1727,7 @@ void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z,
       const dim3 grid8((unsigned)((op->m + 127) / 128));
       const int32_t *cols8 = op->cols_contig ? nullptr : op->d_cols.p;
 #define BSN_CPROD8(NBV, NAV, CV)                                                                          \
-  hipLaunchKernelGGL((k_cprod8<NBV, NAV, CV>), grid8, dim3(512), 0, b->stream, b->d_img, b->pitch, cols8, \
+  BSN_KLAUNCH((k_cprod8<NBV, NAV, CV>), grid8, dim3(512), 0, b->stream, b->d_img, b->pitch, cols8, \
                      op->col0, op->m, q, acc, op->m)
       if (NB == 1) {
         if (op->no_na) { if (op->cols_contig) BSN_CPROD8(1, false, true); else BSN_CPROD8(1, false, false); }
@@ -1480,7 +1783,7 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
   bsn_bed *b = op->bed;
   const int32_t *cols = op->d_cols.p;
 #define BSN_LAUNCH_PROD(RAWP, HASQ, ABLV)                                                               \
-  hipLaunchKernelGGL((k_prod<NB, CONTIG, RAWP, HASQ, 4, ABLV>), grid, dim3(256), 0, b->stream, b->d_img, \
+  BSN_KLAUNCH((k_prod<NB, CONTIG, RAWP, HASQ, 4, ABLV>), grid, dim3(256), 0, b->stream, b->d_img, \
                      b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ)
 #ifdef BSN_ABLATION
   if constexpr (NB == 1 && CONTIG) {  // BSN_TUNE = 61 .. 64: no MFMA / no decode / memory skeleton / compute only
@@ -1502,7 +1805,7 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
     }
     // BSN_TUNE = 77: XCD-aware slab placement on the tiled copy (needs a K split that is a multiple of 8: BSN_KY=16)
     if (tv == 77 && lutP == kLutRaw && has_q && b->d_tiled && (op->col0 & 63) == 0 && grid.y % 8 == 0) {
-      hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 1, 2, 0, true, true>), dim3(grid.x * grid.y),
+      BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 1, 2, 0, true, true>), dim3(grid.x * grid.y),
                          dim3(256), 0, b->stream, b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP,
                          lutQ);
       BSN_HIP(hipGetLastError());
@@ -1510,7 +1813,7 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
     }
     // BSN_TUNE = 76: 8-wave workgroups on the tiled copy (two tiles per step share one digit panel)
     if (tv == 76 && lutP == kLutRaw && has_q && b->d_tiled && (op->col0 & 63) == 0) {
-      hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 8, 0, 1, 2, 0, true>), dim3((grid.x + 1) / 2, grid.y),
+      BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 8, 0, 1, 2, 0, true>), dim3((grid.x + 1) / 2, grid.y),
                          dim3(512), 0, b->stream, b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP,
                          lutQ);
       BSN_HIP(hipGetLastError());
@@ -1519,10 +1822,10 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
     // BSN_TUNE = 74 / 75: three genotype register sets (prefetch three steps ahead) on the plain / tiled image
     if ((tv == 74 || tv == 75) && lutP == kLutRaw && has_q) {
       if (tv == 75 && b->d_tiled && (op->col0 & 63) == 0)
-        hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 1, 3, 0, true>), grid, dim3(256), 0, b->stream,
+        BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 1, 3, 0, true>), grid, dim3(256), 0, b->stream,
                            b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
       else
-        hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 1, 3>), grid, dim3(256), 0, b->stream, b->d_img,
+        BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 1, 3>), grid, dim3(256), 0, b->stream, b->d_img,
                            b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
       BSN_HIP(hipGetLastError());
       return;
@@ -1530,13 +1833,13 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
     // BSN_TUNE = 71 .. 73: samples decoded together 2 / 4, one register set; correct results
     if (tv >= 71 && tv <= 73 && lutP == kLutRaw && has_q) {
       if (tv == 71)
-        hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 2, 2>), grid, dim3(256), 0, b->stream, b->d_img,
+        BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 2, 2>), grid, dim3(256), 0, b->stream, b->d_img,
                            b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
       else if (tv == 72)
-        hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 4, 2>), grid, dim3(256), 0, b->stream, b->d_img,
+        BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 4, 2>), grid, dim3(256), 0, b->stream, b->d_img,
                            b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
       else
-        hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 1, 1>), grid, dim3(256), 0, b->stream, b->d_img,
+        BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 1, 1>), grid, dim3(256), 0, b->stream, b->d_img,
                            b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
       BSN_HIP(hipGetLastError());
       return;
@@ -1546,22 +1849,40 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
 #ifdef BSN_ABLATION
   if constexpr (NB == 2 && CONTIG) {  // BSN_TUNE = 96 .. 98 on the tiled copy: 8-wave workgroups / 2 / 4 samples decoded together
     const int tv = tune_variant();
+    // 161 .. 164: no MFMA / no decode / memory skeleton / compute only; 171 / 172 / 173: sched_group_barrier pipeline /
+    // + s_setprio / s_setprio alone (correct results), all on the plain image
+    if (((tv >= 161 && tv <= 164) || (tv >= 171 && tv <= 174)) && lutP == kLutRaw && has_q) {
+#define BSN_P2(ABLV, SGBV)                                                                                          \
+  BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, ABLV, 1, 2, 0, false, false, false, false, SGBV>), grid,    \
+                     dim3(256), 0, b->stream, b->d_img, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ)
+      if (tv == 161) BSN_P2(1, 0);
+      else if (tv == 162) BSN_P2(2, 0);
+      else if (tv == 163) BSN_P2(3, 0);
+      else if (tv == 164) BSN_P2(32, 0);
+      else if (tv == 171) BSN_P2(0, 1);
+      else if (tv == 172) BSN_P2(0, 3);
+      else if (tv == 174) BSN_P2(0, 4);   // codes as the A operand
+      else BSN_P2(0, 2);
+#undef BSN_P2
+      BSN_HIP(hipGetLastError());
+      return;
+    }
     if (tv == 99 && lutP == kLutRaw && has_q && b->d_tiled && (op->col0 & 63) == 0) {  // three register sets
-      hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 1, 3, 0, true>), grid, dim3(256), 0, b->stream,
+      BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 1, 3, 0, true>), grid, dim3(256), 0, b->stream,
                          b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
       BSN_HIP(hipGetLastError());
       return;
     }
     if (tv >= 96 && tv <= 98 && lutP == kLutRaw && has_q && b->d_tiled && (op->col0 & 63) == 0) {
       if (tv == 96)
-        hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 8, 0, 1, 2, 0, true>), dim3((grid.x + 1) / 2, grid.y),
+        BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 8, 0, 1, 2, 0, true>), dim3((grid.x + 1) / 2, grid.y),
                            dim3(512), 0, b->stream, b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP,
                            lutQ);
       else if (tv == 97)
-        hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 2, 2, 0, true>), grid, dim3(256), 0, b->stream,
+        BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 2, 2, 0, true>), grid, dim3(256), 0, b->stream,
                            b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
       else
-        hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 4, 2, 0, true>), grid, dim3(256), 0, b->stream,
+        BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 4, 2, 0, true>), grid, dim3(256), 0, b->stream,
                            b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
       BSN_HIP(hipGetLastError());
       return;
@@ -1576,17 +1897,17 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
       if (NB == 2 && tune_variant() == 89 && lutP == kLutRaw && op->prof_kind_override != 3) {  // lane halves, 4-wave workgroups
         const dim3 g2(grid.x * 2, grid.y);
         if (has_q)
-          hipLaunchKernelGGL((k_prod<NB, true, true, true, 4, 0, 1, 2, 0, true, false, false, (NB == 2)>), g2, dim3(256), 0,
+          BSN_KLAUNCH((k_prod<NB, true, true, true, 4, 0, 1, 2, 0, true, false, false, (NB == 2)>), g2, dim3(256), 0,
                              b->stream, b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
         else
-          hipLaunchKernelGGL((k_prod<NB, true, true, false, 4, 0, 1, 2, 0, true, false, false, (NB == 2)>), g2, dim3(256), 0,
+          BSN_KLAUNCH((k_prod<NB, true, true, false, 4, 0, 1, 2, 0, true, false, false, (NB == 2)>), g2, dim3(256), 0,
                              b->stream, b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
         BSN_HIP(hipGetLastError());
         return;
       }
       const bool half = NB == 2 && tune_variant() == 90;
 #define BSN_LAUNCH_PROD_TH(RAWP, HASQ, TAGV)                                                                           \
-  hipLaunchKernelGGL((k_prod<NB, true, RAWP, HASQ, 8, 0, 1, 2, TAGV, true, false, (NB == 2)>), grid, dim3(512), 0,     \
+  BSN_KLAUNCH((k_prod<NB, true, RAWP, HASQ, 8, 0, 1, 2, TAGV, true, false, (NB == 2)>), grid, dim3(512), 0,     \
                      b->stream, b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ)
 #else
       constexpr bool half = false;
@@ -1597,7 +1918,7 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
     if (half)                                                                                                   \
       BSN_LAUNCH_PROD_TH(RAWP, HASQ, TAGV);                                                                     \
     else                                                                                                        \
-      hipLaunchKernelGGL((k_prod<NB, true, RAWP, HASQ, 4, 0, 1, 2, TAGV, true>), grid, dim3(256), 0, b->stream, \
+      BSN_KLAUNCH((k_prod<NB, true, RAWP, HASQ, 4, 0, 1, 2, TAGV, true>), grid, dim3(256), 0, b->stream, \
                          b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);             \
   } while (0)
       const bool warm = op->prof_kind_override == 3;
@@ -1616,10 +1937,10 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
   }
   if (lutP == kLutRaw && op->prof_kind_override == 3) {  // warm-start launch: same kernel under its own name
     if (has_q)
-      hipLaunchKernelGGL((k_prod<NB, CONTIG, true, true, 4, 0, 1, 2, 1>), grid, dim3(256), 0, b->stream, b->d_img,
+      BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 1, 2, 1>), grid, dim3(256), 0, b->stream, b->d_img,
                          b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
     else
-      hipLaunchKernelGGL((k_prod<NB, CONTIG, true, false, 4, 0, 1, 2, 1>), grid, dim3(256), 0, b->stream, b->d_img,
+      BSN_KLAUNCH((k_prod<NB, CONTIG, true, false, 4, 0, 1, 2, 1>), grid, dim3(256), 0, b->stream, b->d_img,
                          b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
   } else if (lutP == kLutRaw) {
     if (has_q) BSN_LAUNCH_PROD(true, true, 0);
@@ -1708,7 +2029,7 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
       const int64_t npad8 = npad;
       const int32_t *cols8 = op->d_cols.p;
 #define BSN_PROD8(NBV, NAV, CV)                                                                          \
-  hipLaunchKernelGGL((k_prod8<NBV, NAV, CV>), grid8, dim3(256), 0, b->stream, b->d_img, b->pitch, cols8, \
+  BSN_KLAUNCH((k_prod8<NBV, NAV, CV>), grid8, dim3(256), 0, b->stream, b->d_img, b->pitch, cols8, \
                      op->col0, m_pad, mc, q, acc, npad8)
       if (NB == 1) {
         if (op->no_na) { if (op->cols_contig) BSN_PROD8(1, false, true); else BSN_PROD8(1, false, false); }

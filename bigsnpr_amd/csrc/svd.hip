@@ -449,8 +449,10 @@ struct HipSvdBackend : SvdBackend {
       m_sub = ms < op->m ? ms : op->m;
       op->m = m_sub;
       op->prof_kind_override = 3;
+      roctx_push("svd:warm start (leading 1/16 of the variants)");
       return true;
     }
+    roctx_pop();
     op->m = m_op_full;
     op->prof_kind_override = -1;
     warm_launches += 2;
@@ -469,8 +471,13 @@ struct HipSvdBackend : SvdBackend {
     HipSvdBackend *b;
     int ph;
     std::chrono::steady_clock::time_point t0;
-    Tick(HipSvdBackend *b_, int ph_) : b(b_), ph(ph_), t0(std::chrono::steady_clock::now()) {}
+    Tick(HipSvdBackend *b_, int ph_) : b(b_), ph(ph_), t0(std::chrono::steady_clock::now()) {
+      static const char *names[8] = {"svd:alloc", "svd:crossprod pass (Z = A'Q)", "svd:product pass (W = A Z)", "svd:gram blocks",
+                                     "svd:orthonormalise", "svd:round / copy block", "svd:form u, v", "svd:other"};
+      roctx_push(names[ph & 7]);
+    }
     ~Tick() {
+      roctx_pop();
       if (b->timing)
         b->t_phase[ph] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
@@ -901,6 +908,7 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
   int rc = guarded([&] {
     if (!o) fail("options must not be NULL");
     if (o->k < 1) fail("'k' must be at least 1.");
+    RoctxRange whole("bsn_bed_randomsvd");
     auto t_begin = std::chrono::steady_clock::now();
     auto since = [&]() {
       return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();

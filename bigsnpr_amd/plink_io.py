@@ -31,6 +31,35 @@ def bed_to_bytes(obj_bed, ind_row=None, ind_col=None):
     return out.T
 
 
+def get_code(na_val=3):
+    """getCode() (R/utils.R:21-31): the 4 x 256 raw table readbina decodes with."""
+    t4 = np.array([2, na_val, 1, 0], dtype=np.uint8)          # .bed bit pairs 00, 01, 10, 11
+    return np.ascontiguousarray(t4[(np.arange(256)[None, :] >> (2 * np.arange(4)[:, None])) & 3])
+
+
+def readbina(bedfile, tab=None, n=None, m=None):
+    """readbina (src/read-plink.cpp:13-56) as snp_readBed calls it (R/read-plink.R:42-55: dimensions from the
+    .fam / .bim files unless given): (n x m uint8 FBM bytes of the whole file decoded through the 4 x 256 table `tab`
+    on the GPU, reached-EOF flag).  Like the reference it does not go through the `bed` class: a file longer than
+    n x m genotypes is not an error, the flag says so."""
+    from .bed import _count_lines
+    tab = get_code() if tab is None else np.ascontiguousarray(np.asarray(tab, dtype=np.uint8).reshape(4, 256))
+    bedfile = os.path.expanduser(str(bedfile))
+    n = _count_lines(bedfile[:-4] + ".fam") if n is None else int(n)
+    m = _count_lines(bedfile[:-4] + ".bim") if m is None else int(m)
+    raw = np.fromfile(bedfile, dtype=np.uint8)
+    if raw.size < 3 or not (raw[0] == 108 and raw[1] == 27):
+        raise ValueError("Wrong magic number. Aborting..")
+    nb = (n + 3) // 4
+    if raw.size < 3 + m * nb:
+        raise ValueError("readbina: '%s' holds fewer than %d x %d genotypes" % (bedfile, n, m))
+    b = bed.from_payload(raw[3:3 + m * nb], n, m)
+    out = np.empty((m, n), dtype=np.uint8)
+    # column `byte` of the R matrix is contiguous: tab[4 * byte + e]
+    check(_lib.load().bsn_bed_readbina(b.handle, ptr(np.ascontiguousarray(tab.T), u8p), ptr(out, u8p)))
+    return out.T, bool(raw.size <= 3 + m * nb)
+
+
 def snp_readBed(bedfile, ind_row=None, ind_col=None):
     """R/read-plink.R:27-111 (snp_readBed / snp_readBed2): returns a bigSNP-like dict
     {genotypes: FBM_code256, fam, map}."""

@@ -365,6 +365,45 @@ SEXP _bigsnpr_prod_and_rowSumsSq2(SEXP BM, SEXP ind_row, SEXP ind_col, SEXP cent
   return res;
 }
 
+/* _bigsnpr_readbina(filename, BM, tab) -> logical: the whole .bed file decoded through `tab` (4 x 256 raw,
+ * getCode() of R/utils.R:21-31) into the new FBM's backing file; TRUE when the file ends with the last variant
+ * (src/read-plink.cpp:13-56; snp_readBed warns otherwise, R/read-plink.R:54-55).  Like the reference this does NOT
+ * go through the `bed` class (no "n or p does not match" check: a longer file is the warning case): the payload is
+ * mapped and handed to bsn_bed_from_host.  A file SHORTER than n x m genotypes is an error here (the reference reads
+ * past the end silently and leaves stale buffer bytes in the FBM). */
+SEXP _bigsnpr_readbina(SEXP filename, SEXP BM, SEXP tab) {
+  if (TYPEOF(tab) != RAWSXP || XLENGTH(tab) != 1024) Rf_error("readbina: 'tab' must be a 4 x 256 raw matrix");
+  const char *path = CHAR(STRING_ELT(filename, 0));
+  const int64_t n = (int64_t) Rf_asInteger(field(BM, "nrow")), m = (int64_t) Rf_asInteger(field(BM, "ncol"));
+  const int64_t n_byte = (n + 3) / 4;
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) Rf_error("cannot open '%s'", path);
+  struct stat st;
+  if (fstat(fd, &st) != 0) { close(fd); Rf_error("cannot stat '%s'", path); }
+  if ((int64_t) st.st_size < 3 + m * n_byte) {
+    close(fd);
+    Rf_error("readbina: '%s' holds fewer than %lld x %lld genotypes", path, (long long) n, (long long) m);
+  }
+  const unsigned char *map = (const unsigned char *) mmap(NULL, (size_t) st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (map == MAP_FAILED) Rf_error("cannot map '%s'", path);
+  if (!(map[0] == 108 && map[1] == 27)) {          /* src/read-plink.cpp:31-32 (its third test is an assignment) */
+    munmap((void *) map, (size_t) st.st_size);
+    Rf_error("Wrong magic number. Aborting..");
+  }
+  uint8_t *bytes = (uint8_t *) R_alloc((size_t) n * (size_t) m, 1);
+  bsn_bed *b = NULL;
+  int rc = bsn_bed_from_host(map + 3, n, m, n_byte, &b);
+  if (rc == 0) rc = bsn_bed_readbina(b, RAW(tab), bytes);
+  char msg[512] = "";
+  if (rc != 0) snprintf(msg, sizeof msg, "%s", bsn_last_error());
+  if (b) bsn_bed_close(b);
+  munmap((void *) map, (size_t) st.st_size);
+  if (rc != 0) Rf_error("%s", msg);
+  write_backing(BM, bytes, (size_t) n * (size_t) m);
+  return Rf_ScalarLogical((int64_t) st.st_size <= 3 + m * n_byte);
+}
+
 /* _bigsnpr_readbina2(BM, obj_bed, ind_row, ind_col, ncores): decoded genotypes of the .bed sub-matrix
  * into the (new) FBM's backing file, one byte each (src/read-plink.cpp:61-80) */
 SEXP _bigsnpr_readbina2(SEXP BM, SEXP obj_bed, SEXP ind_row, SEXP ind_col, SEXP ncores) {
@@ -525,6 +564,7 @@ static const R_CallMethodDef CallEntries[] = {
   {"_bigsnpr_prod_and_rowSumsSq2", (DL_FUNC) &_bigsnpr_prod_and_rowSumsSq2, 6},
   {"_bigsnpr_snp_colstats", (DL_FUNC) &_bigsnpr_snp_colstats, 4},
   {"_bigsnpr_multLinReg", (DL_FUNC) &_bigsnpr_multLinReg, 5},
+  {"_bigsnpr_readbina", (DL_FUNC) &_bigsnpr_readbina, 3},
   {"_bigsnpr_readbina2", (DL_FUNC) &_bigsnpr_readbina2, 5},
   {"_bigsnpr_writebina", (DL_FUNC) &_bigsnpr_writebina, 5},
   {"_bigsnpr_corMat", (DL_FUNC) &_bigsnpr_corMat, 8},

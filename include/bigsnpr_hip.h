@@ -171,6 +171,11 @@ int bsn_snp_grid_prs(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int6
  * snp_readBed / snp_readBed2 create (R/read-plink.R:27-111). */
 int bsn_bed_to_fbm(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
                    uint8_t *out);
+/* _bigsnpr_readbina (3 args) src/read-plink.cpp:13-56 (snp_readBed, R/read-plink.R:54): the WHOLE matrix of the
+ * handle as FBM bytes, column-major n x m, every .bed byte decoded through the caller's 4 x 256 raw table
+ * (tab[4 * byte + e] = FBM byte of genotype e of that byte; getCode(), R/utils.R:21-31).  The end-of-file flag
+ * the reference returns is a property of the file, not of the payload: the R shim derives it from the file size. */
+int bsn_bed_readbina(bsn_bed *bed, const uint8_t *tab, uint8_t *out);
 /* _bigsnpr_writebina (5 args) src/write-plink.cpp:13-52: the .bed payload (ceil(n/4) bytes per
  * variant, pad bits 0, no magic header) of the sub-matrix [ind_row, ind_col] of the image;
  * snp_writeBed (R/write-plink.R:15-44) writes magic + this + .bim/.fam. */
@@ -286,6 +291,10 @@ int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int
                       int64_t m, const double *center, const double *scale,
                       const bsn_svd_options *options, double *d, double *u, double *v,
                       bsn_svd_info *info);
+/* Measurement hygiene: the names (as rocprofv3 prints them, without the argument list) of the streaming kernels the
+ * last bsn_bed_randomsvd on this handle launched, one "kind=name" line per kind (cprod, prod, cprod_stats, warm).
+ * bench.py matches them against profiles/pmc_traffic.json before it quotes that record's HBM traffic. */
+int bsn_bed_streaming_kernels(bsn_bed *bed, char *buf, int64_t len);
 /* Streaming layout.  The passes of bsn_bed_randomsvd / bsn_bed_prodvec / bsn_bed_cprodvec over a 64-aligned
  * contiguous range of variants run faster (about 8 %) on a second copy of the 2-bit image stored in tiles of
  * 64 variants x 1024 samples (16 KB): every load of a wavefront then lands in one contiguous run instead of 16 -

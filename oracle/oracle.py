@@ -16,13 +16,15 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libbsn_oracle.so")
+# BSN_SANITIZE=1 (tests/test_sanitizers_cpu.py): the same source under -fsanitize=address,undefined
+_SAN = bool(os.environ.get("BSN_SANITIZE"))
+_SO = os.path.join(_HERE, "libbsn_oracle_san.so" if _SAN else "libbsn_oracle.so")
 
 
 def build(force=False):
     src = os.path.join(_HERE, "bsn_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libbsn_oracle.so"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", os.path.basename(_SO)])
     return _SO
 
 
@@ -126,6 +128,34 @@ def read_bed(bed, ind_row=None, ind_col=None, na_val=-1):
                        C.c_int64(ir.size), _p(ic, C.c_int64), C.c_int64(ic.size),
                        C.c_int32(na_val), _p(out, C.c_int32))
     return out.T  # n x m view (column-major storage like R)
+
+
+def get_code(na_val=3):
+    """getCode(), R/utils.R:21-31: the 4 x 256 raw table of snp_readBed — column `byte` holds the four genotypes of
+    that .bed byte (bit pair 00 -> 2, 10 -> 1, 11 -> 0, 01 -> NA.VAL), lowest bit pair first."""
+    bits = ((np.arange(256)[:, None] >> np.arange(8)[None, :]) & 1) == 0      # !as.logical(rawToBits(0:255))
+    geno1, geno2 = bits[:, 0::2], bits[:, 1::2]                               # s = c(TRUE, FALSE)
+    geno = geno1.astype(np.int64) + geno2
+    geno[~geno1 & geno2] = na_val
+    return np.ascontiguousarray(geno.T.astype(np.uint8))                      # dim 4 x 256
+
+
+def readbina(bedpath, n, m, tab):
+    """readbina, src/read-plink.cpp:13-56: the FBM bytes (n x m, one per genotype) of a whole .bed file decoded
+    through the 4 x 256 table `tab`, and the end-of-file flag (`!myFile.get(c)` after the m-th variant)."""
+    tab = np.asarray(tab, dtype=np.uint8).reshape(4, 256)
+    raw = np.fromfile(bedpath, dtype=np.uint8)
+    assert raw[0] == 108 and raw[1] == 27, "Wrong magic number. Aborting.."   # (:31-32; the third test is an assignment)
+    length, extra = n // 4, n % 4
+    length_extra = length + (extra > 0)
+    out = np.empty((n, m), dtype=np.uint8, order="F")
+    for j in range(m):
+        buf = raw[3 + j * length_extra: 3 + (j + 1) * length_extra]
+        col = tab[:, buf[:length]].T.reshape(-1)                              # std::copy(code_ptr, code_ptr + 4, ptr)
+        if extra:
+            col = np.concatenate([col, tab[:extra, buf[length]]])
+        out[:, j] = col
+    return out, raw.size <= 3 + m * length_extra
 
 
 def read_bed_scaled(bed, ind_row, ind_col, center, scale):

@@ -3,14 +3,17 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SO = os.path.join(HERE, "libnative_test.so")
+# BSN_SANITIZE=1 (tests/test_sanitizers_cpu.py): the same sources under -fsanitize=address,undefined
+SAN = bool(os.environ.get("BSN_SANITIZE"))
+SO = os.path.join(HERE, "libnative_test_san.so" if SAN else "libnative_test.so")
 
 
 def build():
     src = os.path.join(HERE, "native_test.cpp")
     deps = [src] + [os.path.join(ROOT, "bigsnpr_amd", "csrc", f) for f in ("svd_driver.hpp", "dense_small.hpp", "orth_small.hpp")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall",
+        flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if SAN else ["-O2"]
+        subprocess.check_call(["g++"] + flags + ["-std=c++17", "-fPIC", "-shared", "-Wall",
                                "-I", os.path.join(ROOT, "bigsnpr_amd", "csrc"), src, "-o", SO])
     return SO
 

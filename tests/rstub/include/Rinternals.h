@@ -25,6 +25,7 @@ typedef enum { FALSE = 0, TRUE } Rboolean;
 #define STRSXP 16
 #define VECSXP 19
 #define EXTPTRSXP 22
+#define RAWSXP 24
 
 extern SEXP R_NilValue, R_GlobalEnv, R_UnboundValue;
 extern double R_NaReal;
@@ -39,6 +40,8 @@ int TYPEOF(SEXP x);
 R_xlen_t XLENGTH(SEXP x);
 int *INTEGER(SEXP x);
 double *REAL(SEXP x);
+typedef unsigned char Rbyte;
+Rbyte *RAW(SEXP x);
 const char *CHAR(SEXP x);
 SEXP STRING_ELT(SEXP x, R_xlen_t i);
 SEXP SET_VECTOR_ELT(SEXP x, R_xlen_t i, SEXP v);
@@ -52,6 +55,7 @@ SEXP Rf_allocVector(unsigned int type, R_xlen_t n);
 SEXP Rf_allocMatrix(unsigned int type, int nrow, int ncol);
 SEXP Rf_mkNamed(unsigned int type, const char **names);
 SEXP Rf_ScalarInteger(int x);
+SEXP Rf_ScalarLogical(int x);
 int Rf_asInteger(SEXP x);
 double Rf_asReal(SEXP x);
 int Rf_asLogical(SEXP x);

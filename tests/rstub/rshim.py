@@ -28,6 +28,7 @@ class R:
                 ("rstub_nil", vp, []), ("rstub_int", vp, [C.POINTER(C.c_int), C.c_ssize_t]), ("rstub_lgl", vp, [C.c_int]),
                 ("rstub_real", vp, [C.POINTER(C.c_double), C.c_ssize_t]),
                 ("rstub_real_matrix", vp, [C.POINTER(C.c_double), C.c_int, C.c_int]), ("rstub_string", vp, [C.c_char_p]),
+                ("rstub_raw_matrix", vp, [C.POINTER(C.c_ubyte), C.c_int, C.c_int]),
                 ("rstub_env", vp, []), ("rstub_env_set", None, [vp, C.c_char_p, vp]), ("rstub_type", C.c_int, [vp]),
                 ("rstub_length", C.c_ssize_t, [vp]), ("rstub_nrow", C.c_int, [vp]), ("rstub_ncol", C.c_int, [vp]),
                 ("rstub_data", vp, [vp]), ("rstub_list_get", vp, [vp, C.c_ssize_t]),
@@ -63,6 +64,9 @@ class R:
             a = np.array([v], dtype=np.float64)
             return L.rstub_real(a.ctypes.data_as(C.POINTER(C.c_double)), 1)
         a = np.asarray(v)
+        if a.dtype == np.uint8 and a.ndim == 2:      # a raw matrix
+            f = np.asfortranarray(a)
+            return L.rstub_raw_matrix(f.ctypes.data_as(C.POINTER(C.c_ubyte)), a.shape[0], a.shape[1])
         if a.dtype.kind in "iu":
             a = np.ascontiguousarray(a, dtype=np.int32)
             return L.rstub_int(a.ctypes.data_as(C.POINTER(C.c_int)), a.size)

@@ -77,6 +77,7 @@ int *INTEGER(SEXP x) {
   return (int *) x->data;
 }
 double *REAL(SEXP x) { need(x, REALSXP, "REAL()"); return (double *) x->data; }
+Rbyte *RAW(SEXP x) { need(x, RAWSXP, "RAW()"); return (Rbyte *) x->data; }
 const char *CHAR(SEXP x) { need(x, CHARSXP, "CHAR()"); return (const char *) x->data; }
 SEXP STRING_ELT(SEXP x, R_xlen_t i) {
   need(x, STRSXP, "STRING_ELT()");
@@ -110,6 +111,7 @@ SEXP Rf_allocVector(unsigned int type, R_xlen_t n) {
   switch (type) {
     case INTSXP: case LGLSXP: return new_obj((int) type, n, sizeof(int));
     case REALSXP: return new_obj(REALSXP, n, sizeof(double));
+    case RAWSXP: return new_obj(RAWSXP, n, 1);
     case VECSXP: case STRSXP: {
       SEXP x = new_obj((int) type, n, sizeof(SEXP));
       for (R_xlen_t i = 0; i < n; i++) ((SEXP *) x->data)[i] = type == STRSXP ? mkchar("") : R_NilValue;
@@ -245,6 +247,16 @@ SEXP rstub_nil(void) { return R_NilValue; }
 SEXP rstub_int(const int *v, R_xlen_t n) {
   SEXP x = Rf_allocVector(INTSXP, n);
   if (n) memcpy(x->data, v, (size_t) n * sizeof(int));
+  return x;
+}
+SEXP Rf_ScalarLogical(int v) {
+  SEXP x = Rf_allocVector(LGLSXP, 1);
+  ((int *) x->data)[0] = v == NA_LOGICAL ? NA_LOGICAL : (v != 0);
+  return x;
+}
+SEXP rstub_raw_matrix(const unsigned char *v, int nrow, int ncol) {
+  SEXP x = Rf_allocMatrix(RAWSXP, nrow, ncol);
+  if (x->len) memcpy(x->data, v, (size_t) x->len);
   return x;
 }
 SEXP rstub_lgl(int v) {

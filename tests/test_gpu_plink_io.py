@@ -55,3 +55,17 @@ def test_write_read_roundtrip(ba, orc, golden_dir, tmp_path):
     # the written payload equals the oracle's packing of the same sub-matrix
     ob = orc.BedFile(out2)
     np.testing.assert_array_equal(orc.read_bed(ob, na_val=3), g[np.ix_(ir, ic)])
+
+
+def test_readbina_with_the_reference_table_and_a_random_one(ba, orc, golden_dir):
+    """readbina (src/read-plink.cpp:13-56) on the device: any 4 x 256 raw table, whole file, EOF flag."""
+    from bigsnpr_amd import plink_io
+    np.testing.assert_array_equal(plink_io.get_code(), orc.get_code())
+    for name in ("example.bed", "example-missing.bed"):
+        path = os.path.join(golden_dir, name)
+        ob = orc.BedFile(path)
+        for tab in (None, np.random.default_rng(1).integers(0, 256, size=(4, 256)).astype(np.uint8)):
+            got, eof = plink_io.readbina(path, tab)
+            ref, ref_eof = orc.readbina(path, ob.n, ob.m, orc.get_code() if tab is None else tab)
+            np.testing.assert_array_equal(got, ref)
+            assert eof == ref_eof

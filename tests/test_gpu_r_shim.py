@@ -142,3 +142,20 @@ def test_one_backing_file_several_decode_tables_and_writebed(R, orc, golden_dir,
     R.call("_bigsnpr_readbina2", R.env(backingfile=str(bk2)), obj, sel_r + 1, sel_c + 1, 1)
     np.testing.assert_array_equal(np.fromfile(bk2, dtype=np.uint8).reshape((sel_r.size, sel_c.size), order="F"),
                                   g[np.ix_(sel_r, sel_c)])
+    # readbina (snp_readBed, R/read-plink.R:54): the WHOLE file through the caller's 4 x 256 raw table; TRUE at EOF
+    src = os.path.join(golden_dir, "example-missing.bed")
+    for tab in (orc.get_code(), np.random.default_rng(5).integers(0, 256, size=(4, 256)).astype(np.uint8)):
+        bk3 = tmp_path / "readbina.bk"
+        np.zeros(ob.n * ob.m, dtype=np.uint8).tofile(bk3)
+        eof = R.call("_bigsnpr_readbina", src, R.env(backingfile=str(bk3), nrow=float(ob.n), ncol=float(ob.m)), tab)
+        ref, ref_eof = orc.readbina(src, ob.n, ob.m, tab)
+        np.testing.assert_array_equal(np.fromfile(bk3, dtype=np.uint8).reshape((ob.n, ob.m), order="F"), ref)
+        assert bool(eof[0]) is True and ref_eof is True
+    longer = tmp_path / "longer.bed"
+    longer.write_bytes(open(src, "rb").read() + b"\x00")            # a trailing byte: EOF not reached (the warning case)
+    eof = R.call("_bigsnpr_readbina", str(longer), R.env(backingfile=str(bk3), nrow=float(ob.n), ncol=float(ob.m)),
+                 orc.get_code())
+    assert bool(eof[0]) is False and orc.readbina(str(longer), ob.n, ob.m, orc.get_code())[1] is False
+    with pytest.raises(Exception, match="4 x 256"):
+        R.call("_bigsnpr_readbina", src, R.env(backingfile=str(bk3), nrow=float(ob.n), ncol=float(ob.m)),
+               np.zeros((4, 3), dtype=np.uint8))

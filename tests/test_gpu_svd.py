@@ -77,6 +77,56 @@ def test_synthetic_structured(ba, orc, n, m, k):
     np.testing.assert_array_equal(res["u"], res_b["u"])
 
 
+def _angles(ref_d, ref_x, x, k):
+    """sin of the angle between every computed vector and its reference, and the spectral-gap ratio
+    sigma_i^2 / min_j |sigma_i^2 - sigma_j^2| (j over ALL other singular values incl. sigma_{k+1}) that converts a
+    relative eigen-residual into an angle (Davis-Kahan)"""
+    cosv = np.abs(np.sum(x * ref_x[:, :k], axis=0))
+    sin = np.sqrt(np.maximum(0.0, 1.0 - np.minimum(cosv, 1.0) ** 2))
+    lam = ref_d ** 2
+    amp = np.array([lam[i] / np.min(np.abs(lam[i] - np.delete(lam, i))) for i in range(k)])
+    return sin, amp
+
+
+@pytest.mark.parametrize("case", ["example", "synth_1500x4000_k20", "synth_3000x900_k10"])
+def test_vectors_at_default_settings(ba, orc, golden_dir, example_bed, case, capsys):
+    """u and v of the DEFAULT solve (tol 1e-4, automatic block and 16-bit panels) against the oracle's
+    dense SVD.  A Ritz pair whose eigen-residual is rho * sigma^2 lies within rho * sigma_i^2 / gap_i of its
+    eigenvector (Davis-Kahan); rho is what the solve is allowed: tol plus the rounding floor of the 16-bit basis,
+    1.2 * 2^-16.  Asserted with C = 2; the measured worst case is printed (and recorded in
+    DESIGN.md): the leading vectors sit far below the bound, like RSpectra's."""
+    if case == "example":
+        gb, ob, ic, k = ba.bed(os.path.join(golden_dir, "example.bed")), example_bed, None, 10
+    else:
+        n, m, k = (1500, 4000, 20) if "1500" in case else (3000, 900, 10)
+        ob, gb = orc.fake_bed(n, m, seed=21), ba.bed.synthetic(n, m, seed=21)
+        ic = np.nonzero(orc.bed_scaleBinom(ob)["scale"] > 0)[0]
+    ref = orc.dense_svd(ob, None, ic, k=k + 1)
+    res = ba.bed_randomSVD(gb, ind_col=ic, k=k)
+    assert res["converged"]
+    rho = 1e-4 + 1.2 * 2.0 ** (-8 * res["slices"])
+    C = 2.0
+    worst = {}
+    for name in ("u", "v"):
+        sin, amp = _angles(ref["d"], ref[name], res[name], k)
+        ratio = sin / (rho * amp)
+        worst[name] = (float(sin.max()), float(sin[: k // 2].max()), float(ratio.max()))
+        assert np.all(sin <= C * rho * amp), (name, sin, rho * amp)
+    # the k-dimensional subspaces: largest principal angle against rho * sigma_1^2 / (sigma_k^2 - sigma_{k+1}^2)
+    lam = ref["d"] ** 2
+    for name in ("u", "v"):
+        sv = np.linalg.svd(ref[name][:, :k].T @ res[name], compute_uv=False)
+        sin_max = float(np.sqrt(max(0.0, 1.0 - min(sv.min(), 1.0) ** 2)))
+        bound = C * np.sqrt(k) * rho * lam[0] / (lam[k - 1] - lam[k])
+        worst[name + "_subspace"] = (sin_max, float(bound))
+        assert sin_max <= bound, (name, sin_max, bound)
+    with capsys.disabled():
+        print("\n[u/v at defaults] %s block %d slices %d niter %d: sin(u) max %.2e (leading half %.2e, of bound %.3f); "
+              "sin(v) max %.2e (leading half %.2e, of bound %.3f); subspace sin u %.2e v %.2e"
+              % (case, res["block"], res["slices"], res["niter"], worst["u"][0], worst["u"][1], worst["u"][2] / C,
+                 worst["v"][0], worst["v"][1], worst["v"][2] / C, worst["u_subspace"][0], worst["v_subspace"][0]))
+
+
 def test_k_too_large_and_errors(ba, golden_dir):
     gb = ba.bed(os.path.join(golden_dir, "example-missing.bed"))
     with pytest.raises(ba.BsnError, match="larger than the dimensions"):

@@ -253,3 +253,17 @@ def test_fbm_products_are_the_plain_definition(orc, example_bed):
         st = orc.snp_colstats(obj, ir, ic)
         np.testing.assert_allclose(st["sumX"], A.sum(0), rtol=1e-12)
         np.testing.assert_allclose(st["denoX"], (A * A).sum(0) - A.sum(0) ** 2 / ir.size, rtol=1e-9, atol=1e-9)
+
+
+def test_readbina_restatement_against_the_decoder(orc, golden_dir):
+    """readbina + getCode() (src/read-plink.cpp:13-56, R/utils.R:21-31) give what snp_readBed stores: the decoded
+    calls with 3 for a missing value (tests/testthat/test-1-readBed.R: `G[]` of the FBM equals the bed accessor)."""
+    tab = orc.get_code()
+    assert tab.shape == (4, 256) and list(tab[:, 0]) == [2, 2, 2, 2] and list(tab[:, 255]) == [0, 0, 0, 0]
+    assert list(tab[:, 0b00011011]) == [0, 1, 3, 2]          # bit pairs 11, 10, 01, 00, lowest first
+    for name in ("example.bed", "example-missing.bed"):
+        path = os.path.join(golden_dir, name)
+        ob = orc.BedFile(path)
+        got, eof = orc.readbina(path, ob.n, ob.m, tab)
+        np.testing.assert_array_equal(got, orc.read_bed(ob, na_val=3).astype(np.uint8))
+        assert eof

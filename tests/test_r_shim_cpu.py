@@ -16,7 +16,8 @@ HOT_PATH = ["_bigsnpr_bedXPtr", "_bigsnpr_bed_pMatVec4", "_bigsnpr_bed_cpMatVec4
             "_bigsnpr_bed_col_counts_cpp", "_bigsnpr_bed_row_counts_cpp", "_bigsnpr_read_bed", "_bigsnpr_read_bed_scaled",
             "_bigsnpr_snp_colstats", "_bigsnpr_corMat", "_bigsnpr_ld_scores", "_bigsnpr_clumping_chr",
             "_bigsnpr_bed_clumping_chr", "_bigsnpr_clumping_chr_cached", "_bigsnpr_prod_and_rowSumsSq",
-            "_bigsnpr_prod_and_rowSumsSq2", "_bigsnpr_multLinReg", "_bigsnpr_readbina2", "_bigsnpr_writebina"]
+            "_bigsnpr_prod_and_rowSumsSq2", "_bigsnpr_multLinReg", "_bigsnpr_readbina", "_bigsnpr_readbina2",
+            "_bigsnpr_writebina"]
 
 
 def test_shim_compiles_without_warnings():

@@ -14,6 +14,7 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--nvecs", type=str, default="1,4,8")
 ap.add_argument("--slices", type=int, default=4)
 ap.add_argument("--subset", type=float, default=0.0, help="random sorted subset of this fraction of the variants (non-contiguous ind.col)")
+ap.add_argument("--xkind", default="normal", help="normal | ones (a 0/1 panel: constant digits, low operand toggling)")
 ap.add_argument("--dosage", action="store_true", help="byte image of a dosage FBM (uploaded from the host) instead of the 2-bit image")
 a = ap.parse_args()
 L = _lib.load()
@@ -61,10 +62,17 @@ if a.subset > 0:
     print("subset of %d variants" % ic.size, flush=True)
 op = ba.ScaledOp(gb, None, ic, sc["center"], sc["scale"], slices=a.slices)
 for nv in [int(v) for v in a.nvecs.split(",")]:
-    X = ba.DeviceArray.from_numpy(rng.normal(size=(a.m, nv)))
-    R = ba.DeviceArray.from_numpy(rng.normal(size=(a.n, nv)))
+    if a.xkind == "ones":
+        X = ba.DeviceArray.from_numpy((rng.random(size=(a.m, nv)) < 0.5).astype(float))
+        R = ba.DeviceArray.from_numpy((rng.random(size=(a.n, nv)) < 0.5).astype(float))
+    else:
+        X = ba.DeviceArray.from_numpy(rng.normal(size=(a.m, nv)))
+        R = ba.DeviceArray.from_numpy(rng.normal(size=(a.n, nv)))
     Y = ba.DeviceArray(a.n, nv); Z = ba.DeviceArray(a.m, nv)
     t = timed(lambda: op.cprod(R, Z), a.reps)
-    print(json.dumps(dict(kernel="cprod", nvec=nv, ms=t, GBps=bytes_pass / t / 1e6)), flush=True)
+    import hashlib
+    print(json.dumps(dict(kernel="cprod", nvec=nv, ms=t, GBps=bytes_pass / t / 1e6,
+                          sha=hashlib.sha1(Z.to_numpy().tobytes()).hexdigest()[:12])), flush=True)
     t = timed(lambda: op.prod(X, Y), a.reps)
-    print(json.dumps(dict(kernel="prod", nvec=nv, ms=t, GBps=bytes_pass / t / 1e6)), flush=True)
+    print(json.dumps(dict(kernel="prod", nvec=nv, ms=t, GBps=bytes_pass / t / 1e6,
+                          sha=hashlib.sha1(Y.to_numpy().tobytes()).hexdigest()[:12])), flush=True)
