@@ -64,6 +64,11 @@ def parse():
     ap.add_argument("--allow-fallback", action="store_true",
                     help="N > 1 without a working RCCL communicator: take the host all-reduce hook over gloo (labelled in "
                          "config.parallelism) instead of exiting with status 3")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="one GPU, N given: solve on the FIRST of N column shards (m / N variants) with the solver told the "
+                         "total (--m): the per-rank work of an N-GPU run — warm start, block size and step count as there; "
+                         "with --force-dist through the 1-rank RCCL communicator.  The n-side panel algebra is NOT divided "
+                         "by N here (one rank owns all rows), so this is an upper bound of a rank's time without the exchange")
     ap.add_argument("--force-dist", action="store_true",
                     help="go through the RCCL communicator even with one rank (self-test)")
     ap.add_argument("--cpu-sample-cols", type=int, default=0)
@@ -219,6 +224,8 @@ def main():
     n, m_total = a.n, a.m or 1000000
     j0 = (m_total * rank) // world
     j1 = (m_total * (rank + 1)) // world
+    if a.shard_of > 1 and world == 1:
+        j0, j1 = 0, m_total // a.shard_of
     m_local = j1 - j0
     t0 = time.time()
     gb = ba.bed.synthetic(n, m_local, seed=20250905, j_begin=j0)
@@ -267,10 +274,11 @@ def main():
     # warm-start launches stream only a fraction of the variants: counted as that fraction of a pass
     passes = sum(r["nops"] - r["warm_launches"] * (1.0 - r["warm_fraction"]) + (0 if r["fused_stats"] else 1)
                  for r in infos)
-    value = m_total * passes / wall                           # whole job, all ranks
+    m_job = m_local if (a.shard_of > 1 and world == 1) else m_total   # columns this job really streamed per pass
+    value = m_job * passes / wall                             # whole job, all ranks
     bytes_per_launch = ((n + 3) // 4) * m_local               # algorithmic: 2-bit payload of the shard
     kern = {}
-    for key, name in (("prod", "k_prod (A~ panel, contraction over variants)"),
+    for key, name in (("prod", "k_prod / k_prodT (A~ panel, contraction over variants)"),
                       ("cprod", "k_cprod (A~' panel, contraction over samples)"),
                       ("cprod_stats", "k_cprod<STATS> (first A~' pass of a solve: also counts the codes of every variant)")):
         ms = sum(r[key + "_ms"] for r in infos)
@@ -325,7 +333,9 @@ def main():
                                    "sample blocks, b x p Gram all-reduces, all-gather of the basis block"
                                    % (world, blk)) if comm else
                                   ("columns sharded x%d; FALLBACK: host all-reduce hook over gloo (RCCL communicator "
-                                   "unavailable)" % world if hook else "single GPU")},
+                                   "unavailable)" % world if hook else
+                                   ("single GPU holding shard 1 of %d (per-rank work of an %d-GPU run, no exchange)"
+                                    % (a.shard_of, a.shard_of) if a.shard_of > 1 else "single GPU"))},
         "passes_per_solve": passes / a.steps,
         "niter": infos[-1]["niter"], "converged": infos[-1]["converged"],
         "scaling_statistics": "ride along the first crossproduct pass" if infos[-1]["fused_stats"] else "own pass",
@@ -333,10 +343,13 @@ def main():
                        "ms": infos[-1]["warm_ms"]},
         "image_layout": ("streaming kernels read the tiled second copy (64 variants x 1024 samples per 16-KB tile; built once "
                          "per handle before the first solve, + %.0f GB of HBM)" % (bytes_per_launch / 1e9))
-                        if infos[-1]["tiled"] else "variant-major image only",
-        "end_to_end_cols_per_s": m_total * a.steps / wall,
-        "hbm_GBps_whole_solve": passes * ((n + 3) // 4) * m_total / wall / 1e9,
-        "hbm_frac_whole_solve": passes * ((n + 3) // 4) * m_total / wall / 1e9 / HBM_PEAK_GBS / world,
+                        if infos[-1]["tiled"] == 1 else
+                        ("crossproduct passes read the variant-major image, product passes its sample-major second copy "
+                         "(k_prodT; built once per handle before the first solve: one read + one write pass, + %.0f GB of HBM)"
+                         % (bytes_per_launch / 1e9)) if infos[-1]["tiled"] == 2 else "variant-major image only",
+        "end_to_end_cols_per_s": m_job * a.steps / wall,
+        "hbm_GBps_whole_solve": passes * ((n + 3) // 4) * m_job / wall / 1e9,
+        "hbm_frac_whole_solve": passes * ((n + 3) // 4) * m_job / wall / 1e9 / HBM_PEAK_GBS / world,
         "sigma": [float(x) for x in infos[-1]["d"][:5]],
         "generate_s": gen_s,
         "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -5,6 +5,7 @@ called without a HIP device, this raises.
 """
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -62,6 +63,7 @@ SIGNATURES = {
     "bsn_fbm_open": (C.c_int, [u8p, i64, i64, i64, f64p, C.POINTER(vp)]),
     "bsn_bed_bits": (C.c_int, [vp]),
     "bsn_bed_tile": (C.c_int, [vp, C.POINTER(C.c_int)]),
+    "bsn_bed_sample_major": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "bsn_bed_na_known": (i64, [vp]),
     "bsn_bed_synthetic": (C.c_int, [i64, i64, C.c_uint32, C.c_uint32, C.c_uint32, i64, C.POINTER(vp)]),
     "bsn_bed_close": (C.c_int, [vp]),
@@ -220,35 +222,47 @@ class PinnedPool:
     engines write directly.  A block is reused once every numpy array over it has been collected, so
     results stay valid for as long as the caller holds them; at most `keep` bytes of free blocks are kept."""
 
-    def __init__(self, keep=4 << 30):
-        self.free, self.keep = [], keep
+    def __init__(self, keep=None):
+        # free blocks kept for reuse: 1 GiB unless BSN_RESULT_POOL_KEEP (bytes) says otherwise — u + v of the
+        # 400K x 1M, k = 20 solve are 224 MB
+        self.free = []
+        self.keep = int(os.environ.get("BSN_RESULT_POOL_KEEP", 1 << 30)) if keep is None else keep
+        self.lock = threading.Lock()       # __del__ of a block may run on any thread, also inside empty()
 
     def empty(self, shape, dtype=np.float64):
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
         size = max(4096, (n + 4095) // 4096 * 4096)
-        pick = None
-        for i, (addr, sz) in enumerate(self.free):
-            if sz >= size and (pick is None or sz < self.free[pick][1]):
-                pick = i
-        if pick is not None and self.free[pick][1] <= 2 * size:
-            addr, sz = self.free.pop(pick)
-        else:
+        addr = None
+        with self.lock:
+            pick = None
+            for i, (_, sz) in enumerate(self.free):
+                if sz >= size and (pick is None or sz < self.free[pick][1]):
+                    pick = i
+            if pick is not None and self.free[pick][1] <= 2 * size:
+                addr, sz = self.free.pop(pick)
+        if addr is None:
             p = vp()
-            check(load().bsn_host_alloc(C.byref(p), size))
+            if load().bsn_host_alloc(C.byref(p), size) != 0 or not p.value:
+                # page-locked memory is an optimisation (DMA straight into the result): when the host refuses it
+                # (ulimit -l, fragmentation) the result goes to ordinary memory through the staging buffers
+                return np.empty(shape, dtype=dtype)
             addr, sz = p.value, size
         blk = _PinnedBlock(self, addr, sz)
         return np.asarray(blk)[:n].view(dtype).reshape(shape)
 
     def _give_back(self, addr, size):
-        if sum(sz for _, sz in self.free) + size <= self.keep:
-            self.free.append((addr, size))
-        else:
+        with self.lock:
+            keep = sum(sz for _, sz in self.free) + size <= self.keep
+            if keep:
+                self.free.append((addr, size))
+        if not keep:
             load().bsn_host_free(vp(addr))
 
     def drain(self):
-        for addr, _ in self.free:
+        with self.lock:
+            blocks, self.free = self.free, []
+        for addr, _ in blocks:
             load().bsn_host_free(vp(addr))
-        self.free = []
 
 
 result_pool = PinnedPool()

@@ -174,6 +174,16 @@ class bed:
         check(_lib.load().bsn_bed_tile(self.handle, C.byref(built)))
         return bool(built.value)
 
+    def release_workspace(self):
+        """bsn_bed_release_workspace: the solve's workspace, the second copies of the image and the cached work buffers"""
+        check(_lib.load().bsn_bed_release_workspace(self.handle))
+
+    def sample_major(self):
+        """builds the sample-major copy of the image ahead of time (bsn_bed_sample_major); True if it exists"""
+        built = C.c_int(0)
+        check(_lib.load().bsn_bed_sample_major(self.handle, C.byref(built)))
+        return bool(built.value)
+
     def download(self):
         out = np.empty(((self.nrow + 3) // 4) * self.ncol, dtype=np.uint8)
         check(_lib.load().bsn_bed_download(self.handle, ptr(out, u8p)))

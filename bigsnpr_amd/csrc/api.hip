@@ -1,6 +1,7 @@
 // api.hip — the extern "C" surface declared in include/bigsnpr_hip.h.
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <pthread.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -207,7 +208,15 @@ struct CopyJob {
   const void *src = nullptr;
   size_t len = 0;
 };
-static inline void cpu_relax() { __builtin_ia32_pause(); }
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  __asm__ __volatile__("yield");
+#else
+  std::this_thread::yield();
+#endif
+}
 struct CopyPool {
   static constexpr int kMaxHelpers = 6;
   int nh = 2;
@@ -263,7 +272,15 @@ struct CopyPool {
   }
 };
 CopyPool *g_pool = nullptr;
-std::mutex g_pool_mu;   // one copy at a time goes through the pool (calls on different handles may be concurrent)
+// one copy at a time goes through the pool (calls on different handles may be concurrent: the others copy on their own
+// thread instead of queueing behind it).  A raw pointer, so that the child of a fork can start from a fresh mutex: the
+// parent's may have been held by a thread that does not exist in the child.
+std::mutex *g_pool_mu = new std::mutex();
+void pool_atfork_child() {
+  g_pool_mu = new std::mutex();   // (the parent's mutex and pool object are abandoned in the child, not freed)
+  g_pool = nullptr;
+}
+const int g_pool_atfork = pthread_atfork(nullptr, nullptr, pool_atfork_child);
 }  // namespace
 
 // host copy between caller memory and a staging buffer
@@ -276,9 +293,13 @@ static void host_copy(void *dst, const void *src, size_t len) {
     std::memcpy(dst, src, len);
     return;
   }
-  std::lock_guard<std::mutex> lk(g_pool_mu);
+  std::unique_lock<std::mutex> lk(*g_pool_mu, std::try_to_lock);
+  if (!lk.owns_lock()) {   // another thread's copy is in the pool: do not queue behind it
+    std::memcpy(dst, src, len);
+    return;
+  }
   if (!g_pool || g_pool->owner != getpid()) {   // first use, or a forked child (threads do not survive a fork)
-    g_pool = new CopyPool();                     // (the parent's pool object is abandoned in the child, not freed)
+    g_pool = new CopyPool();
     g_pool->start();
   }
   g_pool->copy(dst, src, len);
@@ -357,6 +378,7 @@ void bed_free(bsn_bed *b) {
   }
   if (b->d_img) (void)hipFree(b->d_img);
   if (b->d_tiled) (void)hipFree(b->d_tiled);
+  if (b->d_smaj) (void)hipFree(b->d_smaj);
   if (b->d_lut) (void)hipFree(b->d_lut);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -638,12 +660,19 @@ static void fbm_open(const uint8_t *bytes, int64_t n, int64_t m, int64_t ld, con
       // values like 0.07 are not exactly k * 0.01 in binary: the decoded value must reproduce the table entry to
       // a few units in the last place of the table's range
       const double kr = std::round((code256[c] - off) / step);
-      if (kr < -127 || kr > 127 || std::fabs(off + step * kr - code256[c]) > 4e-16 * (std::fabs(vmax) + std::fabs(vmin) + step))
+      // 16 units in the last place of the table's range: off + step * kr carries three roundings and the table was
+      // written by other arithmetic (i * 0.01, seq(0, 2, by = 0.01), a decimal parser ...) — one ulp of slack (round 3)
+      // sent such tables to the slow generic image for nothing; an entry really off the grid misses by ~step
+      if (kr < -127 || kr > 127 ||
+          std::fabs(off + step * kr - code256[c]) > 16 * 2.220446049250313e-16 * (std::fabs(vmax) + std::fabs(vmin) + step))
         ok = false;
       lut[c] = (uint8_t)(int8_t)kr;
     }
     if (!ok) {
       // any other table: the FBM's own bytes + the table, served by the fp64 look-up kernels only
+      if (getenv("BSN_VERBOSE"))
+        std::fprintf(stderr, "[bsn] code256 is neither calls nor a regular grid of <= 255 steps: generic look-up image "
+                             "(colstats / prodVec / cprodVec only)\n");
       for (int c = 0; c < 256; c++) lut[c] = (uint8_t)c;
       image_alloc(b.get(), n, m, 8);
       b->generic = true;
@@ -753,6 +782,14 @@ int bsn_bed_streaming_kernels(bsn_bed *bed, char *buf, int64_t len) {
   });
 }
 
+int bsn_bed_sample_major(bsn_bed *bed, int *built) {
+  return guarded([&] {
+    BSN_HIP(hipSetDevice(bed->device));
+    const bool ok = image_smaj(bed);
+    if (built) *built = ok ? 1 : 0;
+  });
+}
+
 int bsn_bed_release_workspace(bsn_bed *bed) {
   return guarded([&] {
     BSN_HIP(hipSetDevice(bed->device));
@@ -764,6 +801,11 @@ int bsn_bed_release_workspace(bsn_bed *bed) {
       bed->d_tiled = nullptr;
     }
     bed->tiled_tried = false;
+    if (bed->d_smaj) {  // likewise the sample-major copy
+      BSN_HIP(hipFree(bed->d_smaj));
+      bed->d_smaj = nullptr;
+    }
+    bed->smaj_tried = false;
     dev_cache_flush();
   });
 }

@@ -196,6 +196,18 @@ struct bsn_bed {
   // 100 KB apart.  Built on demand when the device has the room, freed with the handle.
   uint8_t *d_tiled = nullptr;
   bool tiled_tried = false;
+  // Second copy of a 2-bit image in SAMPLE-MAJOR order (image.hip, image_smaj; round 4): the variants are the contiguous
+  // index — four per byte, same device coding, variant 4 k + e in bits 2 e — and the copy is laid out CHUNK-MAJOR: the
+  // 128 bytes "variants 512 ch .. 512 ch + 511 of sample i" sit at (ch * rows_smaj + i) * 128, rows_smaj = n rounded up
+  // to 256 (pad samples are code 0), pitch_smaj / 128 chunks (m + 512 rounded up to 1024 variants; zeros past variant m).
+  // On it the product A~ X contracts over the contiguous index, like the crossproduct does on the variant-major image:
+  // k_prodT is k_cprod's shape (no 4 x 4 byte transposes, 16 instead of 128 accumulator registers, four waves per SIMD
+  // instead of two), and the 512 samples x 128 B a workgroup reads per chunk are one contiguous 64-KB run — DESIGN.md
+  // 3.3b.  Built once per handle by a solve on the two-block kernels when the device has the room (image + 24 GB),
+  // freed with the handle / bsn_bed_release_workspace.  BSN_NO_SMAJ=1 forbids it.
+  uint8_t *d_smaj = nullptr;
+  int64_t pitch_smaj = 0, rows_smaj = 0;
+  bool smaj_tried = false;
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream_up = nullptr;   // second stream (created on first use): uploads beside the kernels of `stream`
@@ -226,6 +238,7 @@ void bed_free(bsn_bed *b);  // api.hip: everything a handle owns
 // a new handle holding the sub-matrix [ind_row, ind_col] (rows in list order, repeats allowed), same coding
 bsn_bed *image_gather(bsn_bed *src, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m);
 bool image_tile(bsn_bed *b);  // true when the streaming-layout copy exists (builds it if memory allows)
+bool image_smaj(bsn_bed *b);  // true when the sample-major copy exists (builds it if memory allows)
 void image_from_host(bsn_bed *b, const uint8_t *payload, int64_t n_byte_src);
 void image_from_file(bsn_bed *b, int fd, int64_t offset, int64_t n_byte_src);
 // FBM bytes -> device image through a 256-entry byte look-up (lut[byte] = device code 0..3 for a 2-bit

@@ -108,6 +108,83 @@ bool image_tile(bsn_bed *b) {
   return true;
 }
 
+// ---- sample-major copy (bsn_internal.hpp) ------------------------------------------------------------------
+// One workgroup transposes 512 variants x 256 samples (2-bit elements): the 512 x 64 B of the variant-major tile go
+// to LDS; thread (sq = t & 63, vq = t >> 6) reads the 64 bytes "4 samples 4 sq .. 4 sq + 3 of variants 64 vq .. + 63"
+// and spreads their 2-bit fields over four 16-byte rows (one per sample, 64 variants each); the 256 x 128 B of the
+// sample-major tile leave through LDS again so that every global store instruction writes whole 128-B lines — and, the
+// copy being chunk-major, the whole tile is one contiguous 32-KB run.  Variants past m are written as zeros.  One-off,
+// about one read + one write pass.
+__global__ __launch_bounds__(512) void k_smaj_build(const uint8_t *__restrict__ img, int64_t pitch, int64_t m,
+                                                    uint8_t *__restrict__ out, int64_t pitch_t, int64_t rows_t) {
+  __shared__ uint32_t sin[512 * 17];   // 512 variant rows of 64 B, row pitch 68 B
+  __shared__ uint4 sout[256 * 9];      // 256 sample rows of 128 B, row pitch 144 B; row of sample 4 sq + e at e * 64 + sq
+  const int t = threadIdx.x;
+  const int64_t s0 = (int64_t)blockIdx.x * 256;
+  const int64_t v0 = ((int64_t)blockIdx.y + (int64_t)blockIdx.z * 65535) * 512;
+  if (v0 / 4 >= pitch_t) return;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int idx = t + 512 * i, row = idx >> 2, seg = idx & 3;
+    const int64_t j = v0 + row;
+    uint4 v = {0, 0, 0, 0};
+    if (j < m) v = *(const uint4 *)(img + j * pitch + (s0 >> 2) + seg * 16);
+    uint32_t *d = sin + row * 17 + seg * 4;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+  const int sq = t & 63, vq = t >> 6;
+  uint32_t o[4][4];
+#pragma unroll
+  for (int e = 0; e < 4; e++)
+#pragma unroll
+    for (int w = 0; w < 4; w++) o[e][w] = 0;
+  const uint8_t *sb = (const uint8_t *)sin;
+#pragma unroll
+  for (int i = 0; i < 64; i++) {
+    const uint32_t b = sb[(vq * 64 + i) * 68 + sq];
+#pragma unroll
+    for (int e = 0; e < 4; e++) o[e][i >> 4] |= ((b >> (2 * e)) & 3u) << (2 * (i & 15));
+  }
+#pragma unroll
+  for (int e = 0; e < 4; e++) sout[(e * 64 + sq) * 9 + vq] = uint4{o[e][0], o[e][1], o[e][2], o[e][3]};
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int idx = t + 512 * i, row = idx >> 3, seg = idx & 7;   // row = sample of the tile
+    const int64_t sidx = s0 + row;
+    // chunk-major: the 128 B "512 variants v0 .. of sample sidx" at ((v0 / 512) * rows_t + sidx) * 128
+    if (sidx < rows_t) *(uint4 *)(out + ((v0 >> 9) * rows_t + sidx) * 128 + seg * 16) = sout[((row & 3) * 64 + (row >> 2)) * 9 + seg];
+  }
+}
+
+bool image_smaj(bsn_bed *b) {
+  if (b->d_smaj) return true;
+  if (b->smaj_tried || b->bits != 2 || getenv("BSN_NO_SMAJ")) return false;
+  b->smaj_tried = true;
+  BSN_HIP(hipSetDevice(b->device));
+  const int64_t pitch_t = round_up((b->m + 3) / 4 + 128, 256), rows_t = round_up(b->n, 256);
+  if (rows_t / 4 > b->pitch) return false;   // (never: pitch = ceil(n / 4) rounded up to 256 B)
+  const size_t bytes = (size_t)rows_t * (size_t)pitch_t;
+  // leave room for the workspace of a solve and for the other entry points' buffers
+  size_t free_b = 0, total_b = 0;
+  BSN_HIP(hipMemGetInfo(&free_b, &total_b));
+  if ((double)(free_b + dev_cache_held()) < (double)bytes + 24e9) return false;
+  if (hipMalloc((void **)&b->d_smaj, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    b->d_smaj = nullptr;
+    return false;
+  }
+  b->pitch_smaj = pitch_t;
+  b->rows_smaj = rows_t;
+  const int64_t nvb = pitch_t * 4 / 512;
+  const int64_t gy = nvb < 65535 ? nvb : 65535, gz = (nvb + 65534) / 65535;
+  hipLaunchKernelGGL(k_smaj_build, dim3((unsigned)(rows_t / 256), (unsigned)gy, (unsigned)gz), dim3(512), 0, b->stream,
+                     b->d_img, b->pitch, b->m, b->d_smaj, pitch_t, rows_t);
+  BSN_HIP(hipGetLastError());
+  return true;
+}
+
 // recode = 1: the rows hold .bed codes (uploads); 0: device codes already (FBM repack)
 static void finish_image(bsn_bed *b, int recode) {
   const int64_t gy = b->m < 65535 ? b->m : 65535, gz = (b->m + 65534) / 65535;
@@ -768,8 +845,9 @@ bsn_bed *image_gather(bsn_bed *src, const int64_t *ind_row, int64_t n, const int
   b->v_step = src->v_step;
   DevBuf<int32_t> d_rows, d_cols;
   BSN_HIP(hipStreamSynchronize(src->stream));   // whatever still writes the source image
-  BSN_HIP(hipMemcpy(d_rows.ensure((size_t)n), rows.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-  BSN_HIP(hipMemcpy(d_cols.ensure((size_t)m), cols.data(), (size_t)m * 4, hipMemcpyHostToDevice));
+  // the index lists go through the new handle's pinned staging buffers (no blocking copy from pageable memory)
+  copy_h2d(b.get(), d_rows.ensure((size_t)n), rows.data(), (size_t)n * 4);
+  copy_h2d(b.get(), d_cols.ensure((size_t)m), cols.data(), (size_t)m * 4);
   BSN_HIP(hipMemsetAsync(b->d_img + b->m * b->pitch, 0, (size_t)(kPadRows * b->pitch), b->stream));
   const int64_t gy = m < 65535 ? m : 65535, gz = (m + 65534) / 65535;
   hipLaunchKernelGGL(k_gather_image, dim3((unsigned)((b->pitch + 255) / 256), (unsigned)gy, (unsigned)gz), dim3(256), 0,

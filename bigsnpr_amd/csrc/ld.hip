@@ -681,27 +681,29 @@ __global__ void k_band_fill(const int32_t *__restrict__ stats, const int2 *__res
   }
 }
 
-// one wave per column j0: counts kept entries (ascending j), + diagonal
+// one wave per column j0 of [c0, c1): counts kept entries (ascending j), + diagonal; cnt is indexed from c0 and so
+// is the band (BandJob::band_at)
 __global__ void k_cor_count(const double *__restrict__ band, const int64_t *__restrict__ lo, int64_t W,
-                            int64_t m, int fill_diag, int32_t *__restrict__ cnt) {
+                            int64_t c0, int64_t c1, int fill_diag, int32_t *__restrict__ cnt) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t j0 = (int64_t)blockIdx.x * 4 + wave;
-  if (j0 >= m) return;
+  const int64_t j0 = c0 + (int64_t)blockIdx.x * 4 + wave;
+  if (j0 >= c1) return;
   const int64_t width = j0 - lo[j0];
   int c = 0;
   for (int64_t w = lane; w < width; w += 64) c += band[j0 * W + w] != 2.0;
   for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-  if (lane == 0) cnt[j0] = c + (fill_diag ? 1 : 0);
+  if (lane == 0) cnt[j0 - c0] = c + (fill_diag ? 1 : 0);
 }
 
+// p[j0 - c0] = first slot of column j0 in oi / ox (offsets within this block of columns)
 __global__ void k_cor_fill(const double *__restrict__ band, const int64_t *__restrict__ lo, int64_t W,
-                           int64_t m, int fill_diag, const int32_t *__restrict__ p,
+                           int64_t c0, int64_t c1, int fill_diag, const int64_t *__restrict__ p,
                            int32_t *__restrict__ oi, double *__restrict__ ox, int *__restrict__ nan_seen) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t j0 = (int64_t)blockIdx.x * 4 + wave;
-  if (j0 >= m) return;
+  const int64_t j0 = c0 + (int64_t)blockIdx.x * 4 + wave;
+  if (j0 >= c1) return;
   const int64_t width = j0 - lo[j0];
-  int64_t base = p[j0];
+  int64_t base = p[j0 - c0];
   // ascending j = descending w
   for (int64_t t0 = 0; t0 < width; t0 += 64) {
     const int64_t t = t0 + lane;  // t-th smallest j: w = width - 1 - t
@@ -725,17 +727,26 @@ __global__ void k_cor_fill(const double *__restrict__ band, const int64_t *__res
 
 // ld[j] = 1 + sum over pairs containing j of r2 (NaN skipped), deterministic order:
 // own row first (j' < j, descending j'), then later columns j0 > j in ascending order.
+// The band holds the columns [c0, c1) (BandJob::band_at); blocks come in ascending order, so a variant's sum is
+// started by the block that holds its own column and continued — same terms, same order, bit for bit — by the
+// blocks after it whose columns still reach it.  One thread per variant j in [jlo, c1), jlo = the first variant any
+// column of the block reaches.
 __global__ void k_ld_sum(const double *__restrict__ band, const int64_t *__restrict__ lo, int64_t W,
-                         int64_t m, double *__restrict__ ld) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= m) return;
-  double s = 1.0;
-  const int64_t width = j - lo[j];
-  for (int64_t w = 0; w < width; w++) {
-    const double v = band[j * W + w];
-    if (!isnan(v)) s += v;
+                         int64_t m, int64_t jlo, int64_t c0, int64_t c1, double *__restrict__ ld) {
+  const int64_t j = jlo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= c1) return;
+  double s;
+  if (j >= c0) {
+    s = 1.0;
+    const int64_t width = j - lo[j];
+    for (int64_t w = 0; w < width; w++) {
+      const double v = band[j * W + w];
+      if (!isnan(v)) s += v;
+    }
+  } else {
+    s = ld[j];
   }
-  for (int64_t j0 = j + 1; j0 < m && lo[j0] <= j; j0++) {
+  for (int64_t j0 = j + 1 > c0 ? j + 1 : c0; j0 < c1 && lo[j0] <= j; j0++) {
     const double v = band[j0 * W + (j0 - j - 1)];
     if (!isnan(v)) s += v;
   }
@@ -794,6 +805,14 @@ struct BandJob {
   bool use_mask = false;
   bool contig = false;    // every tile's variants lie within 2 GB of its first one, in ascending order
   int64_t npairs = 0, npairs_b = 0;
+  // The band is held for `chunk_cols` columns at a time (a multiple of 128; >= m: the whole band, one chunk).  The
+  // reference walks any window (src/corr.cpp:52-53); a dense m x W fp64 band of a long chromosome with ONE wide
+  // region does not fit HBM (1M variants x 40 000 = 320 GB), so snp_cor / snp_ld_scores process the band in blocks of
+  // columns that fit a budget (free device memory, or BSN_LD_BAND_BUDGET bytes), compacting each block to its CSC
+  // columns / adding its LD-score terms before the next — same kernels, same order of every sum.
+  int64_t chunk_cols = 0;
+  std::vector<int64_t> pair_start, pairb_start;   // first tile pair of every 64- / 128-column block of rows (+ end)
+  double *band_at(int64_t c0) const { return d_band.p - c0 * W; }   // indexed with absolute columns >= c0
 };
 
 // lo[j0] = first j with pos[j] >= pos[j0] - size (src/corr.cpp:52-53).  For clumping the
@@ -817,7 +836,7 @@ static void window_bounds(const double *pos, int64_t m, double size, bool two_si
 
 static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t n,
                        const int64_t *ind_col, int64_t m, const double *pos, double size,
-                       bool two_sided = false) {
+                       bool two_sided = false, bool allow_chunks = false, double out_bytes_per_entry = 0.0) {
   if (n <= 0 || m <= 0) fail("'ind.row' and 'ind.col' can't be empty.");
   refuse_generic(bed, "windowed LD (snp_cor / snp_ld_scores / snp_clumping)");
   BSN_HIP(hipSetDevice(bed->device));
@@ -829,17 +848,29 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
   for (int64_t j0 = 0; j0 < m; j0++) W = std::max(W, j0 - J.lo[(size_t)j0]);
   J.W = W;
   {
-    // the dense band (m x W fp64) lives in HBM next to the image: what the device has free, minus room for
-    // the statistics buffers and the caller's outputs
+    // the band (columns x W fp64) lives in HBM next to the image: the whole of it when it fits what the device has
+    // free (minus room for the statistics buffers and — snp_cor — the compacted result), else blocks of columns
     const double need = (double)m * (double)W * 8.0;
-    if (need > 32e9) {
+    double budget = 32e9;
+    if (need > budget || getenv("BSN_LD_BAND_BUDGET")) {
       size_t free_b = 0, total_b = 0;
       BSN_HIP(hipMemGetInfo(&free_b, &total_b));
       free_b += dev_cache_held();
-      if (need > (double)free_b - 4e9)
+      const double avail = (double)free_b - 4e9;
+      // a result that keeps every pair needs 12 bytes per band entry on top of the band itself
+      budget = allow_chunks ? std::max(1e9, avail * (out_bytes_per_entry > 0 ? 8.0 / (8.0 + out_bytes_per_entry) : 1.0)) : avail;
+      if (const char *e = getenv("BSN_LD_BAND_BUDGET")) budget = atof(e);
+      if (need > budget && !allow_chunks)
         fail("LD band of %lld x %lld (%.1f GB) does not fit the %.1f GB of free device memory; use a smaller "
              "window or call it per chromosome / per block of variants",
              (long long)m, (long long)W, need / 1e9, (double)free_b / 1e9);
+    }
+    J.chunk_cols = (m + TR - 1) / TR * TR;
+    if (need > budget) {
+      J.chunk_cols = std::max<int64_t>(TR, (int64_t)(budget / ((double)W * 8.0)) / TR * TR);
+      if ((double)J.chunk_cols * (double)W * 8.0 > budget * 1.0001 && !getenv("BSN_LD_BAND_BUDGET"))
+        fail("LD window of %lld variants: even 128 columns of the band (%.1f GB) do not fit the free device memory",
+             (long long)W, 128.0 * (double)W * 8.0 / 1e9);
     }
   }
   // columns (padded to the tile size with a valid column)
@@ -930,42 +961,57 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
   }
   // tile pairs of the band
   std::vector<int2> pairs;
+  J.pair_start.assign((size_t)mt + 1, 0);
   for (int64_t I = 0; I < mt; I++) {
+    J.pair_start[(size_t)I] = (int64_t)pairs.size();
     int64_t Jlo = J.lo[(size_t)(I * TB)] / TB;
     for (int64_t Jt = Jlo; Jt <= I; Jt++) pairs.push_back(int2{(int)I, (int)Jt});
   }
+  J.pair_start[(size_t)mt] = (int64_t)pairs.size();
   J.npairs = (int64_t)pairs.size();
   copy_h2d(bed, J.d_pairs.ensure(pairs.size()), pairs.data(), pairs.size() * sizeof(int2));
   {
     // the same band in blocks of 128 row variants x 32 column variants (k_pair_stats_b)
     std::vector<int2> pb;
+    J.pairb_start.clear();
     for (int64_t I = 0; I * TR < m; I++) {
+      J.pairb_start.push_back((int64_t)pb.size());
       const int64_t last = std::min<int64_t>(m, (I + 1) * TR) - 1;
       for (int64_t Jb = J.lo[(size_t)(I * TR)] / TC; Jb <= last / TC; Jb++) pb.push_back(int2{(int)I, (int)Jb});
     }
+    J.pairb_start.push_back((int64_t)pb.size());
     J.npairs_b = (int64_t)pb.size();
     copy_h2d(bed, J.d_pairs_b.ensure(pb.size()), pb.data(), pb.size() * sizeof(int2));
   }
   copy_h2d(bed, J.d_lo.ensure((size_t)m), J.lo.data(), (size_t)m * 8);
   BSN_HIP(hipStreamSynchronize(bed->stream));  // host vectors go out of scope
   // statistics in batches of tile pairs (bounded scratch)
-  J.d_band.ensure((size_t)m * (size_t)W);
+  J.d_band.ensure((size_t)std::min<int64_t>(J.chunk_cols, (m + TR - 1) / TR * TR) * (size_t)W);
 }
 
 // runs the statistics + band fill in batches; mode / aux as in pair_value
+// Columns [c0, c1) of the band (c0 a multiple of 128; the whole band by default) go to J.d_band, whose first column
+// is then c0.  `accumulate`: add to the statistics of the previous block instead of starting them.
 static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_v1, const double *d_v2,
-                     double nrows) {
+                     double nrows, int64_t c0 = 0, int64_t c1 = -1, bool accumulate = false) {
   bsn_bed *bed = J.bed;
+  if (c1 < 0 || c1 > J.m) c1 = J.m;
+  if (c0 % TR != 0 || c1 - c0 > J.chunk_cols) fail("internal: LD band block [%lld, %lld)", (long long)c0, (long long)c1);
   const int64_t batch = 4096;  // 4096 x 6 x 64 x 64 x 4 B = 403 MB of int32 statistics (two-stage paths only)
   const bool xy_only = J.complete || mode == 2;  // FBM clumping (mode 2) reads the cross product only (src/clumping.cpp:66-73)
+  // the tile pairs whose row variants (the j0 side) lie in the block: a contiguous run of both pair lists
+  const int64_t pA = J.pair_start[(size_t)(c0 / TB)], pB = J.pair_start[(size_t)((c1 + TB - 1) / TB)];
+  const int64_t qA = J.pairb_start[(size_t)(c0 / TR)], qB = J.pairb_start[(size_t)((c1 + TR - 1) / TR)];
   LdStats ls;
-  ls.tile_pairs = (double)J.npairs;
-  for (int64_t j0 = 0; j0 < J.m; j0++) ls.pairs += (double)(j0 - J.lo[(size_t)j0]);
+  if (accumulate) ls = g_ld_stats;
+  ls.tile_pairs += (double)(pB - pA);
+  for (int64_t j0 = c0; j0 < c1; j0++) ls.pairs += (double)(j0 - J.lo[(size_t)j0]);
   hipEvent_t e0, e1;
   BSN_HIP(hipEventCreate(&e0));
   BSN_HIP(hipEventCreate(&e1));
-  float ms_total = 0;
-  BandOut bo{J.m, J.W, J.d_lo.p, d_thr, d_v1, d_v2, nrows, J.d_band.p, mode};
+  float ms_total = accumulate ? (float)g_ld_stats.stats_ms : 0.f;
+  double *const band = J.band_at(c0);
+  BandOut bo{J.m, J.W, J.d_lo.p, d_thr, d_v1, d_v2, nrows, band, mode};
   if (bed->bits == 8) {
     if (mode == 3) fail("internal: the bed clumping formula does not apply to a byte image");
     const int64_t slice_bytes = 131072;  // samples per int32 accumulator slice
@@ -975,8 +1021,8 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
       // missing values among the selected samples: the six pairwise-complete sums (eight int8 products)
       const int64_t batch8 = 512;   // 512 x 8 x 64 x 64 x 8 B = 134 MB of int64 statistics
       J.d_stats64.ensure((size_t)std::min(batch8, J.npairs) * 8 * TB * TB);
-      for (int64_t p0 = 0; p0 < J.npairs; p0 += batch8) {
-        const int64_t np = std::min(batch8, J.npairs - p0);
+      for (int64_t p0 = pA; p0 < pB; p0 += batch8) {
+        const int64_t np = std::min(batch8, pB - p0);
         // enough workgroups to fill the chip; a split never crosses a 131 072-sample slice
         int64_t ks = std::max<int64_t>(nslice, std::min<int64_t>(std::max<int64_t>(1, 4096 / (np * 4)), bed->pitch / 256));
         int64_t kb = round_up((bed->pitch + ks - 1) / ks, 64);
@@ -989,7 +1035,7 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
         BSN_HIP(hipGetLastError());
         BSN_HIP(hipEventRecord(e1, bed->stream));
         hipLaunchKernelGGL(k_band_fill8na, dim3((unsigned)np), dim3(256), 0, bed->stream, J.d_stats64.p,
-                           J.d_pairs.p + p0, (int)np, J.m, J.d_lo.p, J.W, d_thr, mode, nrows, J.d_band.p);
+                           J.d_pairs.p + p0, (int)np, J.m, J.d_lo.p, J.W, d_thr, mode, nrows, band);
         BSN_HIP(hipGetLastError());
         BSN_HIP(hipEventSynchronize(e1));
         float ms = 0;
@@ -1005,8 +1051,8 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
       return;
     }
     J.d_stats.ensure((size_t)std::min(batch, J.npairs) * 6 * TB * TB);
-    for (int64_t p0 = 0; p0 < J.npairs; p0 += batch) {
-      const int64_t np = std::min(batch, J.npairs - p0);
+    for (int64_t p0 = pA; p0 < pB; p0 += batch) {
+      const int64_t np = std::min(batch, pB - p0);
       // K splits never straddle a slice: one slice -> any 64-byte-aligned split of the row; several ->
       // a power-of-two number of splits per 131 072-byte slice
       const int64_t sl = std::min<int64_t>(slice_bytes, bed->pitch);
@@ -1030,7 +1076,7 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
       BSN_HIP(hipGetLastError());
       BSN_HIP(hipEventRecord(e1, bed->stream));
       hipLaunchKernelGGL(k_band_fill8, dim3((unsigned)np), dim3(256), 0, bed->stream, J.d_stats.p, nslice,
-                         J.d_pairs.p + p0, (int)np, J.m, J.d_lo.p, J.W, d_thr, mode, d_v1, d_v2, nrows, J.d_band.p,
+                         J.d_pairs.p + p0, (int)np, J.m, J.d_lo.p, J.W, d_thr, mode, d_v1, d_v2, nrows, band,
                          J.d_cx.p, J.d_cxx.p, bed->v_step, bed->v_off, J.complete ? (const double *)nullptr : J.d_nna.p);
       BSN_HIP(hipGetLastError());
       BSN_HIP(hipEventSynchronize(e1));
@@ -1048,8 +1094,8 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
   }
   if (!xy_only && J.contig && J.use_mask && J.npairs_b >= 1024 && !getenv("BSN_LD_NO_SHARED_DECODE")) {
     // enough blocks to fill the chip without a K split: the kernel that shares the column operand's decode
-    for (int64_t p0 = 0; p0 < J.npairs_b; p0 += batch) {
-      const int64_t np = std::min(batch, J.npairs_b - p0);
+    for (int64_t p0 = qA; p0 < qB; p0 += batch) {
+      const int64_t np = std::min(batch, qB - p0);
       BSN_HIP(hipEventRecord(e0, bed->stream));
       hipLaunchKernelGGL(k_pair_stats_b, dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
                          J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, bo);
@@ -1062,15 +1108,15 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
       ls.launches += 1;
     }
     ls.kernel = 4;
-    ls.tile_pairs = (double)J.npairs_b;   // blocks of 128 x 32 = the area of a 64 x 64 tile pair
+    ls.tile_pairs += (double)(qB - qA) - (double)(pB - pA);   // blocks of 128 x 32 = the area of a 64 x 64 tile pair
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     ls.stats_ms = ms_total;
     g_ld_stats = ls;
     return;
   }
-  for (int64_t p0 = 0; p0 < J.npairs; p0 += batch) {
-    const int64_t np = std::min(batch, J.npairs - p0);
+  for (int64_t p0 = pA; p0 < pB; p0 += batch) {
+    const int64_t np = std::min(batch, pB - p0);
     // K split: enough workgroups to fill the chip when there are few tile pairs
     int ksplit = (int)std::min<int64_t>(std::max<int64_t>(1, 2048 / np), bed->pitch / 256);
     if (ksplit < 1) ksplit = 1;
@@ -1112,7 +1158,7 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
     if (!fused) {
       hipLaunchKernelGGL(k_band_fill, dim3((unsigned)np), dim3(256), 0, bed->stream, J.d_stats.p,
                          J.d_pairs.p + p0, (int)np, J.m, J.d_lo.p, J.W, d_thr, mode, d_v1, d_v2, nrows,
-                         J.d_band.p, J.complete ? J.d_cx.p : (const double *)nullptr,
+                         band, J.complete ? J.d_cx.p : (const double *)nullptr,
                          J.complete ? J.d_cxx.p : (const double *)nullptr);
       BSN_HIP(hipGetLastError());
     }
@@ -1162,8 +1208,13 @@ static RowView row_view(bsn_bed *bed, const int64_t *ind_row, int64_t n, const i
 struct bsn_cor {
   std::shared_ptr<bsn_bed> owned;   // declared first: the buffers below are released before the image's stream goes
   BandJob job;
-  DevBuf<int32_t> d_p, d_i;
-  DevBuf<double> d_x;
+  // the compacted columns (@i, @x), one piece per block of band columns (one piece when the whole band fits)
+  struct Piece {
+    DevBuf<int32_t> d_i;
+    DevBuf<double> d_x;
+    int64_t nnz = 0;
+  };
+  std::vector<std::unique_ptr<Piece>> pieces;
   int64_t nnz = 0;
   int has_nan = 0;   // an NaN among the stored correlations (a variant without variation, R/corr.R:53-54)
 };
@@ -1180,34 +1231,50 @@ int bsn_cormat(bsn_bed *bed_in, const int64_t *ind_row_in, int64_t n, const int6
     bsn_bed *bed = rv.bed;
     const int64_t *ind_row = rv.ind_row, *ind_col = rv.ind_col;
     C->owned = rv.owned;
-    band_stats(J, bed, ind_row, n, ind_col, m, pos, size);
+    band_stats(J, bed, ind_row, n, ind_col, m, pos, size, false, true, fill_diag ? 12.0 : 12.0);
     copy_h2d(bed, J.d_thr.ensure((size_t)n), thr, (size_t)n * 8);
-    band_run(J, 0, J.d_thr.p, nullptr, nullptr, (double)n);
     DevBuf<int32_t> d_cnt;
-    d_cnt.ensure((size_t)m);
-    hipLaunchKernelGGL(k_cor_count, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, bed->stream, J.d_band.p,
-                       J.d_lo.p, J.W, m, fill_diag, d_cnt.p);
-    BSN_HIP(hipGetLastError());
-    std::vector<int32_t> cnt((size_t)m);
-    copy_d2h(bed, cnt.data(), d_cnt.p, (size_t)m * 4);
-    BSN_HIP(hipStreamSynchronize(bed->stream));
-    int64_t nnz = 0;
-    p_out[0] = 0;
-    for (int64_t j = 0; j < m; j++) {
-      nnz += cnt[(size_t)j];
-      if (nnz > 0x7fffffffLL) fail("more than 2^31 - 1 non-zero correlations");
-      p_out[j + 1] = (int32_t)nnz;
-    }
-    C->nnz = nnz;
-    copy_h2d(bed, C->d_p.ensure((size_t)m + 1), p_out, (size_t)(m + 1) * 4);
-    C->d_i.ensure((size_t)std::max<int64_t>(nnz, 1));
-    C->d_x.ensure((size_t)std::max<int64_t>(nnz, 1));
+    DevBuf<int64_t> d_off;
     DevBuf<int> d_nan;
     BSN_HIP(hipMemsetAsync(d_nan.ensure(1), 0, sizeof(int), bed->stream));
-    hipLaunchKernelGGL(k_cor_fill, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, bed->stream, J.d_band.p,
-                       J.d_lo.p, J.W, m, fill_diag, C->d_p.p, C->d_i.p, C->d_x.p, d_nan.p);
-    BSN_HIP(hipGetLastError());
-    BSN_HIP(hipMemcpyAsync(&C->has_nan, d_nan.p, sizeof(int), hipMemcpyDeviceToHost, bed->stream));
+    std::vector<int32_t> cnt;
+    std::vector<int64_t> off;
+    int64_t nnz = 0;
+    p_out[0] = 0;
+    // blocks of band columns in ascending order (one block when the band fits): statistics -> r -> count -> compact
+    for (int64_t c0 = 0; c0 < m; c0 += J.chunk_cols) {
+      const int64_t c1 = std::min(m, c0 + J.chunk_cols), mc = c1 - c0;
+      band_run(J, 0, J.d_thr.p, nullptr, nullptr, (double)n, c0, c1, c0 > 0);
+      hipLaunchKernelGGL(k_cor_count, dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, bed->stream, J.band_at(c0),
+                         J.d_lo.p, J.W, c0, c1, fill_diag, d_cnt.ensure((size_t)mc));
+      BSN_HIP(hipGetLastError());
+      cnt.resize((size_t)mc);
+      copy_d2h(bed, cnt.data(), d_cnt.p, (size_t)mc * 4);
+      BSN_HIP(hipStreamSynchronize(bed->stream));
+      off.resize((size_t)mc);
+      int64_t nz = 0;
+      for (int64_t j = 0; j < mc; j++) {
+        off[(size_t)j] = nz;
+        nz += cnt[(size_t)j];
+        if (nnz + nz > 0x7fffffffLL) fail("more than 2^31 - 1 non-zero correlations");
+        p_out[c0 + j + 1] = (int32_t)(nnz + nz);
+      }
+      std::unique_ptr<bsn_cor::Piece> P(new bsn_cor::Piece());
+      P->nnz = nz;
+      P->d_i.ensure((size_t)std::max<int64_t>(nz, 1));
+      P->d_x.ensure((size_t)std::max<int64_t>(nz, 1));
+      copy_h2d(bed, d_off.ensure((size_t)mc), off.data(), (size_t)mc * 8);
+      hipLaunchKernelGGL(k_cor_fill, dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, bed->stream, J.band_at(c0),
+                         J.d_lo.p, J.W, c0, c1, fill_diag, d_off.p, P->d_i.p, P->d_x.p, d_nan.p);
+      BSN_HIP(hipGetLastError());
+      BSN_HIP(hipStreamSynchronize(bed->stream));   // `off` is reused by the next block
+      C->pieces.push_back(std::move(P));
+      nnz += nz;
+    }
+    C->nnz = nnz;
+    // (through the handle's pinned staging buffer: a copy into pageable memory leaves every later stream
+    // synchronisation of the process ~4 ms late, bsn_internal.hpp)
+    copy_d2h(bed, &C->has_nan, d_nan.p, sizeof(int));
     BSN_HIP(hipStreamSynchronize(bed->stream));
     J.d_band.release();
     J.d_stats.release();
@@ -1229,9 +1296,13 @@ int bsn_ld_last_stats(double *out) {
 int bsn_cormat_fetch(bsn_cor *c, int32_t *i_out, double *x_out) {
   return guarded([&] {
     BSN_HIP(hipSetDevice(c->job.bed->device));
-    if (c->nnz > 0) {
-      copy_d2h(c->job.bed, i_out, c->d_i.p, (size_t)c->nnz * 4);
-      copy_d2h(c->job.bed, x_out, c->d_x.p, (size_t)c->nnz * 8);
+    int64_t at = 0;
+    for (const auto &P : c->pieces) {
+      if (P->nnz > 0) {
+        copy_d2h(c->job.bed, i_out + at, P->d_i.p, (size_t)P->nnz * 4);
+        copy_d2h(c->job.bed, x_out + at, P->d_x.p, (size_t)P->nnz * 8);
+      }
+      at += P->nnz;
     }
   });
 }
@@ -1251,13 +1322,18 @@ int bsn_ld_scores(bsn_bed *bed_in, const int64_t *ind_row_in, int64_t n, const i
     bsn_bed *bed = rv.bed;
     const int64_t *ind_row = rv.ind_row, *ind_col = rv.ind_col;
     BandJob J;
-    band_stats(J, bed, ind_row, n, ind_col, m, pos, size);
-    band_run(J, 1, nullptr, nullptr, nullptr, (double)n);
+    band_stats(J, bed, ind_row, n, ind_col, m, pos, size, false, true);
     DevBuf<double> d_ld;
     d_ld.ensure((size_t)m);
-    hipLaunchKernelGGL(k_ld_sum, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, bed->stream, J.d_band.p,
-                       J.d_lo.p, J.W, m, d_ld.p);
-    BSN_HIP(hipGetLastError());
+    // blocks of band columns in ascending order (one block when the band fits): r2, then every variant the block's
+    // columns reach takes its terms — the running sums go through the same additions as over the whole band
+    for (int64_t c0 = 0; c0 < m; c0 += J.chunk_cols) {
+      const int64_t c1 = std::min(m, c0 + J.chunk_cols), jlo = J.lo[(size_t)c0];
+      band_run(J, 1, nullptr, nullptr, nullptr, (double)n, c0, c1, c0 > 0);
+      hipLaunchKernelGGL(k_ld_sum, dim3((unsigned)((c1 - jlo + 255) / 256)), dim3(256), 0, bed->stream, J.band_at(c0),
+                         J.d_lo.p, J.W, m, jlo, c0, c1, d_ld.p);
+      BSN_HIP(hipGetLastError());
+    }
     copy_d2h(bed, out, d_ld.p, (size_t)m * 8);
     BSN_HIP(hipStreamSynchronize(bed->stream));
   });

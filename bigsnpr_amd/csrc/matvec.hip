@@ -1036,6 +1036,183 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_prodT: Y = A~ X on the SAMPLE-MAJOR copy of the image (bsn_bed::d_smaj): the contraction index — the variants —
+// is the contiguous one there, so the kernel is k_cprod with the roles of samples and variants exchanged: one wave
+// owns 32 samples (two 16-row MFMA tiles) and walks its slab of variants 512 at a time, the 16 waves of a workgroup
+// share the digit panel of the chunk through LDS (double-buffered).  Against k_prod on the variant-major image: no
+// 4 x 4 byte transposes (11 instead of 13.3 VALU instructions per 4 MFMAs), 16 instead of 128 accumulator registers,
+// four waves per SIMD instead of two.  Same integer sums -> bit-identical results.
+//   A operand: lane l -> sample row (l & 15), k-group (l >> 4): 16 variants of that sample (one decoded dword)
+//   B operand: lane l -> digit column (l & 15), the same 16 variants: w-digits for the code plane, (c w - 3 w)-digits
+//              for the missing-value plane (k_quant mode 1 with the cprod byte order), BOTH into one accumulator
+//   D        : lane l -> digit column (l & 15), sample rows 4 * (l >> 4) + r
+// The variants are split into gridDim.y slabs of `cps` chunks (int32 partial sums per slab, added by k_prod_final in
+// exact int64 like k_prod's): 782 workgroups of 512 samples alone would fill 3.05 rounds of 256 CUs.
+// kbyte0: byte of the operator's first variant in a sample row (col0 / 4, a multiple of 16).
+template <int NB, bool HASQ, int TILES = 2, int WAVES = 16, int TAG = 0, int SGB = 3>
+__global__ __launch_bounds__(64 * WAVES) void k_prodT(const uint8_t *__restrict__ simg, int64_t rows_t, int64_t chunk0,
+                                                      int nchunks, int cps,
+                                                      const int8_t *__restrict__ wq, int32_t *__restrict__ acc_out,
+                                                      int64_t n_pad, uint32_t lutQ) {
+  constexpr int KC = 512, NCOL = 16 * NB, LD = KC / 256;
+  constexpr int XS = KC / 16 * 2 * NCOL;   // uint4 entries of one chunk's digit panel (two planes)
+  constexpr int NT = 64 * WAVES, NX = XS / NT;
+  static_assert(XS % NT == 0 && NX >= 1 && NX <= 4, "digit staging");
+  __shared__ uint4 xs[2][XS];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int c = lane & 15, g = lane >> 4;
+  const int64_t wg_base = (int64_t)blockIdx.x * (WAVES * 16 * TILES);
+  const int64_t row_base = wg_base + wave * (16 * TILES);
+  uint32_t voff[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; t++) {
+    int64_t i = row_base + t * 16 + c;
+    if (i > rows_t - 1) i = rows_t - 1;
+    voff[t] = (uint32_t)((i - wg_base) * (KC / 4) + g * 16);
+  }
+  const int ch_begin = (int)blockIdx.y * cps;
+  int ch_end = ch_begin + cps;
+  if (ch_end > nchunks) ch_end = nchunks;
+  if (ch_begin >= ch_end) return;   // (never: the launch geometry gives every slab at least one chunk)
+  // chunk ch of the slab: the workgroup's 512 sample rows x 128 B are ONE contiguous 64-KB run of the copy
+  const int64_t chunk_stride = rows_t * (KC / 4);
+  const uint8_t *const base0 = simg + ((chunk0 + ch_begin) * rows_t + wg_base) * (KC / 4);
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  auto gload = [&](const int t, const int ch, const int off) -> uint4 {
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(base0 + (int64_t)ch * chunk_stride), 0, 0x7fffffff, 0x00020000);
+    const v4u r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[t], off, 0);
+    return uint4{r.x, r.y, r.z, r.w};
+  };
+  const int nch = ch_end - ch_begin;
+  const uint4 *xq4 = (const uint4 *)wq + (int64_t)ch_begin * XS;
+
+  v4i acc[TILES][NB];
+#pragma unroll
+  for (int t = 0; t < TILES; t++)
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) acc[t][nb] = v4i{0, 0, 0, 0};
+  uint4 ga[2][TILES][LD];
+  uint4 xr0 = {0, 0, 0, 0}, xr1 = {0, 0, 0, 0}, xr2 = {0, 0, 0, 0}, xr3 = {0, 0, 0, 0};   // (scalars: an array captured by the lambda below ends up in scratch)
+#pragma unroll
+  for (int t = 0; t < TILES; t++)
+#pragma unroll
+    for (int it = 0; it < LD; it++) ga[0][t][it] = gload(t, 0, it * 64);
+#pragma unroll
+  for (int x = 0; x < NX; x++) xs[0][tid + x * NT] = xq4[tid + x * NT];
+#pragma unroll
+  for (int t = 0; t < TILES; t++)
+#pragma unroll
+    for (int it = 0; it < LD; it++) ga[1][t][it] = gload(t, nch > 1 ? 1 : 0, it * 64);
+  __syncthreads();
+
+  auto chunk = [&](auto SETC, const int ch) {
+    constexpr int SET = decltype(SETC)::value;
+    // branch-free prefetch as in k_cprod: past the end of the slab its last chunk is loaded again
+    const int ch1 = ch + 1 < nch ? ch + 1 : nch - 1;
+    const int ch2 = ch + 2 < nch ? ch + 2 : nch - 1;
+    xr0 = xq4[(int64_t)ch1 * XS + tid];
+    if constexpr (NX > 1) xr1 = xq4[(int64_t)ch1 * XS + tid + NT];
+    if constexpr (NX > 2) xr2 = xq4[(int64_t)ch1 * XS + tid + 2 * NT];
+    if constexpr (NX > 3) xr3 = xq4[(int64_t)ch1 * XS + tid + 3 * NT];
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SGB & 2) __builtin_amdgcn_s_setprio(2);
+    constexpr int NP = HASQ ? 2 : 1;
+    uint4 bv[NP][NB], bn[NP][NB];
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) bn[p][nb] = bv[p][nb] = xs[SET][((g * 4) * 2 + p) * NCOL + nb * 16 + c];
+#pragma unroll
+    for (int it = 0; it < LD; it++) {
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        if (it * 4 + d + 1 < LD * 4) {
+          const int itn = (it * 4 + d + 1) / 4, dn = (it * 4 + d + 1) % 4;
+#pragma unroll
+          for (int p = 0; p < NP; p++)
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) bn[p][nb] = xs[SET][((itn * 16 + g * 4 + dn) * 2 + p) * NCOL + nb * 16 + c];
+        }
+#pragma unroll
+        for (int t = 0; t < TILES; t++) {
+          const uint32_t w = d == 0 ? ga[SET][t][it].x : d == 1 ? ga[SET][t][it].y
+                             : d == 2 ? ga[SET][t][it].z : ga[SET][t][it].w;
+          const uint32_t s0 = w & 0x03030303u, s1 = (w >> 2) & 0x03030303u, s2 = (w >> 4) & 0x03030303u,
+                         s3 = (w >> 6) & 0x03030303u;
+          const v4i a0 = {(int)s0, (int)s1, (int)s2, (int)s3};
+#pragma unroll
+          for (int nb = 0; nb < NB; nb++) {
+            const v4i b = {(int)bv[0][nb].x, (int)bv[0][nb].y, (int)bv[0][nb].z, (int)bv[0][nb].w};
+            acc[t][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b, acc[t][nb], 0, 0, 0);
+          }
+          if constexpr (HASQ) {
+            const v4i a1 = {(int)lut4(lutQ, s0), (int)lut4(lutQ, s1), (int)lut4(lutQ, s2), (int)lut4(lutQ, s3)};
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) {
+              const v4i b = {(int)bv[1][nb].x, (int)bv[1][nb].y, (int)bv[1][nb].z, (int)bv[1][nb].w};
+              acc[t][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b, acc[t][nb], 0, 0, 0);
+            }
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+#pragma unroll
+          for (int nb = 0; nb < NB; nb++) bv[p][nb] = bn[p][nb];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TILES; t++)
+#pragma unroll
+      for (int it = 0; it < LD; it++) ga[SET][t][it] = gload(t, ch2, it * 64);
+    if constexpr (SGB & 1) {
+      // the explicit MFMA / decode pipeline of k_cprod (0x008 MFMA, 0x002 VALU, 0x100 DS read, 0x020 VMEM read)
+      constexpr int VSTEP = TILES * (7 + (HASQ ? 4 : 0)), MSTEP = TILES * NP * NB;
+      __builtin_amdgcn_sched_group_barrier(0x100, NP * NB, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+      auto slots = [&](auto self, auto IC) {
+        constexpr int i = decltype(IC)::value;
+        if constexpr (i < MSTEP) {
+          constexpr int nv = VSTEP * (i + 1) / MSTEP - VSTEP * i / MSTEP;
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if constexpr (nv > 0) __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);
+          self(self, std::integral_constant<int, i + 1>{});
+        }
+      };
+#pragma unroll
+      for (int stp = 0; stp < LD * 4; stp++) {
+        __builtin_amdgcn_sched_group_barrier(0x100, NP * NB, 0);
+        slots(slots, std::integral_constant<int, 0>{});
+      }
+      __builtin_amdgcn_sched_group_barrier(0x020, TILES * LD, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SGB & 2) __builtin_amdgcn_s_setprio(0);
+    xs[SET ^ 1][tid] = xr0;
+    if constexpr (NX > 1) xs[SET ^ 1][tid + NT] = xr1;
+    if constexpr (NX > 2) xs[SET ^ 1][tid + 2 * NT] = xr2;
+    if constexpr (NX > 3) xs[SET ^ 1][tid + 3 * NT] = xr3;
+    __syncthreads();
+  };
+  for (int ch = 0; ch < nch; ch += 2) {
+    chunk(std::integral_constant<int, 0>{}, ch);
+    if (ch + 1 < nch) chunk(std::integral_constant<int, 1>{}, ch + 1);
+  }
+  // raw accumulators: acc_out[slab][sample][NCOL] (k_prod's layout, read by k_prod_final)
+#pragma unroll
+  for (int t = 0; t < TILES; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int64_t i = row_base + t * 16 + g * 4 + r;
+      if (i < n_pad) {
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+          acc_out[((int64_t)blockIdx.y * n_pad + i) * NCOL + nb * 16 + c] = acc[t][nb][r];
+      }
+    }
+}
+
 // y[i, v] = (sum_ky value(i) - C_v) / qs_v, gathered through rows[].  One thread per output
 // row reads its NCOL contiguous int32 per K-chunk (16 B loads, consecutive rows adjacent).
 template <int NCOL>
@@ -1969,12 +2146,44 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
   // k_prod addresses a 64-variant step with 32-bit offsets from its first row
   if (b->pitch >= ((int64_t)1 << 24)) fail("more than 6.7e7 samples are not supported by the product kernel");
   const int64_t npad = n_padded(b);
-  const int64_t m_pad = round_up(op->m, 64);
+  // Two column blocks over a contiguous range of variants that starts on a 512-variant chunk, and the handle has its
+  // sample-major copy: the product runs as k_prodT (k_cprod's shape, contraction over the contiguous index).
+  const bool smaj = b->bits == 2 && b->d_smaj != nullptr && op->cols_contig && (op->col0 & 511) == 0 && mode == 1 &&
+                    lutP == kLutRaw && lutQ == kLutNA && pick_nb((nvec < vmax ? nvec : vmax) * S) == 2 &&
+                    !getenv("BSN_NO_SMAJ");
+  const int64_t m_pad = round_up(op->m, smaj ? 512 : 64);
   VecMeta *meta = meta_buffer(op);
   // K split so that the grid has a few thousand workgroups
   int64_t wgx = b->bits == 8 ? npad / 256 : npad / 1024;  // workgroups along the samples
   int ky = (int)((4096 + wgx - 1) / wgx);
   int64_t steps = m_pad / 64;
+  int smaj_cps = 0;   // k_prodT: chunks of 512 variants per slab
+  if (smaj) {
+    // one 1024-thread workgroup per CU is resident: among 6 .. 24 slabs the split whose grid fills whole rounds of
+    // the chip best (782 x 17 workgroups = 51.9 rounds of 256 at 400 000 samples); a slab stays below 2.5e6 variants
+    static const int ncu = [] {
+      hipDeviceProp_t pr;
+      int dev = 0;
+      return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+                 ? pr.multiProcessorCount : 256;
+    }();
+    wgx = (b->n + 511) / 512;
+    const int64_t nchunks = m_pad / 512;
+    int best = 1;
+    double best_fill = 0.0;
+    for (int c = 1; c <= 24 && c <= nchunks; c++) {
+      if (c < 6 && c < nchunks && nchunks >= 6) continue;
+      const int64_t W = wgx * c;
+      const double fill = (double)W / ((double)ncu * (double)((W + ncu - 1) / ncu));
+      if (fill > best_fill + 1e-9) best_fill = fill, best = c;
+    }
+    ky = best;
+    if (const char *e = getenv("BSN_KY")) ky = std::max(1, std::min<int>(atoi(e), (int)nchunks));
+    const int64_t ky_min2 = (m_pad + 2499999) / 2500000;
+    if (ky < ky_min2) ky = (int)ky_min2;
+    smaj_cps = (int)((nchunks + ky - 1) / ky);
+    ky = (int)((nchunks + smaj_cps - 1) / smaj_cps);
+  }
   if (ky > steps) ky = (int)steps;
   if (ky > 64) ky = 64;
   if (ky < 1) ky = 1;
@@ -2000,15 +2209,17 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
     ky = best;
   }
 #ifdef BSN_ABLATION
-  if (const char *e = getenv("BSN_KY")) ky = atoi(e);  // grid-shape sweep (correct results)
-  if (ky > steps) ky = (int)steps;
-  if (ky < 1) ky = 1;
+  if (!smaj) {
+    if (const char *e = getenv("BSN_KY")) ky = atoi(e);  // grid-shape sweep (correct results)
+    if (ky > steps) ky = (int)steps;
+    if (ky < 1) ky = 1;
+  }
 #endif
   // int32 accumulators: a slab adds at most 768 per variant (planes up to 4, digits up to 128)
   const int64_t ky_min = (m_pad + 2499999) / 2500000;
-  if (ky < ky_min) ky = (int)ky_min;
+  if (ky < ky_min && !smaj) ky = (int)ky_min;
   int64_t mc = round_up((steps + ky - 1) / ky, 1) * 64;
-  ky = (int)((m_pad + mc - 1) / mc);
+  if (!smaj) ky = (int)((m_pad + mc - 1) / mc);
   // complete variants: the missing-value plane is all zero, skip its look-ups and MFMAs
   const bool has_q = lutQ != 0u && !(op->no_na && lutQ == kLutNA);
   for (int v0 = 0; v0 < nvec; v0 += vmax) {
@@ -2019,11 +2230,23 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
     size_t acc_need = (size_t)ky * npad * ncol;
     if (acc_need < (size_t)2 * op->m * 32) acc_need = (size_t)2 * op->m * 32;
     int32_t *acc = op->d_acc.ensure(acc_need);
-    quantise(op, d_X + (int64_t)v0 * ldx, ldx, op->m, m_pad, nv, mode, S, ncol, 0, 0, meta, q,
+    // (k_prodT decodes like k_cprod: its digit rows take the crossproduct's byte order)
+    quantise(op, d_X + (int64_t)v0 * ldx, ldx, op->m, m_pad, nv, mode, S, ncol, smaj && NB == 2 ? 1 : 0, 0, meta, q,
              d_W2 ? d_W2 + (int64_t)v0 * ldx : nullptr);
     dim3 grid((unsigned)wgx, (unsigned)ky);
     prof_begin(op, 1);
-    if (b->bits == 8) {
+    if (smaj && NB == 2) {
+      const int nchunks = (int)(m_pad / 512);
+      const bool warm = op->prof_kind_override == 3;
+#define BSN_PRODT(HASQV, TAGV)                                                                                      \
+  BSN_KLAUNCH((k_prodT<2, HASQV, 2, 16, TAGV>), grid, dim3(1024), 0, b->stream, b->d_smaj, b->rows_smaj, op->col0 / 512, \
+              nchunks, smaj_cps, q, acc, npad, lutQ)
+      // (workgroup shapes 4 x 8 / 4 x 4 / 2 x 8 / 4 x 16 tiles x waves, chunks of 256 variants: all slower, profiles/r04_smaj.txt)
+      if (has_q) { if (warm) BSN_PRODT(true, 1); else BSN_PRODT(true, 0); }
+      else { if (warm) BSN_PRODT(false, 1); else BSN_PRODT(false, 0); }
+#undef BSN_PRODT
+      BSN_HIP(hipGetLastError());
+    } else if (b->bits == 8) {
       if (mode != 1) fail("internal: plane products are not defined on a byte image");
       const dim3 grid8 = grid;
       const int64_t npad8 = npad;

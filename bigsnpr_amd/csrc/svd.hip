@@ -1011,6 +1011,9 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     // 23.65 ms on the plain image against 23.75 on the copy, k_cprod<2> 21.65 against 21.52: profiles/r03_shape_sweeps.txt),
     // so the default solve at k >= 14 leaves the other half of the HBM alone; a copy that exists is used either way.
     if (so.block * op->slices <= 16 && op->cols_contig && (op->col0 & 63) == 0 && m >= 4096) image_tile(bed);
+    // ... and a solve on the two-block kernels for the sample-major copy: its product passes then run as k_prodT
+    // (k_cprod's shape) instead of k_prod<2> with its transposes and 128 accumulators
+    if (so.block * op->slices > 16 && op->cols_contig && (op->col0 & 511) == 0 && m >= 4096) image_smaj(bed);
     so.resid_floor = 1.2 * std::ldexp(1.0, -8 * op->slices);
     so.warm = o->warm_start < 0 ? 0 : (o->warm_start == 0 ? 1 : o->warm_start);
     so.max_basis = o->max_basis;
@@ -1105,6 +1108,7 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       info->block = so.block;
       info->slices = op->slices;
       info->tiled = (bed->d_tiled != nullptr && op->cols_contig && (op->col0 & 63) == 0) ? 1 : 0;
+      if (bed->d_smaj != nullptr && so.block * op->slices > 16 && op->cols_contig && (op->col0 & 511) == 0) info->tiled = 2;
     }
   });
   return rc != 0 ? rc : (unconverged ? 2 : 0);

@@ -282,7 +282,8 @@ typedef struct bsn_svd_info {
                             (they are counted in nops and in the kernel timings too) */
   double warm_fraction;
   double warm_ms;        /* HIP-event time of those launches (not in cprod_ms / prod_ms) */
-  int32_t tiled;         /* 1 if the streaming kernels read the tiled second copy of the image (bsn_bed_tile) */
+  int32_t tiled;         /* 1 if the streaming kernels read the tiled second copy of the image (bsn_bed_tile); 2 if the
+                            product passes read the sample-major second copy (two-block solves, round 4) */
 } bsn_svd_info;
 /* Returns 0 on success, 1 on error, and 2 when the solve ran to the end of its basis without all
  * k residuals meeting tol (outputs are filled with the best available triplets, bsn_last_error()
@@ -303,6 +304,15 @@ int bsn_bed_streaming_kernels(bsn_bed *bed, char *buf, int64_t len);
  * one-shot products.  *built = 1 if the copy exists afterwards.  It costs one extra pass (read + write) once,
  * doubles the HBM held by the handle, and is freed by bsn_bed_close.  Results are bit-identical. */
 int bsn_bed_tile(bsn_bed *bed, int *built);
+/* Sample-major layout (round 4).  A second copy of the 2-bit image with the VARIANTS contiguous (sample i at
+ * i * pitch, four variants per byte): on it the product A~ X of 9 .. 16 vectors (two MFMA column blocks) contracts
+ * over the contiguous index like the crossproduct does on the variant-major image, and runs as the crossproduct's
+ * kernel shape (no byte transposes, 16 accumulator registers instead of 128).  bsn_bed_randomsvd builds it by itself
+ * for a solve on 16-vector blocks when the device has the room (image size + 24 GB free; BSN_NO_SMAJ=1 forbids it);
+ * this call builds it ahead of time for bsn_op_prod / bsn_bed_prod* on 9 .. 16 vectors.  One extra read + write pass
+ * once, doubles the HBM held by the handle, freed by bsn_bed_close / bsn_bed_release_workspace.  Results are
+ * bit-identical (same exact integer sums). */
+int bsn_bed_sample_major(bsn_bed *bed, int *built);
 
 /* The device workspace of a solve (Krylov basis, panels, quantised operands: about
  * 8 (n + m) (8 k + 4 block) bytes, 4 GB at 400K x 1M, k = 20) stays on the handle for the next

@@ -82,6 +82,53 @@ def test_cor_nan_for_constant_column(ba, orc):
     assert np.isnan(res.x).any()
 
 
+@pytest.mark.parametrize("budget_cols", [128, 384])
+@pytest.mark.parametrize("which", ["missing", "complete"])
+def test_band_in_blocks_of_columns(ba, orc, golden_dir, missing_bed, example_bed, monkeypatch, budget_cols, which):
+    """The reference walks any window (src/corr.cpp:52-53, src/ld-scores.cpp same loop); a dense m x W band that does
+    not fit HBM is processed in blocks of columns (BSN_LD_BAND_BUDGET forces the path here with a budget of 128 / 384
+    columns, so that blocks, a ragged last block and windows that reach across two blocks all occur): @p, @i, @x and the
+    LD scores are IDENTICAL to the one-block result — same kernels, same order of every sum — and match the oracle.
+    `missing`: 200 x 500 with missing values (six-product kernels); `complete`: 517 samples x 1111 variants without
+    (cross-product kernel)."""
+    if which == "missing":
+        ob, name, ic = missing_bed, "example-missing.bed", np.arange(7, missing_bed.m - 6)
+    else:
+        ob, name, ic = example_bed, "example.bed", np.arange(100, 100 + 1111)
+    gb = ba.bed(os.path.join(golden_dir, name))
+    G = ba.FBM_code256(orc.fbm_from_bed(ob).bytes)
+    rng = np.random.default_rng(3)
+    ir = np.sort(rng.choice(ob.n, ob.n - 17, replace=False))
+    pos = np.cumsum(rng.uniform(0.5, 3, ic.size))
+    cases = [dict(size=0.3, infos_pos=pos), dict(size=0.12, infos_pos=pos, alpha=0.2, thr_r2=0.02, fill_diag=False)]
+    dense = [(ba.bed_cor(gb, ir, ic, **kw), ba.snp_cor(G, ir, ic, **kw)) for kw in cases]
+    ld_dense = ba.bed_ld_scores(gb, ir, ic, size=0.3, infos_pos=pos)
+    width = int(np.max(np.arange(ic.size) - np.searchsorted(pos, pos - 300.0, side="left")))
+    assert width > 140                                                # windows wider than a block of 128 columns
+    monkeypatch.setenv("BSN_LD_BAND_BUDGET", str(budget_cols * width * 8))
+    for kw, (d_bed, d_fbm) in zip(cases, dense):
+        for res, ref in ((ba.bed_cor(gb, ir, ic, **kw), d_bed), (ba.snp_cor(G, ir, ic, **kw), d_fbm)):
+            np.testing.assert_array_equal(res.p, ref.p)
+            np.testing.assert_array_equal(res.i, ref.i)
+            np.testing.assert_array_equal(res.x, ref.x)
+        _same_cor(ba.bed_cor(gb, ir, ic, **kw), orc.snp_cor(ob, ir, ic, ncores=8, **kw))
+    ld = ba.bed_ld_scores(gb, ir, ic, size=0.3, infos_pos=pos)
+    np.testing.assert_array_equal(ld, ld_dense)
+    np.testing.assert_allclose(ld, orc.ld_scores(ob, ir, ic, size=0.3, infos_pos=pos), rtol=1e-12)
+    if which == "complete":
+        # a dosage FBM (byte image, other statistics kernels) through the same blocks
+        g8 = rng.integers(7, 208, size=(150, 700)).astype(np.uint8)       # dosages 0.00 .. 2.00, none missing
+        D = ba.FBM_code256(g8, code=ba.CODE_DOSAGE)
+        monkeypatch.delenv("BSN_LD_BAND_BUDGET")
+        ref8, ld8 = ba.snp_cor(D, size=200), ba.snp_ld_scores(D, size=200)
+        monkeypatch.setenv("BSN_LD_BAND_BUDGET", str(budget_cols * 200 * 8))
+        res8 = ba.snp_cor(D, size=200)
+        np.testing.assert_array_equal(res8.p, ref8.p)
+        np.testing.assert_array_equal(res8.i, ref8.i)
+        np.testing.assert_array_equal(res8.x, ref8.x)
+        np.testing.assert_array_equal(ba.snp_ld_scores(D, size=200), ld8)
+
+
 def test_ld_scores(ba, orc, golden_dir, missing_bed, example_bed):
     """test-2-ld-scores.R:15-64"""
     gb = ba.bed(os.path.join(golden_dir, "example-missing.bed"))

@@ -1,0 +1,75 @@
+"""The sample-major second copy of the image (bsn_bed_sample_major, round 4) and k_prodT, the product kernel that
+reads it: same exact integer sums as k_prod on the variant-major image -> bit-identical results, on ragged sizes, with
+missing values, on a chunk-aligned sub-range of the variants, in the warm-started solve, and against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ba():
+    import bigsnpr_amd
+    return bigsnpr_amd
+
+
+@pytest.mark.parametrize("n,m", [(3001, 5003), (517, 9000), (70000, 4500)])
+def test_product_on_the_sample_major_copy_is_bit_identical(ba, orc, n, m, monkeypatch):
+    from bigsnpr_amd import _lib
+    gb = ba.bed.synthetic(n, m, seed=11)
+    ob = orc.fake_bed(n, m, seed=11) if n * m < 5e7 else None
+    sc = ba.bed_scaleBinom(gb)
+    keep = sc["scale"] > 0
+    ce, sa = np.where(keep, sc["center"], 0.0), np.where(keep, sc["scale"], 1.0)
+    rng = np.random.default_rng(0)
+    for ic in (None, np.arange(512, m - 7), np.arange(100, m - 200)):   # whole / chunk-aligned / unaligned range
+        mm = m if ic is None else ic.size
+        cc, ss = (ce, sa) if ic is None else (ce[ic], sa[ic])
+        op = ba.ScaledOp(gb, None, ic, cc, ss, slices=2)
+        X = ba.DeviceArray.from_numpy(rng.normal(size=(mm, 16)))
+        Y = ba.DeviceArray(n, 16)
+        sync = _lib.load().bsn_device_sync          # (the products are queued on the handle's stream)
+        monkeypatch.setenv("BSN_NO_SMAJ", "1")
+        op.prod(X, Y)
+        sync()
+        ref = Y.to_numpy()
+        monkeypatch.delenv("BSN_NO_SMAJ")
+        assert gb.sample_major()
+        op.prod(X, Y)
+        sync()
+        np.testing.assert_array_equal(Y.to_numpy(), ref)
+        assert np.abs(ref).max() > 0
+        if ob is not None and ic is None:   # and both are the reference's product (16-bit panels: 1e-4 of the scale)
+            want = np.stack([orc.bed_prodVec(ob, X.to_numpy()[:, v], None, None, ce, sa, 4) for v in range(2)], axis=1)
+            assert np.abs(ref[:, :2] - want).max() <= 1e-3 * np.abs(want).max()
+        # 9 .. 16 vectors take the copy, 8 do not (one column block): still identical to the plain path
+        X8, Y8 = ba.DeviceArray.from_numpy(rng.normal(size=(mm, 8))), ba.DeviceArray(n, 8)
+        op.prod(X8, Y8)
+        sync()
+        a = Y8.to_numpy()
+        monkeypatch.setenv("BSN_NO_SMAJ", "1")
+        op.prod(X8, Y8)
+        sync()
+        monkeypatch.delenv("BSN_NO_SMAJ")
+        np.testing.assert_array_equal(Y8.to_numpy(), a)
+
+
+def test_complete_data_and_solve(ba, monkeypatch):
+    """no missing values (the kernel variant without the missing-value plane) and the whole 16-vector solve, whose
+    product passes — warm start included — run on the copy: d, u, v bit-identical to the solve without it"""
+    n, m, k = 2500, 300000, 20
+    for na16 in (655, 0):                                   # 1 % missing / none
+        gb = ba.bed.synthetic(n, m, seed=5, na16=na16)
+        monkeypatch.setenv("BSN_NO_SMAJ", "1")
+        ref = ba.bed_randomSVD(gb, k=k, block=16)
+        assert ref["tiled"] == 0
+        monkeypatch.delenv("BSN_NO_SMAJ")
+        res = ba.bed_randomSVD(gb, k=k, block=16)
+        assert res["tiled"] == 2 and res["converged"] and res["warm_launches"] == 2
+        for f in ("d", "u", "v", "center", "scale"):
+            np.testing.assert_array_equal(res[f], ref[f])
+        assert (res["niter"], res["nops"]) == (ref["niter"], ref["nops"])
+        gb.release_workspace()                               # frees the copy too; the next solve builds it again
+        again = ba.bed_randomSVD(gb, k=k, block=16)
+        assert again["tiled"] == 2
+        np.testing.assert_array_equal(again["d"], ref["d"])
