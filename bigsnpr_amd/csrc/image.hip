@@ -771,9 +771,12 @@ __global__ __launch_bounds__(256) void k_readbina(const uint8_t *__restrict__ im
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t j = blockIdx.y + (int64_t)blockIdx.z * 65535;
   if (4 * b >= n || j >= m) return;
-  const uint32_t t = stab[plink_from_dev(img[j * pitch + b]) & 0xFFu];
-  uint8_t *o = out + j * n + 4 * b;
   const int64_t left = n - 4 * b;
+  // the pad genotypes of a variant's last byte are 00 in a .bed file (the image holds them as genotype 0): the table
+  // is indexed with the byte as PLINK writes it
+  const uint32_t keep = left >= 4 ? 0xFFu : (1u << (2 * left)) - 1u;
+  const uint32_t t = stab[plink_from_dev(img[j * pitch + b]) & keep];
+  uint8_t *o = out + j * n + 4 * b;
   if (left >= 4 && (((uintptr_t)o) & 3) == 0) {
     *(uint32_t *)o = t;
   } else {

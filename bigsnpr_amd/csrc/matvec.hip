@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64) void k_quant(const double *__restrict__ X, int6
 // TILED (with CONTIG, col0 a multiple of 64): `img` is the streaming-layout copy (bsn_internal.hpp): variant
 // a, byte o of its row at ((a >> 6) * (pitch >> 8) + (o >> 8)) * 16384 + (a & 63) * 256 + (o & 255).
 template <int NB, int NPLANE, int KC, bool RAW0, bool STATS, bool CONTIG, int ABL = 0, int TILES = 2,
-          int WAVES = 8, int MINW = 1, int TAG = 0, bool TILED = false, int SGB = 0, bool SWAP = false>
+          int WAVES = 8, int MINW = 1, int TAG = 0, bool TILED = false, int SGB = 0>
 __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__restrict__ img, int64_t pitch,
                                                const int32_t *__restrict__ cols, int64_t col0,
                                                int64_t m, const int8_t *__restrict__ xq,
@@ -417,8 +417,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
           if (ABL & 1) {  // ablation: no MFMA, keep the operands alive
             asm volatile("" ::"v"(a), "v"(b));
           } else {
-            acc[t][p][nb] = SWAP ? __builtin_amdgcn_mfma_i32_16x16x64_i8(b, a, acc[t][p][nb], 0, 0, 0)
-                                 : __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[t][p][nb], 0, 0, 0);
+            acc[t][p][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[t][p][nb], 0, 0, 0);
           }
         }
       }
@@ -513,20 +512,6 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
   }
 
   // raw accumulators: acc_out[plane][variant][NCOL]
-  if constexpr (SWAP) {
-    // digits were the A operand: D is transposed — lane -> variant (l & 15), digit columns 4 * (l >> 4) .. + 3
-#pragma unroll
-    for (int t = 0; t < TILES; t++) {
-      const int64_t j = snp_base + t * 16 + c;
-      if (j < m) {
-#pragma unroll
-        for (int p = 0; p < NPLANE; p++)
-#pragma unroll
-          for (int nb = 0; nb < NB; nb++)
-            *(v4i *)(acc_out + ((int64_t)p * m_out + j) * NCOL + nb * 16 + 4 * g) = acc[t][p][nb];
-      }
-    }
-  } else
 #pragma unroll
   for (int t = 0; t < TILES; t++)
 #pragma unroll
@@ -553,166 +538,6 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
         *(int4 *)(counts + 4 * j) =
             int4{(int32_t)(pitch * 4) - n1 - n2 - (int32_t)na - n_pad_samples, n1, n2, (int32_t)na};
       }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// k_cprod32: the crossproduct with TWO column blocks (32 digit columns = 16 vectors x 2 slices) on
-// v_mfma_i32_32x32x32_i8.  Same memory pipeline, same integer arithmetic and the same output as
-// k_cprod<2, ...> (bit-identical), different tile: one wave owns 32 variants as ONE 32-row tile and multiplies
-// them with all 32 digit columns in one instruction.  Why (profiles/r04_mfma32.txt): per 256 B of genotypes the
-// 16 x 16 x 64 shape issues four MFMAs of 16 cycles next to 11 decode instructions — 15 of the 16 issue slots of
-// the matrix pipe's busy time, which no schedule fills (the pipe ran 61-65 % busy); the 32 x 32 x 32 shape issues
-// two MFMAs of 32 cycles: 13 of 32 slots.
-//   A operand: lane l -> variant row (l & 31), K half (l >> 5): 16 samples of that variant (one decoded dword)
-//   B operand: lane l -> digit column (l & 31), the same 16 samples (one ds_read_b128)
-//   D        : lane l -> digit column (l & 31), variant rows 8 * (r / 4) + 4 * (l >> 5) + (r % 4), r = 0 .. 15
-// A lane loads 16 B (64 samples: four K-steps) at byte it * 32 + (l >> 5) * 16 of its row's 128-B chunk, so K-step
-// (it, d) covers the sample blocks it * 8 + h * 4 + d (h = 0, 1) of the chunk's 32 blocks of 16.
-// SWAP (experiment): the digits as the A operand and the codes as B (D transposed).
-typedef int v16i __attribute__((ext_vector_type(16)));
-template <int NPLANE, bool STATS, int WAVES = 16, int TAG = 0, int SGB = 0, bool SWAP = false>
-__global__ __launch_bounds__(64 * WAVES) void k_cprod32(const uint8_t *__restrict__ img, int64_t pitch, int64_t col0,
-                                                        int64_t m, const int8_t *__restrict__ xq,
-                                                        int32_t *__restrict__ acc_out, int64_t m_out, uint32_t lutB,
-                                                        int32_t *__restrict__ counts, int32_t n_pad_samples) {
-  constexpr int KC = 512, NCOL = 32, LD = 4, XS = KC / 16 * NCOL;  // 1024 digit entries of 16 B per chunk
-  constexpr int NT = 64 * WAVES, NX = XS / NT;
-  static_assert(XS % NT == 0 && NX >= 1 && NX <= 4, "digit staging");
-  __shared__ uint4 xs[2][XS];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int r = lane & 31, h = lane >> 5;
-  const int64_t wg_base = (int64_t)blockIdx.x * (WAVES * 32);
-  const int64_t snp_base = wg_base + wave * 32;
-  int64_t jr = snp_base + r;
-  if (jr > m - 1) jr = m - 1;
-  const uint32_t voff = (uint32_t)((jr - wg_base) * pitch + h * 16);
-  const __amdgpu_buffer_rsrc_t rs =
-      __builtin_amdgcn_make_buffer_rsrc((void *)(img + (col0 + wg_base) * pitch), 0, 0x7fffffff, 0x00020000);
-  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-  auto gload = [&](const int off) -> uint4 {
-    const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, off, 0);
-    return uint4{t.x, t.y, t.z, t.w};
-  };
-  const int nchunks = (int)(pitch * 4 / KC);
-  const uint4 *xq4 = (const uint4 *)xq;
-
-  v16i acc[NPLANE];
-#pragma unroll
-  for (int p = 0; p < NPLANE; p++)
-#pragma unroll
-    for (int e = 0; e < 16; e++) acc[p][e] = 0;
-  uint32_t st_lo = 0, st_hi = 0, st_na = 0;
-
-  uint4 ga[2][LD];
-  uint4 xr[NX];
-#pragma unroll
-  for (int it = 0; it < LD; it++) ga[0][it] = gload(it * 32);
-#pragma unroll
-  for (int x = 0; x < NX; x++) xs[0][tid + x * NT] = xq4[tid + x * NT];
-#pragma unroll
-  for (int it = 0; it < LD; it++) ga[1][it] = gload((nchunks > 1 ? KC / 4 : 0) + it * 32);
-  __syncthreads();
-
-  auto chunk = [&](auto SETC, const int ch) {
-    constexpr int SET = decltype(SETC)::value;
-    // branch-free prefetch, as in k_cprod: past the end the last chunk is loaded again
-    const int ch1 = ch + 1 < nchunks ? ch + 1 : nchunks - 1;
-    const int ch2 = ch + 2 < nchunks ? ch + 2 : nchunks - 1;
-#pragma unroll
-    for (int x = 0; x < NX; x++) xr[x] = xq4[(int64_t)ch1 * XS + tid + x * NT];
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (SGB & 2) __builtin_amdgcn_s_setprio(2);
-    const int off2 = ch2 * (KC / 4);
-    uint4 bv = xs[SET][(h * 4) * NCOL + r], bn = bv;
-#pragma unroll
-    for (int it = 0; it < LD; it++) {
-#pragma unroll
-      for (int d = 0; d < 4; d++) {
-        if (it * 4 + d + 1 < LD * 4) {
-          const int itn = (it * 4 + d + 1) / 4, dn = (it * 4 + d + 1) % 4;
-          bn = xs[SET][(itn * 8 + h * 4 + dn) * NCOL + r];
-        }
-        const uint32_t w = d == 0 ? ga[SET][it].x : d == 1 ? ga[SET][it].y : d == 2 ? ga[SET][it].z : ga[SET][it].w;
-        const uint32_t s0 = w & 0x03030303u, s1 = (w >> 2) & 0x03030303u, s2 = (w >> 4) & 0x03030303u,
-                       s3 = (w >> 6) & 0x03030303u;
-        if constexpr (STATS) {
-          const uint32_t lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;
-          st_lo += __popc(lo);
-          st_hi += __popc(hi);
-          st_na += __popc(lo & hi);
-        }
-        const v4i b = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
-        const v4i a0 = {(int)s0, (int)s1, (int)s2, (int)s3};
-        acc[0] = SWAP ? __builtin_amdgcn_mfma_i32_32x32x32_i8(b, a0, acc[0], 0, 0, 0)
-                      : __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b, acc[0], 0, 0, 0);
-        if constexpr (NPLANE == 2) {
-          const v4i a1 = {(int)lut4(lutB, s0), (int)lut4(lutB, s1), (int)lut4(lutB, s2), (int)lut4(lutB, s3)};
-          acc[1] = SWAP ? __builtin_amdgcn_mfma_i32_32x32x32_i8(b, a1, acc[1], 0, 0, 0)
-                        : __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b, acc[1], 0, 0, 0);
-        }
-        bv = bn;
-      }
-    }
-    // the set is consumed: refill it with the chunk two ahead, the four quarters of a 128-B line back to back
-#pragma unroll
-    for (int it = 0; it < LD; it++) ga[SET][it] = gload(off2 + it * 32);
-    if constexpr (SGB & 1) {
-      // the decode of the following K-step in the shadow of the MFMAs: 1 MFMA : 6 / 5 VALU (0x008 MFMA, 0x002 VALU,
-      // 0x100 DS read, 0x020 VMEM read)
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
-#pragma unroll
-      for (int stp = 0; stp < LD * 4; stp++) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, NPLANE == 2 ? 6 : 7, 0);
-        if constexpr (NPLANE == 2) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-        }
-      }
-      __builtin_amdgcn_sched_group_barrier(0x020, LD, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (SGB & 2) __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-    for (int x = 0; x < NX; x++) xs[SET ^ 1][tid + x * NT] = xr[x];
-    __syncthreads();
-  };
-  for (int ch = 0; ch < nchunks; ch += 2) {
-    chunk(std::integral_constant<int, 0>{}, ch);
-    if (ch + 1 < nchunks) chunk(std::integral_constant<int, 1>{}, ch + 1);
-  }
-
-  // raw accumulators: acc_out[plane][variant][32], the layout of k_cprod<2>
-#pragma unroll
-  for (int e = 0; e < 16; e++) {
-    if constexpr (SWAP) {
-      // D transposed: lane -> variant (l & 31), digit columns 8 * (e / 4) + 4 * h + (e % 4)
-      const int64_t j = snp_base + r;
-      const int c = 8 * (e >> 2) + 4 * h + (e & 3);
-      if (j < m) {
-#pragma unroll
-        for (int p = 0; p < NPLANE; p++) acc_out[((int64_t)p * m_out + j) * NCOL + c] = acc[p][e];
-      }
-    } else {
-      const int64_t j = snp_base + 8 * (e >> 2) + 4 * h + (e & 3);
-      if (j < m) {
-#pragma unroll
-        for (int p = 0; p < NPLANE; p++) acc_out[((int64_t)p * m_out + j) * NCOL + r] = acc[p][e];
-      }
-    }
-  }
-  if constexpr (STATS) {
-    uint32_t lo = st_lo, hi = st_hi, na = st_na;  // a variant row is spread over the wave's two K halves
-    lo += __shfl_xor(lo, 32); hi += __shfl_xor(hi, 32); na += __shfl_xor(na, 32);
-    const int64_t j = snp_base + r;
-    if (h == 0 && j < m) {
-      const int32_t n1 = (int32_t)(lo - na), n2 = (int32_t)(hi - na);
-      *(int4 *)(counts + 4 * j) =
-          int4{(int32_t)(pitch * 4) - n1 - n2 - (int32_t)na - n_pad_samples, n1, n2, (int32_t)na};
     }
   }
 }
@@ -790,54 +615,33 @@ __global__ __launch_bounds__(128) void k_cprod_final(const int32_t *__restrict__
 //   D        : lane l -> sample group (l&15), digit columns 4*(l>>4)+r
 // RAWP: the P plane is the device code itself (no look-up).
 // TILED: `img` is the streaming-layout copy; a step of the workgroup (64 variants x 256 B) is one tile.
-// XMAP: 1-D launch of wgx * ky workgroups (ky a multiple of 8) mapped so that all workgroups of a K slab run on
-// one XCD (workgroup i goes to XCD i mod 8): the slab's digit panel then lives in that XCD's L2.
-// HALF (two column blocks): a PAIR of waves owns the 256 samples; both load the same 16 dwords per lane (the second
-// load hits L1) and each keeps the accumulators of 8 of the 16 sample positions — 64 instead of 128 accumulator
-// registers, three waves per SIMD instead of two (the two-block kernels are bound by the matrix pipe and the
-// instruction issue port, where a third wave to pick instructions from is what helps).  The 4 x 4 byte transposes
-// split cleanly: the half that owns sample quads q = 0, 1 needs only the low halves of the first-level permutes.
-template <int NB, bool CONTIG, bool RAWP, bool HASQ = true, int WAVES = 4, int ABL = 0, int UG = 1, int SETS = 2,
-          int TAG = 0, bool TILED = false, bool XMAP = false, bool HALF = false, bool LH = false, int SGB = 0>
-__global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__ img, int64_t pitch,
+// TAG only changes the kernel's name (warm-start launches).  ABL != 0: -DBSN_ABLATION builds only.
+// (Shapes that were measured and dropped — 8-wave workgroups, three register sets, 2 / 4 samples decoded together,
+// XCD-aware slab placement, wave pairs / lane halves with 64 accumulators, an explicit MFMA : VALU schedule, the codes as
+// the A operand: profiles/r02_ablation.txt, r03_shape_sweeps.txt, r04_two_block_kernels.txt.)
+template <int NB, bool CONTIG, bool RAWP, bool HASQ = true, int ABL = 0, int TAG = 0, bool TILED = false>
+__global__ __launch_bounds__(256) void k_prod(const uint8_t *__restrict__ img, int64_t pitch,
                                               const int32_t *__restrict__ cols, int64_t col0,
                                               int64_t m_pad, int64_t mc,
                                               const int8_t *__restrict__ wq,
                                               int32_t *__restrict__ acc_out, int64_t n_pad,
                                               uint32_t lutP, uint32_t lutQ) {
-  constexpr int NCOL = 16 * NB;
+  constexpr int NCOL = 16 * NB, WAVES = 4;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int sg = lane & 15, g = lane >> 4;
-  unsigned bx = blockIdx.x, by = blockIdx.y;
-  if constexpr (XMAP) {  // gridDim.x = wgx * ky
-    const unsigned wgx = (unsigned)(n_pad / (WAVES * 256)), i = blockIdx.x, xcd = i & 7u, t = i >> 3;
-    bx = t % wgx;
-    by = xcd + 8u * (t / wgx);
-  }
-  static_assert(!HALF || (TILED && WAVES == 8 && UG == 1 && SETS == 2 && !XMAP), "wave pairs: tiled copy, 8 waves");
-  static_assert(!LH || (TILED && !HALF && UG == 1 && SETS == 2 && !XMAP), "lane halves: tiled copy");
-  // LH (two column blocks): a wave owns 128 samples — 8 dwords per variant row, lanes 2 d and 2 d + 1 of a k-group load
-  // the same dword (one address, coalesced) and keep one half of its 16 samples each: 64 accumulator registers
-  // instead of 128, and — unlike HALF — in four-wave workgroups, so that a third workgroup fits on a CU.
-  const int swave = HALF ? (wave >> 1) : wave;       // which 256-sample block of the workgroup
-  const int qh = LH ? (sg & 1) : HALF ? (wave & 1) : 0;   // this wave (HALF) / lane (LH) keeps sample quads 2 qh, 2 qh + 1
-  const int dw = LH ? (sg >> 1) : sg;                 // which dword of the wave's sample range
-  constexpr int SW = HALF ? WAVES / 2 : WAVES;        // sample blocks per workgroup
-  constexpr int WSAMP = LH ? 128 : 256;               // samples per wave
-  int64_t wbase = ((int64_t)bx * SW + swave) * WSAMP;  // first sample of this wave
-  const bool active = wbase < n_pad;  // WAVES = 8: the last workgroup may be half empty
-  if (!active) wbase = 0;
-  const int64_t wbyte = wbase / 4 + dw * 4;
+  const unsigned bx = blockIdx.x, by = blockIdx.y;
+  static_assert(!TILED || CONTIG, "streaming layout: contiguous variants");
+  const int64_t wbase = ((int64_t)bx * WAVES + wave) * 256;  // first sample of this wave (n_pad is a multiple of 1024)
+  const int64_t wbyte = wbase / 4 + sg * 4;
   const uint32_t lane_off = (uint32_t)(g * 16 * pitch + wbyte);
   const int64_t j0 = (int64_t)by * mc;
   int64_t j1 = j0 + mc;
   if (j1 > m_pad) j1 = m_pad;
   const uint4 *wq4 = (const uint4 *)wq;
 
-  constexpr int NU = (HALF || LH) ? 8 : 16, NQ = (HALF || LH) ? 2 : 4;
-  v4i acc[NU][NB];
+  v4i acc[16][NB];
 #pragma unroll
-  for (int u = 0; u < NU; u++)
+  for (int u = 0; u < 16; u++)
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) acc[u][nb] = v4i{0, 0, 0, 0};
 
@@ -850,7 +654,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
   // soon as its 4x4 byte transposes are done, so it is refilled with the step two ahead
   // right there.  No branches around loads (see k_cprod); past the end the last step is
   // loaded again.
-  uint32_t X[SETS][16];
+  uint32_t X[2][16];
   uint4 wreg = {0, 0, 0, 0};
   const int wtid = tid & (WS - 1);
   auto load = [&](int64_t jb, uint32_t *dst) {
@@ -858,21 +662,18 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
       // buffer loads: scalar descriptor (re-based per step) + scalar row offset + one 32-bit lane
       // offset, so the 16 addresses of a step cost no VALU (global loads took a 64-bit add each)
       if constexpr (TILED) {
-        // a wave owns 64 B of a 256-B column block: four waves per tile, WAVES / 4 tiles per workgroup and step
-        static_assert(WAVES % 4 == 0, "streaming layout: whole 256-B column blocks per workgroup");
-        const int64_t sbw = __builtin_amdgcn_readfirstlane(active ? (int)((bx * SW + swave) >> (LH ? 3 : 2)) : 0);
+        // a wave owns 64 B of a 256-B column block: the four waves of the workgroup cover one tile per step
+        const int64_t sbw = (int64_t)bx;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(img + (((col0 + jb) >> 6) * (pitch >> 8) + sbw) * 16384), 0, 0x7fffffff, 0x00020000);
-        const int toff = LH ? g * 4096 + (int)((bx * SW + swave) & 7) * 32 + dw * 4 : g * 4096 + (swave & 3) * 64 + sg * 4;
+        const int toff = g * 4096 + wave * 64 + sg * 4;
 #pragma unroll
         for (int r = 0; r < 16; r++) dst[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, toff, r * 256, 0);
       } else {
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          (void *)(img + (col0 + jb) * pitch), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(img + (col0 + jb) * pitch), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-      for (int r = 0; r < 16; r++)
-        dst[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)lane_off, r * (int)pitch,
-                                                                 ((ABL & 64) ? 2 : 0) | ((ABL & 128) ? 16 : 0));
+        for (int r = 0; r < 16; r++) dst[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)lane_off, r * (int)pitch, 0);
       }
     } else {
       const int4 *ip = (const int4 *)(cols + jb + g * 16);
@@ -891,148 +692,85 @@ __global__ __launch_bounds__(64 * WAVES) void k_prod(const uint8_t *__restrict__
   const int64_t jlast = j1 - 64;
   ws[0][wtid] = wq4[(j0 / 16) * 2 * NCOL + wtid];
   load(j0, X[0]);
-  if constexpr (SETS >= 2) load(j0 + 64 < j1 ? j0 + 64 : jlast, X[1]);
-  if constexpr (SETS >= 3) load(j0 + 128 < j1 ? j0 + 128 : jlast, X[2]);
+  load(j0 + 64 < j1 ? j0 + 64 : jlast, X[1]);
   __syncthreads();
-  int wpar = 0;  // SETS == 3: the LDS digit buffer alternates per step, the register set goes round three
 
   auto step = [&](auto SETC, const int64_t jb) {
     constexpr int SET = decltype(SETC)::value;
     const int64_t jn1 = jb + 64 < j1 ? jb + 64 : jlast, jn2 = jb + 128 < j1 ? jb + 128 : jlast;
-    const int64_t jn3 = jb + 192 < j1 ? jb + 192 : jlast;
-    const int WB = SETS == 3 ? wpar : SET;  // LDS buffer of this step's digits
     wreg = wq4[(jn1 / 16) * 2 * NCOL + wtid];  // next step's digits: registers now, LDS later
     __builtin_amdgcn_sched_barrier(0);
     v4i aw[NB], awc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
-      uint4 t0 = ws[WB][(g * 2 + 0) * NCOL + nb * 16 + sg];
-      uint4 t1 = ws[WB][(g * 2 + 1) * NCOL + nb * 16 + sg];
+      uint4 t0 = ws[SET][(g * 2 + 0) * NCOL + nb * 16 + sg];
+      uint4 t1 = ws[SET][(g * 2 + 1) * NCOL + nb * 16 + sg];
       aw[nb] = v4i{(int)t0.x, (int)t0.y, (int)t0.z, (int)t0.w};
       awc[nb] = v4i{(int)t1.x, (int)t1.y, (int)t1.z, (int)t1.w};
     }
-    // T[q][r4]: byte b = byte q of X[4*r4 + b]   (HALF: q counts from 2 qh)
-    uint32_t T[NQ][4];
+    // T[q][r4]: byte b = byte q of X[4*r4 + b]
+    uint32_t T[4][4];
 #pragma unroll
     for (int r4 = 0; r4 < 4; r4++) {
-      constexpr int XS_ = SETS >= 2 ? SET : 0;
-      const uint32_t x0 = X[XS_][4 * r4], x1 = X[XS_][4 * r4 + 1], x2 = X[XS_][4 * r4 + 2],
-                     x3 = X[XS_][4 * r4 + 3];
-      if constexpr (HALF || LH) {
-        const uint32_t sel = qh ? 0x07030602u : 0x05010400u;   // (HALF: uniform per wave; LH: per lane)
-        const uint32_t h01 = perm8(x1, x0, sel), h23 = perm8(x3, x2, sel);
-        T[0][r4] = perm8(h23, h01, 0x05040100u);
-        T[1][r4] = perm8(h23, h01, 0x07060302u);
-      } else {
-        const uint32_t lo01 = perm8(x1, x0, 0x05010400u);  // x0.b0 x1.b0 x0.b1 x1.b1
-        const uint32_t hi01 = perm8(x1, x0, 0x07030602u);  // x0.b2 x1.b2 x0.b3 x1.b3
-        const uint32_t lo23 = perm8(x3, x2, 0x05010400u);
-        const uint32_t hi23 = perm8(x3, x2, 0x07030602u);
-        T[0][r4] = perm8(lo23, lo01, 0x05040100u);  // lo01.b0 lo01.b1 lo23.b0 lo23.b1
-        T[1][r4] = perm8(lo23, lo01, 0x07060302u);
-        T[NQ - 2][r4] = perm8(hi23, hi01, 0x05040100u);
-        T[NQ - 1][r4] = perm8(hi23, hi01, 0x07060302u);
-      }
+      const uint32_t x0 = X[SET][4 * r4], x1 = X[SET][4 * r4 + 1], x2 = X[SET][4 * r4 + 2], x3 = X[SET][4 * r4 + 3];
+      const uint32_t lo01 = perm8(x1, x0, 0x05010400u);  // x0.b0 x1.b0 x0.b1 x1.b1
+      const uint32_t hi01 = perm8(x1, x0, 0x07030602u);  // x0.b2 x1.b2 x0.b3 x1.b3
+      const uint32_t lo23 = perm8(x3, x2, 0x05010400u);
+      const uint32_t hi23 = perm8(x3, x2, 0x07030602u);
+      T[0][r4] = perm8(lo23, lo01, 0x05040100u);  // lo01.b0 lo01.b1 lo23.b0 lo23.b1
+      T[1][r4] = perm8(lo23, lo01, 0x07060302u);
+      T[2][r4] = perm8(hi23, hi01, 0x05040100u);
+      T[3][r4] = perm8(hi23, hi01, 0x07060302u);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (ABL & 32) {  // ablation: no genotype loads after the prologue
 #pragma unroll
-      for (int r = 0; r < 16; r++) X[SETS >= 2 ? SET : 0][r] += (uint32_t)jn2;
+      for (int r = 0; r < 16; r++) X[SET][r] += (uint32_t)jn2;
     } else {
-      load(SETS == 3 ? jn3 : (SETS == 2 ? jn2 : jn1), X[SETS >= 2 ? SET : 0]);
+      load(jn2, X[SET]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (SGB & 2) __builtin_amdgcn_s_setprio(2);
-    // G samples are decoded together and their MFMAs interleaved (g0 of all, then na of all);
-    // G = 1, 2, 4 time the same (profiles/r01_ablation.txt), so the smallest is used
-    constexpr int G = UG;
 #pragma unroll
-    for (int q = 0; q < NQ; q++)
+    for (int q = 0; q < 4; q++)
 #pragma unroll
-      for (int u0 = 0; u0 < 4; u0 += G) {
-        v4i g0[G], na[G];
+      for (int u0 = 0; u0 < 4; u0++) {
+        v4i g0, na;
 #pragma unroll
-        for (int k = 0; k < G; k++)
-#pragma unroll
-          for (int r4 = 0; r4 < 4; r4++) {
-            const uint32_t sel = (T[q][r4] >> (2 * (u0 + k))) & 0x03030303u;
-            if (ABL & 2) {  // ablation: no decode
-              g0[k][r4] = (int)T[q][r4];
-              na[k][r4] = (int)(T[q][r4] ^ lutQ);
-            } else {
-              g0[k][r4] = RAWP ? (int)sel : (int)lut4(lutP, sel);
-              if (HASQ) na[k][r4] = (int)lut4(lutQ, sel);
-            }
+        for (int r4 = 0; r4 < 4; r4++) {
+          const uint32_t sel = (T[q][r4] >> (2 * u0)) & 0x03030303u;
+          if (ABL & 2) {  // ablation: no decode
+            g0[r4] = (int)T[q][r4];
+            na[r4] = (int)(T[q][r4] ^ lutQ);
+          } else {
+            g0[r4] = RAWP ? (int)sel : (int)lut4(lutP, sel);
+            if (HASQ) na[r4] = (int)lut4(lutQ, sel);
           }
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) {
           if (ABL & 1) {  // ablation: no MFMA
-#pragma unroll
-            for (int k = 0; k < G; k++) asm volatile("" ::"v"(g0[k]), "v"(na[k]), "v"(aw[nb]), "v"(awc[nb]));
+            asm volatile("" ::"v"(g0), "v"(na), "v"(aw[nb]), "v"(awc[nb]));
           } else {
-#pragma unroll
-            for (int k = 0; k < G; k++)
-              acc[q * 4 + u0 + k][nb] =
-                  (SGB & 4) ? __builtin_amdgcn_mfma_i32_16x16x64_i8(g0[k], aw[nb], acc[q * 4 + u0 + k][nb], 0, 0, 0)
-                            : __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[nb], g0[k], acc[q * 4 + u0 + k][nb], 0, 0, 0);
-            if (HASQ) {
-#pragma unroll
-              for (int k = 0; k < G; k++)
-                acc[q * 4 + u0 + k][nb] =
-                    (SGB & 4) ? __builtin_amdgcn_mfma_i32_16x16x64_i8(na[k], awc[nb], acc[q * 4 + u0 + k][nb], 0, 0, 0)
-                              : __builtin_amdgcn_mfma_i32_16x16x64_i8(awc[nb], na[k], acc[q * 4 + u0 + k][nb], 0, 0, 0);
-            }
+            acc[q * 4 + u0][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[nb], g0, acc[q * 4 + u0][nb], 0, 0, 0);
+            if (HASQ)
+              acc[q * 4 + u0][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(awc[nb], na, acc[q * 4 + u0][nb], 0, 0, 0);
           }
         }
       }
-    if constexpr (SGB & 1) {
-      // experiment (profiles/r04_sched.txt): 1 MFMA : 3 VALU through the decode + MFMA phase of a step
-#pragma unroll
-      for (int i = 0; i < NU * NB * (HASQ ? 2 : 1); i++) {
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (SGB & 2) __builtin_amdgcn_s_setprio(0);
-    ws[WB ^ 1][wtid] = wreg;
-    wpar ^= 1;
+    ws[SET ^ 1][wtid] = wreg;
     __syncthreads();
   };
-  if constexpr (SETS == 3) {
-    for (int64_t jb = j0; jb < j1; jb += 192) {
-      step(std::integral_constant<int, 0>{}, jb);
-      if (jb + 64 < j1) step(std::integral_constant<int, 1>{}, jb + 64);
-      if (jb + 128 < j1) step(std::integral_constant<int, 2>{}, jb + 128);
-    }
-  } else {
-    for (int64_t jb = j0; jb < j1; jb += 128) {
-      step(std::integral_constant<int, 0>{}, jb);
-      if (jb + 64 < j1) step(std::integral_constant<int, 1>{}, jb + 64);
-    }
+  for (int64_t jb = j0; jb < j1; jb += 128) {
+    step(std::integral_constant<int, 0>{}, jb);
+    if (jb + 64 < j1) step(std::integral_constant<int, 1>{}, jb + 64);
   }
   // raw accumulators: acc_out[ky][sample][NCOL], lane holds columns nb*16 + 4g .. +3
-  if constexpr ((SGB & 4) != 0) {
-    // experiment: codes as the A operand -> D transposed: lane holds digit column (l & 15), sample groups 4 g + r
-    static_assert(!(SGB & 4) || (!HALF && !LH), "operand swap: plain shape only");
-    if (active) {
 #pragma unroll
-      for (int u = 0; u < NU; u++)
+  for (int u = 0; u < 16; u++) {
+    const int64_t i = wbase + sg * 16 + u;
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-          for (int rr = 0; rr < 4; rr++)
-            acc_out[((int64_t)by * n_pad + wbase + (4 * g + rr) * 16 + u) * NCOL + nb * 16 + sg] = acc[u][nb][rr];
-    }
-  } else
-  if (active) {
-#pragma unroll
-    for (int u = 0; u < NU; u++) {
-      const int64_t i = wbase + dw * 16 + ((HALF || LH) ? 8 * qh : 0) + u;
-#pragma unroll
-      for (int nb = 0; nb < NB; nb++)
-        *(v4i *)(acc_out + (((int64_t)by * n_pad + i) * NCOL + nb * 16 + 4 * g)) = acc[u][nb];
-    }
+    for (int nb = 0; nb < NB; nb++)
+      *(v4i *)(acc_out + (((int64_t)by * n_pad + i) * NCOL + nb * 16 + 4 * g)) = acc[u][nb];
   }
 }
 
@@ -1624,8 +1362,7 @@ __global__ __launch_bounds__(256) void k_stats_summary(const int32_t *counts, in
 // the streaming-layout copy serves an operator over a 64-aligned contiguous range of variants
 static bool use_tiled(const bsn_op *op) {
 #ifdef BSN_ABLATION
-  // the ablation variants exist on the plain image only (41 - 46: workgroup shapes on the tiled copy)
-  if (tune_variant() != 0 && !(tune_variant() >= 41 && tune_variant() <= 48) && !(tune_variant() >= 89 && tune_variant() <= 99)) return false;
+  if (tune_variant() != 0) return false;   // the profiling variants exist on the plain image only
 #endif
   return op->bed->d_tiled != nullptr && op->cols_contig && (op->col0 & 63) == 0;
 }
@@ -1637,203 +1374,76 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
   constexpr int KC = 512;
   // int32 accumulators over the whole sample range: a plane adds at most 4 * 128 per sample
   if (b->pitch * 4 > 4000000) fail("more than 4e6 samples are not supported by the crossproduct kernel");
-  dim3 grid((unsigned)((op->m + 255) / 256));
   const int32_t *cols = op->cols_contig ? nullptr : op->d_cols.p;
   const int32_t npad = (int32_t)(b->pitch * 4 - b->n);
+  const bool warm = op->prof_kind_override == 3;   // warm-start launches run under their own kernel name (TAG = 1)
+  // k_cprod<NB, NPLANE, KC, RAW0, STATS, CONTIG, ABL, TILES, WAVES, MINW, TAG, TILED, SGB> on `image`
+#define BSN_CPROD(NBV, CONTIGV, ABLV, TV, WV, TAGV, TILEDV, SGBV, image)                                              \
+  BSN_KLAUNCH((k_cprod<NBV, NPLANE, KC, RAW0, STATS, CONTIGV, ABLV, TV, WV, 1, TAGV, TILEDV, SGBV>),                  \
+              dim3((unsigned)((op->m + 16 * TV * WV - 1) / (16 * TV * WV))), dim3(64 * WV), 0, b->stream, image,      \
+              b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad)
+  // Shapes (profiles/r02_ablation.txt, r03_shape_sweeps.txt, r04_two_block_kernels.txt): one column block — 8 waves x 2
+  // tiles on the plain image, 8 x 4 on the tiled copy (2 % faster there; the counting variant needs 150 registers with
+  // 4 tiles and keeps 2); two column blocks — 16 waves x 2 tiles share one digit panel (half the L2 reads of it), with
+  // the explicit MFMA / decode interleave + raised priority through the MFMA phase (SGB = 3: 2 %).
   if (use_tiled(op)) {
-    // 4 tiles per wave on the tiled copy (a wave = one 64-variant block, 512 variants share a digit panel): 2 %
-    // faster than the 2-tile shape there, and slower on the plain image (profiles/r02_ablation.txt)
-#define BSN_LAUNCH_CPROD_T(NBV, TV, WV, TAGV)                                                                    \
-  BSN_KLAUNCH((k_cprod<NBV, NPLANE, KC, RAW0, STATS, true, 0, TV, WV, 1, TAGV, true, (NBV == 2 ? 3 : 0)>), \
-                     dim3((unsigned)((op->m + 16 * TV * WV - 1) / (16 * TV * WV))), dim3(64 * WV), 0, b->stream, \
-                     b->d_tiled, b->pitch, nullptr, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad)
-#ifdef BSN_ABLATION
-    // BSN_TUNE = 41 .. 48: (tiles per wave, waves, samples per chunk) on the tiled copy; correct results
-    // (48 = 2 x 8 x 512, the shape used on the plain image)
-    if (NB == 1 && tune_variant() >= 41 && tune_variant() <= 48 && op->prof_kind_override != 3) {
-#define BSN_SHAPE_T(TILESV, WAVESV, KCV)                                                                  \
-  BSN_KLAUNCH((k_cprod<1, NPLANE, KCV, RAW0, STATS, true, 0, TILESV, WAVESV, 1, 0, true>),         \
-                     dim3((unsigned)((op->m + 16 * TILESV * WAVESV - 1) / (16 * TILESV * WAVESV))),       \
-                     dim3(64 * WAVESV), 0, b->stream, b->d_tiled, b->pitch, nullptr, op->col0, op->m, q,  \
-                     acc, op->m, l0, l1, l2, counts, npad)
-      const int tv = tune_variant();
-      if (tv == 41) BSN_SHAPE_T(4, 4, 512);
-      else if (tv == 42) BSN_SHAPE_T(4, 8, 512);
-      else if (tv == 43) BSN_SHAPE_T(4, 2, 512);
-      else if (tv == 44) BSN_SHAPE_T(2, 8, 1024);
-      else if (tv == 45) BSN_SHAPE_T(4, 4, 1024);
-      else if (tv == 46) BSN_SHAPE_T(2, 16, 512);
-      else if (tv == 47) BSN_SHAPE_T(4, 16, 512);
-      else BSN_SHAPE_T(2, 8, 512);
-#undef BSN_SHAPE_T
-      BSN_HIP(hipGetLastError());
-      return;
-    }
-#endif
-    if (NB == 1) {
-      // (the counting variant needs 150 registers with 4 tiles - one workgroup per CU - and keeps 2)
-      constexpr int TV = STATS ? 2 : 4;
-      if (op->prof_kind_override == 3) BSN_LAUNCH_CPROD_T(1, TV, 8, 1);
-      else BSN_LAUNCH_CPROD_T(1, TV, 8, 0);
-    } else {
-#ifdef BSN_ABLATION
-      // BSN_TUNE = 91 .. 95: workgroup shapes of the two-column-block kernel on the tiled copy; correct results
-      if (tune_variant() >= 91 && tune_variant() <= 95) {
-#define BSN_SHAPE_T2(TILESV, WAVESV, KCV)                                                                 \
-  BSN_KLAUNCH((k_cprod<2, NPLANE, KCV, RAW0, STATS, true, 0, TILESV, WAVESV, 1, 0, true>),         \
-                     dim3((unsigned)((op->m + 16 * TILESV * WAVESV - 1) / (16 * TILESV * WAVESV))),       \
-                     dim3(64 * WAVESV), 0, b->stream, b->d_tiled, b->pitch, nullptr, op->col0, op->m, q,  \
-                     acc, op->m, l0, l1, l2, counts, npad)
-        const int tv = tune_variant();
-        if (tv == 91) BSN_SHAPE_T2(2, 8, 512);
-        else if (tv == 92) BSN_SHAPE_T2(4, 8, 512);
-        else if (tv == 93) BSN_SHAPE_T2(4, 4, 512);
-        else if (tv == 94) BSN_SHAPE_T2(2, 16, 1024);
-        else BSN_SHAPE_T2(4, 16, 512);
-#undef BSN_SHAPE_T2
-        BSN_HIP(hipGetLastError());
-        return;
-      }
-#endif
-      BSN_LAUNCH_CPROD_T(2, 2, 16, 0);
-    }
-#undef BSN_LAUNCH_CPROD_T
+    constexpr int TV = STATS ? 2 : 4;
+    if (NB == 1) { if (warm) BSN_CPROD(1, true, 0, TV, 8, 1, true, 0, b->d_tiled); else BSN_CPROD(1, true, 0, TV, 8, 0, true, 0, b->d_tiled); }
+    else BSN_CPROD(2, true, 0, 2, 16, 0, true, 3, b->d_tiled);
     BSN_HIP(hipGetLastError());
     return;
   }
-#define BSN_LAUNCH_CPROD_C(NBV, ABLV, CONTIGV)                                                          \
-  BSN_KLAUNCH((k_cprod<NBV, NPLANE, KC, RAW0, STATS, CONTIGV, ABLV, 2, 8, 1>), grid, dim3(512), 0, \
-                     b->stream, b->d_img, b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad)
-#define BSN_LAUNCH_CPROD(NBV, ABLV)                                                                       \
-  do {                                                                                                    \
-    if (op->cols_contig && op->prof_kind_override == 3)                                                   \
-      BSN_KLAUNCH((k_cprod<NBV, NPLANE, KC, RAW0, STATS, true, 0, 2, 8, 1, 1>), grid, dim3(512), 0, \
-                         b->stream, b->d_img, b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2, \
-                         counts, npad);                                                                   \
-    else if (op->cols_contig) BSN_LAUNCH_CPROD_C(NBV, ABLV, true);                                        \
-    else BSN_LAUNCH_CPROD_C(NBV, 0, false);                                                               \
-  } while (0)
 #ifdef BSN_ABLATION
-  // BSN_TUNE = 11 / 12 / 13 / 15 / 16 / 17 / 18 / 19: no MFMA / no decode / neither / no barrier /
-  // no LDS operand reads / no genotype loads / no LDS at all / compute only;
-  // 31 / 32 / 33: nt / sc1 / nt + sc1 cache policy on the genotype loads (correct results)
+  // BSN_TUNE (profiling variants; 11 .. 19 / 111 .. 119 compute wrong numbers by construction):
+  //   11 / 12 / 13 / 15 / 16 / 17 / 18 / 19   one column block: no MFMA / no decode / neither (memory skeleton) / no
+  //                                          barrier / no LDS operand reads / no genotype loads / no LDS at all / compute only
+  //   111 / 112 / 113 / 117 / 119            the same for two column blocks;  114: two blocks WITHOUT the explicit pipeline
+  //   121 / 123                              two blocks: pipeline alone / s_setprio alone (correct results)
   if constexpr (NPLANE == 2 && RAW0 && !STATS) {
     const int abl = tune_variant();
-    if (NB == 1 && abl >= 31 && abl <= 33) {
-      if (abl == 31) BSN_LAUNCH_CPROD(1, 64);
-      else if (abl == 32) BSN_LAUNCH_CPROD(1, 128);
-      else BSN_LAUNCH_CPROD(1, 192);
-      BSN_HIP(hipGetLastError());
-      return;
-    }
-    if (NB == 1 && abl >= 11 && abl <= 19) {
-      if (abl == 11) BSN_LAUNCH_CPROD(1, 1);
-      else if (abl == 12) BSN_LAUNCH_CPROD(1, 2);
-      else if (abl == 13) BSN_LAUNCH_CPROD(1, 3);
-      else if (abl == 15) BSN_LAUNCH_CPROD(1, 8);
-      else if (abl == 16) BSN_LAUNCH_CPROD(1, 16);
-      else if (abl == 17) BSN_LAUNCH_CPROD(1, 32);
-      else if (abl == 18) BSN_LAUNCH_CPROD(1, 24);
-      else BSN_LAUNCH_CPROD(1, 56);
-      BSN_HIP(hipGetLastError());
-      return;
-    }
-    // BSN_TUNE = 131 .. 137: k_cprod32 (32 x 32 x 32 MFMA) plain / pipelined / + s_setprio / operands swapped /
-    // 8-wave workgroups / s_setprio alone / swapped + pipelined (correct results, bit-identical)
-    if (NB == 2 && op->cols_contig && abl >= 131 && abl <= 137) {
-#define BSN_C32(WV, SGBV, SWAPV)                                                                                \
-  BSN_KLAUNCH((k_cprod32<NPLANE, STATS, WV, 0, SGBV, SWAPV>), dim3((unsigned)((op->m + 32 * WV - 1) / (32 * WV))), \
-                     dim3(64 * WV), 0, b->stream, b->d_img, b->pitch, op->col0, op->m, q, acc, op->m, l1, counts, npad)
-      if (abl == 131) BSN_C32(16, 0, false);
-      else if (abl == 132) BSN_C32(16, 1, false);
-      else if (abl == 133) BSN_C32(16, 3, false);
-      else if (abl == 134) BSN_C32(16, 0, true);
-      else if (abl == 135) BSN_C32(8, 0, false);
-      else if (abl == 136) BSN_C32(16, 2, false);
-      else BSN_C32(16, 1, true);
-#undef BSN_C32
-      BSN_HIP(hipGetLastError());
-      return;
-    }
-    // BSN_TUNE = 111 / 112 / 113 / 117 / 119: the same ablations of the two-column-block kernel;
-    // 121 / 122 / 123: its sched_group_barrier pipeline / + s_setprio / s_setprio alone (correct results)
-    if (NB == 2 && op->cols_contig && ((abl >= 111 && abl <= 119) || (abl >= 121 && abl <= 126))) {
-#define BSN_C2(ABLV, SGBV) BSN_C2S(ABLV, SGBV, false)
-#define BSN_C2S(ABLV, SGBV, SWAPV)                                                                           \
-  BSN_KLAUNCH((k_cprod<2, NPLANE, KC, RAW0, STATS, true, ABLV, 2, 16, 1, 0, false, SGBV, SWAPV>),     \
-                     dim3((unsigned)((op->m + 511) / 512)), dim3(1024), 0, b->stream, b->d_img, b->pitch,    \
-                     cols, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad)
-      if (abl == 111) BSN_C2(1, 0);
-      else if (abl == 112) BSN_C2(2, 0);
-      else if (abl == 113) BSN_C2(3, 0);
-      else if (abl == 117) BSN_C2(32, 0);
-      else if (abl == 119) BSN_C2(56, 0);
-      else if (abl == 121) BSN_C2(0, 1);
-      else if (abl == 122) BSN_C2(0, 3);
-      else if (abl == 123) BSN_C2(0, 2);
-      else if (abl == 124) BSN_C2S(0, 0, true);   // digits as the A operand
-      else if (abl == 125) BSN_C2S(0, 1, true);
-      else if (abl == 126) BSN_C2S(0, 3, true);
-      else BSN_C2(0, 0);
-#undef BSN_C2
-#undef BSN_C2S
-      BSN_HIP(hipGetLastError());
-      return;
-    }
-    if (NB == 1 && op->cols_contig && abl == 143) {   // one column block with the explicit pipeline + priority
-      BSN_KLAUNCH((k_cprod<1, NPLANE, KC, RAW0, STATS, true, 0, 2, 8, 1, 0, false, 3>), grid, dim3(512), 0,
-                         b->stream, b->d_img, b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad);
-      BSN_HIP(hipGetLastError());
-      return;
-    }
-    if (NB == 1 && op->cols_contig && (abl == 141 || abl == 142)) {   // one column block with the digits as the A operand
-      if (abl == 141)
-        BSN_KLAUNCH((k_cprod<1, NPLANE, KC, RAW0, STATS, true, 0, 2, 8, 1, 0, false, 0, true>), grid, dim3(512), 0,
-                           b->stream, b->d_img, b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad);
-      else
-        BSN_KLAUNCH((k_cprod<1, NPLANE, KC, RAW0, STATS, true, 0, 2, 8, 1, 0, false, 1, true>), grid, dim3(512), 0,
-                           b->stream, b->d_img, b->pitch, cols, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad);
-      BSN_HIP(hipGetLastError());
-      return;
-    }
-    // BSN_TUNE = 21 .. 27: workgroup shapes (tiles per wave, waves, samples per chunk); correct results
-    if (NB == 1 && abl >= 21 && abl <= 29 && op->cols_contig) {
-#define BSN_SHAPE(TILESV, WAVESV, KCV)                                                                    \
-  BSN_KLAUNCH((k_cprod<1, NPLANE, KCV, RAW0, STATS, true, 0, TILESV, WAVESV, 1>),                  \
-                     dim3((unsigned)((op->m + 16 * TILESV * WAVESV - 1) / (16 * TILESV * WAVESV))),       \
-                     dim3(64 * WAVESV), 0, b->stream, b->d_img, b->pitch, cols, op->col0, op->m, q, acc, \
-                     op->m, l0, l1, l2, counts, npad)
-      if (abl == 21) BSN_SHAPE(1, 8, 512);
-      else if (abl == 22) BSN_SHAPE(1, 8, 1024);
-      else if (abl == 23) BSN_SHAPE(2, 8, 1024);
-      else if (abl == 24) BSN_SHAPE(1, 16, 512);
-      else if (abl == 25) BSN_SHAPE(2, 4, 512);
-      else if (abl == 26) BSN_SHAPE(2, 16, 512);
-      else if (abl == 28) BSN_SHAPE(4, 8, 512);
-      else if (abl == 29) BSN_SHAPE(4, 4, 512);
-      else BSN_SHAPE(1, 16, 1024);
-#undef BSN_SHAPE
-      BSN_HIP(hipGetLastError());
-      return;
+    if (op->cols_contig && abl != 0) {
+      bool done = true;
+      if (NB == 1) {
+        switch (abl) {
+          case 11: BSN_CPROD(1, true, 1, 2, 8, 0, false, 0, b->d_img); break;
+          case 12: BSN_CPROD(1, true, 2, 2, 8, 0, false, 0, b->d_img); break;
+          case 13: BSN_CPROD(1, true, 3, 2, 8, 0, false, 0, b->d_img); break;
+          case 15: BSN_CPROD(1, true, 8, 2, 8, 0, false, 0, b->d_img); break;
+          case 16: BSN_CPROD(1, true, 16, 2, 8, 0, false, 0, b->d_img); break;
+          case 17: BSN_CPROD(1, true, 32, 2, 8, 0, false, 0, b->d_img); break;
+          case 18: BSN_CPROD(1, true, 24, 2, 8, 0, false, 0, b->d_img); break;
+          case 19: BSN_CPROD(1, true, 56, 2, 8, 0, false, 0, b->d_img); break;
+          default: done = false;
+        }
+      } else {
+        switch (abl) {
+          case 111: BSN_CPROD(2, true, 1, 2, 16, 0, false, 0, b->d_img); break;
+          case 112: BSN_CPROD(2, true, 2, 2, 16, 0, false, 0, b->d_img); break;
+          case 113: BSN_CPROD(2, true, 3, 2, 16, 0, false, 0, b->d_img); break;
+          case 114: BSN_CPROD(2, true, 0, 2, 16, 0, false, 0, b->d_img); break;
+          case 117: BSN_CPROD(2, true, 32, 2, 16, 0, false, 0, b->d_img); break;
+          case 119: BSN_CPROD(2, true, 56, 2, 16, 0, false, 0, b->d_img); break;
+          case 121: BSN_CPROD(2, true, 0, 2, 16, 0, false, 1, b->d_img); break;
+          case 123: BSN_CPROD(2, true, 0, 2, 16, 0, false, 2, b->d_img); break;
+          default: done = false;
+        }
+      }
+      if (done) {
+        BSN_HIP(hipGetLastError());
+        return;
+      }
     }
   }
 #endif
   if (NB == 1) {
-    BSN_LAUNCH_CPROD(1, 0);
+    if (!op->cols_contig) BSN_CPROD(1, false, 0, 2, 8, 0, false, 0, b->d_img);
+    else if (warm) BSN_CPROD(1, true, 0, 2, 8, 1, false, 0, b->d_img);
+    else BSN_CPROD(1, true, 0, 2, 8, 0, false, 0, b->d_img);
   } else {
-    // 16 waves share one digit panel: half the L2 reads of it (12.4 vs 12.8 ms on a 50 GB shard); explicit
-    // MFMA / decode interleave + raised priority through the MFMA phase (SGB = 3: 2 %, profiles/r04_sched.txt)
-    if (op->cols_contig)
-      BSN_KLAUNCH((k_cprod<2, NPLANE, KC, RAW0, STATS, true, 0, 2, 16, 1, 0, false, 3>),
-                         dim3((unsigned)((op->m + 511) / 512)), dim3(1024), 0, b->stream, b->d_img, b->pitch, cols,
-                         op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad);
-    else
-      BSN_KLAUNCH((k_cprod<2, NPLANE, KC, RAW0, STATS, false, 0, 2, 16, 1>),
-                         dim3((unsigned)((op->m + 511) / 512)), dim3(1024), 0, b->stream, b->d_img, b->pitch, cols,
-                         op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad);
+    if (op->cols_contig) BSN_CPROD(2, true, 0, 2, 16, 0, false, 3, b->d_img);
+    else BSN_CPROD(2, false, 0, 2, 16, 0, false, 0, b->d_img);
   }
-#undef BSN_LAUNCH_CPROD
-#undef BSN_LAUNCH_CPROD_C
+#undef BSN_CPROD
   BSN_HIP(hipGetLastError());
 }
 
@@ -1959,108 +1569,20 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
                         int64_t npad, uint32_t lutP, uint32_t lutQ, bool has_q) {
   bsn_bed *b = op->bed;
   const int32_t *cols = op->d_cols.p;
-#define BSN_LAUNCH_PROD(RAWP, HASQ, ABLV)                                                               \
-  BSN_KLAUNCH((k_prod<NB, CONTIG, RAWP, HASQ, 4, ABLV>), grid, dim3(256), 0, b->stream, b->d_img, \
-                     b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ)
+  const bool warm = op->prof_kind_override == 3;   // warm-start launches run under their own kernel name (TAG = 1)
+  // k_prod<NB, CONTIG, RAWP, HASQ, ABL, TAG, TILED> on `image`
+#define BSN_PROD(RAWP, HASQ, ABLV, TAGV, TILEDV, image)                                                        \
+  BSN_KLAUNCH((k_prod<NB, CONTIG, RAWP, HASQ, ABLV, TAGV, TILEDV>), grid, dim3(256), 0, b->stream, image,      \
+              b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ)
 #ifdef BSN_ABLATION
-  if constexpr (NB == 1 && CONTIG) {  // BSN_TUNE = 61 .. 64: no MFMA / no decode / memory skeleton / compute only
-    const int tv = tune_variant();
-    if (tv >= 81 && tv <= 83 && lutP == kLutRaw && has_q) {  // nt / sc1 / both on the genotype loads
-      if (tv == 81) BSN_LAUNCH_PROD(true, true, 64);
-      else if (tv == 82) BSN_LAUNCH_PROD(true, true, 128);
-      else BSN_LAUNCH_PROD(true, true, 192);
-      BSN_HIP(hipGetLastError());
-      return;
-    }
+  // BSN_TUNE = 61 .. 64 (one column block) / 161 .. 164 (two): no MFMA / no decode / memory skeleton / compute only
+  if constexpr (CONTIG) {
+    const int tv = tune_variant() - (NB == 2 ? 100 : 0);
     if (tv >= 61 && tv <= 64 && lutP == kLutRaw && has_q) {
-      if (tv == 61) BSN_LAUNCH_PROD(true, true, 1);
-      else if (tv == 62) BSN_LAUNCH_PROD(true, true, 2);
-      else if (tv == 63) BSN_LAUNCH_PROD(true, true, 3);
-      else BSN_LAUNCH_PROD(true, true, 32);
-      BSN_HIP(hipGetLastError());
-      return;
-    }
-    // BSN_TUNE = 77: XCD-aware slab placement on the tiled copy (needs a K split that is a multiple of 8: BSN_KY=16)
-    if (tv == 77 && lutP == kLutRaw && has_q && b->d_tiled && (op->col0 & 63) == 0 && grid.y % 8 == 0) {
-      BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 1, 2, 0, true, true>), dim3(grid.x * grid.y),
-                         dim3(256), 0, b->stream, b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP,
-                         lutQ);
-      BSN_HIP(hipGetLastError());
-      return;
-    }
-    // BSN_TUNE = 76: 8-wave workgroups on the tiled copy (two tiles per step share one digit panel)
-    if (tv == 76 && lutP == kLutRaw && has_q && b->d_tiled && (op->col0 & 63) == 0) {
-      BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 8, 0, 1, 2, 0, true>), dim3((grid.x + 1) / 2, grid.y),
-                         dim3(512), 0, b->stream, b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP,
-                         lutQ);
-      BSN_HIP(hipGetLastError());
-      return;
-    }
-    // BSN_TUNE = 74 / 75: three genotype register sets (prefetch three steps ahead) on the plain / tiled image
-    if ((tv == 74 || tv == 75) && lutP == kLutRaw && has_q) {
-      if (tv == 75 && b->d_tiled && (op->col0 & 63) == 0)
-        BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 1, 3, 0, true>), grid, dim3(256), 0, b->stream,
-                           b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
-      else
-        BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 1, 3>), grid, dim3(256), 0, b->stream, b->d_img,
-                           b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
-      BSN_HIP(hipGetLastError());
-      return;
-    }
-    // BSN_TUNE = 71 .. 73: samples decoded together 2 / 4, one register set; correct results
-    if (tv >= 71 && tv <= 73 && lutP == kLutRaw && has_q) {
-      if (tv == 71)
-        BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 2, 2>), grid, dim3(256), 0, b->stream, b->d_img,
-                           b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
-      else if (tv == 72)
-        BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 4, 2>), grid, dim3(256), 0, b->stream, b->d_img,
-                           b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
-      else
-        BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 1, 1>), grid, dim3(256), 0, b->stream, b->d_img,
-                           b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
-      BSN_HIP(hipGetLastError());
-      return;
-    }
-  }
-#endif
-#ifdef BSN_ABLATION
-  if constexpr (NB == 2 && CONTIG) {  // BSN_TUNE = 96 .. 98 on the tiled copy: 8-wave workgroups / 2 / 4 samples decoded together
-    const int tv = tune_variant();
-    // 161 .. 164: no MFMA / no decode / memory skeleton / compute only; 171 / 172 / 173: sched_group_barrier pipeline /
-    // + s_setprio / s_setprio alone (correct results), all on the plain image
-    if (((tv >= 161 && tv <= 164) || (tv >= 171 && tv <= 174)) && lutP == kLutRaw && has_q) {
-#define BSN_P2(ABLV, SGBV)                                                                                          \
-  BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, ABLV, 1, 2, 0, false, false, false, false, SGBV>), grid,    \
-                     dim3(256), 0, b->stream, b->d_img, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ)
-      if (tv == 161) BSN_P2(1, 0);
-      else if (tv == 162) BSN_P2(2, 0);
-      else if (tv == 163) BSN_P2(3, 0);
-      else if (tv == 164) BSN_P2(32, 0);
-      else if (tv == 171) BSN_P2(0, 1);
-      else if (tv == 172) BSN_P2(0, 3);
-      else if (tv == 174) BSN_P2(0, 4);   // codes as the A operand
-      else BSN_P2(0, 2);
-#undef BSN_P2
-      BSN_HIP(hipGetLastError());
-      return;
-    }
-    if (tv == 99 && lutP == kLutRaw && has_q && b->d_tiled && (op->col0 & 63) == 0) {  // three register sets
-      BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 1, 3, 0, true>), grid, dim3(256), 0, b->stream,
-                         b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
-      BSN_HIP(hipGetLastError());
-      return;
-    }
-    if (tv >= 96 && tv <= 98 && lutP == kLutRaw && has_q && b->d_tiled && (op->col0 & 63) == 0) {
-      if (tv == 96)
-        BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 8, 0, 1, 2, 0, true>), dim3((grid.x + 1) / 2, grid.y),
-                           dim3(512), 0, b->stream, b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP,
-                           lutQ);
-      else if (tv == 97)
-        BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 2, 2, 0, true>), grid, dim3(256), 0, b->stream,
-                           b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
-      else
-        BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 4, 2, 0, true>), grid, dim3(256), 0, b->stream,
-                           b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
+      if (tv == 61) BSN_PROD(true, true, 1, 0, false, b->d_img);
+      else if (tv == 62) BSN_PROD(true, true, 2, 0, false, b->d_img);
+      else if (tv == 63) BSN_PROD(true, true, 3, 0, false, b->d_img);
+      else BSN_PROD(true, true, 32, 0, false, b->d_img);
       BSN_HIP(hipGetLastError());
       return;
     }
@@ -2068,65 +1590,25 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
 #endif
   if constexpr (CONTIG) {
     if (use_tiled(op)) {  // streaming-layout copy: same arithmetic, contiguous 16-KB steps
-      // (BSN_TUNE = 90, ablation build: wave pairs that split the 16 sample positions (HALF): three waves per SIMD
-      // instead of two, but every wave still loads and shifts all 16 dwords — 30.9 ms against 24.2)
-#ifdef BSN_ABLATION
-      if (NB == 2 && tune_variant() == 89 && lutP == kLutRaw && op->prof_kind_override != 3) {  // lane halves, 4-wave workgroups
-        const dim3 g2(grid.x * 2, grid.y);
-        if (has_q)
-          BSN_KLAUNCH((k_prod<NB, true, true, true, 4, 0, 1, 2, 0, true, false, false, (NB == 2)>), g2, dim3(256), 0,
-                             b->stream, b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
-        else
-          BSN_KLAUNCH((k_prod<NB, true, true, false, 4, 0, 1, 2, 0, true, false, false, (NB == 2)>), g2, dim3(256), 0,
-                             b->stream, b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
-        BSN_HIP(hipGetLastError());
-        return;
-      }
-      const bool half = NB == 2 && tune_variant() == 90;
-#define BSN_LAUNCH_PROD_TH(RAWP, HASQ, TAGV)                                                                           \
-  BSN_KLAUNCH((k_prod<NB, true, RAWP, HASQ, 8, 0, 1, 2, TAGV, true, false, (NB == 2)>), grid, dim3(512), 0,     \
-                     b->stream, b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ)
-#else
-      constexpr bool half = false;
-#define BSN_LAUNCH_PROD_TH(RAWP, HASQ, TAGV) ((void)0)
-#endif
-#define BSN_LAUNCH_PROD_T(RAWP, HASQ, TAGV)                                                                     \
-  do {                                                                                                          \
-    if (half)                                                                                                   \
-      BSN_LAUNCH_PROD_TH(RAWP, HASQ, TAGV);                                                                     \
-    else                                                                                                        \
-      BSN_KLAUNCH((k_prod<NB, true, RAWP, HASQ, 4, 0, 1, 2, TAGV, true>), grid, dim3(256), 0, b->stream, \
-                         b->d_tiled, b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);             \
-  } while (0)
-      const bool warm = op->prof_kind_override == 3;
       if (lutP == kLutRaw) {
-        if (has_q) { if (warm) BSN_LAUNCH_PROD_T(true, true, 1); else BSN_LAUNCH_PROD_T(true, true, 0); }
-        else { if (warm) BSN_LAUNCH_PROD_T(true, false, 1); else BSN_LAUNCH_PROD_T(true, false, 0); }
+        if (has_q) { if (warm) BSN_PROD(true, true, 0, 1, true, b->d_tiled); else BSN_PROD(true, true, 0, 0, true, b->d_tiled); }
+        else { if (warm) BSN_PROD(true, false, 0, 1, true, b->d_tiled); else BSN_PROD(true, false, 0, 0, true, b->d_tiled); }
       } else {
-        if (has_q) BSN_LAUNCH_PROD_T(false, true, 0);
-        else BSN_LAUNCH_PROD_T(false, false, 0);
+        if (has_q) BSN_PROD(false, true, 0, 0, true, b->d_tiled);
+        else BSN_PROD(false, false, 0, 0, true, b->d_tiled);
       }
-#undef BSN_LAUNCH_PROD_T
-#undef BSN_LAUNCH_PROD_TH
       BSN_HIP(hipGetLastError());
       return;
     }
   }
-  if (lutP == kLutRaw && op->prof_kind_override == 3) {  // warm-start launch: same kernel under its own name
-    if (has_q)
-      BSN_KLAUNCH((k_prod<NB, CONTIG, true, true, 4, 0, 1, 2, 1>), grid, dim3(256), 0, b->stream, b->d_img,
-                         b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
-    else
-      BSN_KLAUNCH((k_prod<NB, CONTIG, true, false, 4, 0, 1, 2, 1>), grid, dim3(256), 0, b->stream, b->d_img,
-                         b->pitch, cols, op->col0, m_pad, mc, q, acc, npad, lutP, lutQ);
-  } else if (lutP == kLutRaw) {
-    if (has_q) BSN_LAUNCH_PROD(true, true, 0);
-    else BSN_LAUNCH_PROD(true, false, 0);
+  if (lutP == kLutRaw) {
+    if (has_q) { if (warm) BSN_PROD(true, true, 0, 1, false, b->d_img); else BSN_PROD(true, true, 0, 0, false, b->d_img); }
+    else { if (warm) BSN_PROD(true, false, 0, 1, false, b->d_img); else BSN_PROD(true, false, 0, 0, false, b->d_img); }
   } else {
-    if (has_q) BSN_LAUNCH_PROD(false, true, 0);
-    else BSN_LAUNCH_PROD(false, false, 0);
+    if (has_q) BSN_PROD(false, true, 0, 0, false, b->d_img);
+    else BSN_PROD(false, false, 0, 0, false, b->d_img);
   }
-#undef BSN_LAUNCH_PROD
+#undef BSN_PROD
   BSN_HIP(hipGetLastError());
 }
 
@@ -2149,8 +1631,8 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
   // Two column blocks over a contiguous range of variants that starts on a 512-variant chunk, and the handle has its
   // sample-major copy: the product runs as k_prodT (k_cprod's shape, contraction over the contiguous index).
   const bool smaj = b->bits == 2 && b->d_smaj != nullptr && op->cols_contig && (op->col0 & 511) == 0 && mode == 1 &&
-                    lutP == kLutRaw && lutQ == kLutNA && pick_nb((nvec < vmax ? nvec : vmax) * S) == 2 &&
-                    !getenv("BSN_NO_SMAJ");
+                    lutP == kLutRaw && lutQ == kLutNA && nvec <= vmax && pick_nb(nvec * S) == 2 &&
+                    !getenv("BSN_NO_SMAJ");   // (one launch of two column blocks: the geometry below is k_prodT's)
   const int64_t m_pad = round_up(op->m, smaj ? 512 : 64);
   VecMeta *meta = meta_buffer(op);
   // K split so that the grid has a few thousand workgroups
@@ -2178,7 +1660,6 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
       if (fill > best_fill + 1e-9) best_fill = fill, best = c;
     }
     ky = best;
-    if (const char *e = getenv("BSN_KY")) ky = std::max(1, std::min<int>(atoi(e), (int)nchunks));
     const int64_t ky_min2 = (m_pad + 2499999) / 2500000;
     if (ky < ky_min2) ky = (int)ky_min2;
     smaj_cps = (int)((nchunks + ky - 1) / ky);

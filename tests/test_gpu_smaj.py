@@ -69,6 +69,13 @@ def test_complete_data_and_solve(ba, monkeypatch):
         for f in ("d", "u", "v", "center", "scale"):
             np.testing.assert_array_equal(res[f], ref[f])
         assert (res["niter"], res["nops"]) == (ref["niter"], ref["nops"])
+        # several launches per pass (5 vectors x 7 slices = 28 + 7 digit columns: a two-block and a one-block launch):
+        # the copy exists but such a pass stays on k_prod — same numbers as without the copy
+        wide = ba.bed_randomSVD(gb, k=5, block=5, slices=7, tol=1e-8, return_uv=False)
+        monkeypatch.setenv("BSN_NO_SMAJ", "1")
+        wide0 = ba.bed_randomSVD(gb, k=5, block=5, slices=7, tol=1e-8, return_uv=False)
+        monkeypatch.delenv("BSN_NO_SMAJ")
+        np.testing.assert_array_equal(wide["d"], wide0["d"])
         gb.release_workspace()                               # frees the copy too; the next solve builds it again
         again = ba.bed_randomSVD(gb, k=k, block=16)
         assert again["tiled"] == 2

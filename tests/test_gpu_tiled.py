@@ -50,6 +50,7 @@ def test_products_bit_identical_on_the_tiled_copy(ba, orc, monkeypatch):
 @pytest.mark.parametrize("block", [0, 16])
 def test_solve_bit_identical_with_and_without_the_tiled_copy(ba, monkeypatch, block):
     n, m, k = 2500, 290000 if block == 0 else 9000, 6      # 290 000 variants: with the warm start
+    monkeypatch.setenv("BSN_NO_SMAJ", "1")                  # (the sample-major copy of 16-vector solves: tests/test_gpu_smaj.py)
     res = {}
     for tiled in (False, True):
         if tiled:
