@@ -87,6 +87,7 @@ SIGNATURES = {
     "bsn_mult_lin_reg": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, i64, f64p]),
     "bsn_bed_to_fbm": (C.c_int, [vp, i64p, i64, i64p, i64, u8p]),
     "bsn_bed_readbina": (C.c_int, [vp, u8p, u8p]),
+    "bsn_bed_is_streamed": (C.c_int, [vp]),
     "bsn_bed_streaming_kernels": (C.c_int, [vp, C.c_char_p, i64]),
     "bsn_bed_subset_payload": (C.c_int, [vp, i64p, i64, i64p, i64, u8p]),
     "bsn_op_create": (C.c_int, [vp, i64p, i64, i64p, i64, f64p, f64p, C.POINTER(vp)]),

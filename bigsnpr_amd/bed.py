@@ -174,6 +174,12 @@ class bed:
         check(_lib.load().bsn_bed_tile(self.handle, C.byref(built)))
         return bool(built.value)
 
+    @property
+    def streamed(self):
+        """True for an out-of-core handle: the image did not fit the device (or BSN_IMAGE_BUDGET) when the file was
+        opened; products, counts and the accessor then walk the mapped file in slabs (bsn_bed_is_streamed)"""
+        return bool(_lib.load().bsn_bed_is_streamed(self.handle))
+
     def release_workspace(self):
         """bsn_bed_release_workspace: the solve's workspace, the second copies of the image and the cached work buffers"""
         check(_lib.load().bsn_bed_release_workspace(self.handle))

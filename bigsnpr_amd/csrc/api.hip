@@ -377,6 +377,7 @@ void bed_free(bsn_bed *b) {
     if (b->ev_stage[i]) (void)hipEventDestroy(b->ev_stage[i]);
   }
   if (b->d_img) (void)hipFree(b->d_img);
+  if (b->map_base) (void)munmap(b->map_base, b->map_len);
   if (b->d_tiled) (void)hipFree(b->d_tiled);
   if (b->d_smaj) (void)hipFree(b->d_smaj);
   if (b->d_lut) (void)hipFree(b->d_lut);
@@ -397,6 +398,7 @@ void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n, const 
              int64_t m, const double *center, const double *scale, bool defer_scale) {
   if (n <= 0 || m <= 0) fail("'ind.row' and 'ind.col' can't be empty.");
   if (bed->n >= (int64_t)1 << 31 || bed->m >= (int64_t)1 << 31) fail("dimension too large");
+  require_resident(bed, "this function");
   BSN_HIP(hipSetDevice(bed->device));
   op->bed = bed;
   op->n = n;
@@ -471,8 +473,62 @@ static void counts_device(bsn_op *op, const int64_t *ind_row, int64_t n, int32_t
 }
 
 // the same into a host 4 x m int32 array
+void require_resident(const bsn_bed *b, const char *what) {
+  if (b->streamed())
+    fail("%s needs the genotype image resident on the device: this handle streams its file (%.1f GB do not fit the device "
+         "memory that was free when it was opened); bed_prodVec, bed_cprodVec, counts / colstats / MAF / scaleBinom and the "
+         "`[` accessor are served out of core",
+         what, (double)b->m * (double)b->pitch / 1e9);
+}
+
+// ---- out-of-core handles: the one-shot entry points over slabs of variants --------------------------------------
+// The selected variants are grouped by slab (order inside a slab = order in ind_col); `f(slab image, positions in
+// ind_col, local variant indices)` runs per non-empty slab on a resident image of that slab, in ascending slab order.
+namespace {
+struct SlabWalk {
+  bsn_bed *bed;
+  std::unique_ptr<bsn_bed, void (*)(bsn_bed *)> img;
+  SlabWalk(bsn_bed *b) : bed(b), img(new bsn_bed(), bed_free) {
+    BSN_HIP(hipSetDevice(b->device));
+    image_alloc(img.get(), b->n, b->slab_cols);
+  }
+  template <class F>
+  void run(const int64_t *ind_col, int64_t m, F f) {
+    const int64_t nslab = (bed->m + bed->slab_cols - 1) / bed->slab_cols;
+    std::vector<std::vector<int64_t>> pos((size_t)nslab);
+    for (int64_t p = 0; p < m; p++) {
+      const int64_t c = ind_col ? ind_col[p] : p;
+      if (c < 0 || c >= bed->m) fail("Tested %lld < %lld. Subscript out of bounds (ind.col).", (long long)c, (long long)bed->m);
+      pos[(size_t)(c / bed->slab_cols)].push_back(p);
+    }
+    std::vector<int64_t> local;
+    for (int64_t sl = 0; sl < nslab; sl++) {
+      const std::vector<int64_t> &P = pos[(size_t)sl];
+      if (P.empty()) continue;
+      const int64_t j0 = sl * bed->slab_cols, cnt = std::min(bed->slab_cols, bed->m - j0);
+      img->m = cnt;
+      img->na_cnt.clear();
+      image_from_host(img.get(), bed->h_map + j0 * bed->n_byte, bed->n_byte);   // upload + recode + zero pad rows
+      local.resize(P.size());
+      for (size_t k = 0; k < P.size(); k++) local[k] = (ind_col ? ind_col[P[k]] : P[k]) - j0;
+      f(img.get(), P, local);
+    }
+  }
+};
+}  // namespace
+
 void counts_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
                  int64_t m, int32_t *res) {
+  if (bed->streamed()) {
+    SlabWalk W(bed);
+    std::vector<int32_t> part;
+    W.run(ind_col, m, [&](bsn_bed *sb, const std::vector<int64_t> &P, const std::vector<int64_t> &local) {
+      part.resize(4 * P.size());
+      counts_host(sb, ind_row, n, local.data(), (int64_t)local.size(), part.data());
+      for (size_t k = 0; k < P.size(); k++) std::memcpy(res + 4 * P[k], part.data() + 4 * k, 16);
+    });
+    return;
+  }
   bsn_op op;
   fill_op(&op, bed, ind_row, n, ind_col, m, nullptr, nullptr, true);
   DevBuf<int32_t> d_counts;
@@ -600,11 +656,39 @@ int bsn_bed_open(const char *path, int64_t n, int64_t m, bsn_bed **out) {
       fail("n or p does not match the dimensions of the file.");
     require_gpu();
     std::unique_ptr<bsn_bed, void (*)(bsn_bed *)> b(new bsn_bed(), free_bed);
-    image_alloc(b.get(), n, m);
-    image_from_file(b.get(), fd, 3, n_byte);
+    // does the image fit?  free device memory less 2 GB of working room, or BSN_IMAGE_BUDGET (bytes)
+    const int64_t pitch = round_up(n_byte, 256);
+    const double image_bytes = (double)(m + 64) * (double)pitch;
+    size_t free_b = 0, total_b = 0;
+    BSN_HIP(hipMemGetInfo(&free_b, &total_b));
+    double budget = (double)(free_b + dev_cache_held()) - 2e9;
+    if (const char *e = getenv("BSN_IMAGE_BUDGET")) budget = atof(e);
+    if (image_bytes <= budget) {
+      image_alloc(b.get(), n, m);
+      image_from_file(b.get(), fd, 3, n_byte);
+      *out = b.release();
+      return;
+    }
+    // out-of-core: keep the file mapped, walk it in slabs (bsn_internal.hpp)
+    void *map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (map == MAP_FAILED) fail("Error when mapping file:\n  %s.\n", strerror(errno));
+    image_alloc(b.get(), n, 1);   // stream, events, geometry; no variants resident
+    (void)hipFree(b->d_img);
+    b->d_img = nullptr;
+    b->m = m;
+    b->map_base = map;
+    b->map_len = size;
+    b->h_map = (const uint8_t *)map + 3;
+    b->slab_cols = std::max<int64_t>(64, (int64_t)(std::max(budget, 0.0) / (double)pitch) / 64 * 64 - 64);
+    if (b->slab_cols > m) b->slab_cols = round_up(m, 64);
+    if (getenv("BSN_VERBOSE"))
+      std::fprintf(stderr, "[bsn] %s: image of %.1f GB does not fit (%.1f GB available): out-of-core handle, slabs of %lld variants\n",
+                   path, image_bytes / 1e9, budget / 1e9, (long long)b->slab_cols);
     *out = b.release();
   });
 }
+
+int bsn_bed_is_streamed(const bsn_bed *bed) { return bed->streamed() ? 1 : 0; }
 
 // FBM.code256 -> device image.  The 256 decoded values decide the image kind:
 //   all of them in {0, 1, 2, NA}          -> 2-bit image (CODE_012, CODE_IMPUTE_PRED, ...): every entry point
@@ -817,6 +901,10 @@ int64_t bsn_bed_bytes(const bsn_bed *bed) { return bed->pitch * bed->m; }
 int bsn_bed_download(bsn_bed *bed, uint8_t *payload_out) {
   return guarded([&] {
     BSN_HIP(hipSetDevice(bed->device));
+    if (bed->streamed()) {   // the payload is the mapped file itself
+      std::memcpy(payload_out, bed->h_map, (size_t)bed->n_byte * (size_t)bed->m);
+      return;
+    }
     image_download(bed, payload_out);
   });
 }
@@ -869,6 +957,35 @@ int bsn_op_sync(bsn_op *op) {
 static void matvec_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
                         int64_t m, const double *center, const double *scale, const double *x,
                         double *out, bool transpose, bsn_comm *comm = nullptr) {
+  if (bed->streamed()) {
+    // out of core: A~' x slab by slab is the result slab by slab; A~ x is the sum of the slabs' products (added on the
+    // host in ascending slab order: deterministic)
+    if (comm) fail("sharded products are not available for an out-of-core handle");
+    SlabWalk W(bed);
+    std::vector<double> ce, sc, xs, part;
+    if (!transpose) std::fill(out, out + n, 0.0);
+    W.run(ind_col, m, [&](bsn_bed *sb, const std::vector<int64_t> &P, const std::vector<int64_t> &local) {
+      const int64_t k = (int64_t)P.size();
+      if (center) { ce.resize((size_t)k); for (int64_t t = 0; t < k; t++) ce[(size_t)t] = center[P[(size_t)t]]; }
+      if (scale) { sc.resize((size_t)k); for (int64_t t = 0; t < k; t++) sc[(size_t)t] = scale[P[(size_t)t]]; }
+      if (transpose) {
+        part.resize((size_t)k);
+        matvec_host(sb, ind_row, n, local.data(), k, center ? ce.data() : nullptr, scale ? sc.data() : nullptr, x,
+                    part.data(), true);
+        BSN_HIP(hipStreamSynchronize(sb->stream));
+        for (int64_t t = 0; t < k; t++) out[P[(size_t)t]] = part[(size_t)t];
+      } else {
+        xs.resize((size_t)k);
+        for (int64_t t = 0; t < k; t++) xs[(size_t)t] = x[P[(size_t)t]];
+        part.resize((size_t)n);
+        matvec_host(sb, ind_row, n, local.data(), k, center ? ce.data() : nullptr, scale ? sc.data() : nullptr, xs.data(),
+                    part.data(), false);
+        BSN_HIP(hipStreamSynchronize(sb->stream));
+        for (int64_t i = 0; i < n; i++) out[i] += part[(size_t)i];
+      }
+    });
+    return;
+  }
   bsn_op op;
   // A~' x needs centre / scale only in its finalize kernel: their upload is queued on the second stream and runs
   // beside the streaming kernel (2-bit image; the byte and look-up kernels read them earlier)
@@ -1034,6 +1151,26 @@ static void read_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int
                       int32_t *out_i, double *out_d) {
   if (n <= 0 || m <= 0) fail("'ind.row' and 'ind.col' can't be empty.");
   BSN_HIP(hipSetDevice(bed->device));
+  if (bed->streamed()) {   // out of core: the columns of every slab, placed where ind.col has them
+    SlabWalk W(bed);
+    std::vector<int32_t> pi;
+    std::vector<double> pd, ce, sc;
+    W.run(ind_col, m, [&](bsn_bed *sb, const std::vector<int64_t> &P, const std::vector<int64_t> &local) {
+      const int64_t k = (int64_t)P.size();
+      if (center) { ce.resize((size_t)k); for (int64_t t = 0; t < k; t++) ce[(size_t)t] = center[P[(size_t)t]]; }
+      if (scale) { sc.resize((size_t)k); for (int64_t t = 0; t < k; t++) sc[(size_t)t] = scale[P[(size_t)t]]; }
+      if (out_i) pi.resize((size_t)(n * k));
+      if (out_d) pd.resize((size_t)(n * k));
+      read_host(sb, ind_row, n, local.data(), k, center ? ce.data() : nullptr, scale ? sc.data() : nullptr, na_val,
+                out_i ? pi.data() : nullptr, out_d ? pd.data() : nullptr);
+      BSN_HIP(hipStreamSynchronize(sb->stream));
+      for (int64_t t = 0; t < k; t++) {
+        if (out_i) std::memcpy(out_i + P[(size_t)t] * n, pi.data() + t * n, (size_t)n * 4);
+        if (out_d) std::memcpy(out_d + P[(size_t)t] * n, pd.data() + t * n, (size_t)n * 8);
+      }
+    });
+    return;
+  }
   auto r = to_i32(ind_row, n, bed->n, "ind.row");
   auto c = to_i32(ind_col, m, bed->m, "ind.col");
   DevBuf<int32_t> d_r, d_c, d_oi;

@@ -205,6 +205,17 @@ struct bsn_bed {
   // instead of two), and the 512 samples x 128 B a workgroup reads per chunk are one contiguous 64-KB run — DESIGN.md
   // 3.3b.  Built once per handle by a solve on the two-block kernels when the device has the room (image + 24 GB),
   // freed with the handle / bsn_bed_release_workspace.  BSN_NO_SMAJ=1 forbids it.
+  // Out-of-core handle (round 4).  A .bed file whose 2-bit image does not fit the free device memory (or the budget
+  // BSN_IMAGE_BUDGET, bytes) is not refused — the reference maps a file of any size (src/bed-acc.h:46,
+  // src/bed-acc-xptr.cpp:14-35): the file stays mapped (h_map = its payload), d_img is NULL, and the one-shot entry
+  // points (bed_prodVec, bed_cprodVec, column counts / colstats / MAF / scaleBinom) walk it in slabs of `slab_cols`
+  // variants, each uploaded into one resident slab image and served by the same kernels: PCIe-bound (~30 GB/s)
+  // instead of HBM-bound.  Every other entry point names the reason it needs a resident image.
+  const uint8_t *h_map = nullptr;   // first payload byte of the mapped file
+  void *map_base = nullptr;
+  size_t map_len = 0;
+  int64_t slab_cols = 0;
+  bool streamed() const { return d_img == nullptr && h_map != nullptr; }
   uint8_t *d_smaj = nullptr;
   int64_t pitch_smaj = 0, rows_smaj = 0;
   bool smaj_tried = false;
@@ -324,6 +335,8 @@ struct RoctxRange {
   RoctxRange(const RoctxRange &) = delete;
   RoctxRange &operator=(const RoctxRange &) = delete;
 };
+// api.hip: fails with the reason when `b` is an out-of-core handle (bsn_bed::streamed)
+void require_resident(const bsn_bed *b, const char *what);
 void prof_begin(bsn_op *op, int kind);
 void prof_end(bsn_op *op);
 // sums the recorded launches: ms[kind], count[kind]; clears the records

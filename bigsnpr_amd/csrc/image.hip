@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void k_tile_image(const uint8_t *__restrict__ 
 
 bool image_tile(bsn_bed *b) {
   if (b->d_tiled) return true;
+  if (b->streamed()) return false;
   if (b->tiled_tried || b->bits != 2 || getenv("BSN_NO_TILED")) return false;
   b->tiled_tried = true;
   BSN_HIP(hipSetDevice(b->device));
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(512) void k_smaj_build(const uint8_t *__restrict__ 
 
 bool image_smaj(bsn_bed *b) {
   if (b->d_smaj) return true;
+  if (b->streamed()) return false;
   if (b->smaj_tried || b->bits != 2 || getenv("BSN_NO_SMAJ")) return false;
   b->smaj_tried = true;
   BSN_HIP(hipSetDevice(b->device));
@@ -830,6 +832,7 @@ __global__ void k_gather_image(const uint8_t *img, int64_t pitch, int bits, cons
 bsn_bed *image_gather(bsn_bed *src, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m) {
   if (n <= 0 || m <= 0) fail("'ind.row' and 'ind.col' can't be empty.");
   if (src->generic) fail("internal: image_gather on a look-up image");
+  require_resident(src, "a row list with repeated samples");
   BSN_HIP(hipSetDevice(src->device));
   std::vector<int32_t> rows((size_t)n), cols((size_t)m);
   for (int64_t i = 0; i < n; i++) {
@@ -863,6 +866,7 @@ bsn_bed *image_gather(bsn_bed *src, const int64_t *ind_row, int64_t n, const int
 void to_bytes(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t m,
               uint8_t *d_out) {
   require_bits(b, 2, "readbina2");
+  require_resident(b, "readbina2");
   int64_t gy = m < 65535 ? m : 65535, gz = (m + 65534) / 65535;
   hipLaunchKernelGGL(k_to_bytes, dim3((unsigned)((n + 255) / 256), (unsigned)gy, (unsigned)gz), dim3(256),
                      0, b->stream, b->d_img, b->pitch, d_rows, n, d_cols, m, d_out);
@@ -871,6 +875,7 @@ void to_bytes(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_col
 
 void readbina_bytes(bsn_bed *b, const uint8_t *d_tab, uint8_t *d_out) {
   require_bits(b, 2, "readbina");
+  require_resident(b, "readbina");
   const int64_t nb = (b->n + 3) / 4;
   int64_t gy = b->m < 65535 ? b->m : 65535, gz = (b->m + 65534) / 65535;
   hipLaunchKernelGGL(k_readbina, dim3((unsigned)((nb + 255) / 256), (unsigned)gy, (unsigned)gz), dim3(256), 0,
@@ -881,6 +886,7 @@ void readbina_bytes(bsn_bed *b, const uint8_t *d_tab, uint8_t *d_out) {
 void subset_pack(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t m,
                  uint8_t *d_out) {
   require_bits(b, 2, "writebina");
+  require_resident(b, "writebina");
   int64_t nb = (n + 3) / 4;
   int64_t gy = m < 65535 ? m : 65535, gz = (m + 65534) / 65535;
   hipLaunchKernelGGL(k_subset_pack, dim3((unsigned)((nb + 255) / 256), (unsigned)gy, (unsigned)gz),

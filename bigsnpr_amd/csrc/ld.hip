@@ -839,6 +839,7 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
                        bool two_sided = false, bool allow_chunks = false, double out_bytes_per_entry = 0.0) {
   if (n <= 0 || m <= 0) fail("'ind.row' and 'ind.col' can't be empty.");
   refuse_generic(bed, "windowed LD (snp_cor / snp_ld_scores / snp_clumping)");
+  require_resident(bed, "windowed LD (snp_cor / snp_ld_scores / snp_clumping)");
   BSN_HIP(hipSetDevice(bed->device));
   J.bed = bed;
   J.n = n;

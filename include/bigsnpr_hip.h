@@ -48,6 +48,12 @@ int bsn_selftest(void);
  * file.", "Variant-major is the only mode supported.", "n or p does not match the
  * dimensions of the file." */
 int bsn_bed_open(const char *path, int64_t n, int64_t m, bsn_bed **out);
+/* 1 if the handle is OUT OF CORE (round 4): the file's 2-bit image did not fit the free device memory (or the budget
+ * BSN_IMAGE_BUDGET, bytes) when bsn_bed_open was called, so the file stays mapped and bsn_bed_prodvec, bsn_bed_cprodvec,
+ * bsn_bed_col_counts and bsn_bed_colstats walk it in slabs of variants (PCIe-bound instead of HBM-bound; same kernels,
+ * same results).  The reference maps a file of any size (src/bed-acc.h:46); every other entry point refuses such a
+ * handle with the reason. */
+int bsn_bed_is_streamed(const bsn_bed *bed);
 /* same, from a payload already in host memory (n_byte = bytes per variant, >= ceil(n/4)) */
 int bsn_bed_from_host(const uint8_t *payload, int64_t n, int64_t m, int64_t n_byte, bsn_bed **out);
 /* FBM.code256 (bigstatsr, one byte per genotype, column-major, n_total rows) with the

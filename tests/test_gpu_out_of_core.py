@@ -1,0 +1,62 @@
+"""Out-of-core handles (round 4): a .bed whose image does not fit the device is not refused — the reference maps a file
+of any size (src/bed-acc.h:46, src/bed-acc-xptr.cpp:14-35) — but walked in slabs of variants by the one-shot entry
+points.  BSN_IMAGE_BUDGET forces the path on the reference's own example files with slabs of 64 variants: counts,
+colstats, MAF, scaling, the `[` accessor and bed_cprodVec are IDENTICAL to the resident handle's (same kernels on the
+same bytes), bed_prodVec — a sum over the slabs instead of one pass — agrees to 1e-13 and with the oracle; everything
+else names the reason it needs a resident image."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ba():
+    import bigsnpr_amd
+    return bigsnpr_amd
+
+
+@pytest.mark.parametrize("name", ["example-missing.bed", "example.bed"])
+def test_streamed_handle_equals_resident(ba, orc, golden_dir, monkeypatch, name):
+    path = os.path.join(golden_dir, name)
+    res = ba.bed(path)
+    assert not res.streamed
+    pitch = (res.nrow + 3) // 4 + 255 & ~255
+    monkeypatch.setenv("BSN_IMAGE_BUDGET", str(130 * pitch))          # room for 64 variants (+ the pad rows) per slab
+    ooc = ba.bed(path)
+    monkeypatch.delenv("BSN_IMAGE_BUDGET")
+    assert ooc.streamed and (ooc.nrow, ooc.ncol) == (res.nrow, res.ncol)
+    ob = orc.BedFile(path)
+    n, m = res.nrow, res.ncol
+    rng = np.random.default_rng(2)
+    ir = np.sort(rng.choice(n, n - 11, replace=False))
+    for ic in (None, np.sort(rng.choice(m, m // 3, replace=False)), rng.permutation(m)[: m // 2]):
+        kw = dict(ind_row=ir, ind_col=ic)
+        np.testing.assert_array_equal(ba.bed_counts(ooc, **kw), ba.bed_counts(res, **kw))
+        a, b = ba.bed_colstats(ooc, **kw), ba.bed_colstats(res, **kw)
+        for f in ("sumX", "denoX", "nb_nona_col"):
+            np.testing.assert_array_equal(a[f], b[f])
+        np.testing.assert_array_equal(ba.bed_MAF(ooc, **kw)["maf"], ba.bed_MAF(res, **kw)["maf"])
+        sc = ba.bed_scaleBinom(res, **kw)
+        sc2 = ba.bed_scaleBinom(ooc, **kw)
+        np.testing.assert_array_equal(sc2["center"], sc["center"])
+        np.testing.assert_array_equal(sc2["scale"], sc["scale"])
+        mm = m if ic is None else ic.size
+        ce, sa = sc["center"], np.where(sc["scale"] > 0, sc["scale"], 1.0)
+        y, x = rng.normal(size=ir.size), rng.normal(size=mm)
+        np.testing.assert_array_equal(ba.bed_cprodVec(ooc, y, ir, ic, ce, sa), ba.bed_cprodVec(res, y, ir, ic, ce, sa))
+        p1, p0 = ba.bed_prodVec(ooc, x, ir, ic, ce, sa), ba.bed_prodVec(res, x, ir, ic, ce, sa)
+        assert np.abs(p1 - p0).max() <= 1e-13 * np.abs(p0).max()
+        cols = np.arange(m) if ic is None else ic
+        ref = orc.bed_prodVec(ob, x, ir, cols, ce, sa, 4)
+        assert np.abs(p1 - ref).max() <= 1e-9 * np.abs(ref).max()
+    # the accessor, columns across slab borders in any order
+    rows, cols = np.array([5, 0, 17, 17, n - 1]), np.array([m - 1, 63, 64, 0, 200, 65])
+    np.testing.assert_array_equal(ooc[rows, cols], res[rows, cols])
+    np.testing.assert_array_equal(ooc.download(), res.download())
+    # what needs a resident image says so
+    for call in (lambda: ba.bed_randomSVD(ooc, k=3), lambda: ba.bed_cor(ooc, size=10), lambda: ba.bed_tcrossprodSelf(ooc)):
+        with pytest.raises(ba.BsnError, match="streams its file"):
+            call()
