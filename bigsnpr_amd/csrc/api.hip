@@ -378,6 +378,7 @@ void bed_free(bsn_bed *b) {
   }
   if (b->d_img) (void)hipFree(b->d_img);
   if (b->map_base) (void)munmap(b->map_base, b->map_len);
+  if (b->fd_file >= 0) (void)close(b->fd_file);
   if (b->d_tiled) (void)hipFree(b->d_tiled);
   if (b->d_smaj) (void)hipFree(b->d_smaj);
   if (b->d_lut) (void)hipFree(b->d_lut);
@@ -508,7 +509,8 @@ struct SlabWalk {
       const int64_t j0 = sl * bed->slab_cols, cnt = std::min(bed->slab_cols, bed->m - j0);
       img->m = cnt;
       img->na_cnt.clear();
-      image_from_host(img.get(), bed->h_map + j0 * bed->n_byte, bed->n_byte);   // upload + recode + zero pad rows
+      // upload (pread into pinned buffers, double-buffered against the DMA) + recode + zero pad rows
+      image_from_file(img.get(), bed->fd_file, 3 + j0 * bed->n_byte, bed->n_byte);
       local.resize(P.size());
       for (size_t k = 0; k < P.size(); k++) local[k] = (ind_col ? ind_col[P[k]] : P[k]) - j0;
       f(img.get(), P, local);
@@ -679,6 +681,8 @@ int bsn_bed_open(const char *path, int64_t n, int64_t m, bsn_bed **out) {
     b->map_base = map;
     b->map_len = size;
     b->h_map = (const uint8_t *)map + 3;
+    b->fd_file = dup(fd);
+    if (b->fd_file < 0) fail("Error when mapping file:\n  %s.\n", strerror(errno));
     b->slab_cols = std::max<int64_t>(64, (int64_t)(std::max(budget, 0.0) / (double)pitch) / 64 * 64 - 64);
     if (b->slab_cols > m) b->slab_cols = round_up(m, 64);
     if (getenv("BSN_VERBOSE"))

@@ -215,6 +215,7 @@ struct bsn_bed {
   void *map_base = nullptr;
   size_t map_len = 0;
   int64_t slab_cols = 0;
+  int fd_file = -1;                 // the open file: slabs are read through the pinned double-buffered upload of image_from_file
   bool streamed() const { return d_img == nullptr && h_map != nullptr; }
   uint8_t *d_smaj = nullptr;
   int64_t pitch_smaj = 0, rows_smaj = 0;

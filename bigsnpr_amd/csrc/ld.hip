@@ -241,6 +241,9 @@ __global__ __launch_bounds__(256) void k_pair_stats(const uint8_t *__restrict__ 
 // 60 % of its bandwidth at three workgroups per CU.
 // pairs: (index of the 128-variant row block, index of the 32-variant column block); fused fp64 epilogue.
 constexpr int TR = 128, TC = 32;
+// (Round 4: an explicit MFMA : VALU schedule through __builtin_amdgcn_sched_group_barrier, as in k_cprod — 1 or 2 VALU
+// offered behind every MFMA, the column operand's decode pulled into the last K-step — needs 210 registers, and forced
+// back to 168 for the third wave it runs 422 - 434 ms against 292 at C5: profiles/r04_ld.txt.  Not kept.)
 __global__ __launch_bounds__(256, 2) void k_pair_stats_b(const uint8_t *__restrict__ img, int64_t pitch,
                                                       const int32_t *__restrict__ cols,
                                                       const int2 *__restrict__ pairs,
