@@ -16,11 +16,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def kind_of(name):
-    m = re.match(r"(?:void )?bsn::(k_c?prod)<(.*)>$", name)
+    m = re.match(r"(?:void )?bsn::(k_c?prodT?)<(.*)>$", name)
     if not m:
         return None
     args = [a.strip() for a in m.group(2).split(",")]
-    if m.group(1) == "k_prod":
+    if m.group(1) in ("k_prod", "k_prodT"):   # k_prodT: the product on the sample-major copy (two column blocks)
         return "prod"
     return "cprod_stats" if args[4] == "true" else "cprod"     # k_cprod<NB, NPLANE, KC, RAW0, STATS, ...>
 
