@@ -379,6 +379,8 @@ void bed_free(bsn_bed *b) {
   if (b->d_img) (void)hipFree(b->d_img);
   if (b->map_base) (void)munmap(b->map_base, b->map_len);
   if (b->fd_file >= 0) (void)close(b->fd_file);
+  if (b->slab_stage) delete (bsn::FileStage *)b->slab_stage;
+  if (b->slab_img) bed_free(b->slab_img);
   if (b->d_tiled) (void)hipFree(b->d_tiled);
   if (b->d_smaj) (void)hipFree(b->d_smaj);
   if (b->d_lut) (void)hipFree(b->d_lut);
@@ -488,10 +490,18 @@ void require_resident(const bsn_bed *b, const char *what) {
 namespace {
 struct SlabWalk {
   bsn_bed *bed;
-  std::unique_ptr<bsn_bed, void (*)(bsn_bed *)> img;
-  SlabWalk(bsn_bed *b) : bed(b), img(new bsn_bed(), bed_free) {
+  bsn_bed *img;        // the resident slab image: kept on the handle between calls, like its staging buffers
+  FileStage *stage;
+  SlabWalk(bsn_bed *b) : bed(b) {
     BSN_HIP(hipSetDevice(b->device));
-    image_alloc(img.get(), b->n, b->slab_cols);
+    if (!b->slab_img) {
+      std::unique_ptr<bsn_bed, void (*)(bsn_bed *)> im(new bsn_bed(), bed_free);
+      image_alloc(im.get(), b->n, b->slab_cols);
+      b->slab_img = im.release();
+    }
+    if (!b->slab_stage) b->slab_stage = new FileStage();
+    img = b->slab_img;
+    stage = (FileStage *)b->slab_stage;
   }
   template <class F>
   void run(const int64_t *ind_col, int64_t m, F f) {
@@ -510,10 +520,10 @@ struct SlabWalk {
       img->m = cnt;
       img->na_cnt.clear();
       // upload (pread into pinned buffers, double-buffered against the DMA) + recode + zero pad rows
-      image_from_file(img.get(), bed->fd_file, 3 + j0 * bed->n_byte, bed->n_byte);
+      image_from_file(img, bed->fd_file, 3 + j0 * bed->n_byte, bed->n_byte, stage);
       local.resize(P.size());
       for (size_t k = 0; k < P.size(); k++) local[k] = (ind_col ? ind_col[P[k]] : P[k]) - j0;
-      f(img.get(), P, local);
+      f(img, P, local);
     }
   }
 };

@@ -216,6 +216,8 @@ struct bsn_bed {
   size_t map_len = 0;
   int64_t slab_cols = 0;
   int fd_file = -1;                 // the open file: slabs are read through the pinned double-buffered upload of image_from_file
+  bsn_bed *slab_img = nullptr;      // the resident slab image and its staging buffers, kept between calls (api.hip, SlabWalk)
+  void *slab_stage = nullptr;       // bsn::FileStage
   bool streamed() const { return d_img == nullptr && h_map != nullptr; }
   uint8_t *d_smaj = nullptr;
   int64_t pitch_smaj = 0, rows_smaj = 0;
@@ -252,7 +254,18 @@ bsn_bed *image_gather(bsn_bed *src, const int64_t *ind_row, int64_t n, const int
 bool image_tile(bsn_bed *b);  // true when the streaming-layout copy exists (builds it if memory allows)
 bool image_smaj(bsn_bed *b);  // true when the sample-major copy exists (builds it if memory allows)
 void image_from_host(bsn_bed *b, const uint8_t *payload, int64_t n_byte_src);
-void image_from_file(bsn_bed *b, int fd, int64_t offset, int64_t n_byte_src);
+// the two page-locked staging buffers (+ their events) of image_from_file; a caller that uploads many pieces (the slabs of an
+// out-of-core handle) keeps one set alive instead of paying two hipHostMalloc of 256 MB per piece
+struct FileStage {
+  uint8_t *pin[2] = {nullptr, nullptr};
+  hipEvent_t done[2] = {nullptr, nullptr};
+  size_t bytes = 0;
+  ~FileStage();
+  FileStage() = default;
+  FileStage(const FileStage &) = delete;
+  FileStage &operator=(const FileStage &) = delete;
+};
+void image_from_file(bsn_bed *b, int fd, int64_t offset, int64_t n_byte_src, FileStage *stage = nullptr);
 // FBM bytes -> device image through a 256-entry byte look-up (lut[byte] = device code 0..3 for a 2-bit
 // image, int8 grid index or 0x80 for a byte image); pinned double-buffered upload
 void image_from_fbm(bsn_bed *b, const uint8_t *bytes, int64_t ld, const uint8_t *lut);

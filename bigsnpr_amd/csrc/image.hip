@@ -215,27 +215,30 @@ void image_from_host(bsn_bed *b, const uint8_t *payload, int64_t n_byte_src) {
 // time (4.8 GB/s measured); instead a few threads pread() slices of a 256-MiB column chunk into
 // one of two pinned buffers while the other one is on its way to the device (DMA, 2-D copy
 // into the padded pitch).
-void image_from_file(bsn_bed *b, int fd, int64_t offset, int64_t n_byte_src) {
+FileStage::~FileStage() {
+  for (int i = 0; i < 2; i++) {
+    if (pin[i]) (void)hipHostFree(pin[i]);
+    if (done[i]) (void)hipEventDestroy(done[i]);
+  }
+}
+
+void image_from_file(bsn_bed *b, int fd, int64_t offset, int64_t n_byte_src, FileStage *stage) {
   const int64_t chunk_bytes = 256ll << 20;
   int64_t cols_per = chunk_bytes / n_byte_src;
   if (cols_per < 1) cols_per = 1;
-  uint8_t *pin[2] = {nullptr, nullptr};
-  hipEvent_t done[2];
-  struct Cleanup {
-    uint8_t **pin;
-    hipEvent_t *ev;
-    int nev = 0;
-    ~Cleanup() {
-      for (int i = 0; i < 2; i++)
-        if (pin[i]) (void)hipHostFree(pin[i]);
-      for (int i = 0; i < nev; i++) (void)hipEventDestroy(ev[i]);
+  FileStage own;
+  FileStage &fs = stage ? *stage : own;
+  if (fs.bytes < (size_t)(cols_per * n_byte_src)) {
+    for (int i = 0; i < 2; i++) {
+      if (fs.pin[i]) (void)hipHostFree(fs.pin[i]);
+      fs.pin[i] = nullptr;
+      BSN_HIP(hipHostMalloc((void **)&fs.pin[i], (size_t)(cols_per * n_byte_src), hipHostMallocDefault));
+      if (!fs.done[i]) BSN_HIP(hipEventCreateWithFlags(&fs.done[i], hipEventDisableTiming));
     }
-  } cleanup{pin, done};
-  for (int i = 0; i < 2; i++) {
-    BSN_HIP(hipHostMalloc((void **)&pin[i], (size_t)(cols_per * n_byte_src), hipHostMallocDefault));
-    BSN_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
-    cleanup.nev = i + 1;
+    fs.bytes = (size_t)(cols_per * n_byte_src);
   }
+  uint8_t **pin = fs.pin;
+  hipEvent_t *done = fs.done;
   unsigned hw = std::thread::hardware_concurrency();
   const int nthr = (int)std::max(1u, std::min(16u, hw ? hw / 2 : 4u));
   int k = 0;
