@@ -1235,7 +1235,7 @@ int bsn_cormat(bsn_bed *bed_in, const int64_t *ind_row_in, int64_t n, const int6
     bsn_bed *bed = rv.bed;
     const int64_t *ind_row = rv.ind_row, *ind_col = rv.ind_col;
     C->owned = rv.owned;
-    band_stats(J, bed, ind_row, n, ind_col, m, pos, size, false, true, fill_diag ? 12.0 : 12.0);
+    band_stats(J, bed, ind_row, n, ind_col, m, pos, size, false, true, 12.0);   // @i + @x: 12 bytes per kept pair
     copy_h2d(bed, J.d_thr.ensure((size_t)n), thr, (size_t)n * 8);
     DevBuf<int32_t> d_cnt;
     DevBuf<int64_t> d_off;

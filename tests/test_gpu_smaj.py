@@ -80,3 +80,29 @@ def test_complete_data_and_solve(ba, monkeypatch):
         again = ba.bed_randomSVD(gb, k=k, block=16)
         assert again["tiled"] == 2
         np.testing.assert_array_equal(again["d"], ref["d"])
+
+
+def test_random_small_shapes(ba, monkeypatch):
+    """k_prodT on shapes around its tile sizes: fewer samples than a tile (16) or a workgroup (512), fewer variants than
+    a chunk (512), one / two / many slabs, ragged everything — bit-identical to k_prod."""
+    from bigsnpr_amd import _lib
+    sync = _lib.load().bsn_device_sync
+    rng = np.random.default_rng(77)
+    shapes = [(5, 100), (16, 512), (17, 513), (511, 1025), (513, 4097), (1000, 70000), (33, 20000), (2049, 3000)]
+    shapes += [(int(rng.integers(1, 3000)), int(rng.integers(1, 9000))) for _ in range(8)]
+    for n, m in shapes:
+        gb = ba.bed.synthetic(n, m, seed=n + m, na16=int(rng.choice([0, 655, 6000])))
+        nv = int(rng.integers(9, 17))
+        ce, sa = rng.uniform(0.1, 1.9, m), rng.uniform(0.3, 1.0, m)
+        op = ba.ScaledOp(gb, None, None, ce, sa, slices=2)
+        X, Y = ba.DeviceArray.from_numpy(rng.normal(size=(m, nv))), ba.DeviceArray(n, nv)
+        monkeypatch.setenv("BSN_NO_SMAJ", "1")
+        op.prod(X, Y)
+        sync()
+        ref = Y.to_numpy()
+        monkeypatch.delenv("BSN_NO_SMAJ")
+        assert gb.sample_major()
+        op.prod(X, Y)
+        sync()
+        np.testing.assert_array_equal(Y.to_numpy(), ref, err_msg="n=%d m=%d nv=%d" % (n, m, nv))
+        gb.close()
