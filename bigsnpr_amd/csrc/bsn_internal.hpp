@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -324,6 +325,20 @@ void comm_all_gather(bsn_comm *c, const double *d_send, double *d_recv, int64_t 
 // matvec.hip
 void op_poll_stats(bsn_op *op);  // after a stream synchronisation: pick up the missing-value total
 void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy);
+// The product pass in SEGMENTS of sample blocks (sharded solve, svd.hip: the reduce-scatter of a finished segment runs
+// on a second stream while the next segment computes).  The samples are seen as `pieces` equal pieces (the ranks' sample
+// blocks) of `stride` workgroup blocks of 512 samples each; segment s covers blocks [off, off + bs) of EVERY piece, and
+// its result goes to d_out in the blocked layout [piece][vector][row of the segment] (what a reduce-scatter exchanges).
+// d_rows lists the segment's samples piece by piece (pieces * bs * 512 entries, -1 = padding past the last sample: zero).
+// `after(s)` is called once the kernels of segment s are queued.  Returns false — nothing queued — when the pass cannot
+// run as ONE k_prodT launch geometry (no sample-major copy, several launches, ...): the caller takes op_prod.
+struct ProdSegment {
+  int bs = 0, off = 0;
+  const int32_t *d_rows = nullptr;
+  double *d_out = nullptr;
+};
+bool op_prod_segments(bsn_op *op, const double *d_X, int64_t ldx, int nvec, int pieces, int stride, int nseg,
+                      const ProdSegment *segs, const std::function<void(int)> &after);
 void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z, int64_t ldz);
 // the quantisation half of op_cprod for a panel that fits one launch, queued ahead of time (the SVD driver
 // does it while the host still works on the previous step); op_cprod with the same panel then starts with

@@ -787,12 +787,12 @@ __global__ __launch_bounds__(256) void k_prod(const uint8_t *__restrict__ img, i
 //   D        : lane l -> digit column (l & 15), sample rows 4 * (l >> 4) + r
 // The variants are split into gridDim.y slabs of `cps` chunks (int32 partial sums per slab, added by k_prod_final in
 // exact int64 like k_prod's): 782 workgroups of 512 samples alone would fill 3.05 rounds of 256 CUs.
-// kbyte0: byte of the operator's first variant in a sample row (col0 / 4, a multiple of 16).
+// The copy is CHUNK-MAJOR (bsn_bed::d_smaj): byte of the operator's first variant in a sample row (col0 / 4, a multiple of 16).
 template <int NB, bool HASQ, int TILES = 2, int WAVES = 16, int TAG = 0, int SGB = 3>
 __global__ __launch_bounds__(64 * WAVES) void k_prodT(const uint8_t *__restrict__ simg, int64_t rows_t, int64_t chunk0,
                                                       int nchunks, int cps,
                                                       const int8_t *__restrict__ wq, int32_t *__restrict__ acc_out,
-                                                      int64_t n_pad, uint32_t lutQ) {
+                                                      int64_t n_pad, uint32_t lutQ, int seg_bs, int seg_stride, int seg_off) {
   constexpr int KC = 512, NCOL = 16 * NB, LD = KC / 256;
   constexpr int XS = KC / 16 * 2 * NCOL;   // uint4 entries of one chunk's digit panel (two planes)
   constexpr int NT = 64 * WAVES, NX = XS / NT;
@@ -800,7 +800,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_prodT(const uint8_t *__restrict_
   __shared__ uint4 xs[2][XS];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int c = lane & 15, g = lane >> 4;
-  const int64_t wg_base = (int64_t)blockIdx.x * (WAVES * 16 * TILES);
+  // seg_bs > 0 (a segment of the sharded solve's product pass, op_prod_segments): the launch covers blocks
+  // [seg_off, seg_off + seg_bs) of every piece of seg_stride blocks
+  const unsigned bx = seg_bs > 0 ? (blockIdx.x / (unsigned)seg_bs) * (unsigned)seg_stride + (unsigned)seg_off + blockIdx.x % (unsigned)seg_bs
+                                 : blockIdx.x;
+  const int64_t wg_base = (int64_t)bx * (WAVES * 16 * TILES);
   const int64_t row_base = wg_base + wave * (16 * TILES);
   uint32_t voff[TILES];
 #pragma unroll
@@ -953,13 +957,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_prodT(const uint8_t *__restrict_
 
 // y[i, v] = (sum_ky value(i) - C_v) / qs_v, gathered through rows[].  One thread per output
 // row reads its NCOL contiguous int32 per K-chunk (16 B loads, consecutive rows adjacent).
+// blk_rows > 0: blocked output for the reduce-scatter of a segment (op_prod_segments) — row i belongs to piece
+// i / blk_rows and goes to Y[(piece * nv + v) * blk_rows + i % blk_rows]; rows[i] < 0 is padding (zero).
 template <int NCOL>
 __global__ void k_prod_final(const int32_t *__restrict__ acc, int64_t n_pad, int ky, int S, int nv,
                              const VecMeta *meta, const int32_t *rows, int64_t n, double *Y,
-                             int64_t ldy, int sub_const, double beta) {
+                             int64_t ldy, int sub_const, double beta, int64_t blk_rows = 0) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int64_t i2 = rows ? (int64_t)rows[i] : i;
+  if (i2 < 0) {
+    for (int v = 0; v < nv; v++) Y[(i / blk_rows * nv + v) * blk_rows + i % blk_rows] = 0.0;
+    return;
+  }
   long long d[NCOL];
 #pragma unroll
   for (int c = 0; c < NCOL; c++) d[c] = 0;
@@ -986,7 +996,10 @@ __global__ void k_prod_final(const int32_t *__restrict__ acc, int64_t n_pad, int
     double qs = meta[v].qscale;
     double y = qs > 0 ? (r - C) / qs : 0.0;
     if (meta[v].nonfinite) y = __longlong_as_double(0x7ff8000000000000LL);
-    Y[i + v * ldy] = beta != 0.0 ? beta * Y[i + v * ldy] + y : y;
+    if (blk_rows > 0)
+      Y[(i / blk_rows * nv + v) * blk_rows + i % blk_rows] = y;
+    else
+      Y[i + v * ldy] = beta != 0.0 ? beta * Y[i + v * ldy] + y : y;
   }
 }
 
@@ -1617,9 +1630,15 @@ static void launch_prod(bsn_op *op, dim3 grid, int64_t m_pad, int64_t mc, const 
 // mode 1: W1 = X / scale, W2 = center * W1 derived from the operator's centre / scale (the
 // scaled product A~ X; lutP must be kLutRaw and lutQ kLutNA: the quantiser then stores W2 - 3 W1
 // in the second plane, see k_quant); mode 2: W1 = d_X, W2 = d_W2 given directly (raw plane weights).
+struct ProdSegments {   // op_prod_segments
+  int pieces, stride, nseg;
+  const ProdSegment *segs;
+  const std::function<void(int)> *after;
+  bool done = false;
+};
 static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64_t ldx, int nvec,
                         double *d_Y, int64_t ldy, int mode, uint32_t lutP, uint32_t lutQ, int sub_const,
-                        double beta, int S) {
+                        double beta, int S, ProdSegments *sg = nullptr) {
   bsn_bed *b = op->bed;
   refuse_generic(b, "this function (it needs the streaming products)");
   const int vmax = 32 / S;
@@ -1633,6 +1652,7 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
   const bool smaj = b->bits == 2 && b->d_smaj != nullptr && op->cols_contig && (op->col0 & 511) == 0 && mode == 1 &&
                     lutP == kLutRaw && lutQ == kLutNA && nvec <= vmax && pick_nb(nvec * S) == 2 &&
                     !getenv("BSN_NO_SMAJ");   // (one launch of two column blocks: the geometry below is k_prodT's)
+  if (sg && !smaj) return;   // (nothing queued: the caller takes the plain pass)
   const int64_t m_pad = round_up(op->m, smaj ? 512 : 64);
   VecMeta *meta = meta_buffer(op);
   // K split so that the grid has a few thousand workgroups
@@ -1719,12 +1739,32 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
     if (smaj && NB == 2) {
       const int nchunks = (int)(m_pad / 512);
       const bool warm = op->prof_kind_override == 3;
-#define BSN_PRODT(HASQV, TAGV)                                                                                      \
-  BSN_KLAUNCH((k_prodT<2, HASQV, 2, 16, TAGV>), grid, dim3(1024), 0, b->stream, b->d_smaj, b->rows_smaj, op->col0 / 512, \
-              nchunks, smaj_cps, q, acc, npad, lutQ)
-      // (workgroup shapes 4 x 8 / 4 x 4 / 2 x 8 / 4 x 16 tiles x waves, chunks of 256 variants: all slower, profiles/r04_smaj.txt)
-      if (has_q) { if (warm) BSN_PRODT(true, 1); else BSN_PRODT(true, 0); }
-      else { if (warm) BSN_PRODT(false, 1); else BSN_PRODT(false, 0); }
+#define BSN_PRODT(HASQV, TAGV, GRID, BS, STRIDE, OFF)                                                               \
+  BSN_KLAUNCH((k_prodT<2, HASQV, 2, 16, TAGV>), GRID, dim3(1024), 0, b->stream, b->d_smaj, b->rows_smaj, op->col0 / 512, \
+              nchunks, smaj_cps, q, acc, npad, lutQ, BS, STRIDE, OFF)
+      // (workgroup shapes 4 x 8 / 4 x 4 / 2 x 8 / 4 x 16 tiles x waves, chunks of 256 variants: all slower, profiles/r04_sample_major.txt)
+      if (sg) {
+        // the pass in segments of sample blocks: kernel + finalize of a segment, then the caller's hook (svd.hip queues the
+        // segment's reduce-scatter on its second stream) while the next segment's kernel is queued behind on this one
+        for (int sidx = 0; sidx < sg->nseg; sidx++) {
+          const ProdSegment &sgm = sg->segs[sidx];
+          const dim3 gs((unsigned)(sg->pieces * sgm.bs), (unsigned)ky);
+          if (has_q) BSN_PRODT(true, 0, gs, sgm.bs, sg->stride, sgm.off);
+          else BSN_PRODT(false, 0, gs, sgm.bs, sg->stride, sgm.off);
+          BSN_HIP(hipGetLastError());
+          const int64_t rows_s = (int64_t)sgm.bs * 512, tot = rows_s * sg->pieces;
+          hipLaunchKernelGGL((k_prod_final<32>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, b->stream, acc, npad, ky,
+                             S, nv, meta, sgm.d_rows, tot, sgm.d_out, (int64_t)0, sub_const, 0.0, rows_s);
+          BSN_HIP(hipGetLastError());
+          if (sidx + 1 == sg->nseg) prof_end(op);
+          (*sg->after)(sidx);
+        }
+        op->passes++;
+        sg->done = true;
+        continue;
+      }
+      if (has_q) { if (warm) BSN_PRODT(true, 1, grid, 0, 0, 0); else BSN_PRODT(true, 0, grid, 0, 0, 0); }
+      else { if (warm) BSN_PRODT(false, 1, grid, 0, 0, 0); else BSN_PRODT(false, 0, grid, 0, 0, 0); }
 #undef BSN_PRODT
       BSN_HIP(hipGetLastError());
     } else if (b->bits == 8) {
@@ -1809,6 +1849,14 @@ void op_cprod_raw(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *
 
 void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy) {
   prod_planes(op, d_X, nullptr, ldx, nvec, d_Y, ldy, 1, kLutRaw, kLutNA, 1, 0.0, op->slices);
+}
+
+bool op_prod_segments(bsn_op *op, const double *d_X, int64_t ldx, int nvec, int pieces, int stride, int nseg,
+                      const ProdSegment *segs, const std::function<void(int)> &after) {
+  if (!op->rows_identity || op->prof_kind_override == 3) return false;
+  ProdSegments sg{pieces, stride, nseg, segs, &after};
+  prod_planes(op, d_X, nullptr, ldx, nvec, nullptr, 0, 1, kLutRaw, kLutNA, 1, 0.0, op->slices, &sg);
+  return sg.done;
 }
 
 // rowSumsSq[i] = sum_j A~[i, j]^2 over the non-missing genotypes (src/bed-fun.cpp:121-123):

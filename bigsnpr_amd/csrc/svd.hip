@@ -359,6 +359,13 @@ __global__ void k_unblock(const double *__restrict__ blk, int64_t n, int cb, int
   const int64_t gi = t % n, j = t / n;
   full[t] = blk[((gi / nr) * cb + j) * nr + gi % nr];
 }
+// a received segment (rows x cb, ld rows) into rows [r0, r0 + rows) of the panel W (ld nr)
+__global__ void k_place_rows(const double *__restrict__ src, int64_t rows, int cb, int64_t r0, int64_t nr,
+                             double *__restrict__ W) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * cb) return;
+  W[r0 + t % rows + (t / rows) * nr] = src[t];
+}
 // W (nr x cb, ld nr) = rows [row0, row0 + nr) of full (n x cb, ld n), zero past n
 __global__ void k_take_rows(const double *__restrict__ full, int64_t n, int cb, int64_t nr, int64_t row0,
                             double *__restrict__ W) {
@@ -393,6 +400,15 @@ struct SvdWorkspace {
   double *h_pin = nullptr;
   size_t h_pin_n = 0;
   hipEvent_t ev_small = nullptr;   // the small matrices of a block step have reached the host
+  // sharded solve, product pass in segments (A_Zblock): the stream the reduce-scatters run on, one event per segment
+  // ("its partial sums are ready") and one for "all segments have arrived"; the segments' sample lists and receive buffer
+  hipStream_t st_comm = nullptr;
+  hipEvent_t ev_seg[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_arrived = nullptr;
+  DevBuf<int32_t> seg_rows;
+  DevBuf<double> Wrecv;
+  int64_t seg_n = -1, seg_nr = -1;
+  int seg_world = -1;
   double *pinned(size_t count) {
     if (count > h_pin_n) {
       if (h_pin) (void)hipHostFree(h_pin);
@@ -403,6 +419,10 @@ struct SvdWorkspace {
     return h_pin;
   }
   ~SvdWorkspace() {
+    for (auto &e : ev_seg)
+      if (e) (void)hipEventDestroy(e);
+    if (ev_arrived) (void)hipEventDestroy(ev_arrived);
+    if (st_comm) (void)hipStreamDestroy(st_comm);
     if (ev_small) (void)hipEventDestroy(ev_small);
     if (h_pin) (void)hipHostFree(h_pin);
   }
@@ -495,6 +515,10 @@ struct HipSvdBackend : SvdBackend {
     dist = comm != nullptr || hook != nullptr;
     if (!dist) world = 1, rank = 0;
     nr = dist ? (n + world - 1) / world : n;
+    // RCCL path with sample blocks of at least 4096 rows: whole workgroup blocks of 512 samples per rank, so that the
+    // product pass can be cut into segments of blocks whose reduce-scatters overlap the next segment (A_Zblock); the
+    // padding (< 512 rows per rank) is zero rows like the padding of the last block has always been
+    if (dist && comm && nr >= 4096) nr = (nr + 511) / 512 * 512;
     row0 = (int64_t)rank * nr;
   }
   void alloc(int cap_, int b_) override {
@@ -580,9 +604,75 @@ struct HipSvdBackend : SvdBackend {
     Tick tk(this, 1);
     op_cprod(op, newest_block(p0), n, cb, Z.p + (int64_t)p0 * m_local, m_local);
   }
+  // The product pass of a sharded solve in up to four SEGMENTS of sample blocks (every rank's sample block cut at the
+  // same workgroup-block boundaries): as soon as a segment's partial sums are finalised into the blocked layout its
+  // reduce-scatter is queued on a second stream behind an event, and runs while the next segment's k_prodT computes;
+  // the stream of the solve waits for the last arrival.  BSN_NO_OVERLAP=1: the same segments with every collective on
+  // the solve's own stream (A/B: identical results).  Needs the sample-major copy (k_prodT) and sample blocks of whole
+  // 512-sample workgroup blocks; otherwise — and through the host hook — the pass runs whole, followed by ONE
+  // reduce-scatter.  The sums over the ranks are the same per element either way.
+  bool product_in_segments(int p0, int cb) {
+    if (!comm || nr % 512 != 0 || nr < 4096 || getenv("BSN_NO_SEGMENTS")) return false;
+    const int B = (int)(nr / 512), nseg = B >= 16 ? 4 : 2;
+    if (ws.seg_n != n || ws.seg_nr != nr || ws.seg_world != world) {   // the segments' sample lists, piece by piece
+      std::vector<int32_t> rows((size_t)world * nr);
+      size_t at = 0;
+      for (int sgi = 0; sgi < nseg; sgi++) {
+        const int b0 = (int)((int64_t)B * sgi / nseg), b1 = (int)((int64_t)B * (sgi + 1) / nseg);
+        for (int r = 0; r < world; r++)
+          for (int64_t t = (int64_t)b0 * 512; t < (int64_t)b1 * 512; t++) {
+            const int64_t gi = (int64_t)r * nr + t;
+            rows[at++] = gi < n ? (int32_t)gi : -1;
+          }
+      }
+      copy_h2d(op->bed, ws.seg_rows.ensure(rows.size()), rows.data(), rows.size() * 4);
+      BSN_HIP(hipStreamSynchronize(st));
+      ws.seg_n = n; ws.seg_nr = nr; ws.seg_world = world;
+    }
+    const bool overlap = !getenv("BSN_NO_OVERLAP");
+    if (overlap && !ws.st_comm) BSN_HIP(hipStreamCreateWithFlags(&ws.st_comm, hipStreamNonBlocking));
+    for (int i = 0; i < nseg; i++)
+      if (!ws.ev_seg[i]) BSN_HIP(hipEventCreateWithFlags(&ws.ev_seg[i], hipEventDisableTiming));
+    if (!ws.ev_arrived) BSN_HIP(hipEventCreateWithFlags(&ws.ev_arrived, hipEventDisableTiming));
+    ws.Wrecv.ensure((size_t)nr * kMaxB);
+    ProdSegment segs[4];
+    for (int sgi = 0; sgi < nseg; sgi++) {
+      const int b0 = (int)((int64_t)B * sgi / nseg), b1 = (int)((int64_t)B * (sgi + 1) / nseg);
+      segs[sgi].bs = b1 - b0;
+      segs[sgi].off = b0;
+      segs[sgi].d_rows = ws.seg_rows.p + (size_t)world * 512 * b0;
+      segs[sgi].d_out = Wblk.p + (size_t)world * cb * 512 * b0;
+    }
+    hipStream_t sc = overlap ? ws.st_comm : st;
+    const std::function<void(int)> after = [&](int sgi) {
+      const int64_t rows_s = (int64_t)segs[sgi].bs * 512, r0 = (int64_t)segs[sgi].off * 512;
+      if (overlap) {
+        BSN_HIP(hipEventRecord(ws.ev_seg[sgi], st));
+        BSN_HIP(hipStreamWaitEvent(sc, ws.ev_seg[sgi], 0));
+      }
+      double *recv = ws.Wrecv.p + (size_t)cb * r0;
+      comm_reduce_scatter_sum(comm, segs[sgi].d_out, recv, rows_s * cb, sc);
+      hipLaunchKernelGGL(k_place_rows, dim3((unsigned)((rows_s * cb + 255) / 256)), dim3(256), 0, sc, recv, rows_s, cb,
+                         r0, nr, Wc);
+      BSN_HIP(hipGetLastError());
+    };
+    if (overlap) {   // the second stream must not run ahead of what produced Wc / Wblk's previous contents
+      BSN_HIP(hipEventRecord(ws.ev_arrived, st));
+      BSN_HIP(hipStreamWaitEvent(sc, ws.ev_arrived, 0));
+    }
+    if (!op_prod_segments(op, Z.p + (int64_t)p0 * m_local, m_local, cb, world, B, nseg, segs, after)) return false;
+    if (overlap) {
+      BSN_HIP(hipEventRecord(ws.ev_arrived, sc));
+      BSN_HIP(hipStreamWaitEvent(st, ws.ev_arrived, 0));
+    }
+    n_seg_passes++;
+    return true;
+  }
+  int n_seg_passes = 0;   // product passes that ran in segments (diagnostics / tests)
   void A_Zblock(int p0, int cb) override {
     Tick tk(this, 2);
     mx_valid = false;
+    if (dist && product_in_segments(p0, cb)) return;
     op_prod(op, Z.p + (int64_t)p0 * m_local, m_local, cb, dist ? Wfull.p : Wc, n);
     if (dist) reduce_scatter_W(cb);
   }
@@ -1108,7 +1198,10 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       info->block = so.block;
       info->slices = op->slices;
       info->tiled = (bed->d_tiled != nullptr && op->cols_contig && (op->col0 & 63) == 0) ? 1 : 0;
-      if (bed->d_smaj != nullptr && so.block * op->slices > 16 && op->cols_contig && (op->col0 & 511) == 0) info->tiled = 2;
+      if (bed->d_smaj != nullptr && so.block * op->slices > 16 && so.block * op->slices <= 32 && op->cols_contig &&
+          (op->col0 & 511) == 0)
+        info->tiled = 2;   // (one launch of two column blocks per product pass: k_prodT)
+      info->segmented_passes = bk.n_seg_passes;
     }
   });
   return rc != 0 ? rc : (unconverged ? 2 : 0);

@@ -76,4 +76,5 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
                 n_prod=info.n_prod, block=info.block, slices=info.slices,
                 fused_stats=bool(info.fused_stats), cprod_stats_ms=info.cprod_stats_ms,
                 n_cprod_stats=info.n_cprod_stats, warm_launches=info.warm_launches,
-                warm_fraction=info.warm_fraction, warm_ms=info.warm_ms, tiled=int(info.tiled))
+                warm_fraction=info.warm_fraction, warm_ms=info.warm_ms, tiled=int(info.tiled),
+                segmented_passes=int(info.segmented_passes))

@@ -290,6 +290,8 @@ typedef struct bsn_svd_info {
   double warm_ms;        /* HIP-event time of those launches (not in cprod_ms / prod_ms) */
   int32_t tiled;         /* 1 if the streaming kernels read the tiled second copy of the image (bsn_bed_tile); 2 if the
                             product passes read the sample-major second copy (two-block solves, round 4) */
+  int32_t segmented_passes; /* sharded solve: product passes that ran in segments of sample blocks with their reduce-scatters
+                            queued behind each segment (on a second stream unless BSN_NO_OVERLAP=1); round 4 */
 } bsn_svd_info;
 /* Returns 0 on success, 1 on error, and 2 when the solve ran to the end of its basis without all
  * k residuals meeting tol (outputs are filled with the best available triplets, bsn_last_error()

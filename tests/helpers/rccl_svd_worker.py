@@ -24,7 +24,9 @@ def main():
     comm = ba.Comm(uid[0], rank, world)
     j0, j1 = (m * rank) // world, (m * (rank + 1)) // world
     gb = ba.bed.synthetic(n, j1 - j0, seed=31, j_begin=j0)
-    res = ba.bed_randomSVD(gb, k=k, tol=1e-9, comm=comm, m_total=m)
+    # BSN_TEST_BLOCK / BSN_TEST_TOL: the configuration of the segmented product pass test (16-vector blocks)
+    res = ba.bed_randomSVD(gb, k=k, tol=float(os.environ.get("BSN_TEST_TOL", "1e-9")), comm=comm, m_total=m,
+                           block=int(os.environ.get("BSN_TEST_BLOCK", "0")))
     d_all = [None] * world
     dist.all_gather_object(d_all, (res["d"].tolist(), res["niter"], float(np.abs(res["u"]).sum())))
     # one-shot product of the column shards: x is the same seeded vector on every rank, each takes its slice
@@ -32,7 +34,8 @@ def main():
     y = ba.bed_prodVec(gb, x[j0:j1], center=res["center"], scale=res["scale"], comm=comm)
     if rank == 0:
         json.dump(dict(d=res["d"].tolist(), niter=res["niter"], same=all(x_ == d_all[0] for x_ in d_all),
-                       y=y.tolist()), open(out, "w"))
+                       y=y.tolist(), usum=float(np.abs(res["u"]).sum()), vsum=float(np.abs(res["v"]).sum()),
+                       segmented_passes=res["segmented_passes"], tiled=res["tiled"]), open(out, "w"))
     dist.barrier()
     comm.close()
     dist.destroy_process_group()

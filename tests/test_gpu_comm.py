@@ -83,3 +83,39 @@ def test_ranks_over_the_collective_calls(tmp_path, ba, transport, world, n):
     x = np.random.default_rng(7).normal(size=m)
     yref = ba.bed_prodVec(gb, x, center=ref["center"], scale=ref["scale"])
     np.testing.assert_allclose(got["y"], yref, rtol=0, atol=1e-9 * np.abs(yref).max())
+
+
+@pytest.mark.parametrize("world,n", [(2, 9000), (3, 13001)])
+def test_product_pass_in_segments_with_overlapped_reduce_scatter(tmp_path, ba, world, n):
+    """Round 4: with 16-vector blocks (k_prodT on the ranks' sample-major copies) and sample blocks of whole 512-sample
+    workgroup blocks the product pass of a sharded solve runs in segments whose reduce-scatters are queued on a second
+    stream behind each segment.  Three runs of the same solve through the stand-in transport — segments + second stream
+    (default), segments on the solve's own stream (BSN_NO_OVERLAP=1), the whole pass followed by one reduce-scatter
+    (BSN_NO_SEGMENTS=1) — must agree bit for bit (the sums over the ranks are the same per element), and with the
+    unsharded solve to 1e-6 (both at the default tolerance 1e-4)."""
+    m, k = world * 5000 + 96, 20
+    runs = {}
+    for tag, extra in (("overlap", {}), ("one_stream", {"BSN_NO_OVERLAP": "1"}), ("whole", {"BSN_NO_SEGMENTS": "1"})):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", BSN_RCCL_LIBRARY=_mock_rccl(), BSN_TEST_BLOCK="16", BSN_TEST_TOL="1e-4",
+                   **extra)
+        out = str(tmp_path / ("seg_%s.json" % tag))
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = str(sock.getsockname()[1])
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", port,
+               os.path.join(ROOT, "tests", "helpers", "rccl_svd_worker.py"), str(n), str(m), str(k), out]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs[tag] = json.load(open(out))
+        assert runs[tag]["same"], "ranks diverged"
+    assert runs["overlap"]["segmented_passes"] > 0 and runs["one_stream"]["segmented_passes"] > 0
+    assert runs["whole"]["segmented_passes"] == 0 and runs["overlap"]["tiled"] == 2
+    for tag in ("one_stream", "whole"):
+        assert runs[tag]["d"] == runs["overlap"]["d"] and runs[tag]["niter"] == runs["overlap"]["niter"]
+        assert runs[tag]["usum"] == runs["overlap"]["usum"] and runs[tag]["vsum"] == runs["overlap"]["vsum"]
+        assert runs[tag]["y"] == runs["overlap"]["y"]
+    gb = ba.bed.synthetic(n, m, seed=31)
+    ref = ba.bed_randomSVD(gb, k=k, tol=1e-4, block=16)      # (default tolerance: 16-bit panels, 16 vectors = one launch)
+    np.testing.assert_allclose(runs["overlap"]["d"], ref["d"], rtol=1e-6)
