@@ -39,7 +39,7 @@ class SvdInfo(C.Structure):
                 ("n_prod", C.c_int32), ("block", C.c_int32), ("slices", C.c_int32),
                 ("n_bad", C.c_int32), ("fused_stats", C.c_int32), ("cprod_stats_ms", C.c_double),
                 ("n_cprod_stats", C.c_int32), ("warm_launches", C.c_int32), ("warm_fraction", C.c_double),
-                ("warm_ms", C.c_double), ("tiled", C.c_int32), ("segmented_passes", C.c_int32)]
+                ("warm_ms", C.c_double), ("tiled", C.c_int32), ("segmented_passes", C.c_int32), ("compact_gathers", C.c_int32)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check that every symbol

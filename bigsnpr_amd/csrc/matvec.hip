@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
     for (int p = 0; p < NPLANE; p++)
 #pragma unroll
       for (int nb = 0; nb < NB; nb++) acc[t][p][nb] = v4i{0, 0, 0, 0};
-  uint32_t st_lo[TILES], st_hi[TILES], st_na[TILES];  // popcounts of the low / high / both bits
+  uint32_t st_lo[TILES], st_hi[TILES], st_na[TILES];  // popcounts of the low / all / both bits
 #pragma unroll
   for (int t = 0; t < TILES; t++) st_lo[t] = st_hi[t] = st_na[t] = 0;
 
@@ -395,10 +395,11 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
       uint32_t s0 = w & 0x03030303u, s1 = (w >> 2) & 0x03030303u,
                s2 = (w >> 4) & 0x03030303u, s3 = (w >> 6) & 0x03030303u;
       if constexpr (STATS) {
-        const uint32_t lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;
+        // six instructions per dword: the count of the high bits is (all bits) - (low bits), taken at the end
+        const uint32_t lo = w & 0x55555555u;
         st_lo[t] += __popc(lo);
-        st_hi[t] += __popc(hi);
-        st_na[t] += __popc(lo & hi);
+        st_hi[t] += __popc(w);              // all bits set (low + high)
+        st_na[t] += __popc(lo & (w >> 1));  // both bits of a genotype
       }
 #pragma unroll
       for (int p = 0; p < NPLANE; p++) {
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
       // MFMAs —, the digit reads one K-step ahead, the refill loads last.  The compiler's own order issues the MFMAs
       // in back-to-back pairs, the second of which stalls its wave for the 12 remaining cycles of the first.
       // masks: 0x008 MFMA, 0x002 VALU, 0x100 DS read, 0x020 VMEM read
-      constexpr int VSTEP = TILES * (7 + (NPLANE - (RAW0 ? 1 : 0)) * 4 + (STATS ? 7 : 0));  // VALU per K-step
+      constexpr int VSTEP = TILES * (7 + (NPLANE - (RAW0 ? 1 : 0)) * 4 + (STATS ? 6 : 0));  // VALU per K-step
       constexpr int MSTEP = TILES * NPLANE * NB;                                             // MFMA per K-step
       __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
     // a variant row is spread over the 4 k-groups of the wave (lanes c, c+16, c+32, c+48)
 #pragma unroll
     for (int t = 0; t < TILES; t++) {
-      uint32_t lo = st_lo[t], hi = st_hi[t], na = st_na[t];
+      uint32_t lo = st_lo[t], hi = st_hi[t] - st_lo[t], na = st_na[t];
       lo += __shfl_xor(lo, 16); hi += __shfl_xor(hi, 16); na += __shfl_xor(na, 16);
       lo += __shfl_xor(lo, 32); hi += __shfl_xor(hi, 32); na += __shfl_xor(na, 32);
       const int64_t j = snp_base + t * 16 + c;

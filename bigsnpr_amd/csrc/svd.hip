@@ -359,6 +359,51 @@ __global__ void k_unblock(const double *__restrict__ blk, int64_t n, int cb, int
   const int64_t gi = t % n, j = t / n;
   full[t] = blk[((gi / nr) * cb + j) * nr + gi % nr];
 }
+// ---- the all-gather of a finished basis block as the 16-bit integers it is rounded to (sharded solve, round 4) ----
+// mx[v] = max over the ranks of their column maxima (bit patterns of non-negative doubles order like integers)
+__global__ void k_max_over_ranks(const unsigned long long *__restrict__ all, int world, int cb,
+                                 unsigned long long *__restrict__ mx) {
+  const int v = threadIdx.x;
+  if (v >= cb) return;
+  unsigned long long m = 0;
+  for (int r = 0; r < world; r++) m = all[r * cb + v] > m ? all[r * cb + v] : m;
+  mx[v] = m;
+}
+// the rounding of k_round_cols on this rank's rows: the integers go to q (column-major, nr rows), the rounded values
+// back into W
+__global__ void k_pack_i16(double *__restrict__ W, int64_t nr, const unsigned long long *__restrict__ mx, int slices,
+                           int16_t *__restrict__ q) {
+  const int v = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nr) return;
+  const double m = __longlong_as_double((long long)mx[v]);
+  if (!(m > 0)) {
+    q[i + v * nr] = 0;
+    return;   // (an all-zero column stays as it is, like in k_round_cols)
+  }
+  int e;
+  frexp(ldexp(0.98, 8 * slices - 1) / m, &e);
+  const double qs = ldexp(1.0, e - 1), iq = ldexp(1.0, 1 - e);
+  const long long k = llrint(W[i + v * nr] * qs);
+  q[i + v * nr] = (int16_t)k;
+  W[i + v * nr] = (double)k * iq;
+}
+// all ranks' integers ([rank][column][row of the block]) -> the rounded block with all n rows (column-major, ld n)
+__global__ void k_unpack_i16(const int16_t *__restrict__ q, int64_t n, int cb, int64_t nr,
+                             const unsigned long long *__restrict__ mx, int slices, double *__restrict__ full) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * cb) return;
+  const int64_t gi = t % n, v = t / n;
+  const double m = __longlong_as_double((long long)mx[v]);
+  double val = 0.0;
+  if (m > 0) {
+    int e;
+    frexp(ldexp(0.98, 8 * slices - 1) / m, &e);
+    val = (double)q[((gi / nr) * cb + v) * nr + gi % nr] * ldexp(1.0, 1 - e);
+  }
+  full[t] = val;
+}
+
 // a received segment (rows x cb, ld rows) into rows [r0, r0 + rows) of the panel W (ld nr)
 __global__ void k_place_rows(const double *__restrict__ src, int64_t rows, int cb, int64_t r0, int64_t nr,
                              double *__restrict__ W) {
@@ -669,6 +714,7 @@ struct HipSvdBackend : SvdBackend {
     return true;
   }
   int n_seg_passes = 0;   // product passes that ran in segments (diagnostics / tests)
+  int n_compact_gathers = 0;   // basis blocks all-gathered as 16-bit integers
   void A_Zblock(int p0, int cb) override {
     Tick tk(this, 2);
     mx_valid = false;
@@ -720,6 +766,27 @@ struct HipSvdBackend : SvdBackend {
     if (!dist) {
       round_cols(Wc, n, cb, mx_valid);
       mx_valid = false;
+      return;
+    }
+    if (comm && op->slices <= 2 && nr % 4 == 0 && !getenv("BSN_NO_COMPACT_GATHER")) {
+      // The block is rounded to 8 * slices <= 16 bits anyway: with the column maxima over ALL rows known first (an
+      // all-gather of cb numbers), every rank rounds its own rows and the all-gather ships the int16 integers — a
+      // quarter of the fp64 volume, the same rounded values bit for bit (a zero column keeps an unscaled zero: as in
+      // k_round_cols).  The integers travel as nr * cb / 4 doubles: an all-gather only moves bytes.
+      unsigned long long *mx = (unsigned long long *)dorth.p;
+      BSN_HIP(hipMemsetAsync(mx, 0, (size_t)cb * 8, st));
+      hipLaunchKernelGGL(k_col_absmax, dim3(64, cb), dim3(1024), 0, st, Wc, nr, nr, mx);
+      double *gmax = ws.Wrecv.ensure((size_t)nr * kMaxB);   // (free here: the segments' receive buffer)
+      comm_all_gather(comm, (const double *)mx, gmax, cb, st);
+      hipLaunchKernelGGL(k_max_over_ranks, dim3(1), dim3(64), 0, st, (const unsigned long long *)gmax, world, cb, mx);
+      int16_t *q_send = (int16_t *)Wfull.p, *q_all = (int16_t *)Wblk.p;
+      hipLaunchKernelGGL(k_pack_i16, dim3((unsigned)((nr + 255) / 256), cb), dim3(256), 0, st, Wc, nr, mx, op->slices, q_send);
+      BSN_HIP(hipGetLastError());
+      comm_all_gather(comm, (const double *)q_send, (double *)q_all, nr * cb / 4, st);
+      hipLaunchKernelGGL(k_unpack_i16, dim3((unsigned)((n * cb + 255) / 256)), dim3(256), 0, st, q_all, n, cb, nr, mx,
+                         op->slices, Qfull.p);
+      BSN_HIP(hipGetLastError());
+      n_compact_gathers++;
       return;
     }
     // every rank rounds the same gathered block (column maxima over all n rows), then keeps its rows
@@ -1202,6 +1269,7 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
           (op->col0 & 511) == 0)
         info->tiled = 2;   // (one launch of two column blocks per product pass: k_prodT)
       info->segmented_passes = bk.n_seg_passes;
+      info->compact_gathers = bk.n_compact_gathers;
     }
   });
   return rc != 0 ? rc : (unconverged ? 2 : 0);

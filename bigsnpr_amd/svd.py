@@ -77,4 +77,4 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
                 fused_stats=bool(info.fused_stats), cprod_stats_ms=info.cprod_stats_ms,
                 n_cprod_stats=info.n_cprod_stats, warm_launches=info.warm_launches,
                 warm_fraction=info.warm_fraction, warm_ms=info.warm_ms, tiled=int(info.tiled),
-                segmented_passes=int(info.segmented_passes))
+                segmented_passes=int(info.segmented_passes), compact_gathers=int(info.compact_gathers))

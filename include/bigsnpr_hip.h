@@ -292,6 +292,8 @@ typedef struct bsn_svd_info {
                             product passes read the sample-major second copy (two-block solves, round 4) */
   int32_t segmented_passes; /* sharded solve: product passes that ran in segments of sample blocks with their reduce-scatters
                             queued behind each segment (on a second stream unless BSN_NO_OVERLAP=1); round 4 */
+  int32_t compact_gathers;  /* sharded solve: basis blocks all-gathered as the 16-bit integers they are rounded to (a quarter
+                            of the fp64 volume, same values; BSN_NO_COMPACT_GATHER=1: fp64); round 4 */
 } bsn_svd_info;
 /* Returns 0 on success, 1 on error, and 2 when the solve ran to the end of its basis without all
  * k residuals meeting tol (outputs are filled with the best available triplets, bsn_last_error()

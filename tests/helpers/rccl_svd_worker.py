@@ -35,7 +35,7 @@ def main():
     if rank == 0:
         json.dump(dict(d=res["d"].tolist(), niter=res["niter"], same=all(x_ == d_all[0] for x_ in d_all),
                        y=y.tolist(), usum=float(np.abs(res["u"]).sum()), vsum=float(np.abs(res["v"]).sum()),
-                       segmented_passes=res["segmented_passes"], tiled=res["tiled"]), open(out, "w"))
+                       segmented_passes=res["segmented_passes"], compact_gathers=res["compact_gathers"], tiled=res["tiled"]), open(out, "w"))
     dist.barrier()
     comm.close()
     dist.destroy_process_group()

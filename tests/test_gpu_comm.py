@@ -95,7 +95,8 @@ def test_product_pass_in_segments_with_overlapped_reduce_scatter(tmp_path, ba, w
     unsharded solve to 1e-6 (both at the default tolerance 1e-4)."""
     m, k = world * 5000 + 96, 20
     runs = {}
-    for tag, extra in (("overlap", {}), ("one_stream", {"BSN_NO_OVERLAP": "1"}), ("whole", {"BSN_NO_SEGMENTS": "1"})):
+    for tag, extra in (("overlap", {}), ("one_stream", {"BSN_NO_OVERLAP": "1"}), ("whole", {"BSN_NO_SEGMENTS": "1"}),
+                       ("fp64_gather", {"BSN_NO_COMPACT_GATHER": "1"})):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", BSN_RCCL_LIBRARY=_mock_rccl(), BSN_TEST_BLOCK="16", BSN_TEST_TOL="1e-4",
                    **extra)
         out = str(tmp_path / ("seg_%s.json" % tag))
@@ -112,7 +113,9 @@ def test_product_pass_in_segments_with_overlapped_reduce_scatter(tmp_path, ba, w
         assert runs[tag]["same"], "ranks diverged"
     assert runs["overlap"]["segmented_passes"] > 0 and runs["one_stream"]["segmented_passes"] > 0
     assert runs["whole"]["segmented_passes"] == 0 and runs["overlap"]["tiled"] == 2
-    for tag in ("one_stream", "whole"):
+    # ... and the all-gather of every finished basis block as the 16-bit integers it is rounded to (default) against fp64
+    assert runs["overlap"]["compact_gathers"] > 0 and runs["fp64_gather"]["compact_gathers"] == 0
+    for tag in ("one_stream", "whole", "fp64_gather"):
         assert runs[tag]["d"] == runs["overlap"]["d"] and runs[tag]["niter"] == runs["overlap"]["niter"]
         assert runs[tag]["usum"] == runs["overlap"]["usum"] and runs[tag]["vsum"] == runs["overlap"]["vsum"]
         assert runs[tag]["y"] == runs["overlap"]["y"]
