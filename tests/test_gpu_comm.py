@@ -85,7 +85,7 @@ def test_ranks_over_the_collective_calls(tmp_path, ba, transport, world, n):
     np.testing.assert_allclose(got["y"], yref, rtol=0, atol=1e-9 * np.abs(yref).max())
 
 
-@pytest.mark.parametrize("world,n", [(2, 9000), (3, 13001)])
+@pytest.mark.parametrize("world,n", [(2, 9000), (3, 13001), (8, 33601)])
 def test_product_pass_in_segments_with_overlapped_reduce_scatter(tmp_path, ba, world, n):
     """Round 4: with 16-vector blocks (k_prodT on the ranks' sample-major copies) and sample blocks of whole 512-sample
     workgroup blocks the product pass of a sharded solve runs in segments whose reduce-scatters are queued on a second
