@@ -349,6 +349,10 @@ def main():
                                    ("single GPU holding shard 1 of %d (per-rank work of an %d-GPU run, no exchange)"
                                     % (a.shard_of, a.shard_of) if a.shard_of > 1 else "single GPU"))},
         "passes_per_solve": passes / a.steps,
+        # sharded solve: product passes cut into segments whose reduce-scatters overlap the next segment, basis blocks
+        # all-gathered as int16 (0 / 0 on one GPU without a communicator)
+        "exchange": {"segmented_product_passes": infos[-1].get("segmented_passes", 0),
+                     "int16_all_gathers": infos[-1].get("compact_gathers", 0)},
         "niter": infos[-1]["niter"], "converged": infos[-1]["converged"],
         "scaling_statistics": "ride along the first crossproduct pass" if infos[-1]["fused_stats"] else "own pass",
         "warm_start": {"launches": infos[-1]["warm_launches"], "fraction_of_variants": infos[-1]["warm_fraction"],
