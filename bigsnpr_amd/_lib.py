@@ -29,7 +29,8 @@ class SvdOptions(C.Structure):
                 ("allreduce_ctx", C.c_void_p), ("hook_rank", C.c_int32), ("hook_world", C.c_int32),
                 ("comm", C.c_void_p), ("binom_scaling", C.c_int32),
                 ("center_out", C.POINTER(C.c_double)), ("scale_out", C.POINTER(C.c_double)),
-                ("warm_start", C.c_int32), ("warm_denominator", C.c_int32), ("max_restarts", C.c_int32)]
+                ("warm_start", C.c_int32), ("warm_denominator", C.c_int32), ("max_restarts", C.c_int32),
+                ("vec_floor", C.c_double)]
 
 
 class SvdInfo(C.Structure):
@@ -39,7 +40,10 @@ class SvdInfo(C.Structure):
                 ("n_prod", C.c_int32), ("block", C.c_int32), ("slices", C.c_int32),
                 ("n_bad", C.c_int32), ("fused_stats", C.c_int32), ("cprod_stats_ms", C.c_double),
                 ("n_cprod_stats", C.c_int32), ("warm_launches", C.c_int32), ("warm_fraction", C.c_double),
-                ("warm_ms", C.c_double), ("tiled", C.c_int32), ("segmented_passes", C.c_int32), ("compact_gathers", C.c_int32)]
+                ("warm_ms", C.c_double), ("tiled", C.c_int32), ("segmented_passes", C.c_int32), ("compact_gathers", C.c_int32),
+                ("slices_max", C.c_int32), ("wide_steps", C.c_int32), ("wide_cprod_ms", C.c_double),
+                ("wide_prod_ms", C.c_double), ("n_wide_cprod", C.c_int32), ("n_wide_prod", C.c_int32),
+                ("lead_rel_resid", C.c_double)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check that every symbol

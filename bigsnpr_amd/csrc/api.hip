@@ -861,9 +861,9 @@ int bsn_bed_streaming_kernels(bsn_bed *bed, char *buf, int64_t len) {
     if (!buf || len < 1) fail("bsn_bed_streaming_kernels: no buffer");
     buf[0] = 0;
     if (!bed->svd_op) return;
-    static const char *kinds[4] = {"cprod", "prod", "cprod_stats", "warm"};
+    static const char *kinds[kProfKinds] = {"cprod", "prod", "cprod_stats", "warm", "cprod_wide", "prod_wide"};
     std::string out;
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < kProfKinds; k++) {
       const void *fn = bed->svd_op->prof_kernel[k];
       if (!fn) continue;
       const char *mangled = hipKernelNameRefByPtr(fn, bed->stream);

@@ -118,6 +118,7 @@ struct bsn_comm {
   hipStream_t stream = nullptr;           // bsn_comm_allreduce (stand-alone self-test); a solve's collectives run on the solve's stream
 };
 
+constexpr int kProfKinds = 6;   // timing classes of the streaming launches of a solve (prof_collect)
 struct bsn_op {
   bsn_bed *bed = nullptr;
   int64_t n = 0, m = 0;        // dimensions of the sub-view
@@ -143,14 +144,14 @@ struct bsn_op {
   // op_cprod_prequant: the digits of this panel are already in d_q (quantised ahead of the call that uses them)
   const double *preq_X = nullptr;
   int64_t preq_ldx = 0;
-  int preq_nvec = 0;
+  int preq_nvec = 0, preq_S = 0;
   // per-launch HIP-event timing of the streaming kernels (kind 0 = k_cprod, 1 = k_prod, 2 = the k_cprod
   // launch that also counts the codes, first pass of a solve with fused scaling statistics)
   bool profile = false;
   int prof_kind_override = -1;  // >= 0: every launch is filed under this kind (3 = warm-start launches on a subset)
   std::vector<hipEvent_t> ev_begin, ev_end;
   std::vector<int> ev_kind;
-  const void *prof_kernel[4] = {nullptr, nullptr, nullptr, nullptr};  // host stub of the last kernel launched under each kind
+  const void *prof_kernel[kProfKinds] = {};  // host stub of the last kernel launched under each kind
   ~bsn_op() {
     for (auto e : ev_begin) (void)hipEventDestroy(e);
     for (auto e : ev_end) (void)hipEventDestroy(e);
@@ -369,6 +370,7 @@ void require_resident(const bsn_bed *b, const char *what);
 void prof_begin(bsn_op *op, int kind);
 void prof_end(bsn_op *op);
 // sums the recorded launches: ms[kind], count[kind]; clears the records
-void prof_collect(bsn_op *op, double ms[4], int count[4]);  // kind 2: k_cprod carrying the code counts; 3: warm start
+// kind 2: k_cprod carrying the code counts; 3: warm start; 4 / 5: the three-column-block launches of k_cprod / k_prodT
+void prof_collect(bsn_op *op, double ms[kProfKinds], int count[kProfKinds]);
 
 }  // namespace bsn

@@ -361,10 +361,13 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
   for (int t = 0; t < TILES; t++)
 #pragma unroll
     for (int it = 0; it < LD; it++) ga[0][t][it] = gload(t, it * 64);
-  if (XFULL || tid < XS) xs[0][tid] = xq4[tid];
-  if constexpr (NX > 1) xs[0][tid + NT] = xq4[tid + NT];
-  if constexpr (NX > 2) xs[0][tid + 2 * NT] = xq4[tid + 2 * NT];
-  if constexpr (NX > 3) xs[0][tid + 3 * NT] = xq4[tid + 3 * NT];
+  // entry x of a thread's staging set exists when the panel is a whole number of workgroups, or below its end
+  // (three column blocks shared by 16 waves: 1536 entries for 1024 threads)
+  auto staged = [&](const int x) -> bool { return XFULL || tid + x * NT < XS; };
+  if (staged(0)) xs[0][tid] = xq4[tid];
+  if constexpr (NX > 1) if (staged(1)) xs[0][tid + NT] = xq4[tid + NT];
+  if constexpr (NX > 2) if (staged(2)) xs[0][tid + 2 * NT] = xq4[tid + 2 * NT];
+  if constexpr (NX > 3) if (staged(3)) xs[0][tid + 3 * NT] = xq4[tid + 3 * NT];
 #pragma unroll
   for (int t = 0; t < TILES; t++)
 #pragma unroll
@@ -382,10 +385,12 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
     {
       // the digit panel of the next chunk: into registers now, into LDS after the compute
       const uint4 *src = xq4 + (int64_t)ch1 * XS;
-      if (XFULL || tid < XS) xr0 = src[tid];
-      if constexpr (NX > 1) xr1 = src[tid + NT];
-      if constexpr (NX > 2) xr2 = src[tid + 2 * NT];
-      if constexpr (NX > 3) xr3 = src[tid + 3 * NT];
+      // (unconditional loads at a clamped index: a branch around a load costs the prefetch its waitcnt, see below)
+      auto at = [&](const int x) -> int { return XFULL ? tid + x * NT : (tid + x * NT < XS ? tid + x * NT : XS - 1); };
+      xr0 = src[at(0)];
+      if constexpr (NX > 1) xr1 = src[at(1)];
+      if constexpr (NX > 2) xr2 = src[at(2)];
+      if constexpr (NX > 3) xr3 = src[at(3)];
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the digit loads up here, a chunk ahead of their use
     if constexpr (SGB & 2) __builtin_amdgcn_s_setprio(2);  // experiment: the MFMA phase outranks waves that are loading
@@ -423,12 +428,17 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
         }
       }
     };
-    uint4 bv[NB], bn[NB];
+    // (three column blocks: the digit operands of a K-step are read at its start — a second register copy of them,
+    // one K-step ahead, does not fit beside 48 accumulators; the other waves' MFMAs cover the LDS latency)
+    constexpr bool PFB = NB <= 2;
+    uint4 bv[NB], bn[PFB ? NB : 1];
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) bv[nb] = xs[SET][(g * 4) * NCOL + nb * 16 + c];
-    if (ABL & 4) {  // ablation: digit operand read once per chunk instead of once per K-step
+    if constexpr (PFB) {
+      if (ABL & 4) {  // ablation: digit operand read once per chunk instead of once per K-step
 #pragma unroll
-      for (int nb = 0; nb < NB; nb++) bn[nb] = bv[nb];
+        for (int nb = 0; nb < NB; nb++) bn[nb] = bv[nb];
+      }
     }
 #pragma unroll
     for (int it = 0; it < LD; it++) {
@@ -436,7 +446,12 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
       for (int d = 0; d < 4; d++) {
         // prefetch the digit operand of the next K-step so that its LDS latency hides
         // under this step's decode + MFMA
-        if (ABL & 16) {  // ablation: no LDS read of the digit operand
+        if constexpr (!PFB) {
+          if (it * 4 + d > 0) {
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) bv[nb] = xs[SET][(it * 16 + g * 4 + d) * NCOL + nb * 16 + c];
+          }
+        } else if (ABL & 16) {  // ablation: no LDS read of the digit operand
 #pragma unroll
           for (int nb = 0; nb < NB; nb++) { bn[nb] = bv[nb]; bn[nb].x += 1; }
         } else if (!(ABL & 4) && it * 4 + d + 1 < LD * 4) {
@@ -450,8 +465,10 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
                              : d == 2 ? ga[SET][t][it].z : ga[SET][t][it].w;
           kstep(t, w, bv);
         }
+        if constexpr (PFB) {
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++) bv[nb] = bn[nb];
+          for (int nb = 0; nb < NB; nb++) bv[nb] = bn[nb];
+        }
       }
     }
     // This set is consumed: refill it with the chunk two ahead.  All loads of a tile go out
@@ -500,10 +517,10 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (SGB & 2) __builtin_amdgcn_s_setprio(0);
     {
-      if (XFULL || tid < XS) xs[SET ^ 1][tid] = xr0;
-      if constexpr (NX > 1) xs[SET ^ 1][tid + NT] = xr1;
-      if constexpr (NX > 2) xs[SET ^ 1][tid + 2 * NT] = xr2;
-      if constexpr (NX > 3) xs[SET ^ 1][tid + 3 * NT] = xr3;
+      if (staged(0)) xs[SET ^ 1][tid] = xr0;
+      if constexpr (NX > 1) if (staged(1)) xs[SET ^ 1][tid + NT] = xr1;
+      if constexpr (NX > 2) if (staged(2)) xs[SET ^ 1][tid + 2 * NT] = xr2;
+      if constexpr (NX > 3) if (staged(3)) xs[SET ^ 1][tid + 3 * NT] = xr3;
     }
     if (!(ABL & 8)) __syncthreads();  // ablation 8: no barrier
   };
@@ -862,16 +879,27 @@ __global__ __launch_bounds__(64 * WAVES) void k_prodT(const uint8_t *__restrict_
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (SGB & 2) __builtin_amdgcn_s_setprio(2);
     constexpr int NP = HASQ ? 2 : 1;
-    uint4 bv[NP][NB], bn[NP][NB];
+    constexpr bool PFB = NB <= 2;   // (as in k_cprod: no second register copy of the digit operands with three column blocks)
+    uint4 bv[NP][NB], bn[PFB ? NP : 1][PFB ? NB : 1];
 #pragma unroll
     for (int p = 0; p < NP; p++)
 #pragma unroll
-      for (int nb = 0; nb < NB; nb++) bn[p][nb] = bv[p][nb] = xs[SET][((g * 4) * 2 + p) * NCOL + nb * 16 + c];
+      for (int nb = 0; nb < NB; nb++) {
+        bv[p][nb] = xs[SET][((g * 4) * 2 + p) * NCOL + nb * 16 + c];
+        if constexpr (PFB) bn[p][nb] = bv[p][nb];
+      }
 #pragma unroll
     for (int it = 0; it < LD; it++) {
 #pragma unroll
       for (int d = 0; d < 4; d++) {
-        if (it * 4 + d + 1 < LD * 4) {
+        if constexpr (!PFB) {
+          if (it * 4 + d > 0) {
+#pragma unroll
+            for (int p = 0; p < NP; p++)
+#pragma unroll
+              for (int nb = 0; nb < NB; nb++) bv[p][nb] = xs[SET][((it * 16 + g * 4 + d) * 2 + p) * NCOL + nb * 16 + c];
+          }
+        } else if (it * 4 + d + 1 < LD * 4) {
           const int itn = (it * 4 + d + 1) / 4, dn = (it * 4 + d + 1) % 4;
 #pragma unroll
           for (int p = 0; p < NP; p++)
@@ -899,10 +927,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_prodT(const uint8_t *__restrict_
             }
           }
         }
+        if constexpr (PFB) {
 #pragma unroll
-        for (int p = 0; p < NP; p++)
+          for (int p = 0; p < NP; p++)
 #pragma unroll
-          for (int nb = 0; nb < NB; nb++) bv[p][nb] = bn[p][nb];
+            for (int nb = 0; nb < NB; nb++) bv[p][nb] = bn[p][nb];
+        }
       }
     }
 #pragma unroll
@@ -961,7 +991,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prodT(const uint8_t *__restrict_
 // blk_rows > 0: blocked output for the reduce-scatter of a segment (op_prod_segments) — row i belongs to piece
 // i / blk_rows and goes to Y[(piece * nv + v) * blk_rows + i % blk_rows]; rows[i] < 0 is padding (zero).
 template <int NCOL>
-__global__ void k_prod_final(const int32_t *__restrict__ acc, int64_t n_pad, int ky, int S, int nv,
+__global__ __launch_bounds__(256) void k_prod_final(const int32_t *__restrict__ acc, int64_t n_pad, int ky, int S, int nv,
                              const VecMeta *meta, const int32_t *rows, int64_t n, double *Y,
                              int64_t ldy, int sub_const, double beta, int64_t blk_rows = 0) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1229,11 +1259,10 @@ void prof_begin(bsn_op *op, int kind) {
 void prof_end(bsn_op *op) {
   if (!op->profile) return;
   BSN_HIP(hipEventRecord(op->ev_end.back(), op->bed->stream));
-  op->prof_kernel[op->ev_kind.back() & 3] = g_last_kernel;
+  op->prof_kernel[op->ev_kind.back() % kProfKinds] = g_last_kernel;
 }
-void prof_collect(bsn_op *op, double ms[4], int count[4]) {
-  ms[0] = ms[1] = ms[2] = ms[3] = 0;
-  count[0] = count[1] = count[2] = count[3] = 0;
+void prof_collect(bsn_op *op, double ms[kProfKinds], int count[kProfKinds]) {
+  for (int k = 0; k < kProfKinds; k++) ms[k] = 0, count[k] = 0;
   for (size_t i = 0; i < op->ev_begin.size(); i++) {
     BSN_HIP(hipEventSynchronize(op->ev_end[i]));
     float t = 0;
@@ -1248,8 +1277,16 @@ void prof_collect(bsn_op *op, double ms[4], int count[4]) {
   op->ev_kind.clear();
 }
 
-static int pick_nb(int ncols_needed) { return ncols_needed <= 16 ? 1 : 2; }
-constexpr int kMetaVecs = 32;   // vectors per launch at most (NB <= 2, one slice)
+// Column blocks of 16 digit columns per launch.  Three (48 columns: 16 vectors x 3 slices, the early steps of a solve
+// whose vectors are wanted beyond the 16-bit floor, svd_driver.hpp) exist for the two shapes such a solve runs on —
+// k_cprod on the 2-bit image and k_prodT on its sample-major copy; everything else stays at two.
+constexpr int kMaxCols = 48;
+static int pick_nb(int ncols_needed) { return ncols_needed <= 16 ? 1 : ncols_needed <= 32 ? 2 : 3; }
+static bool nb3_allowed() {
+  static const bool on = getenv("BSN_NO_NB3") == nullptr;   // A/B switch: the same sums in two launches (bit-identical)
+  return on;
+}
+constexpr int kMetaVecs = 32;   // vectors per launch at most
 static VecMeta *meta_buffer(bsn_op *op) {
   return (VecMeta *)op->d_meta.ensure((size_t)kMetaVecs * 8 + (size_t)kMetaVecs * 256 * 2);
 }
@@ -1400,6 +1437,16 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
   // tiles on the plain image, 8 x 4 on the tiled copy (2 % faster there; the counting variant needs 150 registers with
   // 4 tiles and keeps 2); two column blocks — 16 waves x 2 tiles share one digit panel (half the L2 reads of it), with
   // the explicit MFMA / decode interleave + raised priority through the MFMA phase (SGB = 3: 2 %).
+  if (NB == 3) {   // three column blocks: 16 waves x 2 tiles on the plain image (contiguous or gathered variants)
+    if constexpr (STATS || NPLANE == 3) {
+      fail("internal: no three-block counting kernel");
+    } else {
+      if (op->cols_contig) BSN_CPROD(3, true, 0, 2, 16, 0, false, 3, b->d_img);
+      else BSN_CPROD(3, false, 0, 2, 16, 0, false, 0, b->d_img);
+    }
+    BSN_HIP(hipGetLastError());
+    return;
+  }
   if (use_tiled(op)) {
     constexpr int TV = STATS ? 2 : 4;
     if (NB == 1) { if (warm) BSN_CPROD(1, true, 0, TV, 8, 1, true, 0, b->d_tiled); else BSN_CPROD(1, true, 0, TV, 8, 0, true, 0, b->d_tiled); }
@@ -1493,37 +1540,47 @@ void op_poll_stats(bsn_op *op) {
   if (t == 0 && !getenv("BSN_FORCE_NA_PLANE")) op->no_na = true;  // complete data: skip the missing-value plane from now on
 }
 
+// vectors per crossproduct launch: three column blocks on a 2-bit image unless the launch also counts the codes
+static int cprod_vmax(const bsn_op *op, int S) {
+  const int nbmax = (op->bed->bits == 2 && !op->stats_pending && nb3_allowed()) ? 3 : 2;
+  int v = 16 * nbmax / S;
+  if (v > kMetaVecs) v = kMetaVecs;
+  return v < 1 ? 1 : v;
+}
+
 void op_cprod_prequant(bsn_op *op, const double *d_X, int64_t ldx, int nvec) {
   bsn_bed *b = op->bed;
   const int S = op->slices;
   op->preq_X = nullptr;
-  if (nvec <= 0 || nvec > 32 / S || !op->rows_identity) return;
+  if (nvec <= 0 || nvec > cprod_vmax(op, S) || !op->rows_identity) return;
   const int64_t npad = n_padded(b);
   quantise(op, d_X, ldx, b->n, npad, nvec, 0, S, 16 * pick_nb(nvec * S), 1, 0, meta_buffer(op),
-           op->d_q.ensure((size_t)npad * 32 * 2));
+           op->d_q.ensure((size_t)npad * kMaxCols * 2));
   op->preq_X = d_X;
   op->preq_ldx = ldx;
   op->preq_nvec = nvec;
+  op->preq_S = S;
 }
 
 void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z, int64_t ldz) {
   bsn_bed *b = op->bed;
   refuse_generic(b, "this function (it needs the streaming products)");
   const int S = op->slices;
-  const int vmax = 32 / S;  // vectors per launch (NB <= 2)
   if (nvec <= 0) return;
-  const bool have_digits = op->preq_X == d_X && op->preq_ldx == ldx && op->preq_nvec == nvec && d_X != nullptr;
+  const bool have_digits = op->preq_X == d_X && op->preq_ldx == ldx && op->preq_nvec == nvec && d_X != nullptr &&
+                           op->preq_S == S && nvec <= cprod_vmax(op, S);
   op->preq_X = nullptr;
   const double *xsrc = scatter_rows_if_needed(op, d_X, &ldx, nvec);
   const int64_t npad = n_padded(b);
   VecMeta *meta = meta_buffer(op);
-  for (int v0 = 0; v0 < nvec; v0 += vmax) {
+  for (int v0 = 0, vmax = 0; v0 < nvec; v0 += vmax) {
+    vmax = cprod_vmax(op, S);  // vectors of this launch (the launch that counts the codes is limited to two column blocks)
     int nv = nvec - v0 < vmax ? nvec - v0 : vmax;
     int NB = pick_nb(nv * S), ncol = 16 * NB;
-    int8_t *q = op->d_q.ensure((size_t)npad * 32 * 2);
-    int32_t *acc = op->d_acc.ensure((size_t)2 * op->m * 32);
+    int8_t *q = op->d_q.ensure((size_t)npad * kMaxCols * 2);
+    int32_t *acc = op->d_acc.ensure((size_t)2 * op->m * kMaxCols);
     if (!have_digits) quantise(op, xsrc + (int64_t)v0 * ldx, ldx, b->n, npad, nv, 0, S, ncol, 1, 0, meta, q);
-    prof_begin(op, op->stats_pending ? 2 : 0);  // the pass that carries the code counts is timed apart
+    prof_begin(op, op->stats_pending ? 2 : NB == 3 ? 4 : 0);  // the pass that carries the code counts is timed apart
     if (b->bits == 8) {
       const dim3 grid8((unsigned)((op->m + 127) / 128));
       const int32_t *cols8 = op->cols_contig ? nullptr : op->d_cols.p;
@@ -1571,8 +1628,11 @@ void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z,
     if (NB == 1)
       hipLaunchKernelGGL((k_cprod_final<16>), dim3((unsigned)((op->m + 127) / 128)), dim3(128), 0, b->stream, acc, op->m,
                          S, nv, meta, op->d_center.p, op->d_scale.p, d_Z + (int64_t)v0 * ldz, ldz, has_q ? 1 : 0);
-    else
+    else if (NB == 2)
       hipLaunchKernelGGL((k_cprod_final<32>), dim3((unsigned)((op->m + 127) / 128)), dim3(128), 0, b->stream, acc, op->m,
+                         S, nv, meta, op->d_center.p, op->d_scale.p, d_Z + (int64_t)v0 * ldz, ldz, has_q ? 1 : 0);
+    else
+      hipLaunchKernelGGL((k_cprod_final<48>), dim3((unsigned)((op->m + 127) / 128)), dim3(128), 0, b->stream, acc, op->m,
                          S, nv, meta, op->d_center.p, op->d_scale.p, d_Z + (int64_t)v0 * ldz, ldz, has_q ? 1 : 0);
     BSN_HIP(hipGetLastError());
   }
@@ -1642,17 +1702,17 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
                         double beta, int S, ProdSegments *sg = nullptr) {
   bsn_bed *b = op->bed;
   refuse_generic(b, "this function (it needs the streaming products)");
-  const int vmax = 32 / S;
   if (nvec <= 0) return;
   op->preq_X = nullptr;
   // k_prod addresses a 64-variant step with 32-bit offsets from its first row
   if (b->pitch >= ((int64_t)1 << 24)) fail("more than 6.7e7 samples are not supported by the product kernel");
   const int64_t npad = n_padded(b);
-  // Two column blocks over a contiguous range of variants that starts on a 512-variant chunk, and the handle has its
-  // sample-major copy: the product runs as k_prodT (k_cprod's shape, contraction over the contiguous index).
-  const bool smaj = b->bits == 2 && b->d_smaj != nullptr && op->cols_contig && (op->col0 & 511) == 0 && mode == 1 &&
-                    lutP == kLutRaw && lutQ == kLutNA && nvec <= vmax && pick_nb(nvec * S) == 2 &&
-                    !getenv("BSN_NO_SMAJ");   // (one launch of two column blocks: the geometry below is k_prodT's)
+  // Two or three column blocks over a contiguous range of variants that starts on a 512-variant chunk, and the handle
+  // has its sample-major copy: the product runs as k_prodT (k_cprod's shape, contraction over the contiguous index).
+  const bool smaj_ok = b->bits == 2 && b->d_smaj != nullptr && op->cols_contig && (op->col0 & 511) == 0 && mode == 1 &&
+                       lutP == kLutRaw && lutQ == kLutNA && !getenv("BSN_NO_SMAJ");
+  const int vmax = std::min(kMetaVecs, (smaj_ok && nb3_allowed() && nvec * S > 32 ? kMaxCols : 32) / S);
+  const bool smaj = smaj_ok && nvec <= vmax && pick_nb(nvec * S) >= 2;   // (ONE launch: the geometry below is k_prodT's)
   if (sg && !smaj) return;   // (nothing queued: the caller takes the plain pass)
   const int64_t m_pad = round_up(op->m, smaj ? 512 : 64);
   VecMeta *meta = meta_buffer(op);
@@ -1727,22 +1787,26 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
   for (int v0 = 0; v0 < nvec; v0 += vmax) {
     int nv = nvec - v0 < vmax ? nvec - v0 : vmax;
     int NB = pick_nb(nv * S), ncol = 16 * NB;
-    int8_t *q = op->d_q.ensure((size_t)npad * 32 * 2 > (size_t)m_pad * 32 * 2 ? (size_t)npad * 64
-                                                                             : (size_t)m_pad * 64);
+    int8_t *q = op->d_q.ensure((size_t)(npad > m_pad ? npad : m_pad) * kMaxCols * 2);
     size_t acc_need = (size_t)ky * npad * ncol;
-    if (acc_need < (size_t)2 * op->m * 32) acc_need = (size_t)2 * op->m * 32;
+    if (acc_need < (size_t)2 * op->m * kMaxCols) acc_need = (size_t)2 * op->m * kMaxCols;
     int32_t *acc = op->d_acc.ensure(acc_need);
     // (k_prodT decodes like k_cprod: its digit rows take the crossproduct's byte order)
-    quantise(op, d_X + (int64_t)v0 * ldx, ldx, op->m, m_pad, nv, mode, S, ncol, smaj && NB == 2 ? 1 : 0, 0, meta, q,
+    quantise(op, d_X + (int64_t)v0 * ldx, ldx, op->m, m_pad, nv, mode, S, ncol, smaj && NB >= 2 ? 1 : 0, 0, meta, q,
              d_W2 ? d_W2 + (int64_t)v0 * ldx : nullptr);
     dim3 grid((unsigned)wgx, (unsigned)ky);
-    prof_begin(op, 1);
-    if (smaj && NB == 2) {
+    prof_begin(op, NB == 3 ? 5 : 1);
+    if (smaj && NB >= 2) {
       const int nchunks = (int)(m_pad / 512);
       const bool warm = op->prof_kind_override == 3;
-#define BSN_PRODT(HASQV, TAGV, GRID, BS, STRIDE, OFF)                                                               \
-  BSN_KLAUNCH((k_prodT<2, HASQV, 2, 16, TAGV>), GRID, dim3(1024), 0, b->stream, b->d_smaj, b->rows_smaj, op->col0 / 512, \
+#define BSN_PRODT_(NBV, HASQV, TAGV, GRID, BS, STRIDE, OFF)                                                          \
+  BSN_KLAUNCH((k_prodT<NBV, HASQV, 2, 16, TAGV>), GRID, dim3(1024), 0, b->stream, b->d_smaj, b->rows_smaj, op->col0 / 512, \
               nchunks, smaj_cps, q, acc, npad, lutQ, BS, STRIDE, OFF)
+#define BSN_PRODT(HASQV, TAGV, GRID, BS, STRIDE, OFF)                                                                \
+  do {                                                                                                               \
+    if (NB == 2) BSN_PRODT_(2, HASQV, TAGV, GRID, BS, STRIDE, OFF);                                                  \
+    else BSN_PRODT_(3, HASQV, 0, GRID, BS, STRIDE, OFF);                                                             \
+  } while (0)
       // (workgroup shapes 4 x 8 / 4 x 4 / 2 x 8 / 4 x 16 tiles x waves, chunks of 256 variants: all slower, profiles/r04_sample_major.txt)
       if (sg) {
         // the pass in segments of sample blocks: kernel + finalize of a segment, then the caller's hook (svd.hip queues the
@@ -1754,8 +1818,12 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
           else BSN_PRODT(false, 0, gs, sgm.bs, sg->stride, sgm.off);
           BSN_HIP(hipGetLastError());
           const int64_t rows_s = (int64_t)sgm.bs * 512, tot = rows_s * sg->pieces;
-          hipLaunchKernelGGL((k_prod_final<32>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, b->stream, acc, npad, ky,
-                             S, nv, meta, sgm.d_rows, tot, sgm.d_out, (int64_t)0, sub_const, 0.0, rows_s);
+          if (NB == 2)
+            hipLaunchKernelGGL((k_prod_final<32>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, b->stream, acc, npad, ky,
+                               S, nv, meta, sgm.d_rows, tot, sgm.d_out, (int64_t)0, sub_const, 0.0, rows_s);
+          else
+            hipLaunchKernelGGL((k_prod_final<48>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, b->stream, acc, npad, ky,
+                               S, nv, meta, sgm.d_rows, tot, sgm.d_out, (int64_t)0, sub_const, 0.0, rows_s);
           BSN_HIP(hipGetLastError());
           if (sidx + 1 == sg->nseg) prof_end(op);
           (*sg->after)(sidx);
@@ -1767,7 +1835,10 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
       if (has_q) { if (warm) BSN_PRODT(true, 1, grid, 0, 0, 0); else BSN_PRODT(true, 0, grid, 0, 0, 0); }
       else { if (warm) BSN_PRODT(false, 1, grid, 0, 0, 0); else BSN_PRODT(false, 0, grid, 0, 0, 0); }
 #undef BSN_PRODT
+#undef BSN_PRODT_
       BSN_HIP(hipGetLastError());
+    } else if (NB > 2) {
+      fail("internal: three column blocks without the sample-major copy");
     } else if (b->bits == 8) {
       if (mode != 1) fail("internal: plane products are not defined on a byte image");
       const dim3 grid8 = grid;
@@ -1799,8 +1870,12 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
       hipLaunchKernelGGL((k_prod_final<16>), dim3((unsigned)((op->n + 255) / 256)), dim3(256), 0, b->stream,
                          acc, npad, ky, S, nv, meta, op->rows_identity ? nullptr : op->d_rows.p, op->n,
                          d_Y + (int64_t)v0 * ldy, ldy, sub_const, beta);
-    else
+    else if (NB == 2)
       hipLaunchKernelGGL((k_prod_final<32>), dim3((unsigned)((op->n + 255) / 256)), dim3(256), 0, b->stream,
+                         acc, npad, ky, S, nv, meta, op->rows_identity ? nullptr : op->d_rows.p, op->n,
+                         d_Y + (int64_t)v0 * ldy, ldy, sub_const, beta);
+    else
+      hipLaunchKernelGGL((k_prod_final<48>), dim3((unsigned)((op->n + 255) / 256)), dim3(256), 0, b->stream,
                          acc, npad, ky, S, nv, meta, op->rows_identity ? nullptr : op->d_rows.p, op->n,
                          d_Y + (int64_t)v0 * ldy, ldy, sub_const, beta);
     BSN_HIP(hipGetLastError());
@@ -1836,8 +1911,8 @@ void op_cprod_raw(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *
   for (int v0 = 0; v0 < nvec; v0 += vmax) {
     int nv = nvec - v0 < vmax ? nvec - v0 : vmax;
     int NB = pick_nb(nv * S), ncol = 16 * NB;
-    int8_t *q = op->d_q.ensure((size_t)npad * 32 * 2);
-    int32_t *acc = op->d_acc.ensure((size_t)2 * op->m * 32);
+    int8_t *q = op->d_q.ensure((size_t)npad * kMaxCols * 2);
+    int32_t *acc = op->d_acc.ensure((size_t)2 * op->m * kMaxCols);
     quantise(op, xsrc + (int64_t)v0 * ldx, ldx, b->n, npad, nv, 0, S, ncol, 1, 0, meta, q);
     launch_cprod<2, true, false>(op, NB, q, acc, kLutRaw, kLutNA, 0);
     op->passes++;

@@ -371,8 +371,9 @@ __global__ void k_max_over_ranks(const unsigned long long *__restrict__ all, int
 }
 // the rounding of k_round_cols on this rank's rows: the integers go to q (column-major, nr rows), the rounded values
 // back into W
-__global__ void k_pack_i16(double *__restrict__ W, int64_t nr, const unsigned long long *__restrict__ mx, int slices,
-                           int16_t *__restrict__ q) {
+template <typename INT>   // int16_t up to 16 bits, int32_t up to 32
+__global__ void k_pack_int(double *__restrict__ W, int64_t nr, const unsigned long long *__restrict__ mx, int slices,
+                           INT *__restrict__ q) {
   const int v = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nr) return;
@@ -385,11 +386,12 @@ __global__ void k_pack_i16(double *__restrict__ W, int64_t nr, const unsigned lo
   frexp(ldexp(0.98, 8 * slices - 1) / m, &e);
   const double qs = ldexp(1.0, e - 1), iq = ldexp(1.0, 1 - e);
   const long long k = llrint(W[i + v * nr] * qs);
-  q[i + v * nr] = (int16_t)k;
+  q[i + v * nr] = (INT)k;
   W[i + v * nr] = (double)k * iq;
 }
 // all ranks' integers ([rank][column][row of the block]) -> the rounded block with all n rows (column-major, ld n)
-__global__ void k_unpack_i16(const int16_t *__restrict__ q, int64_t n, int cb, int64_t nr,
+template <typename INT>
+__global__ void k_unpack_int(const INT *__restrict__ q, int64_t n, int cb, int64_t nr,
                              const unsigned long long *__restrict__ mx, int slices, double *__restrict__ full) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * cb) return;
@@ -713,6 +715,15 @@ struct HipSvdBackend : SvdBackend {
     n_seg_passes++;
     return true;
   }
+  // precision schedule of the driver: the digits of the following product pass, of the rounding of the block it
+  // produces and of the crossproduct pass that reads that block (everything reads op->slices when it is queued)
+  int min_slices = 8;
+  void set_precision(int S) override {
+    if (S < 1) S = 1;
+    if (S > 7) S = 7;
+    op->slices = S;
+    if (S < min_slices) min_slices = S;
+  }
   int n_seg_passes = 0;   // product passes that ran in segments (diagnostics / tests)
   int n_compact_gathers = 0;   // basis blocks all-gathered as 16-bit integers
   void A_Zblock(int p0, int cb) override {
@@ -768,23 +779,32 @@ struct HipSvdBackend : SvdBackend {
       mx_valid = false;
       return;
     }
-    if (comm && op->slices <= 2 && nr % 4 == 0 && !getenv("BSN_NO_COMPACT_GATHER")) {
-      // The block is rounded to 8 * slices <= 16 bits anyway: with the column maxima over ALL rows known first (an
-      // all-gather of cb numbers), every rank rounds its own rows and the all-gather ships the int16 integers — a
-      // quarter of the fp64 volume, the same rounded values bit for bit (a zero column keeps an unscaled zero: as in
-      // k_round_cols).  The integers travel as nr * cb / 4 doubles: an all-gather only moves bytes.
+    if (comm && op->slices <= 4 && nr % 4 == 0 && !getenv("BSN_NO_COMPACT_GATHER")) {
+      // The block is rounded to 8 * slices <= 32 bits anyway: with the column maxima over ALL rows known first (an
+      // all-gather of cb numbers), every rank rounds its own rows and the all-gather ships the integers — int16 up to
+      // 16 bits (a quarter of the fp64 volume), int32 up to 32 (half) —, the same rounded values bit for bit (a zero
+      // column keeps an unscaled zero: as in k_round_cols).  The integers travel as doubles: an all-gather only moves bytes.
       unsigned long long *mx = (unsigned long long *)dorth.p;
       BSN_HIP(hipMemsetAsync(mx, 0, (size_t)cb * 8, st));
       hipLaunchKernelGGL(k_col_absmax, dim3(64, cb), dim3(1024), 0, st, Wc, nr, nr, mx);
-      double *gmax = ws.Wrecv.ensure((size_t)nr * kMaxB);   // (free here: the segments' receive buffer)
+      // (the segments' receive buffer is free here; it also has to hold world * cb maxima when the sample blocks are short)
+      double *gmax = ws.Wrecv.ensure(std::max((size_t)nr * kMaxB, (size_t)world * kMaxB));
       comm_all_gather(comm, (const double *)mx, gmax, cb, st);
       hipLaunchKernelGGL(k_max_over_ranks, dim3(1), dim3(64), 0, st, (const unsigned long long *)gmax, world, cb, mx);
-      int16_t *q_send = (int16_t *)Wfull.p, *q_all = (int16_t *)Wblk.p;
-      hipLaunchKernelGGL(k_pack_i16, dim3((unsigned)((nr + 255) / 256), cb), dim3(256), 0, st, Wc, nr, mx, op->slices, q_send);
-      BSN_HIP(hipGetLastError());
-      comm_all_gather(comm, (const double *)q_send, (double *)q_all, nr * cb / 4, st);
-      hipLaunchKernelGGL(k_unpack_i16, dim3((unsigned)((n * cb + 255) / 256)), dim3(256), 0, st, q_all, n, cb, nr, mx,
-                         op->slices, Qfull.p);
+      const dim3 gp((unsigned)((nr + 255) / 256), cb), gu((unsigned)((n * cb + 255) / 256));
+      if (op->slices <= 2) {
+        int16_t *q_send = (int16_t *)Wfull.p, *q_all = (int16_t *)Wblk.p;
+        hipLaunchKernelGGL((k_pack_int<int16_t>), gp, dim3(256), 0, st, Wc, nr, mx, op->slices, q_send);
+        BSN_HIP(hipGetLastError());
+        comm_all_gather(comm, (const double *)q_send, (double *)q_all, nr * cb / 4, st);
+        hipLaunchKernelGGL((k_unpack_int<int16_t>), gu, dim3(256), 0, st, q_all, n, cb, nr, mx, op->slices, Qfull.p);
+      } else {
+        int32_t *q_send = (int32_t *)Wfull.p, *q_all = (int32_t *)Wblk.p;
+        hipLaunchKernelGGL((k_pack_int<int32_t>), gp, dim3(256), 0, st, Wc, nr, mx, op->slices, q_send);
+        BSN_HIP(hipGetLastError());
+        comm_all_gather(comm, (const double *)q_send, (double *)q_all, nr * cb / 2, st);
+        hipLaunchKernelGGL((k_unpack_int<int32_t>), gu, dim3(256), 0, st, q_all, n, cb, nr, mx, op->slices, Qfull.p);
+      }
       BSN_HIP(hipGetLastError());
       n_compact_gathers++;
       return;
@@ -865,7 +885,7 @@ struct HipSvdBackend : SvdBackend {
     a.Ri = Ri;
     a.Rout = dRout;
     a.flag = flag;
-    a.iters = op->slices >= 2 ? 2 : 4;   // |Q'Q - I| ~ 2^-8S: its cube (fifth power) is below rounding
+    a.iters = std::min(min_slices, op->slices) >= 2 ? 2 : 4;   // |Q'Q - I| ~ 2^-8S (coarsest block): its cube (fifth power) is below rounding
     a.Cs = a.Gs = a.Rs = a.Ris = a.Ro = a.Dv = a.tmp = nullptr;
     for (int pass = 0; pass < 2; pass++) {
       double *HG = pass == 0 ? HG1 : HG2;
@@ -1161,16 +1181,31 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       }
       so.block = bb;
       op->slices = ss;
+      // precision schedule (svd_driver.hpp): wider panels for the early steps when the vectors are wanted beyond the floor
+      // of `ss` digits; a caller who fixed the digits gets them at every step unless he also names a floor
+      double vf = o->vec_floor;
+      if (vf == 0.0) vf = o->slices > 0 ? -1.0 : 7.5e-8;
+      if (const char *e = getenv("BSN_VEC_FLOOR")) vf = atof(e);   // (A/B and the accuracy sweeps of the tests)
+      so.slices_base = ss;
+      so.slices_max = ss;
+      so.vec_floor = 0.0;
+      if (vf > 0) {
+        int sm = ss;
+        while (sm < 7 && 1.2 * std::ldexp(1.0, -8 * sm) > vf) sm++;
+        so.slices_max = sm;
+        so.vec_floor = vf;
+      }
+      if (const char *e = getenv("BSN_START_SLICES")) so.slices_start = atoi(e);
     }
     // a solve streams the image a dozen times: the ONE-block kernels, which are bound by HBM, get their layout (a
     // second copy in 64-variant x 256-B tiles, one extra pass of copying, kept on the handle) when the device has the
     // room: 2 - 4 % per pass.  The two-block kernels are bound by instruction issue and gain nothing from it (k_prod<2>
     // 23.65 ms on the plain image against 23.75 on the copy, k_cprod<2> 21.65 against 21.52: profiles/r03_shape_sweeps.txt),
     // so the default solve at k >= 14 leaves the other half of the HBM alone; a copy that exists is used either way.
-    if (so.block * op->slices <= 16 && op->cols_contig && (op->col0 & 63) == 0 && m >= 4096) image_tile(bed);
+    if (so.block * so.slices_max <= 16 && op->cols_contig && (op->col0 & 63) == 0 && m >= 4096) image_tile(bed);
     // ... and a solve on the two-block kernels for the sample-major copy: its product passes then run as k_prodT
     // (k_cprod's shape) instead of k_prod<2> with its transposes and 128 accumulators
-    if (so.block * op->slices > 16 && op->cols_contig && (op->col0 & 511) == 0 && m >= 4096) image_smaj(bed);
+    if (so.block * so.slices_max > 16 && op->cols_contig && (op->col0 & 511) == 0 && m >= 4096) image_smaj(bed);
     so.resid_floor = 1.2 * std::ldexp(1.0, -8 * op->slices);
     so.warm = o->warm_start < 0 ? 0 : (o->warm_start == 0 ? 1 : o->warm_start);
     so.max_basis = o->max_basis;
@@ -1187,6 +1222,8 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
         std::fprintf(stderr, "[bsn svd] Krylov space exhausted with a relative residual of %.3g on %d-bit products: "
                              "again with 56-bit products\n", r.max_rel_resid, 8 * op->slices);
       op->slices = 7;
+      so.slices_base = so.slices_max = 7;
+      so.vec_floor = 0.0;
       so.block = std::min(so.block, 32 / 7);
       so.resid_floor = 1.2 * std::ldexp(1.0, -8 * op->slices);
       const SvdResult r1 = r;
@@ -1250,9 +1287,16 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       info->converged = r.converged;
       info->max_rel_resid = r.max_rel_resid;
       info->gpu_ms = ms;
-      double pms[4];
-      int pc[4];
+      double pms[kProfKinds];
+      int pc[kProfKinds];
       prof_collect(op, pms, pc);
+      info->wide_cprod_ms = pms[4];
+      info->wide_prod_ms = pms[5];
+      info->n_wide_cprod = pc[4];
+      info->n_wide_prod = pc[5];
+      info->slices_max = r.slices_used_max > 0 ? r.slices_used_max : so.slices_base;
+      info->wide_steps = r.wide_steps;
+      info->lead_rel_resid = r.lead_rel_resid;
       info->cprod_ms = pms[0];
       info->prod_ms = pms[1];
       info->n_cprod = pc[0];
@@ -1263,9 +1307,9 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       info->warm_launches = bk.warm_launches;
       info->warm_fraction = bk.m_sub > 0 && bk.m_op_full > 0 ? (double)bk.m_sub / (double)bk.m_op_full : 0.0;
       info->block = so.block;
-      info->slices = op->slices;
+      info->slices = so.slices_base;
       info->tiled = (bed->d_tiled != nullptr && op->cols_contig && (op->col0 & 63) == 0) ? 1 : 0;
-      if (bed->d_smaj != nullptr && so.block * op->slices > 16 && so.block * op->slices <= 32 && op->cols_contig &&
+      if (bed->d_smaj != nullptr && so.block * so.slices_max > 16 && so.block * so.slices_max <= 48 && op->cols_contig &&
           (op->col0 & 511) == 0)
         info->tiled = 2;   // (one launch of two column blocks per product pass: k_prodT)
       info->segmented_passes = bk.n_seg_passes;

@@ -83,6 +83,10 @@ struct SvdBackend {
     (void)pp; (void)keep; (void)S; (void)rn; (void)Mk;
     return false;
   }
+  // Precision of what follows: the expansion W = A Z (the stored Z is rounded to 8 S bits on its way into the
+  // product) and the grid the NEXT basis block is rounded to (hence the crossproduct pass that reads it).  Called
+  // between the crossproduct and the product pass of a block step; backends with exact products ignore it.
+  virtual void set_precision(int slices) { (void)slices; }
   // Warm start: restrict the two products to a leading subset of the variants (on) or restore all of
   // them (off).  Returns false if the backend has no cheap subset (then the start block stays random).
   virtual bool subset(bool on) {
@@ -119,6 +123,21 @@ struct SvdOptions {
   // implicit restart of RSpectra::svds does for the reference, R/autoSVD.R:216-218); after max_restarts
   // compressions the solve gives up (RSpectra: maxitr).  < 0: never restart (a full basis ends the solve).
   int max_restarts = 100;
+  // Precision schedule (round 5).  The rounding of step j (Z_j on its way into W = A Z_j, and the grid of Q_j+1) leaves
+  //   A A' Q_j = [Q_1 .. Q_j+1] T_j + F_j,   |F_j| ~ 2^(-8 S_j) |A A' Q_j|,
+  // and a Ritz vector y = Q s feels  sum_j F_j s_j: step j enters with the weight |s_j| of the vector's component in
+  // block j — which is what the residual of that vector was one step earlier (inexact-Krylov relaxation: the early
+  // steps need the precision, the late ones do not).  With slices_base digits throughout, every vector that converges
+  // early — the leading ones — keeps a residual of 1.2 * 2^(-8 slices_base) (1.8e-5 at 16 bits: angles of 1e-4 .. 3e-4
+  // to the true singular vectors, where a Lanczos solve in fp64 leaves them at 1e-7).  vec_floor > 0 asks for that
+  // floor instead: step j runs with the smallest S in slices_base .. slices_max for which
+  //   1.2 * 2^(-8 S) * rho_(j-1) <= vec_floor,   rho = largest relative residual of the LEADING HALF of the k pairs
+  // after the previous step (1 before the first Rayleigh-Ritz step).  The Ritz values, the residual estimate and the
+  // stopping rule are those of the uniform solve; only the cost of the early passes changes.
+  int slices_base = 0;     // 0: no schedule (set_precision is never called)
+  int slices_max = 0;
+  int slices_start = 0;    // grid of the start block (it only chooses where the iteration starts); 0 -> slices_base
+  double vec_floor = 0.0;
 };
 
 struct SvdResult {
@@ -131,6 +150,9 @@ struct SvdResult {
   int exhausted = 0;  // the iteration ended because the Krylov space had no direction left (rank(A) + block <= basis)
   double exhausted_resid = 0;  // ... and what the coupling block of the last step says about the triplets that are not zero
   double max_rel_resid = 0;
+  double lead_rel_resid = 0;   // the same over the leading half of the k pairs
+  int wide_steps = 0;          // block steps that ran with more than slices_base digits (precision schedule)
+  int slices_used_max = 0;
 };
 
 // d: k singular values (descending); u: n x k; v: m_local x k (column-major, host)
@@ -224,6 +246,19 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
     return r;
   };
 
+  // precision schedule (SvdOptions): digits of the next block step from the leading half's residuals
+  const bool sched = opt.slices_base > 0 && opt.slices_max > opt.slices_base && opt.vec_floor > 0;
+  const int klead = (k + 1) / 2;
+  double rho_lead = 1.0;
+  auto step_slices = [&]() -> int {
+    int S = opt.slices_base;
+    if (sched) {
+      const double rho = rho_lead < 1.0 ? rho_lead : 1.0;
+      while (S < opt.slices_max && 1.2 * std::ldexp(1.0, -8 * S) * rho > opt.vec_floor) S++;
+    }
+    return S;
+  };
+  if (opt.slices_base > 0) bk.set_precision(opt.slices_start > 0 ? opt.slices_start : opt.slices_base);
   // start block
   bk.random_W(b, opt.seed);
   int r = orth(0, b, C2, Rt);
@@ -249,6 +284,13 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
   while (cb > 0) {
     const int p0 = p - cb;
     bk.At_Qblock(p0, cb);
+    if (opt.slices_base > 0) {
+      const int S = step_slices();
+      bk.set_precision(S);
+      if (S > opt.slices_base) res.wide_steps++;
+      if (S > res.slices_used_max) res.slices_used_max = S;
+      if (opt.verbose) std::fprintf(stderr, "[bsn svd] step %d: %d-bit products (leading residual %.2e)\n", res.niter + 1, 8 * S, rho_lead);
+    }
     bk.A_Zblock(p0, cb);
     res.nops += 2;
     res.niter++;
@@ -367,7 +409,7 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
     bool done = false;
     double worst_sig = 0;   // the same over the triplets that are not numerically zero (theta > 1e-10 theta_max)
     if (pp >= k) {
-      double worst = 0;
+      double worst = 0, lead = 0;
       for (int t = 0; t < k; t++) {
         int col = pp - 1 - t;
         double theta = eval[col];
@@ -380,9 +422,12 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
         }
         double rel = std::sqrt(rs) / std::max(std::fabs(theta), 1e-300);
         worst = std::max(worst, rel);
+        if (t < klead) lead = std::max(lead, rel);
         if (theta > 1e-10 * eval[pp - 1]) worst_sig = std::max(worst_sig, rel);
       }
       res.max_rel_resid = worst;
+      res.lead_rel_resid = lead;
+      rho_lead = lead;
       if (opt.verbose)
         std::fprintf(stderr, "[bsn svd] step %d basis %d max rel resid %.3e sigma1 %.6g\n", res.niter,
                      pp, worst, std::sqrt(std::max(eval[pp - 1], 0.0)));

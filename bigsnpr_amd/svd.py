@@ -19,9 +19,11 @@ from .bed import _args, assert_bed, bed_scaleBinom
 def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=None, k=10,
                   tol=1e-4, verbose=False, ncores=1, block=0, slices=0, max_basis=0, seed=1,
                   comm=None, allreduce=None, rank=0, world=1, m_total=0, return_uv=True, warm_start=0, warm_denominator=0,
-                  max_restarts=0):
+                  max_restarts=0, vec_floor=0.0):
     """Partial SVD of the scaled matrix.  Extra (non-reference) arguments: ``block``
-    (vectors per streaming pass), ``slices`` (int8 slices per fp64 value); column-sharded
+    (vectors per streaming pass), ``slices`` (int8 slices per fp64 value), ``vec_floor`` (relative
+    residual floor wanted for the singular vectors that converge beyond ``tol``: 0 = 7.5e-8 unless
+    ``slices`` is given, < 0 = none, i.e. every step on ``slices`` digits; include/bigsnpr_hip.h); column-sharded
     multi-GPU: ``comm`` (a bigsnpr_amd.Comm: the exchange runs inside the library over RCCL),
     ``m_total`` (columns over all ranks); tests: ``allreduce`` (callable(ptr, count) summing a
     device buffer of doubles over ranks) with ``rank`` / ``world``."""
@@ -41,6 +43,7 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
     opts.k, opts.tol, opts.block, opts.slices = int(k), float(tol), int(block), int(slices)
     opts.warm_start, opts.warm_denominator = int(warm_start), int(warm_denominator)
     opts.max_restarts = int(max_restarts)
+    opts.vec_floor = float(vec_floor)
     opts.max_basis, opts.seed, opts.verbose, opts.m_total = int(max_basis), int(seed), int(verbose), int(m_total)
     cb = None
     if comm is not None:
@@ -77,4 +80,8 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
                 fused_stats=bool(info.fused_stats), cprod_stats_ms=info.cprod_stats_ms,
                 n_cprod_stats=info.n_cprod_stats, warm_launches=info.warm_launches,
                 warm_fraction=info.warm_fraction, warm_ms=info.warm_ms, tiled=int(info.tiled),
-                segmented_passes=int(info.segmented_passes), compact_gathers=int(info.compact_gathers))
+                segmented_passes=int(info.segmented_passes), compact_gathers=int(info.compact_gathers),
+                slices_max=int(info.slices_max), wide_steps=int(info.wide_steps),
+                wide_cprod_ms=info.wide_cprod_ms, wide_prod_ms=info.wide_prod_ms,
+                n_wide_cprod=int(info.n_wide_cprod), n_wide_prod=int(info.n_wide_prod),
+                lead_rel_resid=info.lead_rel_resid)

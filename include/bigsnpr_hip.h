@@ -267,6 +267,15 @@ typedef struct bsn_svd_options {
    * implicitly).  0 -> at most 100 restarts, n > 0 -> n, < 0 -> none: a full basis ends the solve with return
    * code 2. */
   int32_t max_restarts;
+  /* Accuracy of the singular VECTORS (round 5).  The Ritz values do not see the rounding of the panels (exact-product
+   * Rayleigh-Ritz), the vectors do: at `slices` digits every vector that converges early keeps a relative residual
+   * of 1.2 * 2^(-8 slices) — 1.8e-5 at 16 bits, i.e. angles of 1e-4 .. 3e-4 to the true singular vectors, where the
+   * reference's fp64 Lanczos leaves its leading vectors at 1e-7.  vec_floor is the residual floor wanted instead:
+   * the early block steps (while the leading half of the k pairs is still far from converged) then run on wider
+   * panels — 24 bits for the default — and the late ones, whose rounding enters a converged vector with the small
+   * weight of its last components, stay narrow.  0 -> 7.5e-8 when `slices` is 0 (automatic), none when the caller
+   * fixed `slices`; > 0 -> that floor (digits up to 56 bits); < 0 -> none: every step at `slices` (round 4). */
+  double vec_floor;
 } bsn_svd_options;
 typedef struct bsn_svd_info {
   int32_t niter;      /* block steps */
@@ -294,6 +303,13 @@ typedef struct bsn_svd_info {
                             queued behind each segment (on a second stream unless BSN_NO_OVERLAP=1); round 4 */
   int32_t compact_gathers;  /* sharded solve: basis blocks all-gathered as the 16-bit integers they are rounded to (a quarter
                             of the fp64 volume, same values; BSN_NO_COMPACT_GATHER=1: fp64); round 4 */
+  /* precision schedule (vec_floor): widest panels used, block steps that ran wider than `slices`, and the
+   * streaming launches with THREE column blocks (48 digit columns: 16 vectors x 24 bits), timed apart from
+   * cprod_ms / prod_ms */
+  int32_t slices_max, wide_steps;
+  double wide_cprod_ms, wide_prod_ms;
+  int32_t n_wide_cprod, n_wide_prod;
+  double lead_rel_resid;    /* residual estimate of the leading half of the k pairs at exit (max_rel_resid: all k) */
 } bsn_svd_info;
 /* Returns 0 on success, 1 on error, and 2 when the solve ran to the end of its basis without all
  * k residuals meeting tol (outputs are filled with the best available triplets, bsn_last_error()

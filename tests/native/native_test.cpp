@@ -68,6 +68,13 @@ struct HostBackend : SvdBackend {
     }
   }
   void round_W(int cb) override { round_cols(W.data(), n, cb, 0.98); }
+  // the driver's precision schedule: what the product backend does with it (digits of the next product pass, of the
+  // rounding of the block it produces and of the crossproduct pass that reads that block)
+  std::vector<int> sched_log;
+  void set_precision(int S) override {
+    if (slices > 0) slices = S;
+    sched_log.push_back(S);
+  }
   void ZtZ(int p, int p0, int cb, double *G) override {
     for (int c = 0; c < cb; c++)
       for (int a = 0; a < p; a++) {
@@ -237,12 +244,25 @@ struct HostBackend : SvdBackend {
 };
 
 static int g_slices = 0, g_fused = 0, g_max_restarts = 100;
+static int g_slices_max = 0, g_slices_start = 0, g_sched_log[64], g_sched_n = 0;
+static double g_vec_floor = 0.0;
 static int g_counts[2] = {0, 0};
 
 extern "C" {
 
 // emulate the product's fixed-point products in the host backend (0 = exact)
 void nt_set_slices(int slices) { g_slices = slices; }
+// precision schedule of the driver (SvdOptions::vec_floor / slices_max / slices_start); 0, 0, 0 = none
+void nt_set_schedule(double vec_floor, int slices_max, int slices_start) {
+  g_vec_floor = vec_floor;
+  g_slices_max = slices_max;
+  g_slices_start = slices_start;
+}
+// digits handed to set_precision by the last solve, in call order (first = start block); returns the count
+int nt_schedule_log(int *out, int cap) {
+  for (int i = 0; i < g_sched_n && i < cap; i++) out[i] = g_sched_log[i];
+  return g_sched_n;
+}
 // 1: the host backend takes the product's fused two-pass block step (orth_small.hpp)
 void nt_set_fused(int on) { g_fused = on; }
 // thick restarts of a full basis (negative: none: a full basis ends the solve unconverged)
@@ -289,7 +309,16 @@ void nt_svd_host(const double *A, int64_t n, int64_t m_local, int64_t m_total, i
   o.seed = seed;
   o.max_restarts = g_max_restarts;
   o.resid_floor = g_slices > 0 ? 1.2 * std::ldexp(1.0, -8 * g_slices) : 0.0;
+  if (g_slices > 0) {
+    o.slices_base = g_slices;
+    o.slices_max = g_slices_max > g_slices ? g_slices_max : g_slices;
+    o.slices_start = g_slices_start;
+    o.vec_floor = g_vec_floor;
+  }
   SvdResult r = block_lanczos_svd(bk, o, d, u, v);
+  g_sched_n = 0;
+  for (int S : bk.sched_log)
+    if (g_sched_n < 64) g_sched_log[g_sched_n++] = S;
   g_counts[0] = bk.n_fused;
   g_counts[1] = bk.n_careful;
   info[0] = r.niter;

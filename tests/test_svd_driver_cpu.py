@@ -295,3 +295,46 @@ def test_converged_is_never_claimed_on_faith(nt):
     finally:
         nt.nt_set_slices(0)
     assert claimed > 60, (claimed, refused)
+
+
+def _sines(U, Ut):
+    U = U / np.linalg.norm(U, axis=0)
+    c = np.abs((U * Ut).sum(0))
+    return np.sqrt(np.maximum(0.0, 1.0 - c * c))
+
+
+def test_precision_schedule_gives_the_vectors_of_wide_panels(nt, fused):
+    """Round 5 (SvdOptions::vec_floor): the early block steps on 24-bit panels, the late ones on 16 bits.  On a matrix
+    with separated leading singular values (the genotype case: population structure over a noise bulk) the leading
+    vectors of the scheduled solve are as close to the true ones as those of the solve that runs EVERY step on 24
+    bits, and two orders of magnitude closer than the 16-bit solve's; the singular values agree in all three."""
+    rng = np.random.default_rng(11)
+    n, m, r, k, b = 400, 1200, 12, 8, 8
+    edge = np.sqrt(n) + np.sqrt(m)
+    s = edge * 12 * 0.95 ** np.arange(r)
+    U0 = np.linalg.qr(rng.normal(size=(n, r)))[0]
+    V0 = np.linalg.qr(rng.normal(size=(m, r)))[0]
+    A = rng.normal(size=(n, m)) + (U0 * s) @ V0.T
+    Ut, d, _ = np.linalg.svd(A, full_matrices=False)
+    out = {}
+    log = np.zeros(64, dtype=np.int32)
+    try:
+        for name, (S, vf, smax) in dict(narrow=(2, 0.0, 0), wide=(3, 0.0, 0), scheduled=(2, 7.5e-8, 3)).items():
+            nt.nt_set_slices(S)
+            nt.nt_set_schedule(C.c_double(vf), smax, 0)
+            res = host_svd(nt, A, k, tol=1e-4, block=b)
+            assert res["converged"]
+            np.testing.assert_allclose(res["d"], d[:k], rtol=1e-6)
+            cnt = nt.nt_schedule_log(log.ctypes.data_as(C.POINTER(C.c_int32)), 64)
+            out[name] = (_sines(res["u"], Ut[:, :k]), res["niter"], list(log[:cnt]))
+    finally:
+        nt.nt_set_slices(0)
+        nt.nt_set_schedule(C.c_double(0.0), 0, 0)
+    lead = slice(0, k // 2)
+    sn, sw, ss = out["narrow"][0][lead].max(), out["wide"][0][lead].max(), out["scheduled"][0][lead].max()
+    sched = out["scheduled"][2]
+    # the schedule starts wide and ends narrow, and the solve takes the steps of the uniform ones
+    assert sched[0] == 2 and sched[1] == 3 and sched[-1] == 2 and 3 in sched, sched
+    assert out["scheduled"][1] == out["wide"][1] == out["narrow"][1]
+    assert sn > 3e-6, sn                       # the 16-bit floor is visible on this matrix ...
+    assert ss < 3.0 * sw and ss < sn / 30, (sn, sw, ss)   # ... and gone with the early steps on 24 bits
