@@ -1184,7 +1184,7 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       // precision schedule (svd_driver.hpp): wider panels for the early steps when the vectors are wanted beyond the floor
       // of `ss` digits; a caller who fixed the digits gets them at every step unless he also names a floor
       double vf = o->vec_floor;
-      if (vf == 0.0) vf = o->slices > 0 ? -1.0 : 7.5e-8;
+      if (vf == 0.0) vf = o->slices > 0 ? -1.0 : 2.5e-7;   // a quarter of north_star's 1e-6, as the digits sit a quarter below tol
       if (const char *e = getenv("BSN_VEC_FLOOR")) vf = atof(e);   // (A/B and the accuracy sweeps of the tests)
       so.slices_base = ss;
       so.slices_max = ss;
@@ -1195,19 +1195,31 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
         so.slices_max = sm;
         so.vec_floor = vf;
       }
+      // the START block only chooses where the iteration begins: an 8-bit grid serves, and the first full crossproduct
+      // pass — the one that also counts the codes — then carries `block` digit columns instead of twice as many
+      // (16 vectors: one column block, 21 instead of 26 ms per 100 GB; same residuals, same vectors)
+      so.slices_start = o->slices > 0 ? 0 : 1;
       if (const char *e = getenv("BSN_START_SLICES")) so.slices_start = atoi(e);
+      // columns standardised by bed_scaleBinom: a random vector is amplified by sqrt(n) (svd_driver.hpp)
+      so.noise_gain = fused ? std::sqrt((double)n) : 0.0;
+      if (getenv("BSN_NO_ZQ_SPLIT")) so.noise_gain = 0.0;
     }
     // a solve streams the image a dozen times: the ONE-block kernels, which are bound by HBM, get their layout (a
     // second copy in 64-variant x 256-B tiles, one extra pass of copying, kept on the handle) when the device has the
     // room: 2 - 4 % per pass.  The two-block kernels are bound by instruction issue and gain nothing from it (k_prod<2>
     // 23.65 ms on the plain image against 23.75 on the copy, k_cprod<2> 21.65 against 21.52: profiles/r03_shape_sweeps.txt),
     // so the default solve at k >= 14 leaves the other half of the HBM alone; a copy that exists is used either way.
-    if (so.block * so.slices_max <= 16 && op->cols_contig && (op->col0 & 63) == 0 && m >= 4096) image_tile(bed);
-    // ... and a solve on the two-block kernels for the sample-major copy: its product passes then run as k_prodT
-    // (k_cprod's shape) instead of k_prod<2> with its transposes and 128 accumulators
-    if (so.block * so.slices_max > 16 && op->cols_contig && (op->col0 & 511) == 0 && m >= 4096) image_smaj(bed);
+    // ... and a solve with passes of two or three column blocks (16 vectors; 8 vectors on the 24-bit panels of the
+    // precision schedule) the sample-major copy: its product passes then run as k_prodT (k_cprod's shape; DESIGN.md
+    // 3.3b) instead of k_prod<2> with its transposes and 128 accumulators — and three column blocks exist on that copy
+    // only.  One second copy per handle: when the sample-major one is not to be had (no room, BSN_NO_SMAJ) the
+    // one-block passes of the solve still get theirs.
+    bool have_smaj = false;
+    if (so.block * so.slices_max > 16 && op->cols_contig && (op->col0 & 511) == 0 && m >= 4096) have_smaj = image_smaj(bed);
+    if (!have_smaj && so.block * so.slices_base <= 16 && op->cols_contig && (op->col0 & 63) == 0 && m >= 4096) image_tile(bed);
     so.resid_floor = 1.2 * std::ldexp(1.0, -8 * op->slices);
-    so.warm = o->warm_start < 0 ? 0 : (o->warm_start == 0 ? 1 : o->warm_start);
+    // (two iterations since round 5: + 2.5 ms, every residual of the 400K x 1M solve 4 - 10 x lower at the same step)
+    so.warm = o->warm_start < 0 ? 0 : (o->warm_start == 0 ? 2 : o->warm_start);
     so.max_basis = o->max_basis;
     so.max_restarts = o->max_restarts == 0 ? 100 : o->max_restarts;
     so.seed = o->seed ? o->seed : 1;

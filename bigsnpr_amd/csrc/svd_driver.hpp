@@ -132,12 +132,22 @@ struct SvdOptions {
   // to the true singular vectors, where a Lanczos solve in fp64 leaves them at 1e-7).  vec_floor > 0 asks for that
   // floor instead: step j runs with the smallest S in slices_base .. slices_max for which
   //   1.2 * 2^(-8 S) * rho_(j-1) <= vec_floor,   rho = largest relative residual of the LEADING HALF of the k pairs
-  // after the previous step (1 before the first Rayleigh-Ritz step).  The Ritz values, the residual estimate and the
-  // stopping rule are those of the uniform solve; only the cost of the early passes changes.
+  // after the previous step (1 before the first Rayleigh-Ritz step, which is taken as soon as the basis holds the
+  // leading half).  The Ritz values, the residual estimate and the stopping rule are those of the uniform solve; only
+  // the cost of the early passes changes.
+  // F_j has two sources and they are scheduled apart: the grid of Q_j+1 (enters as E_j+1 B_j+1: the rule above, digits
+  // of the NEXT crossproduct pass) and the digits of Z_j in the product pass (enters as A dZ, dZ white noise of the size
+  // of Z_j's rounding: a random vector, which A amplifies by sqrt(|A|_F^2 / m) — sqrt(n) for standardised columns —
+  // where it amplifies the block itself by its singular values).  noise_gain = that factor when the backend knows it
+  // (0: unknown, the product pass then follows the rule above): the product pass runs with the smallest S for which
+  //   1.2 * 2^(-8 S) * rho_(j-1) * min(1, noise_gain * sigma_1 / sigma_h^2) <= vec_floor,  sigma_h = smallest of the
+  // leading half's Ritz values — on a genotype matrix with population structure (sigma >> sqrt(n)) one step earlier
+  // narrow than the crossproduct pass.
   int slices_base = 0;     // 0: no schedule (set_precision is never called)
   int slices_max = 0;
   int slices_start = 0;    // grid of the start block (it only chooses where the iteration starts); 0 -> slices_base
   double vec_floor = 0.0;
+  double noise_gain = 0.0;
 };
 
 struct SvdResult {
@@ -249,12 +259,12 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
   // precision schedule (SvdOptions): digits of the next block step from the leading half's residuals
   const bool sched = opt.slices_base > 0 && opt.slices_max > opt.slices_base && opt.vec_floor > 0;
   const int klead = (k + 1) / 2;
-  double rho_lead = 1.0;
-  auto step_slices = [&]() -> int {
+  double rho_lead = 1.0, z_gain = 1.0;   // leading half: largest relative residual; relative weight of the product pass's rounding
+  auto step_slices = [&](const double gain) -> int {
     int S = opt.slices_base;
     if (sched) {
       const double rho = rho_lead < 1.0 ? rho_lead : 1.0;
-      while (S < opt.slices_max && 1.2 * std::ldexp(1.0, -8 * S) * rho > opt.vec_floor) S++;
+      while (S < opt.slices_max && 1.2 * std::ldexp(1.0, -8 * S) * rho * gain > opt.vec_floor) S++;
     }
     return S;
   };
@@ -284,14 +294,19 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
   while (cb > 0) {
     const int p0 = p - cb;
     bk.At_Qblock(p0, cb);
+    int S_next = 0;
     if (opt.slices_base > 0) {
-      const int S = step_slices();
-      bk.set_precision(S);
-      if (S > opt.slices_base) res.wide_steps++;
-      if (S > res.slices_used_max) res.slices_used_max = S;
-      if (opt.verbose) std::fprintf(stderr, "[bsn svd] step %d: %d-bit products (leading residual %.2e)\n", res.niter + 1, 8 * S, rho_lead);
+      const int Sz = step_slices(z_gain);   // digits of Z in the product pass
+      S_next = step_slices(1.0);            // grid of the block it produces = digits of the next crossproduct pass
+      bk.set_precision(Sz);
+      if (S_next > opt.slices_base || Sz > opt.slices_base) res.wide_steps++;
+      if (std::max(Sz, S_next) > res.slices_used_max) res.slices_used_max = std::max(Sz, S_next);
+      if (opt.verbose)
+        std::fprintf(stderr, "[bsn svd] step %d: %d-bit product pass, next block on %d bits (leading residual %.2e, product weight %.3f)\n",
+                     res.niter + 1, 8 * Sz, 8 * S_next, rho_lead, z_gain);
     }
     bk.A_Zblock(p0, cb);
+    if (opt.slices_base > 0) bk.set_precision(S_next);
     res.nops += 2;
     res.niter++;
     // Gram blocks of the new columns p0 .. p-1 (Z of this step is complete now, Q was stored rounded)
@@ -335,7 +350,7 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
     // Rayleigh-Ritz on span(Q[:, :pp]): (Gz) s = theta (Mq) s with Mq = R'R,
     // i.e. the standard problem for R^-T Gz R^-1, s = R^-1 y.  Not needed while the basis is smaller
     // than k and the iteration goes on (the device idles while the host works here).
-    if (pp >= k || rn == 0 || exhausted || want_restart) {
+    if (pp >= (sched ? std::min(k, klead) : k) || rn == 0 || exhausted || want_restart) {
       std::vector<double> Mp((size_t)pp * pp), Gp((size_t)pp * pp), Rm, Rmi, tmp((size_t)pp * pp);
       for (int j = 0; j < pp; j++)
         for (int i = 0; i < pp; i++) {
@@ -428,6 +443,10 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
       res.max_rel_resid = worst;
       res.lead_rel_resid = lead;
       rho_lead = lead;
+      if (opt.noise_gain > 0) {
+        const double th1 = eval[pp - 1], thh = eval[pp - klead];
+        z_gain = thh > 0 ? std::min(1.0, opt.noise_gain * std::sqrt(std::max(th1, 0.0)) / thh) : 1.0;
+      }
       if (opt.verbose)
         std::fprintf(stderr, "[bsn svd] step %d basis %d max rel resid %.3e sigma1 %.6g\n", res.niter,
                      pp, worst, std::sqrt(std::max(eval[pp - 1], 0.0)));
@@ -435,6 +454,27 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
         done = true;
         res.converged = 1;
       }
+    }
+    if (sched && pp < k && pp >= klead && !eval.empty()) {
+      // the basis does not hold k vectors yet, but it holds the leading half: their residuals steer the schedule
+      double lead = 0;
+      for (int t = 0; t < klead; t++) {
+        const int col = pp - 1 - t;
+        double rs = 0;
+        for (int i = 0; i < rl_rows; i++) {
+          double s = 0;
+          for (int j = 0; j < rl_cols; j++)
+            s += Rlast[(size_t)i + (size_t)j * rl_rows] * evec[(size_t)(pp - rl_cols + j) + (size_t)col * pp];
+          rs += s * s;
+        }
+        lead = std::max(lead, std::sqrt(rs) / std::max(std::fabs(eval[col]), 1e-300));
+      }
+      rho_lead = lead;
+      if (opt.noise_gain > 0) {
+        const double th1 = eval[pp - 1], thh = eval[pp - klead];
+        z_gain = thh > 0 ? std::min(1.0, opt.noise_gain * std::sqrt(std::max(th1, 0.0)) / thh) : 1.0;
+      }
+      if (opt.verbose) std::fprintf(stderr, "[bsn svd] step %d basis %d leading-half rel resid %.3e\n", res.niter, pp, lead);
     }
     if (!done && want_restart) {
       // keep the k + b largest Ritz pairs (room for at least the next block must remain)

@@ -22,7 +22,7 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
                   max_restarts=0, vec_floor=0.0):
     """Partial SVD of the scaled matrix.  Extra (non-reference) arguments: ``block``
     (vectors per streaming pass), ``slices`` (int8 slices per fp64 value), ``vec_floor`` (relative
-    residual floor wanted for the singular vectors that converge beyond ``tol``: 0 = 7.5e-8 unless
+    residual floor wanted for the singular vectors that converge beyond ``tol``: 0 = 2.5e-7 unless
     ``slices`` is given, < 0 = none, i.e. every step on ``slices`` digits; include/bigsnpr_hip.h); column-sharded
     multi-GPU: ``comm`` (a bigsnpr_amd.Comm: the exchange runs inside the library over RCCL),
     ``m_total`` (columns over all ranks); tests: ``allreduce`` (callable(ptr, count) summing a

@@ -258,8 +258,8 @@ typedef struct bsn_svd_options {
   double *center_out, *scale_out;
   /* warm start: power iterations of the random start block on the leading 1/16 of the variants before
    * the first full pass (each costs two streaming launches over that subset, 1/8 of a pass together).
-   * 0 -> 1 (default), n > 0 -> n, -1 -> none.  Matrices with fewer than 262 144 variants (over all ranks)
-   * skip it. */
+   * 0 -> 2 (default since round 5; 1 before), n > 0 -> n, -1 -> none.  Matrices with fewer than 262 144 variants
+   * (over all ranks) skip it. */
   int32_t warm_start;
   int32_t warm_denominator; /* the subset is the leading 1 / warm_denominator of the variants (0 -> 16) */
   /* A Krylov basis that fills up (max_basis) before the residuals meet tol is compressed to the k + block
@@ -273,7 +273,7 @@ typedef struct bsn_svd_options {
    * reference's fp64 Lanczos leaves its leading vectors at 1e-7.  vec_floor is the residual floor wanted instead:
    * the early block steps (while the leading half of the k pairs is still far from converged) then run on wider
    * panels — 24 bits for the default — and the late ones, whose rounding enters a converged vector with the small
-   * weight of its last components, stay narrow.  0 -> 7.5e-8 when `slices` is 0 (automatic), none when the caller
+   * weight of its last components, stay narrow.  0 -> 2.5e-7 when `slices` is 0 (automatic), none when the caller
    * fixed `slices`; > 0 -> that floor (digits up to 56 bits); < 0 -> none: every step at `slices` (round 4). */
   double vec_floor;
 } bsn_svd_options;

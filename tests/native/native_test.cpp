@@ -245,7 +245,7 @@ struct HostBackend : SvdBackend {
 
 static int g_slices = 0, g_fused = 0, g_max_restarts = 100;
 static int g_slices_max = 0, g_slices_start = 0, g_sched_log[64], g_sched_n = 0;
-static double g_vec_floor = 0.0;
+static double g_vec_floor = 0.0, g_noise_gain = 0.0;
 static int g_counts[2] = {0, 0};
 
 extern "C" {
@@ -258,6 +258,8 @@ void nt_set_schedule(double vec_floor, int slices_max, int slices_start) {
   g_slices_max = slices_max;
   g_slices_start = slices_start;
 }
+// SvdOptions::noise_gain: amplification of a random vector by A (sqrt(|A|_F^2 / m)); 0 = unknown
+void nt_set_noise_gain(double g) { g_noise_gain = g; }
 // digits handed to set_precision by the last solve, in call order (first = start block); returns the count
 int nt_schedule_log(int *out, int cap) {
   for (int i = 0; i < g_sched_n && i < cap; i++) out[i] = g_sched_log[i];
@@ -314,6 +316,7 @@ void nt_svd_host(const double *A, int64_t n, int64_t m_local, int64_t m_total, i
     o.slices_max = g_slices_max > g_slices ? g_slices_max : g_slices;
     o.slices_start = g_slices_start;
     o.vec_floor = g_vec_floor;
+    o.noise_gain = g_noise_gain;
   }
   SvdResult r = block_lanczos_svd(bk, o, d, u, v);
   g_sched_n = 0;

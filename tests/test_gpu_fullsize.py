@@ -65,9 +65,24 @@ def test_c3_randomsvd_full_size_properties(ba):
     assert np.linalg.norm(av - d[k - 1] * u[:, k - 1]) <= 1e-3 * d[k - 1]
     # north_star: singular values within 1e-6 of the reference's — pinned at full size (where no
     # oracle can run) by a solve on 56-bit panels to tol 1e-10 with another block size
-    tight = ba.bed_randomSVD(gb, k=k, tol=1e-10, slices=7, block=5, return_uv=False)
+    tight = ba.bed_randomSVD(gb, k=k, tol=1e-10, slices=7, block=5)
     assert tight["converged"]
     np.testing.assert_allclose(d, tight["d"], rtol=1e-6)
+    # ... and (round 5) the VECTORS of the default solve against the tight solve's: per vector || x sign - x_tight ||
+    # within the Davis-Kahan bound of the solve's own residual estimate + the floor of its precision schedule (2.5e-7:
+    # the early block steps run on 24-bit panels), for the leading half with the leading half's estimate; measured at
+    # this size: u 1.2e-6 / v 6.6e-8 over the leading half (16-bit panels at every step: 3.5e-5 / 1.2e-6)
+    assert res["slices_max"] == 3 and 1 <= res["wide_steps"] < res["niter"]
+    lam = tight["d"] ** 2
+    amp = np.array([lam[i] / np.min(np.abs(lam[i] - np.delete(lam, i))) for i in range(k)])
+    h = (k + 1) // 2
+    for name in ("u", "v"):
+        s = np.sign(np.sum(res[name] * tight[name], axis=0))
+        a = np.linalg.norm(res[name] * s - tight[name], axis=0)
+        assert np.all(a <= 2.0 * (res["max_rel_resid"] + 1.2 * 2.0 ** -16) * amp), (name, a)
+        assert np.all(a[:h] <= 2.0 * (res["lead_rel_resid"] + 2.5e-7) * amp[:h]), (name, a[:h])
+        assert a[:h].max() <= (3e-6 if name == "u" else 3e-7), (name, a[:h])
+        print("[C3 %s vs 56-bit tol-1e-10 solve] leading half %.2e, all %.2e" % (name, a[:h].max(), a.max()))
 
 
 def test_c5_ld_window_full_size_spot_checks(ba):

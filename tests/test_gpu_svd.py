@@ -102,7 +102,7 @@ def test_vectors_at_default_settings(ba, orc, golden_dir, example_bed, case, cap
         ob, gb = orc.fake_bed(n, m, seed=21), ba.bed.synthetic(n, m, seed=21)
         ic = np.nonzero(orc.bed_scaleBinom(ob)["scale"] > 0)[0]
     ref = orc.dense_svd(ob, None, ic, k=k + 1)
-    res = ba.bed_randomSVD(gb, ind_col=ic, k=k)
+    res = ba.bed_randomSVD(gb, ind_col=ic, k=k, vec_floor=-1.0)   # (every step on 16-bit panels: round 4's default)
     assert res["converged"]
     rho = 1e-4 + 1.2 * 2.0 ** (-8 * res["slices"])
     C = 2.0
@@ -125,6 +125,61 @@ def test_vectors_at_default_settings(ba, orc, golden_dir, example_bed, case, cap
               "sin(v) max %.2e (leading half %.2e, of bound %.3f); subspace sin u %.2e v %.2e"
               % (case, res["block"], res["slices"], res["niter"], worst["u"][0], worst["u"][1], worst["u"][2] / C,
                  worst["v"][0], worst["v"][1], worst["v"][2] / C, worst["u_subspace"][0], worst["v_subspace"][0]))
+
+
+def _small_angles(ref_x, x, k):
+    """|| x sign - ref || per column: 2 sin(theta / 2), exact down to 1e-16 (1 - cos^2 bottoms out at 1e-8)"""
+    s = np.sign(np.sum(x * ref_x[:, :k], axis=0))
+    return np.linalg.norm(x * s - ref_x[:, :k], axis=0)
+
+
+@pytest.mark.parametrize("case", ["example", "synth_1500x4000_k20", "synth_3000x900_k10"])
+def test_vector_accuracy_frontier(ba, orc, golden_dir, example_bed, case, capsys):
+    """per-vector angle of u and v to the oracle's dense SVD at tol 1e-4 for the DEFAULT solve (precision
+    schedule, round 5: the early block steps on 24-bit panels) and for uniform panels of 16 / 24 / 32 / 56 bits.
+    What is asserted: a Ritz vector whose eigen-residual is rho sigma_i^2 lies within rho sigma_i^2 / gap_i of the
+    eigenvector (Davis-Kahan, C = 2), with rho = the solve's own residual estimate + the rounding floor of its panels —
+    for ALL k vectors with the estimate over all k, for the LEADING HALF with the estimate over the leading half; the
+    default solve's floor is 2.5e-7 (uniform 16 bits: 1.8e-5), so its leading vectors come out as those of the 56-bit
+    solve (both limited by how far the Lanczos process has converged when the k-th pair meets tol), and every leading
+    vector whose bound is below 1e-6 IS below 1e-6 (north_star's tolerance)."""
+    if case == "example":
+        gb, ob, ic, k = ba.bed(os.path.join(golden_dir, "example.bed")), example_bed, None, 10
+    else:
+        n, m, k = (1500, 4000, 20) if "1500" in case else (3000, 900, 10)
+        ob, gb = orc.fake_bed(n, m, seed=21), ba.bed.synthetic(n, m, seed=21)
+        ic = np.nonzero(orc.bed_scaleBinom(ob)["scale"] > 0)[0]
+    ref = orc.dense_svd(ob, None, ic, k=k + 1)
+    lam = ref["d"] ** 2
+    amp = np.array([lam[i] / np.min(np.abs(lam[i] - np.delete(lam, i))) for i in range(k)])
+    h = (k + 1) // 2
+    rows = []
+    lead = {}
+    for name, kw, floor in (("default", dict(), 2.5e-7), ("16 bit", dict(slices=2), 1.2 * 2.0 ** -16),
+                            ("24 bit", dict(slices=3), 1.2 * 2.0 ** -24), ("32 bit", dict(slices=4), 1.2 * 2.0 ** -32),
+                            ("56 bit", dict(slices=7), 1.2 * 2.0 ** -56)):
+        res = ba.bed_randomSVD(gb, ind_col=ic, k=k, **kw)
+        assert res["converged"]
+        np.testing.assert_allclose(res["d"], ref["d"][:k], rtol=1e-6)
+        if name == "default":
+            assert res["slices"] == 2 and res["slices_max"] == 3 and res["wide_steps"] >= 1
+        else:
+            assert res["slices_max"] == res["slices"] == kw["slices"] and res["wide_steps"] == 0
+        au, av = _small_angles(ref["u"], res["u"], k), _small_angles(ref["v"], res["v"], k)
+        for a in (au, av):
+            assert np.all(a <= 2.0 * (res["max_rel_resid"] + 1.2 * 2.0 ** (-8 * res["slices"])) * amp), (name, a)
+            assert np.all(a[:h] <= 2.0 * (res["lead_rel_resid"] + floor) * amp[:h] + 1e-12), (name, a[:h])
+            if name == "default":   # north_star's 1e-6 wherever the spectrum allows it
+                ok = 2.0 * (res["lead_rel_resid"] + floor) * amp[:h] <= 1e-6
+                assert np.all(a[:h][ok] <= 1e-6)
+        lead[name] = (float(au[:h].max()), float(av[:h].max()))
+        rows.append("%-8s block %2d steps %2d (wide %2d) resid lead %.1e all %.1e | u lead %.1e all %.1e | v lead %.1e all %.1e"
+                    % (name, res["block"], res["niter"], res["wide_steps"], res["lead_rel_resid"], res["max_rel_resid"],
+                       au[:h].max(), au.max(), av[:h].max(), av.max()))
+    # the schedule removes the 16-bit floor from the leading vectors
+    assert lead["default"][0] <= 0.2 * lead["16 bit"][0] and lead["default"][1] <= 0.2 * lead["16 bit"][1], lead
+    with capsys.disabled():
+        print("\n[u/v frontier] %s k %d, relative gaps of the leading half %s\n  " % (case, k, np.round(1.0 / amp[:h], 3)) + "\n  ".join(rows))
 
 
 def test_k_too_large_and_errors(ba, golden_dir):
@@ -162,7 +217,7 @@ def test_warm_start_on_a_variant_subset(ba):
     gb = ba.bed.synthetic(n, m, seed=13)
     cold = ba.bed_randomSVD(gb, k=k, warm_start=-1)
     warm = ba.bed_randomSVD(gb, k=k)
-    assert cold["warm_launches"] == 0 and warm["warm_launches"] == 2
+    assert cold["warm_launches"] == 0 and warm["warm_launches"] == 4
     assert abs(warm["warm_fraction"] - 1.0 / 16) < 1e-3
     assert warm["converged"] and warm["niter"] <= cold["niter"]
     np.testing.assert_allclose(warm["d"], cold["d"], rtol=1e-6)

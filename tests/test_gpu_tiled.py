@@ -65,7 +65,7 @@ def test_solve_bit_identical_with_and_without_the_tiled_copy(ba, monkeypatch, bl
         gb.close()
     a, b = res[False], res[True]
     assert a["niter"] == b["niter"] and a["nops"] == b["nops"] and a["warm_launches"] == b["warm_launches"]
-    assert a["warm_launches"] == (2 if block == 0 else 0)
+    assert a["warm_launches"] == (4 if block == 0 else 0)
     for key in ("d", "u", "v", "center", "scale"):
         np.testing.assert_array_equal(a[key], b[key])
 

@@ -319,9 +319,11 @@ def test_precision_schedule_gives_the_vectors_of_wide_panels(nt, fused):
     out = {}
     log = np.zeros(64, dtype=np.int32)
     try:
-        for name, (S, vf, smax) in dict(narrow=(2, 0.0, 0), wide=(3, 0.0, 0), scheduled=(2, 7.5e-8, 3)).items():
+        for name, (S, vf, smax, gain) in dict(narrow=(2, 0.0, 0, 0.0), wide=(3, 0.0, 0, 0.0), scheduled=(2, 2.5e-7, 3, 0.0),
+                                              split=(2, 2.5e-7, 3, np.sqrt(n))).items():
             nt.nt_set_slices(S)
             nt.nt_set_schedule(C.c_double(vf), smax, 0)
+            nt.nt_set_noise_gain(C.c_double(gain))
             res = host_svd(nt, A, k, tol=1e-4, block=b)
             assert res["converged"]
             np.testing.assert_allclose(res["d"], d[:k], rtol=1e-6)
@@ -330,11 +332,19 @@ def test_precision_schedule_gives_the_vectors_of_wide_panels(nt, fused):
     finally:
         nt.nt_set_slices(0)
         nt.nt_set_schedule(C.c_double(0.0), 0, 0)
+        nt.nt_set_noise_gain(C.c_double(0.0))
     lead = slice(0, k // 2)
     sn, sw, ss = out["narrow"][0][lead].max(), out["wide"][0][lead].max(), out["scheduled"][0][lead].max()
     sched = out["scheduled"][2]
+    # (log: start block, then per block step the digits of the product pass and the grid of the block it produces)
     # the schedule starts wide and ends narrow, and the solve takes the steps of the uniform ones
-    assert sched[0] == 2 and sched[1] == 3 and sched[-1] == 2 and 3 in sched, sched
-    assert out["scheduled"][1] == out["wide"][1] == out["narrow"][1]
+    assert sched[0] == 2 and sched[1] == 3 and sched[2] == 3 and sched[-1] == 2 and sched[-2] == 2, sched
+    assert out["scheduled"][1] == out["wide"][1] == out["narrow"][1] == out["split"][1]
+    # with the amplification of a random vector known (sqrt(n) against singular values of 12 x the bulk edge) the
+    # PRODUCT passes go narrow earlier than the grids, and the leading vectors stay within the floor that was asked
+    # for (2.5e-7 in the residual: angles below north_star's 1e-6)
+    split = out["split"][2]
+    assert sum(split[1::2]) < sum(sched[1::2]) and split[2::2] == sched[2::2], (split, sched)
+    assert out["split"][0][lead].max() < 1e-6 and out["split"][0][lead].max() < sn / 8, (out["split"][0][lead].max(), sn)
     assert sn > 3e-6, sn                       # the 16-bit floor is visible on this matrix ...
     assert ss < 3.0 * sw and ss < sn / 30, (sn, sw, ss)   # ... and gone with the early steps on 24 bits
