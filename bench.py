@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--no-wide", action="store_true",
                     help="skip the two extra solves on 32- and 56-bit panels that fill `fp64_equivalent`")
     ap.add_argument("--no-ingest", action="store_true")
+    ap.add_argument("--no-accuracy", action="store_true",
+                    help="svd: skip the accuracy record (u / v of the last timed solve against a 56-bit tol-1e-10 solve, outside "
+                         "the timed region)")
     ap.add_argument("--ingest-gb", type=float, default=8.0, help="size of the .bed file written and re-opened")
     ap.add_argument("--allow-fallback", action="store_true",
                     help="N > 1 without a working RCCL communicator: take the host all-reduce hook over gloo (labelled in "
@@ -292,7 +295,9 @@ def main():
     kern = {}
     for key, name in (("prod", "k_prod / k_prodT (A~ panel, contraction over variants)"),
                       ("cprod", "k_cprod (A~' panel, contraction over samples)"),
-                      ("cprod_stats", "k_cprod<STATS> (first A~' pass of a solve: also counts the codes of every variant)")):
+                      ("cprod_stats", "k_cprod<STATS> (first A~' pass of a solve: also counts the codes of every variant)"),
+                      ("wide_prod", "k_prodT<3> (A~ panel on 24-bit digits: 16 vectors x 3 slices = three column blocks)"),
+                      ("wide_cprod", "k_cprod<3> (A~' panel on 24-bit digits: three column blocks)")):
         ms = sum(r[key + "_ms"] for r in infos)
         cnt = sum(r["n_" + key] for r in infos)
         if cnt:
@@ -301,31 +306,49 @@ def main():
     dom = kern[dom_key]
     # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside
     # the process, so this is the committed rocprofv3 measurement of the same workload
-    traffic, traffic_note = None, None
+    traffic, traffic_note, clock_ghz = None, None, None
     blk, sl = infos[-1]["block"], infos[-1]["slices"]
-    nb = 1 if blk * sl <= 16 else 2          # MFMA column blocks of the streaming kernels
     running = streaming_kernel_names(L, gb)  # what this build launched in the last solve, by kind
+    run_key = {"wide_prod": "prod_wide", "wide_cprod": "cprod_wide"}.get(dom_key, dom_key)
+
+    def nb_from_name(kind):   # MFMA column blocks of the kernel launched under a kind: its first template argument
+        import re
+        mm = re.search(r"<\s*(\d+)", running.get({"wide_prod": "prod_wide", "wide_cprod": "cprod_wide"}.get(kind, kind), ""))
+        return int(mm.group(1)) if mm else (3 if kind.startswith("wide_") else (1 if blk * sl <= 16 else 2))
+    nb_of = {kind: nb_from_name(kind) for kind in kern}
+    nb = nb_of[dom_key]   # (three: the 24-bit passes of the precision schedule)
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        # the counters are per kernel variant: one column block (block x slices <= 16) or two.  The record is only
+        # the counters are per kernel variant: one column block (block x slices <= 16), two or three.  The record is only
         # quoted when it was taken on the SAME kernel instantiation built from the SAME source as the running library
-        rec = pm["kernels" if nb == 1 else "kernels_nb2"][dom_key]
+        rec = pm["kernels" if nb == 1 else "kernels_nb%d" % nb][dom_key]
         if pm["workload"] != {"n": n, "m_per_gpu": m_local}:
             traffic_note = "profiles/pmc_traffic.json was taken on another workload"
         elif pm.get("matvec_sha256") != source_sha256("matvec.hip"):
             traffic_note = "profiles/pmc_traffic.json was taken on another build of matvec.hip"
-        elif norm_kernel(rec["name"]) != norm_kernel(running.get(dom_key, "")):
+        elif norm_kernel(rec["name"]) != norm_kernel(running.get(run_key, "")):
             traffic_note = ("profiles/pmc_traffic.json holds %s, this build launched %s"
-                            % (rec["name"], running.get(dom_key)))
+                            % (rec["name"], running.get(run_key)))
         else:
             traffic = rec["hbm_read_bytes"]
+            clock_ghz = rec.get("effective_GHz")   # GRBM_GUI_ACTIVE / 8 XCDs / kernel time, same pass
     except Exception as e:
         traffic, traffic_note = None, "no usable profiles/pmc_traffic.json (%s)" % e
     achieved = bytes_per_launch / (dom["avg_ms"] * 1e-3) / 1e9
     # the same launch priced against the matrix pipe: per 16 variants x 64 samples one v_mfma_i32_16x16x64_i8
     # (32 768 int8 ops) per plane (genotype, missing-value) and column block
-    mfma_ops = (n / 64.0) * (m_local / 16.0) * 2 * nb * 32768.0
-    mfma_tops = mfma_ops / (dom["avg_ms"] * 1e-3) / 1e12
+    def mfma_price(nblk, ms):
+        return (n / 64.0) * (m_local / 16.0) * 2 * nblk * 32768.0 / (ms * 1e-3) / 1e12
+    mfma_tops = mfma_price(nb, dom["avg_ms"])
+    hbm_obj = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
+    mfma_obj = {"achieved": mfma_tops, "peak": I8_PEAK_TOPS, "unit": "TOP/s", "frac": mfma_tops / I8_PEAK_TOPS, "column_blocks": nb}
+    if clock_ghz:
+        # the matrix pipe at the clock the power cap leaves (MI355X_MICROARCH.md: 1 024 SIMDs x 2 048 int8 ops per cycle)
+        mfma_obj["clock_GHz"] = clock_ghz
+        mfma_obj["frac_at_clock"] = mfma_tops / (1024 * 2048 * clock_ghz * 1e9 / 1e12)
+    # which roofline binds: the resource with the higher utilisation; "power" when the clock sits > 15 % below 2.4 GHz
+    # (the launch is then paced by the package power cap: cycles / clock)
+    primary = ("mfma", mfma_obj) if mfma_obj["frac"] > hbm_obj["frac"] else ("hbm", hbm_obj)
     out = {
         "metric": "SNP-cols/sec for bed_randomSVD k=%d (m*passes/wall)" % a.k,
         "value": value, "unit": "SNP-cols/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -335,8 +358,10 @@ def main():
         "time_to_solution_ms": wall / a.steps * 1e3,
         "result_on_host": ["d", "center", "scale"] + ([] if a.no_uv else ["u", "v"]),
         "vs_baseline": None,
-        "dtype": "i8 (2-bit codes x %d-bit fixed-point image of the fp64 basis, %d int8 slices, exact int32 "
-                 "MFMA accumulation; fp64 panel algebra and Rayleigh-Ritz)" % (8 * sl, sl),
+        "dtype": "i8 (2-bit codes x %s fixed-point image of the fp64 basis in int8 slices, exact int32 "
+                 "MFMA accumulation; fp64 panel algebra and Rayleigh-Ritz)"
+                 % ("%d-bit" % (8 * sl) if infos[-1]["slices_max"] <= sl else
+                    "%d-bit (early block steps) / %d-bit (late block steps)" % (8 * infos[-1]["slices_max"], 8 * sl)),
         "data": "synthetic",
         "config": {"workload": "bed_randomSVD k=%d on synthetic %dx%d 2-bit .bed image resident in HBM"
                                % (a.k, n, m_total),
@@ -369,8 +394,11 @@ def main():
         "sigma": [float(x) for x in infos[-1]["d"][:5]],
         "generate_s": gen_s,
         "sample_major_copy_build_s": smaj_s,
-        "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "roofline": {"bound": primary[0], "kernel": dom["name"], "achieved": primary[1]["achieved"], "peak": primary[1]["peak"],
+                     "unit": primary[1]["unit"], "frac": primary[1]["frac"], "traffic": traffic,
+                     "paced_by": ("power cap (clock %.2f GHz under this kernel against 2.4)" % clock_ghz)
+                                 if clock_ghz and clock_ghz < 0.85 * 2.4 else None,
+                     "hbm": hbm_obj,
                      "traffic_source": ("profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2, bytes per launch; same kernel "
                                         "instantiation and matvec.hip hash as this build)") if traffic else traffic_note,
                      "kernels_launched": running,
@@ -378,17 +406,21 @@ def main():
                      "launches": dom["launches"],
                      # the two-column-block kernels (16 vectors per pass) are bound by the matrix pipe / the VALU issue
                      # port next to it, not by HBM: both prices of the same launch
-                     "mfma": {"achieved": mfma_tops, "peak": I8_PEAK_TOPS, "unit": "TOP/s", "frac": mfma_tops / I8_PEAK_TOPS,
-                              "column_blocks": nb},
+                     "mfma": mfma_obj,
                      "other": {k: {"avg_ms": v["avg_ms"], "launches": v["launches"],
-                                   "GBps": bytes_per_launch / (v["avg_ms"] * 1e-3) / 1e9}
+                                   "GBps": bytes_per_launch / (v["avg_ms"] * 1e-3) / 1e9,
+                                   "column_blocks": nb_of[k], "mfma_TOPs": mfma_price(nb_of[k], v["avg_ms"])}
                                for k, v in kern.items()}},
     }
 
     if rank == 0 and world == 1:
+        ref = None
+        if not a.no_accuracy and not a.no_uv and a.shard_of <= 1:
+            out["accuracy"], ref = accuracy(ba, gb, a, infos[-1], last_uv)
+            log("accuracy against the 56-bit tol-1e-10 solve done")
         if not a.no_wide:
-            out["fp64_equivalent"] = wide_solves(ba, gb, a, infos[-1], sync)
-            log("wide-arithmetic solves done")
+            out["fp64_equivalent"] = wide_solves(ba, gb, a, infos[-1], sync, ref)
+            log("alternative-precision solves done")
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ba, gb, n, a.cpu_sample_cols)
             log("cpu baseline done")
@@ -431,17 +463,56 @@ def streaming_kernel_names(L, gb):
     return dict(line.split("=", 1) for line in buf.value.decode().splitlines() if "=" in line)
 
 
-def wide_solves(ba, gb, a, default_info, sync):
-    """What the 16-bit panels of the default solve buy: the SAME solve with the panels carried at 32 and
-    56 bits (--slices 4 / 7; 56 bits is the width at which the products are as exact as the reference's own fp64
-    summation), one timed solve each after one untimed, with the relative difference of d to the default solve."""
+def _angles(x, ref):
+    """per column || x sign - ref || = 2 sin(theta / 2): the angle between a computed singular vector and its reference"""
     import numpy as np
-    res = {"default": {"slices": default_info["slices"], "block": default_info["block"]}}
+    s = np.sign(np.sum(x * ref, axis=0))
+    return np.linalg.norm(x * s - ref, axis=0)
+
+
+def _angle_record(r_u, r_v, ref, k):
+    h = (k + 1) // 2
+    au, av = _angles(r_u, ref["u"]), _angles(r_v, ref["v"])
+    return {"u_leading_half": float(au[:h].max()), "u_all": float(au.max()),
+            "v_leading_half": float(av[:h].max()), "v_all": float(av.max())}
+
+
+def accuracy(ba, gb, a, info, uv):
+    """what the timed configuration delivers, measured OUTSIDE the timed region — u and v of the last
+    timed solve against a solve of the same matrix on 56-bit panels to tol 1e-10 with another block size (the
+    full-size stand-in for the reference's fp64 Lanczos: no oracle runs at this size), per vector the angle
+    || x sign - x_ref ||, worst over the leading half of the k vectors and over all of them; north_star asks for 1e-6."""
+    import numpy as np
+    t0 = time.perf_counter()
+    ref = ba.bed_randomSVD(gb, k=a.k, tol=1e-10, slices=7, block=4 if a.block != 4 else 5)
+    rec = _angle_record(uv[0], uv[1], ref, a.k)
+    rec.update({"reference": "bed_randomSVD of the same matrix, 56-bit panels, tol 1e-10, block %d (%d block steps, %.1f s)"
+                             % (ref["block"], ref["niter"], time.perf_counter() - t0),
+                "d_max_rel_diff": float(np.max(np.abs(np.asarray(info["d"]) / ref["d"] - 1.0))),
+                "residual_estimate": {"leading_half": info["lead_rel_resid"], "all": info["max_rel_resid"]},
+                "precision_schedule": {"panel_bits": 8 * info["slices"], "widest_panel_bits": 8 * info["slices_max"],
+                                       "wide_block_steps": info["wide_steps"], "of_block_steps": info["niter"],
+                                       "three_block_launches": info["n_wide_cprod"] + info["n_wide_prod"]},
+                "north_star_tolerance": 1e-6,
+                "leading_half_within_tolerance": bool(rec["u_leading_half"] <= 1e-6 and rec["v_leading_half"] <= 1e-6)})
+    return rec, ref
+
+
+def wide_solves(ba, gb, a, default_info, sync, ref=None):
+    """The accuracy / cost frontier around the timed configuration: the SAME solve (a) with every
+    block step on the narrow panels of the default (round 4's default: no precision schedule), (b) / (c) with the panels
+    carried at 32 and 56 bits throughout (56 bits is the width at which the products are as exact as the reference's
+    own fp64 summation) — one timed solve each after one untimed, the relative difference of d to the default solve and,
+    when the tight reference solve is at hand, the angles of ITS u / v to that reference."""
+    import numpy as np
+    res = {"default": {"slices": default_info["slices"], "slices_max": default_info["slices_max"],
+                       "wide_block_steps": default_info["wide_steps"], "block": default_info["block"]}}
     d0 = np.asarray(default_info["d"])
-    for sl in (4, 7):
+    for tag, kw in (("narrow_panels_every_step", dict(vec_floor=-1.0, slices=a.slices)), ("slices_4", dict(slices=4)),
+                    ("slices_7", dict(slices=7))):
         def one():
-            return ba.bed_randomSVD(gb, k=a.k, tol=a.tol, block=a.block, slices=sl, return_uv=not a.no_uv,
-                                    warm_start=a.warm_start, warm_denominator=a.warm_den)
+            return ba.bed_randomSVD(gb, k=a.k, tol=a.tol, block=a.block, return_uv=not a.no_uv,
+                                    warm_start=a.warm_start, warm_denominator=a.warm_den, **kw)
         one()
         sync()
         t0 = time.perf_counter()
@@ -449,9 +520,11 @@ def wide_solves(ba, gb, a, default_info, sync):
         sync()
         ms = (time.perf_counter() - t0) * 1e3
         passes = r["nops"] - r["warm_launches"] * (1.0 - r["warm_fraction"]) + (0 if r["fused_stats"] else 1)
-        res["slices_%d" % sl] = {"panel_bits": 8 * sl, "ms": ms, "block": r["block"], "niter": r["niter"],
-                                 "passes": passes, "converged": r["converged"],
-                                 "max_rel_diff_d_vs_default": float(np.max(np.abs(np.asarray(r["d"]) / d0 - 1.0)))}
+        res[tag] = {"panel_bits": 8 * r["slices"], "ms": ms, "block": r["block"], "niter": r["niter"],
+                    "passes": passes, "converged": r["converged"],
+                    "max_rel_diff_d_vs_default": float(np.max(np.abs(np.asarray(r["d"]) / d0 - 1.0)))}
+        if ref is not None and r.get("u") is not None:
+            res[tag]["angles_to_reference"] = _angle_record(r["u"], r["v"], ref, a.k)
         del r
     return res
 

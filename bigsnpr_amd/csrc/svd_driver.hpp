@@ -87,6 +87,9 @@ struct SvdBackend {
   // product) and the grid the NEXT basis block is rounded to (hence the crossproduct pass that reads it).  Called
   // between the crossproduct and the product pass of a block step; backends with exact products ignore it.
   virtual void set_precision(int slices) { (void)slices; }
+  // hold = true: the fused block step must not round the block it produces ahead of the driver's round_W (the
+  // driver wants this step's residuals before it chooses that block's grid)
+  virtual void hold_rounding(bool hold) { (void)hold; }
   // Warm start: restrict the two products to a leading subset of the variants (on) or restore all of
   // them (off).  Returns false if the backend has no cheap subset (then the start block stays random).
   virtual bool subset(bool on) {
@@ -134,7 +137,9 @@ struct SvdOptions {
   //   1.2 * 2^(-8 S) * rho_(j-1) <= vec_floor,   rho = largest relative residual of the LEADING HALF of the k pairs
   // after the previous step (1 before the first Rayleigh-Ritz step, which is taken as soon as the basis holds the
   // leading half).  The Ritz values, the residual estimate and the stopping rule are those of the uniform solve; only
-  // the cost of the early passes changes.
+  // the cost of the early passes changes.  The grid of Q_j+1 enters with the weight of the residual AFTER step j
+  // (E_j+1 B_j+1 s_j: |B_j+1 s_j| is that residual), so while the schedule is wide the rounding of the new block
+  // waits for the step's Rayleigh-Ritz result instead of being queued ahead of it.
   // F_j has two sources and they are scheduled apart: the grid of Q_j+1 (enters as E_j+1 B_j+1: the rule above, digits
   // of the NEXT crossproduct pass) and the digits of Z_j in the product pass (enters as A dZ, dZ white noise of the size
   // of Z_j's rounding: a random vector, which A amplifies by sqrt(|A|_F^2 / m) — sqrt(n) for standardised columns —
@@ -306,7 +311,13 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
                      res.niter + 1, 8 * Sz, 8 * S_next, rho_lead, z_gain);
     }
     bk.A_Zblock(p0, cb);
-    if (opt.slices_base > 0) bk.set_precision(S_next);
+    // the grid of the block this step produces: narrow already by the previous step's residuals -> queued behind the
+    // orthonormalisation as always; else decided below, once this step's residuals are known
+    const bool hold = sched && S_next > opt.slices_base;
+    if (opt.slices_base > 0) {
+      bk.set_precision(S_next);
+      bk.hold_rounding(hold);
+    }
     res.nops += 2;
     res.niter++;
     // Gram blocks of the new columns p0 .. p-1 (Z of this step is complete now, Q was stored rounded)
@@ -475,6 +486,12 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
         z_gain = thh > 0 ? std::min(1.0, opt.noise_gain * std::sqrt(std::max(th1, 0.0)) / thh) : 1.0;
       }
       if (opt.verbose) std::fprintf(stderr, "[bsn svd] step %d basis %d leading-half rel resid %.3e\n", res.niter, pp, lead);
+    }
+    if (hold) {   // (rho_lead is this step's now, unless the basis is still smaller than the leading half)
+      const int S = step_slices(1.0);
+      bk.set_precision(S);
+      if (S > res.slices_used_max) res.slices_used_max = S;
+      if (opt.verbose) std::fprintf(stderr, "[bsn svd] step %d: next block on %d bits (leading residual %.2e)\n", res.niter, 8 * S, rho_lead);
     }
     if (!done && want_restart) {
       // keep the k + b largest Ritz pairs (room for at least the next block must remain)
