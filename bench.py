@@ -60,6 +60,11 @@ def parse():
     ap.add_argument("--no-wide", action="store_true",
                     help="skip the two extra solves on 32- and 56-bit panels that fill `fp64_equivalent`")
     ap.add_argument("--no-ingest", action="store_true")
+    ap.add_argument("--exchange", choices=["overlap", "one_stream", "whole"], default=None,
+                    help="sharded svd: take this exchange of the product pass (else the fastest one that passes the first-contact "
+                         "probe: bigsnpr_amd.comm.negotiate)")
+    ap.add_argument("--exchange-timeout-ms", type=int, default=30000,
+                    help="sharded svd: watchdog of the first-contact probe and (x 4) of every later solve")
     ap.add_argument("--no-accuracy", action="store_true",
                     help="svd: skip the accuracy record (u / v of the last timed solve against a 56-bit tol-1e-10 solve, outside "
                          "the timed region)")
@@ -169,33 +174,36 @@ def main():
 
     comm = None
     hook = None
+    exchange_report = None
+
+    def host_bcast(obj):                # rank 0's object on every rank (gloo)
+        box = [obj]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def host_min(i):                    # all ranks take the same path: the minimum of their flags (gloo)
+        if world == 1:
+            return int(i)
+        import torch as _t0
+        t = _t0.tensor([int(i)])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item())
+
     if world > 1 or a.force_dist:
         err = None
+        # First contact with the transport: a MINIATURE sharded solve in each exchange mode — segments of
+        # the product pass with their reduce-scatters on a second stream, the same on one stream, the whole pass + one
+        # reduce-scatter — under the library's watchdog, compared bit for bit, the ranks agreeing over gloo; the timed
+        # solves then run in the fastest mode that survived (exchange.mode in the JSON), with a fresh communicator if
+        # one had to be aborted.  A communicator that cannot even carry the plainest pattern is found here too.
         try:
-            uid = [ba.Comm.unique_id() if rank == 0 else None]
-        except Exception as e:          # RCCL cannot be loaded on rank 0: every rank must learn it
-            uid, err = [None], e
-        if world > 1:
-            dist.broadcast_object_list(uid, src=0)
-        if uid[0] is not None:
-            try:
-                comm = ba.Comm(uid[0], rank, world)
-                # first collective on a known vector: a communicator that initialises but cannot move data
-                # (IPC / topology trouble) must be found here, not inside the timed solves
-                import numpy as _np0
-                probe = ba.DeviceArray.from_numpy(_np0.full(1024, float(rank + 1)))
-                comm.allreduce(probe)
-                got = probe.to_numpy()
-                if not _np0.all(got == world * (world + 1) / 2.0):
-                    raise RuntimeError("RCCL all-reduce self-test returned %r" % got[:2])
-            except Exception as e:
-                err = e
-                if comm is not None:
-                    try:
-                        comm.close()
-                    except Exception:
-                        pass
-                comm = None
+            comm, exchange_report = ba.comm.negotiate(rank, world, host_bcast, host_min, timeout_ms=a.exchange_timeout_ms,
+                                                      modes=[a.exchange] if a.exchange else None,
+                                                      log=lambda msg: log(msg) if rank == 0 else None)
+            log("exchange of the sharded solve: %s" % exchange_report["mode"])
+        except Exception as e:
+            err, comm = e, None
         if world > 1:                   # all ranks take the same path
             import torch as _t
             ok = _t.tensor([1 if comm is not None else 0])
@@ -260,12 +268,42 @@ def main():
         return ba.bed_randomSVD(gb, k=a.k, tol=a.tol, block=a.block, slices=a.slices, comm=comm,
                                 allreduce=hook, rank=rank, world=world,
                                 m_total=m_total, return_uv=not a.no_uv, verbose=a.verbose, warm_start=a.warm_start,
-                                warm_denominator=a.warm_den)
+                                warm_denominator=a.warm_den,
+                                # sharded: every collective bracketed by HIP events (exchange.ms in the JSON), and a watchdog
+                                # that turns a collective which never completes into an error
+                                exchange_timing=comm is not None,
+                                exchange_timeout_ms=4 * a.exchange_timeout_ms if comm is not None else 0)
 
-    wres = None
-    for _ in range(a.warmup):
-        wres = step()
-    del wres
+    # The warm-up solves are the first FULL-SIZE contact of the chosen exchange (the probe above moved 1 / 100 of the
+    # bytes): if one fails on any rank — watchdog, RCCL error — every rank drops to the next more conservative mode with
+    # a fresh communicator and warms up again; only the whole-pass exchange failing ends the run (status 4).
+    while True:
+        ok, werr = 1, None
+        try:
+            for _ in range(a.warmup):
+                step()
+        except Exception as e:
+            ok, werr = 0, e
+        if comm is None:
+            if not ok:
+                raise werr
+            break
+        if host_min(ok):
+            break
+        mode_now = exchange_report["mode"]
+        nxt = {"overlap": "one_stream", "one_stream": "whole"}.get(mode_now)
+        log("a warm-up solve failed in exchange mode %s (%s)%s" % (mode_now, werr, "" if nxt is None else ": falling back to " + nxt))
+        exchange_report.setdefault("full_size_failures", []).append(dict(mode=mode_now, error=None if werr is None else str(werr)[:300]))
+        comm.close()
+        if nxt is None:
+            if world > 1:
+                dist.barrier()
+                dist.destroy_process_group()
+            sys.exit(4)
+        uid = host_bcast(ba.Comm.unique_id() if rank == 0 else None)
+        comm = ba.Comm(uid, rank, world)
+        ba.set_exchange_mode(nxt)
+        exchange_report["mode"] = nxt
     sync()
     log("warmup done")
     t0 = time.perf_counter()
@@ -279,7 +317,17 @@ def main():
     sync()
     wall = time.perf_counter() - t0
     log("timed solves done (%.1f ms per solve)" % (1e3 * wall / a.steps))
+    per_rank = None
     if world > 1:
+        # every rank's own wall time and streaming-kernel averages travel to rank 0 (gloo): the JSON names the slowest
+        # rank and what ITS kernels and collectives cost, not only rank 0's
+        mine = dict(rank=rank, ms_per_step=1e3 * wall / a.steps,
+                    kernels={key: sum(r[key + "_ms"] for r in infos) / max(1, sum(r["n_" + key] for r in infos))
+                             for key in ("prod", "cprod", "cprod_stats", "wide_prod", "wide_cprod")
+                             if sum(r["n_" + key] for r in infos)},
+                    exchange_ms={c: sum(r["exchange_ms"][c] for r in infos) / a.steps for c in infos[-1]["exchange_ms"]})
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
         t = torch.tensor([wall], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
@@ -376,8 +424,7 @@ def main():
         "passes_per_solve": passes / a.steps,
         # sharded solve: product passes cut into segments whose reduce-scatters overlap the next segment, basis blocks
         # all-gathered as int16 (0 / 0 on one GPU without a communicator)
-        "exchange": {"segmented_product_passes": infos[-1].get("segmented_passes", 0),
-                     "int16_all_gathers": infos[-1].get("compact_gathers", 0)},
+        "exchange": exchange_record(infos, a.steps, exchange_report, per_rank),
         "niter": infos[-1]["niter"], "converged": infos[-1]["converged"],
         "scaling_statistics": "ride along the first crossproduct pass" if infos[-1]["fused_stats"] else "own pass",
         "warm_start": {"launches": infos[-1]["warm_launches"], "fraction_of_variants": infos[-1]["warm_fraction"],
@@ -437,6 +484,34 @@ def main():
     if rank == 0:
         real_stdout.write(json.dumps(out) + "\n")   # the ONE stdout line
         real_stdout.flush()
+
+
+def exchange_record(infos, steps, report, per_rank):
+    """what the sharded solve exchanged and what it cost: the mode that ran (and how it was chosen), HIP-event
+    time per solve and number of collectives by class — reduce-scatters of the panel / of its segments, all-gathers of a basis
+    block and of u, the small all-reduces / all-gathers, and the time the solve's stream WAITED for the exchange stream (what of
+    the overlapped reduce-scatters stayed exposed) —, and per rank: wall time per solve, the slowest rank's kernel averages"""
+    last = infos[-1]
+    rec = {"mode": last.get("exchange_mode", "none"),
+           "segmented_product_passes": last.get("segmented_passes", 0),
+           "compact_all_gathers": last.get("compact_gathers", 0)}
+    if report is not None:
+        rec["first_contact"] = report
+    if any(last.get("n_exchange", {}).values()):
+        rec["ms_per_solve"] = {c: sum(r["exchange_ms"][c] for r in infos) / steps for c in last["exchange_ms"]}
+        rec["collectives_per_solve"] = {c: sum(r["n_exchange"][c] for r in infos) / steps for c in last["n_exchange"]}
+        # on the solve's stream and therefore exposed: everything but the reduce-scatters of an overlapped pass, + the wait
+        over = last.get("exchange_mode", "").endswith("second stream")
+        m = rec["ms_per_solve"]
+        rec["exposed_ms_per_solve"] = m["all_gather"] + m["small"] + (m["exposed_wait"] if over else m["reduce_scatter"])
+        rec["hidden_ms_per_solve"] = max(0.0, m["reduce_scatter"] - m["exposed_wait"]) if over else 0.0
+    if per_rank:
+        ms = [p["ms_per_step"] for p in per_rank]
+        slow = per_rank[max(range(len(ms)), key=lambda i: ms[i])]
+        rec["per_rank"] = {"ms_per_step_min": min(ms), "ms_per_step_max": max(ms), "ms_per_step": ms,
+                           "slowest_rank": slow["rank"], "slowest_rank_kernels_avg_ms": slow["kernels"],
+                           "slowest_rank_exchange_ms_per_solve": slow["exchange_ms"]}
+    return rec
 
 
 def norm_kernel(name):

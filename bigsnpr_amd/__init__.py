@@ -9,7 +9,7 @@ from .bed import (ERROR_DIM, ScaledOp, bed, bed_colstats, bed_counts, bed_cprodV
                   bed_MAF, bed_prodVec, bed_scaleBinom, cols_along, read_bed,
                   read_bed_scaled, rows_along, sub_bed)
 from .svd import bed_randomSVD  # noqa: F401,E402
-from .comm import Comm  # noqa: F401,E402
+from .comm import Comm, negotiate as negotiate_exchange, set_exchange_mode  # noqa: F401,E402
 from .ld import (CODE_012, CODE_DOSAGE, CODE_IMPUTE_PRED, FBM_code256, bed_clumping, bed_cor,  # noqa: F401,E402
                  bed_ld_scores, big_cprodVec, big_prodVec, big_randomSVD, snp_clumping, snp_fake, snp_colstats, snp_cor, snp_ld_scores, snp_MAF, snp_scaleAlpha,
                  snp_scaleBinom)

@@ -30,7 +30,7 @@ class SvdOptions(C.Structure):
                 ("comm", C.c_void_p), ("binom_scaling", C.c_int32),
                 ("center_out", C.POINTER(C.c_double)), ("scale_out", C.POINTER(C.c_double)),
                 ("warm_start", C.c_int32), ("warm_denominator", C.c_int32), ("max_restarts", C.c_int32),
-                ("vec_floor", C.c_double)]
+                ("vec_floor", C.c_double), ("exchange_timing", C.c_int32), ("exchange_timeout_ms", C.c_int32)]
 
 
 class SvdInfo(C.Structure):
@@ -43,7 +43,8 @@ class SvdInfo(C.Structure):
                 ("warm_ms", C.c_double), ("tiled", C.c_int32), ("segmented_passes", C.c_int32), ("compact_gathers", C.c_int32),
                 ("slices_max", C.c_int32), ("wide_steps", C.c_int32), ("wide_cprod_ms", C.c_double),
                 ("wide_prod_ms", C.c_double), ("n_wide_cprod", C.c_int32), ("n_wide_prod", C.c_int32),
-                ("lead_rel_resid", C.c_double)]
+                ("lead_rel_resid", C.c_double), ("exchange_mode", C.c_int32), ("n_exchange", C.c_int32 * 4),
+                ("exchange_ms", C.c_double * 4)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check that every symbol
@@ -59,6 +60,7 @@ SIGNATURES = {
     "bsn_comm_rank": (C.c_int, [vp]),
     "bsn_comm_world": (C.c_int, [vp]),
     "bsn_comm_allreduce": (C.c_int, [vp, vp, i64]),
+    "bsn_comm_abort": (C.c_int, [vp]),
     "bsn_comm_destroy": (C.c_int, [vp]),
     "bsn_ld_last_stats": (C.c_int, [f64p]),
     "bsn_bed_open": (C.c_int, [C.c_char_p, i64, i64, C.POINTER(vp)]),

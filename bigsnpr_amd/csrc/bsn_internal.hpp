@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <functional>
@@ -112,10 +113,24 @@ struct SvdWorkspace;  // svd.hip
 }
 
 // RCCL communicator of a column-sharded solve (comm.hip); `comm` is an ncclComm_t
+constexpr int kCommClasses = 4;   // timing classes of a solve's collectives: reduce-scatter, all-gather of a block, small, wait
 struct bsn_comm {
   void *comm = nullptr;
   int rank = 0, world = 1, device = 0;
   hipStream_t stream = nullptr;           // bsn_comm_allreduce (stand-alone self-test); a solve's collectives run on the solve's stream
+  // set by comm_abort (the watchdog of a sharded solve, bsn_comm_abort): the communicator is gone, every later call fails
+  std::atomic<int> aborted{0};
+  // HIP-event timing of every collective of a solve (bsn_svd_options::exchange_timing): class 0 = reduce-scatter of the
+  // panel (or of a segment of it), 1 = all-gather of a basis block / of u, 2 = the small all-reduces and all-gathers,
+  // 3 = time the solve's stream WAITED for the exchange stream (what of the overlapped reduce-scatters stayed exposed)
+  bool timing = false;
+  struct Timed { hipEvent_t a, b; int cls; };
+  std::vector<Timed> timed;
+  std::vector<hipEvent_t> ev_pool;
+  ~bsn_comm() {
+    for (auto &t : timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (auto e : ev_pool) (void)hipEventDestroy(e);
+  }
 };
 
 constexpr int kProfKinds = 6;   // timing classes of the streaming launches of a solve (prof_collect)
@@ -318,6 +333,13 @@ void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n, const 
              int64_t m, const double *center, const double *scale, bool defer_scale = false);
 
 // comm.hip: RCCL collectives on device buffers of doubles, enqueued on `st`
+// (exchange timing) a pair of events around `what` on `st`, filed under class cls; no-ops unless c->timing
+hipEvent_t comm_time_begin(bsn_comm *c, hipStream_t st);
+void comm_time_end(bsn_comm *c, hipEvent_t begin, int cls, hipStream_t st);
+// sums (ms) and counts per class of everything timed since the last call; waits for the events
+void comm_time_collect(bsn_comm *c, double ms[kCommClasses], int count[kCommClasses]);
+// ncclCommAbort: collectives in flight end, later ones fail; returns false if the RCCL at hand has no such entry point
+bool comm_abort(bsn_comm *c);
 void comm_allreduce_sum(bsn_comm *c, double *d_buf, int64_t count, hipStream_t st);
 void comm_reduce_scatter_sum(bsn_comm *c, const double *d_send, double *d_recv, int64_t recv_count,
                              hipStream_t st);

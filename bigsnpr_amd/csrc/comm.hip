@@ -31,6 +31,7 @@ struct Rccl {
   decltype(&ncclReduceScatter) ReduceScatter = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;   // optional
 };
 
 static Rccl &rccl() {
@@ -55,6 +56,7 @@ static Rccl &rccl() {
   BSN_SYM(GetUniqueId) BSN_SYM(CommInitRank) BSN_SYM(CommDestroy) BSN_SYM(AllReduce)
   BSN_SYM(ReduceScatter) BSN_SYM(AllGather) BSN_SYM(GetErrorString)
 #undef BSN_SYM
+  r.CommAbort = (decltype(r.CommAbort))dlsym(h, "ncclCommAbort");
   r.h = h;
   return r;
 }
@@ -67,15 +69,74 @@ static Rccl &rccl() {
                   __LINE__, #expr);                                                         \
   } while (0)
 
+static void check_alive(bsn_comm *c) {
+  if (c->aborted.load()) fail("the communicator was aborted (a collective of a sharded solve did not finish in time)");
+}
+hipEvent_t comm_time_begin(bsn_comm *c, hipStream_t st) {
+  if (!c->timing) return nullptr;
+  hipEvent_t e = nullptr;
+  if (!c->ev_pool.empty()) {
+    e = c->ev_pool.back();
+    c->ev_pool.pop_back();
+  } else {
+    BSN_HIP(hipEventCreate(&e));
+  }
+  BSN_HIP(hipEventRecord(e, st));
+  return e;
+}
+void comm_time_end(bsn_comm *c, hipEvent_t begin, int cls, hipStream_t st) {
+  if (!begin) return;
+  hipEvent_t e = nullptr;
+  if (!c->ev_pool.empty()) {
+    e = c->ev_pool.back();
+    c->ev_pool.pop_back();
+  } else {
+    BSN_HIP(hipEventCreate(&e));
+  }
+  BSN_HIP(hipEventRecord(e, st));
+  c->timed.push_back({begin, e, cls});
+}
+void comm_time_collect(bsn_comm *c, double ms[kCommClasses], int count[kCommClasses]) {
+  for (int k = 0; k < kCommClasses; k++) ms[k] = 0, count[k] = 0;
+  for (auto &t : c->timed) {
+    float f = 0;
+    if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&f, t.a, t.b) == hipSuccess) {
+      ms[t.cls] += f;
+      count[t.cls]++;
+    }
+    c->ev_pool.push_back(t.a);
+    c->ev_pool.push_back(t.b);
+  }
+  c->timed.clear();
+  (void)hipGetLastError();
+}
+bool comm_abort(bsn_comm *c) {
+  if (c->aborted.exchange(1)) return true;
+  if (!rccl().CommAbort || !c->comm) return false;
+  // (the handle stays in place: the solve's thread may be inside a collective call that holds it; bsn_comm_destroy
+  // does not hand an aborted communicator to ncclCommDestroy)
+  (void)rccl().CommAbort((ncclComm_t)c->comm);
+  return true;
+}
+
 void comm_allreduce_sum(bsn_comm *c, double *d_buf, int64_t count, hipStream_t st) {
+  check_alive(c);
+  hipEvent_t t0 = comm_time_begin(c, st);
   BSN_NCCL(rccl().AllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, (ncclComm_t)c->comm, st));
+  comm_time_end(c, t0, 2, st);
 }
 void comm_reduce_scatter_sum(bsn_comm *c, const double *d_send, double *d_recv, int64_t recv_count,
                              hipStream_t st) {
+  check_alive(c);
+  hipEvent_t t0 = comm_time_begin(c, st);
   BSN_NCCL(rccl().ReduceScatter(d_send, d_recv, (size_t)recv_count, ncclDouble, ncclSum, (ncclComm_t)c->comm, st));
+  comm_time_end(c, t0, 0, st);
 }
 void comm_all_gather(bsn_comm *c, const double *d_send, double *d_recv, int64_t send_count, hipStream_t st) {
+  check_alive(c);
+  hipEvent_t t0 = comm_time_begin(c, st);
   BSN_NCCL(rccl().AllGather(d_send, d_recv, (size_t)send_count, ncclDouble, (ncclComm_t)c->comm, st));
+  comm_time_end(c, t0, send_count >= 4096 ? 1 : 2, st);   // (a basis block / u against the column maxima)
 }
 
 }  // namespace bsn
@@ -131,11 +192,18 @@ int bsn_comm_allreduce(bsn_comm *c, double *d_buf, int64_t count) {
   });
 }
 
+int bsn_comm_abort(bsn_comm *c) {
+  return guarded([&] {
+    if (!c) return;
+    if (!comm_abort(c)) fail("this RCCL has no ncclCommAbort");
+  });
+}
+
 int bsn_comm_destroy(bsn_comm *c) {
   return guarded([&] {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->comm) (void)rccl().CommDestroy((ncclComm_t)c->comm);
+    if (c->comm && !c->aborted.load()) (void)rccl().CommDestroy((ncclComm_t)c->comm);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
   });

@@ -4,6 +4,11 @@
 // (matvec.hip); the tall-skinny fp64 panel algebra below is memory-bound on the basis Q
 // (n x p doubles) and is a few percent of a step.
 #include <chrono>
+#include <unistd.h>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -710,9 +715,12 @@ struct HipSvdBackend : SvdBackend {
     if (!op_prod_segments(op, Z.p + (int64_t)p0 * m_local, m_local, cb, world, B, nseg, segs, after)) return false;
     if (overlap) {
       BSN_HIP(hipEventRecord(ws.ev_arrived, sc));
+      hipEvent_t t0 = comm_time_begin(comm, st);   // what the solve's stream waits here is the exposed part of the exchange
       BSN_HIP(hipStreamWaitEvent(st, ws.ev_arrived, 0));
+      comm_time_end(comm, t0, 3, st);
     }
     n_seg_passes++;
+    exchange_mode = std::max(exchange_mode, overlap ? 3 : 2);
     return true;
   }
   // precision schedule of the driver: the digits of the following product pass, of the rounding of the block it
@@ -727,13 +735,17 @@ struct HipSvdBackend : SvdBackend {
     if (S < min_slices) min_slices = S;
   }
   int n_seg_passes = 0;   // product passes that ran in segments (diagnostics / tests)
+  int exchange_mode = 0;  // bsn_svd_info::exchange_mode
   int n_compact_gathers = 0;   // basis blocks all-gathered as 16-bit integers
   void A_Zblock(int p0, int cb) override {
     Tick tk(this, 2);
     mx_valid = false;
     if (dist && product_in_segments(p0, cb)) return;
     op_prod(op, Z.p + (int64_t)p0 * m_local, m_local, cb, dist ? Wfull.p : Wc, n);
-    if (dist) reduce_scatter_W(cb);
+    if (dist) {
+      reduce_scatter_W(cb);
+      exchange_mode = std::max(exchange_mode, 1);
+    }
   }
   // dC (p x cb, leading dimension ldc) = A[:, :p]' B[:, :cb] for operands with `rows` rows (leading
   // dimension = rows); local rows only
@@ -1061,6 +1073,47 @@ struct HipSvdBackend : SvdBackend {
 
 using namespace bsn;
 
+// Watchdog of a sharded solve (bsn_svd_options::exchange_timeout_ms): when the solve has not returned in time the
+// communicator is aborted — the collectives in flight end, the next one fails, the call returns an error instead
+// of hanging in a stream synchronisation for ever.  If even that does not bring the call back (a transport without
+// ncclCommAbort, a wedged device) the process ends with status 86 after a grace period: a run that cannot finish
+// must not outlive its driver's patience either.
+struct ExchangeWatchdog {
+  bsn_comm *c;
+  int ms;
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool done = false;
+  std::atomic<int> fired{0};
+  ExchangeWatchdog(bsn_comm *c_, int ms_) : c(c_), ms(ms_) {
+    if (!c || ms <= 0) return;
+    th = std::thread([this] {
+      std::unique_lock<std::mutex> lk(mu);
+      if (cv.wait_for(lk, std::chrono::milliseconds(ms), [this] { return done; })) return;
+      fired.store(1);
+      lk.unlock();
+      const bool could = comm_abort(c);
+      std::fprintf(stderr, "[bsn svd] rank %d: the sharded solve did not return within %d ms: communicator %s\n", c->rank, ms,
+                   could ? "aborted" : "cannot be aborted (no ncclCommAbort)");
+      lk.lock();
+      if (cv.wait_for(lk, std::chrono::seconds(20), [this] { return done; })) return;
+      std::fprintf(stderr, "[bsn svd] rank %d: still blocked 20 s after the abort: giving up (exit status 86)\n", c->rank);
+      std::fflush(stderr);
+      _exit(86);
+    });
+  }
+  ~ExchangeWatchdog() {
+    if (!th.joinable()) return;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      done = true;
+    }
+    cv.notify_all();
+    th.join();
+  }
+};
+
 // bed_scaleBinom from host code counts (the path of row subsets, where the statistics cannot ride
 // along a crossproduct pass over all samples): R/binom-scaling.R:133-142
 static void binom_scale_host(const std::vector<int32_t> &cnt, int64_t n, int64_t m, std::vector<double> &center,
@@ -1229,7 +1282,32 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     so.seed = o->seed ? o->seed : 1;
     so.verbose = o->verbose;
     BSN_HIP(hipEventRecord(bed->ev0, bed->stream));
-    SvdResult r = block_lanczos_svd(bk, so, d, u, v);
+    int wd_ms = o->exchange_timeout_ms;
+    if (wd_ms == 0)
+      if (const char *e = getenv("BSN_EXCHANGE_TIMEOUT_MS")) wd_ms = atoi(e);
+    ExchangeWatchdog watchdog(bk.comm, wd_ms);
+    if (bk.comm) {
+      double junk_ms[kCommClasses];
+      int junk_n[kCommClasses];
+      bk.comm->timing = o->exchange_timing != 0;
+      comm_time_collect(bk.comm, junk_ms, junk_n);   // (leftovers of a solve that failed)
+    }
+    struct TimingOff {
+      bsn_comm *c;
+      ~TimingOff() { if (c) c->timing = false; }
+    } timing_off{bk.comm};
+    SvdResult r;
+    try {
+      r = block_lanczos_svd(bk, so, d, u, v);
+    } catch (const std::exception &ex) {
+      if (watchdog.fired.load())
+        fail("the exchange of the sharded solve did not finish within %d ms (exchange: %s) and the communicator was aborted; "
+             "what the solve saw: %s", wd_ms,
+             bk.exchange_mode == 3 ? "segments, reduce-scatters on a second stream" : bk.exchange_mode == 2 ? "segments, one stream"
+             : getenv("BSN_NO_SEGMENTS") ? "whole pass" : getenv("BSN_NO_OVERLAP") ? "segments, one stream" : "segments, reduce-scatters on a second stream",
+             ex.what());
+      throw;
+    }
     if (r.exhausted && r.exhausted_resid > 1e-9 && o->slices <= 0 && op->slices < 7) {
       // a Krylov space exhausted on rounded products (svd_driver.hpp): only matrices whose rank fits the basis get
       // here, so the second solve — 56-bit digits, at most four vectors per pass — is cheap, and it is run whenever
@@ -1330,6 +1408,14 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
         info->tiled = 2;   // (one launch of two column blocks per product pass: k_prodT)
       info->segmented_passes = bk.n_seg_passes;
       info->compact_gathers = bk.n_compact_gathers;
+      info->exchange_mode = bk.exchange_mode;
+      for (int c = 0; c < 4; c++) info->exchange_ms[c] = 0, info->n_exchange[c] = 0;
+      if (bk.comm && o->exchange_timing) {
+        double ems[kCommClasses];
+        int en[kCommClasses];
+        comm_time_collect(bk.comm, ems, en);
+        for (int c = 0; c < 4 && c < kCommClasses; c++) info->exchange_ms[c] = ems[c], info->n_exchange[c] = en[c];
+      }
     }
   });
   return rc != 0 ? rc : (unconverged ? 2 : 0);

@@ -19,7 +19,7 @@ from .bed import _args, assert_bed, bed_scaleBinom
 def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=None, k=10,
                   tol=1e-4, verbose=False, ncores=1, block=0, slices=0, max_basis=0, seed=1,
                   comm=None, allreduce=None, rank=0, world=1, m_total=0, return_uv=True, warm_start=0, warm_denominator=0,
-                  max_restarts=0, vec_floor=0.0):
+                  max_restarts=0, vec_floor=0.0, exchange_timing=False, exchange_timeout_ms=0):
     """Partial SVD of the scaled matrix.  Extra (non-reference) arguments: ``block``
     (vectors per streaming pass), ``slices`` (int8 slices per fp64 value), ``vec_floor`` (relative
     residual floor wanted for the singular vectors that converge beyond ``tol``: 0 = 2.5e-7 unless
@@ -44,6 +44,7 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
     opts.warm_start, opts.warm_denominator = int(warm_start), int(warm_denominator)
     opts.max_restarts = int(max_restarts)
     opts.vec_floor = float(vec_floor)
+    opts.exchange_timing, opts.exchange_timeout_ms = int(bool(exchange_timing)), int(exchange_timeout_ms)
     opts.max_basis, opts.seed, opts.verbose, opts.m_total = int(max_basis), int(seed), int(verbose), int(m_total)
     cb = None
     if comm is not None:
@@ -84,4 +85,8 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
                 slices_max=int(info.slices_max), wide_steps=int(info.wide_steps),
                 wide_cprod_ms=info.wide_cprod_ms, wide_prod_ms=info.wide_prod_ms,
                 n_wide_cprod=int(info.n_wide_cprod), n_wide_prod=int(info.n_wide_prod),
-                lead_rel_resid=info.lead_rel_resid)
+                lead_rel_resid=info.lead_rel_resid,
+                exchange_mode=("none", "whole pass", "segments, one stream", "segments, reduce-scatters on a second stream")[
+                    max(0, min(3, int(info.exchange_mode)))],
+                exchange_ms=dict(zip(("reduce_scatter", "all_gather", "small", "exposed_wait"), [float(x) for x in info.exchange_ms])),
+                n_exchange=dict(zip(("reduce_scatter", "all_gather", "small", "exposed_wait"), [int(x) for x in info.n_exchange])))

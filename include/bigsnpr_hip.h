@@ -234,6 +234,10 @@ int bsn_comm_rank(const bsn_comm *comm);
 int bsn_comm_world(const bsn_comm *comm);
 /* sum of a device buffer of doubles over the ranks, in place, blocking (tests, host-side reductions) */
 int bsn_comm_allreduce(bsn_comm *comm, double *d_buf, int64_t count);
+/* ncclCommAbort: ends the collectives in flight on this communicator and makes every later call fail; the handle must
+ * still be given to bsn_comm_destroy.  What the watchdog of a sharded solve calls (bsn_svd_options.exchange_timeout_ms);
+ * exported for hosts that run their own. */
+int bsn_comm_abort(bsn_comm *comm);
 int bsn_comm_destroy(bsn_comm *comm);
 typedef struct bsn_svd_options {
   int32_t k;          /* number of singular triplets (R default 10) */
@@ -276,6 +280,15 @@ typedef struct bsn_svd_options {
    * weight of its last components, stay narrow.  0 -> 2.5e-7 when `slices` is 0 (automatic), none when the caller
    * fixed `slices`; > 0 -> that floor (digits up to 56 bits); < 0 -> none: every step at `slices` (round 4). */
   double vec_floor;
+  /* Sharded solve (comm != NULL), round 5.  exchange_timing = 1: every collective of the solve is bracketed by HIP
+   * events on the stream it runs on; bsn_svd_info.exchange_ms reports the sums.  exchange_timeout_ms > 0: a watchdog
+   * thread aborts the communicator (ncclCommAbort) when the solve has not returned after that many milliseconds — a
+   * collective that never completes (the first contact of the overlapped exchange with a real transport) then ends
+   * the call with an error instead of hanging the process; the communicator is dead afterwards (destroy it, make a
+   * new one, choose a more conservative exchange: BSN_NO_OVERLAP=1, BSN_NO_SEGMENTS=1 — bigsnpr_amd.comm.negotiate
+   * does exactly that on a miniature solve).  0: the environment variable BSN_EXCHANGE_TIMEOUT_MS, else no watchdog. */
+  int32_t exchange_timing;
+  int32_t exchange_timeout_ms;
 } bsn_svd_options;
 typedef struct bsn_svd_info {
   int32_t niter;      /* block steps */
@@ -310,6 +323,14 @@ typedef struct bsn_svd_info {
   double wide_cprod_ms, wide_prod_ms;
   int32_t n_wide_cprod, n_wide_prod;
   double lead_rel_resid;    /* residual estimate of the leading half of the k pairs at exit (max_rel_resid: all k) */
+  /* sharded solve: how the product passes exchanged their panel — 0 no exchange, 1 whole pass + one reduce-scatter,
+   * 2 segments of sample blocks on the solve's stream, 3 segments with the reduce-scatters on a second stream — and,
+   * with exchange_timing, HIP-event time (ms) and number of its collectives by class: [0] reduce-scatter of the
+   * panel / of its segments, [1] all-gather of a basis block or of u, [2] small all-reduces / all-gathers, [3] what
+   * the solve's stream WAITED for the exchange stream (the part of the overlapped reduce-scatters left exposed) */
+  int32_t exchange_mode;
+  int32_t n_exchange[4];
+  double exchange_ms[4];
 } bsn_svd_info;
 /* Returns 0 on success, 1 on error, and 2 when the solve ran to the end of its basis without all
  * k residuals meeting tol (outputs are filled with the best available triplets, bsn_last_error()

@@ -45,6 +45,8 @@ struct Shared {
 
 struct Comm {
   int rank = 0, world = 1;
+  std::atomic<int> abort{0};            // ncclCommAbort
+  std::vector<hipStream_t> seen;        // streams that have carried an all-reduce / all-gather of this communicator
   char name[64] = {0};
   uint8_t *base = nullptr;
   size_t bytes = 0;
@@ -71,6 +73,20 @@ ncclResult_t collective(int kind, const void *send, void *recv, size_t count, Co
   if (trace && c->rank == 0)
     std::fprintf(stderr, "[mock rccl] %s count %zu (%zu bytes in, %zu out) stream %p\n",
                  kind == 0 ? "all-reduce" : kind == 1 ? "reduce-scatter" : "all-gather", count, in * 8, out * 8, (void *)st);
+  if (c->abort.load()) return fail("communicator aborted");
+  // MOCK_RCCL_STALL=second_stream: a reduce-scatter on a stream that never carried an all-reduce / all-gather of this
+  // communicator — the exchange stream of the overlapped product pass (svd.hip) — never completes: the call blocks
+  // until ncclCommAbort, like a transport that cannot progress two streams at once.  What the watchdog of a sharded
+  // solve and the fall-back of bigsnpr_amd.comm.negotiate are tested against.
+  static const char *stall = getenv("MOCK_RCCL_STALL");
+  bool known = false;
+  for (hipStream_t s : c->seen) known = known || s == st;
+  if (kind != 1 && !known) c->seen.push_back(st);
+  if (stall && !std::strcmp(stall, "second_stream") && kind == 1 && !known) {
+    if (trace) std::fprintf(stderr, "[mock rccl] rank %d: stalling the reduce-scatter on stream %p\n", c->rank, (void *)st);
+    while (!c->abort.load()) usleep(2000);
+    return fail("collective aborted");
+  }
   if (in * 8 > kSlot) return fail("message larger than the mock's slot");
   if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;
   if (hipMemcpy(c->slot(c->rank), send, in * 8, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
@@ -149,6 +165,12 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
   }
   if (!sync_ranks(c)) return fail("barrier");
   *out = c;
+  return ncclSuccess;
+}
+
+ncclResult_t ncclCommAbort(ncclComm_t comm) {
+  Comm *c = (Comm *)comm;
+  if (c) c->abort.store(1);   // (nothing is unmapped: a stalled call of another thread is still reading the handle)
   return ncclSuccess;
 }
 

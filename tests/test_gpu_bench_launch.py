@@ -56,7 +56,7 @@ def test_two_ranks_on_one_gpu_fall_back_and_agree():
     assert two["converged"] and one["converged"]
     np.testing.assert_allclose(two["sigma"], one["sigma"], rtol=1e-6)
     for rec in (one, two):
-        assert rec["value"] > 0 and rec["unit"] == "SNP-cols/s" and rec["roofline"]["bound"] == "hbm"
+        assert rec["value"] > 0 and rec["unit"] == "SNP-cols/s" and rec["roofline"]["bound"] in ("hbm", "mfma")
         # whole-job value = total columns x passes / wall
         np.testing.assert_allclose(rec["value"],
                                    rec["config"]["m_total"] * rec["passes_per_solve"] / (rec["ms_per_step"] * 1e-3),
@@ -79,6 +79,37 @@ def test_two_ranks_through_the_in_library_collectives():
                     BSN_RCCL_LIBRARY=mock)
     assert "falling back" not in err
     assert two["n_gpus"] == 2 and "in-library RCCL" in two["config"]["parallelism"]
+    assert two["converged"] and two["niter"] == one["niter"]
+    np.testing.assert_allclose(two["sigma"], one["sigma"], rtol=1e-6)
+    # round 5: the line explains its exchange — the mode the first-contact probe chose (all three passed: the fastest),
+    # HIP-event time per collective class, exposed against hidden, per-rank wall times and the slowest rank's kernels
+    ex = two["exchange"]
+    assert ex["first_contact"]["mode"] == "overlap" and [t["mode"] for t in ex["first_contact"]["tried"]] == ["whole", "overlap"]
+    assert all(t["ok"] for t in ex["first_contact"]["tried"])
+    assert set(ex["ms_per_solve"]) == {"reduce_scatter", "all_gather", "small", "exposed_wait"}
+    assert ex["collectives_per_solve"]["reduce_scatter"] >= two["niter"] and ex["ms_per_solve"]["reduce_scatter"] > 0
+    assert ex["exposed_ms_per_solve"] > 0 and len(ex["per_rank"]["ms_per_step"]) == 2
+    assert ex["per_rank"]["ms_per_step_max"] >= ex["per_rank"]["ms_per_step_min"] > 0 and ex["per_rank"]["slowest_rank_kernels_avg_ms"]
+
+
+def test_a_stalled_exchange_stream_is_survived():
+    """the overlapped exchange meets a transport that never completes a reduce-scatter on the second stream
+    (the stand-in's MOCK_RCCL_STALL=second_stream).  The first-contact probe's watchdog ends the miniature solve with an
+    error instead of a hang, the ranks agree over gloo, a fresh communicator is made and the run goes on in the
+    one-stream exchange — same singular values, and the JSON says what happened."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "native"))
+    import build_native
+    mock = build_native.build_mock_rccl()
+    one, _ = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS)
+    two, err = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                     "--master-addr", "127.0.0.1", "--master-port", _port(), "bench.py", "--gpus", "2",
+                     "--exchange-timeout-ms", "3000"] + ARGS, BSN_RCCL_LIBRARY=mock, MOCK_RCCL_STALL="second_stream")
+    fc = two["exchange"]["first_contact"]
+    assert fc["mode"] == "one_stream"
+    tried = {t["mode"]: t for t in fc["tried"]}
+    assert tried["whole"]["ok"] and not tried["overlap"]["ok"] and tried["one_stream"]["ok"]
+    assert "did not finish within 3000 ms" in tried["overlap"]["error"] and tried["overlap"]["ms"] >= 3000
+    assert "communicator aborted" in err
     assert two["converged"] and two["niter"] == one["niter"]
     np.testing.assert_allclose(two["sigma"], one["sigma"], rtol=1e-6)
 

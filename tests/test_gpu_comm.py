@@ -122,3 +122,42 @@ def test_product_pass_in_segments_with_overlapped_reduce_scatter(tmp_path, ba, w
     gb = ba.bed.synthetic(n, m, seed=31)
     ref = ba.bed_randomSVD(gb, k=k, tol=1e-4, block=16)      # (default tolerance: 16-bit panels, 16 vectors = one launch)
     np.testing.assert_allclose(runs["overlap"]["d"], ref["d"], rtol=1e-6)
+
+
+def _negotiate(tmp_path, world, tag, **extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", BSN_RCCL_LIBRARY=_mock_rccl(), **extra)
+    out = str(tmp_path / ("neg_%s.json" % tag))
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    n, m, k = world * 4608, world * 5000 + 96, 20
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(ROOT, "tests", "helpers", "negotiate_worker.py"), str(n), str(m), str(k), "2500", out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.load(open(out)), r.stderr
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_first_contact_negotiation(tmp_path, world):
+    """Round 5: bigsnpr_amd.comm.negotiate on a healthy transport picks the overlapped exchange; on one
+    that never completes a reduce-scatter issued on the second stream (MOCK_RCCL_STALL=second_stream) the watchdog of
+    the miniature solve aborts the communicator after its 2.5 s, every rank gets an error instead of a hang, they agree,
+    start over with a fresh communicator and settle on the one-stream exchange.  The solve that follows runs in the
+    chosen mode and finds the same numbers bit for bit either way; its collectives are timed by class."""
+    good, _ = _negotiate(tmp_path, world, "good")
+    assert good["report"]["mode"] == "overlap" and good["mode"].endswith("second stream")
+    assert [t["mode"] for t in good["report"]["tried"]] == ["whole", "overlap"] and all(t["ok"] for t in good["report"]["tried"])
+    assert good["env"] == {"BSN_NO_OVERLAP": None, "BSN_NO_SEGMENTS": None}
+    assert good["n_exchange"]["reduce_scatter"] > 0 and good["n_exchange"]["exposed_wait"] > 0
+    assert good["exchange_ms"]["reduce_scatter"] > 0 and good["n_exchange"]["small"] > 0 and good["n_exchange"]["all_gather"] > 0
+    bad, err = _negotiate(tmp_path, world, "stall", MOCK_RCCL_STALL="second_stream")
+    tried = {t["mode"]: t for t in bad["report"]["tried"]}
+    assert bad["report"]["mode"] == "one_stream" and bad["mode"] == "segments, one stream"
+    assert tried["whole"]["ok"] and tried["one_stream"]["ok"] and not tried["overlap"]["ok"]
+    assert "did not finish within 2500 ms" in tried["overlap"]["error"] and 2500 <= tried["overlap"]["ms"] < 20000
+    assert bad["env"] == {"BSN_NO_OVERLAP": "1", "BSN_NO_SEGMENTS": None}
+    assert bad["n_exchange"]["exposed_wait"] == 0
+    assert bad["d"] == good["d"] and bad["usum"] == good["usum"]
