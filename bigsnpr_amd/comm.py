@@ -79,7 +79,7 @@ def negotiate(rank, world, bcast, agree_min, modes=None, timeout_ms=30000, sampl
     must call this collectively, each with its own device selected.  report = {"mode": chosen, "tried": [{"mode", "ok",
     "ms", "error"} ...]}; raises RuntimeError when not even the whole-pass exchange works on every rank."""
     import time
-    from . import bed as _bed
+    from .bed import bed as _bed_class
     from .svd import bed_randomSVD
 
     log = log or (lambda msg: None)
@@ -107,7 +107,7 @@ def negotiate(rank, world, bcast, agree_min, modes=None, timeout_ms=30000, sampl
         return comm
 
     n, m_loc = samples_per_rank * world, variants_per_rank
-    gb = _bed.bed.synthetic(n, m_loc, seed=77, j_begin=rank * m_loc)
+    gb = _bed_class.synthetic(n, m_loc, seed=77, j_begin=rank * m_loc)
 
     def attempt(comm, mode):
         set_exchange_mode(mode)

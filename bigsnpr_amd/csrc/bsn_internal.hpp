@@ -39,9 +39,11 @@ int guarded(F &&f) {
     return 0;
   } catch (const std::exception &ex) {
     set_error(ex.what());
-    return 1;
+    (void)hipGetLastError();   // a failed runtime call stays "the last error" of the thread until it is read: the next
+    return 1;                  // entry point's launch check must not trip over it
   } catch (...) {
     set_error("unknown C++ exception");
+    (void)hipGetLastError();
     return 1;
   }
 }

@@ -1264,14 +1264,17 @@ void prof_end(bsn_op *op) {
 void prof_collect(bsn_op *op, double ms[kProfKinds], int count[kProfKinds]) {
   for (int k = 0; k < kProfKinds; k++) ms[k] = 0, count[k] = 0;
   for (size_t i = 0; i < op->ev_begin.size(); i++) {
-    BSN_HIP(hipEventSynchronize(op->ev_end[i]));
     float t = 0;
-    BSN_HIP(hipEventElapsedTime(&t, op->ev_begin[i], op->ev_end[i]));
-    ms[op->ev_kind[i]] += t;
-    count[op->ev_kind[i]]++;
+    // (a pair whose end was never recorded — a launch that failed, a solve that was aborted — is dropped, not an error)
+    if (hipEventSynchronize(op->ev_end[i]) == hipSuccess &&
+        hipEventElapsedTime(&t, op->ev_begin[i], op->ev_end[i]) == hipSuccess) {
+      ms[op->ev_kind[i]] += t;
+      count[op->ev_kind[i]]++;
+    }
     (void)hipEventDestroy(op->ev_begin[i]);
     (void)hipEventDestroy(op->ev_end[i]);
   }
+  (void)hipGetLastError();
   op->ev_begin.clear();
   op->ev_end.clear();
   op->ev_kind.clear();

@@ -1300,6 +1300,11 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     try {
       r = block_lanczos_svd(bk, so, d, u, v);
     } catch (const std::exception &ex) {
+      {   // the timing events of the launches that did run are of no use to anybody
+        double pms[kProfKinds];
+        int pc[kProfKinds];
+        prof_collect(op, pms, pc);
+      }
       if (watchdog.fired.load())
         fail("the exchange of the sharded solve did not finish within %d ms (exchange: %s) and the communicator was aborted; "
              "what the solve saw: %s", wd_ms,
