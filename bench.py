@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--no-wide", action="store_true",
                     help="skip the two extra solves on 32- and 56-bit panels that fill `fp64_equivalent`")
     ap.add_argument("--no-ingest", action="store_true")
+    ap.add_argument("--ind-col-fraction", type=float, default=0.0,
+                    help="svd: solve over a sorted random subset of this fraction of the variants (ind.col = ind.keep of "
+                         "bed_autoSVD, R/autoSVD.R:296-301) instead of all of them; one GPU")
     ap.add_argument("--exchange", choices=["overlap", "one_stream", "whole"], default=None,
                     help="sharded svd: take this exchange of the product pass (else the fastest one that passes the first-contact "
                          "probe: bigsnpr_amd.comm.negotiate)")
@@ -249,7 +252,7 @@ def main():
     smaj_s = None
     # (the library's rule for the default block: 16 vectors when 4 k >= 56 and the warm start applies)
     two_blocks = a.block == 16 or (a.block == 0 and 4 * a.k >= 56 and m_total >= 262144 and a.warm_start >= 0)
-    if two_blocks and a.slices in (0, 2) and not os.environ.get("BSN_NO_SMAJ"):
+    if two_blocks and a.slices in (0, 2) and not os.environ.get("BSN_NO_SMAJ") and a.ind_col_fraction <= 0:
         t0 = time.time()
         built = gb.sample_major()
         L.bsn_device_sync()
@@ -264,8 +267,16 @@ def main():
             dist.barrier()
             L.bsn_device_sync()
 
+    ind_col = None
+    m_image = m_local
+    if a.ind_col_fraction > 0 and world == 1:
+        import numpy as _npf
+        ind_col = _npf.sort(_npf.random.default_rng(20250905).choice(m_local, int(round(a.ind_col_fraction * m_local)), replace=False))
+        m_local = m_total = int(ind_col.size)        # the columns a pass streams
+        log("ind.col: %d of %d variants (sorted random subset)" % (m_local, m_image))
+
     def step():
-        return ba.bed_randomSVD(gb, k=a.k, tol=a.tol, block=a.block, slices=a.slices, comm=comm,
+        return ba.bed_randomSVD(gb, ind_col=ind_col, k=a.k, tol=a.tol, block=a.block, slices=a.slices, comm=comm,
                                 allreduce=hook, rank=rank, world=world,
                                 m_total=m_total, return_uv=not a.no_uv, verbose=a.verbose, warm_start=a.warm_start,
                                 warm_denominator=a.warm_den,
@@ -274,6 +285,9 @@ def main():
                                 exchange_timing=comm is not None,
                                 exchange_timeout_ms=4 * a.exchange_timeout_ms if comm is not None else 0)
 
+    first_compact_ms = 0.0
+    if ind_col is not None:        # one untimed solve so that the one-off copy is reported apart even with --warmup 0
+        first_compact_ms = step()["compact_ms"]
     # The warm-up solves are the first FULL-SIZE contact of the chosen exchange (the probe above moved 1 / 100 of the
     # bytes): if one fails on any rank — watchdog, RCCL error — every rank drops to the next more conservative mode with
     # a fresh communicator and warms up again; only the whole-pass exchange failing ends the run (status 4).
@@ -422,6 +436,10 @@ def main():
                                    ("single GPU holding shard 1 of %d (per-rank work of an %d-GPU run, no exchange)"
                                     % (a.shard_of, a.shard_of) if a.shard_of > 1 else "single GPU"))},
         "passes_per_solve": passes / a.steps,
+        "ind_col": None if ind_col is None else {
+            "selected_variants": m_local, "of": m_image,
+            "path": ("compacted copy of the selection (gathered once, %.1f ms in the first solve; the timed solves found it on the "
+                     "handle)" % first_compact_ms) if infos[-1].get("compacted") else "gather lists on the full image"},
         # sharded solve: product passes cut into segments whose reduce-scatters overlap the next segment, basis blocks
         # all-gathered as int16 (0 / 0 on one GPU without a communicator)
         "exchange": exchange_record(infos, a.steps, exchange_report, per_rank),

@@ -44,7 +44,7 @@ class SvdInfo(C.Structure):
                 ("slices_max", C.c_int32), ("wide_steps", C.c_int32), ("wide_cprod_ms", C.c_double),
                 ("wide_prod_ms", C.c_double), ("n_wide_cprod", C.c_int32), ("n_wide_prod", C.c_int32),
                 ("lead_rel_resid", C.c_double), ("exchange_mode", C.c_int32), ("n_exchange", C.c_int32 * 4),
-                ("exchange_ms", C.c_double * 4)]
+                ("exchange_ms", C.c_double * 4), ("compacted", C.c_int32), ("compact_ms", C.c_double)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check that every symbol
@@ -234,7 +234,9 @@ class PinnedPool:
         # 400K x 1M, k = 20 solve are 224 MB
         self.free = []
         self.keep = int(os.environ.get("BSN_RESULT_POOL_KEEP", 1 << 30)) if keep is None else keep
-        self.lock = threading.Lock()       # __del__ of a block may run on any thread, also inside empty()
+        # re-entrant: __del__ of a block may run on any thread, also on THIS one inside empty() (a cyclic-GC pass
+        # triggered by an allocation under the lock finalises a block, whose _give_back takes the lock again)
+        self.lock = threading.RLock()
 
     def empty(self, shape, dtype=np.float64):
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize

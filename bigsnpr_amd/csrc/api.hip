@@ -381,6 +381,7 @@ void bed_free(bsn_bed *b) {
   if (b->fd_file >= 0) (void)close(b->fd_file);
   if (b->slab_stage) delete (bsn::FileStage *)b->slab_stage;
   if (b->slab_img) bed_free(b->slab_img);
+  if (b->sub) bed_free(b->sub);
   if (b->d_tiled) (void)hipFree(b->d_tiled);
   if (b->d_smaj) (void)hipFree(b->d_smaj);
   if (b->d_lut) (void)hipFree(b->d_lut);
@@ -674,12 +675,28 @@ int bsn_bed_open(const char *path, int64_t n, int64_t m, bsn_bed **out) {
     size_t free_b = 0, total_b = 0;
     BSN_HIP(hipMemGetInfo(&free_b, &total_b));
     double budget = (double)(free_b + dev_cache_held()) - 2e9;
-    if (const char *e = getenv("BSN_IMAGE_BUDGET")) budget = atof(e);
-    if (image_bytes <= budget) {
-      image_alloc(b.get(), n, m);
-      image_from_file(b.get(), fd, 3, n_byte);
-      *out = b.release();
-      return;
+    const char *forced = getenv("BSN_IMAGE_BUDGET");
+    if (forced) budget = atof(forced);
+    // The resident image is tried first whenever it could fit at all: a device that other handles have filled to
+    // within the 2 GB of working room must not turn a small file into a streamed handle, which most entry points
+    // refuse.  Only an allocation that really fails — or a file beyond the budget — goes out of core.
+    bool resident = image_bytes <= budget;
+    if (!resident && !forced && image_bytes <= (double)(free_b + dev_cache_held())) resident = true;
+    if (resident) {
+      bool ok = true;
+      try {
+        image_alloc(b.get(), n, m);
+      } catch (const std::exception &) {
+        if (forced || image_bytes <= budget - 8e9) throw;   // (not a matter of room)
+        (void)hipGetLastError();
+        ok = false;
+        b.reset(new bsn_bed());
+      }
+      if (ok) {
+        image_from_file(b.get(), fd, 3, n_byte);
+        *out = b.release();
+        return;
+      }
     }
     // out-of-core: keep the file mapped, walk it in slabs (bsn_internal.hpp)
     void *map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
@@ -693,7 +710,9 @@ int bsn_bed_open(const char *path, int64_t n, int64_t m, bsn_bed **out) {
     b->h_map = (const uint8_t *)map + 3;
     b->fd_file = dup(fd);
     if (b->fd_file < 0) fail("Error when mapping file:\n  %s.\n", strerror(errno));
-    b->slab_cols = std::max<int64_t>(64, (int64_t)(std::max(budget, 0.0) / (double)pitch) / 64 * 64 - 64);
+    // one resident slab image, kept on the handle between calls (bsn_bed_release_workspace frees it): a slab of at most
+    // 16 GB — PCIe paces the walk, a larger slab buys nothing and would pin the device memory other handles need
+    b->slab_cols = std::max<int64_t>(64, (int64_t)(std::min(std::max(budget, 0.0), 16e9) / (double)pitch) / 64 * 64 - 64);
     if (b->slab_cols > m) b->slab_cols = round_up(m, 64);
     if (getenv("BSN_VERBOSE"))
       std::fprintf(stderr, "[bsn] %s: image of %.1f GB does not fit (%.1f GB available): out-of-core handle, slabs of %lld variants\n",
@@ -904,6 +923,20 @@ int bsn_bed_release_workspace(bsn_bed *bed) {
       bed->d_smaj = nullptr;
     }
     bed->smaj_tried = false;
+    bed->smaj_cap = 0;
+    if (bed->sub) {     // the compacted sub-image of the last solve over a column list (and everything IT holds)
+      bed_free(bed->sub);
+      bed->sub = nullptr;
+      bed->sub_key = 0;
+    }
+    if (bed->slab_img) {   // out-of-core handle: the resident slab image and its page-locked staging buffers
+      bed_free(bed->slab_img);
+      bed->slab_img = nullptr;
+    }
+    if (bed->slab_stage) {
+      delete (bsn::FileStage *)bed->slab_stage;
+      bed->slab_stage = nullptr;
+    }
     dev_cache_flush();
   });
 }

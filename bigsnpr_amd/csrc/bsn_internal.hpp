@@ -241,6 +241,17 @@ struct bsn_bed {
   uint8_t *d_smaj = nullptr;
   int64_t pitch_smaj = 0, rows_smaj = 0;
   bool smaj_tried = false;
+  size_t smaj_cap = 0;              // bytes of the d_smaj allocation
+  int64_t cap_m = 0;                // variants the d_img allocation holds (image_alloc)
+  // Compacted sub-image (round 5, svd.hip compacted_view): a solve over a NON-contiguous list of variants — every
+  // solve of bed_autoSVD / snp_autoSVD, whose ind.col is the clumped set (R/autoSVD.R:296-301) — runs on a gathered
+  // copy of the selected variants (and samples, when ind.row is a proper list) instead of through gather lists: the
+  // copy is a contiguous image, so the fast kernel family applies to it (buffer loads, its own sample-major copy,
+  // k_prodT, three column blocks, the counts riding along the first pass).  One gather pass buys every pass of the
+  // solve.  Owned by this handle, keyed by a hash of the lists, re-gathered IN PLACE when the next selection fits the
+  // allocation (the rounds of autoSVD only remove variants), freed with the handle / bsn_bed_release_workspace.
+  bsn_bed *sub = nullptr;
+  uint64_t sub_key = 0;
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream_up = nullptr;   // second stream (created on first use): uploads beside the kernels of `stream`
@@ -269,7 +280,10 @@ namespace bsn {
 void image_alloc(bsn_bed *b, int64_t n, int64_t m, int bits = 2);
 void bed_free(bsn_bed *b);  // api.hip: everything a handle owns
 // a new handle holding the sub-matrix [ind_row, ind_col] (rows in list order, repeats allowed), same coding
-bsn_bed *image_gather(bsn_bed *src, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m);
+// `reuse`: a handle made by an earlier call whose allocation holds the new sub-matrix (same number of samples, at
+// least m variants): gathered into in place, its sample-major copy rebuilt if it has one
+bsn_bed *image_gather(bsn_bed *src, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                      bsn_bed *reuse = nullptr);
 bool image_tile(bsn_bed *b);  // true when the streaming-layout copy exists (builds it if memory allows)
 bool image_smaj(bsn_bed *b);  // true when the sample-major copy exists (builds it if memory allows)
 void image_from_host(bsn_bed *b, const uint8_t *payload, int64_t n_byte_src);

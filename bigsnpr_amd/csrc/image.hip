@@ -63,6 +63,7 @@ void image_alloc(bsn_bed *b, int64_t n, int64_t m, int bits) {
   BSN_HIP(hipEventCreate(&b->ev1));
   size_t bytes = (size_t)(m + kPadRows) * (size_t)b->pitch;
   BSN_HIP(hipMalloc((void **)&b->d_img, bytes));
+  b->cap_m = m;
 }
 
 // ---- streaming layout (second copy) --------------------------------------------------------
@@ -159,6 +160,16 @@ __global__ __launch_bounds__(512) void k_smaj_build(const uint8_t *__restrict__ 
   }
 }
 
+static void smaj_launch(bsn_bed *b, int64_t pitch_t, int64_t rows_t) {
+  b->pitch_smaj = pitch_t;
+  b->rows_smaj = rows_t;
+  const int64_t nvb = pitch_t * 4 / 512;
+  const int64_t gy = nvb < 65535 ? nvb : 65535, gz = (nvb + 65534) / 65535;
+  hipLaunchKernelGGL(k_smaj_build, dim3((unsigned)(rows_t / 256), (unsigned)gy, (unsigned)gz), dim3(512), 0, b->stream,
+                     b->d_img, b->pitch, b->m, b->d_smaj, pitch_t, rows_t);
+  BSN_HIP(hipGetLastError());
+}
+
 bool image_smaj(bsn_bed *b) {
   if (b->d_smaj) return true;
   if (b->streamed()) return false;
@@ -177,14 +188,25 @@ bool image_smaj(bsn_bed *b) {
     b->d_smaj = nullptr;
     return false;
   }
-  b->pitch_smaj = pitch_t;
-  b->rows_smaj = rows_t;
-  const int64_t nvb = pitch_t * 4 / 512;
-  const int64_t gy = nvb < 65535 ? nvb : 65535, gz = (nvb + 65534) / 65535;
-  hipLaunchKernelGGL(k_smaj_build, dim3((unsigned)(rows_t / 256), (unsigned)gy, (unsigned)gz), dim3(512), 0, b->stream,
-                     b->d_img, b->pitch, b->m, b->d_smaj, pitch_t, rows_t);
-  BSN_HIP(hipGetLastError());
+  b->smaj_cap = bytes;
+  smaj_launch(b, pitch_t, rows_t);
   return true;
+}
+
+// the image changed in place (image_gather with `reuse`): an existing sample-major copy is rebuilt inside its
+// allocation when it fits, dropped otherwise (the next solve asks for a new one)
+static void smaj_refresh(bsn_bed *b) {
+  b->smaj_tried = false;
+  if (!b->d_smaj) return;
+  const int64_t pitch_t = round_up((b->m + 3) / 4 + 128, 256), rows_t = round_up(b->n, 256);
+  if ((size_t)rows_t * (size_t)pitch_t <= b->smaj_cap) {
+    smaj_launch(b, pitch_t, rows_t);
+    return;
+  }
+  BSN_HIP(hipStreamSynchronize(b->stream));
+  (void)hipFree(b->d_smaj);
+  b->d_smaj = nullptr;
+  b->smaj_cap = 0;
 }
 
 // recode = 1: the rows hold .bed codes (uploads); 0: device codes already (FBM repack)
@@ -832,7 +854,17 @@ __global__ void k_gather_image(const uint8_t *img, int64_t pitch, int bits, cons
   out[j * pitch_out + b] = (uint8_t)v;
 }
 
-bsn_bed *image_gather(bsn_bed *src, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m) {
+// all samples in file order: a variant row of the copy IS a variant row of the source (16-byte copies, one
+// workgroup row per variant)
+__global__ void k_copy_rows(const uint8_t *__restrict__ img, int64_t pitch, const int32_t *__restrict__ cols, int64_t m,
+                            uint8_t *__restrict__ out) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t j = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (q * 16 >= pitch || j >= m) return;
+  ((uint4 *)(out + j * pitch))[q] = ((const uint4 *)(img + (int64_t)cols[j] * pitch))[q];
+}
+
+bsn_bed *image_gather(bsn_bed *src, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m, bsn_bed *reuse) {
   if (n <= 0 || m <= 0) fail("'ind.row' and 'ind.col' can't be empty.");
   if (src->generic) fail("internal: image_gather on a look-up image");
   require_resident(src, "a row list with repeated samples");
@@ -848,22 +880,40 @@ bsn_bed *image_gather(bsn_bed *src, const int64_t *ind_row, int64_t n, const int
     if (c < 0 || c >= src->m) fail("Tested %lld < %lld. Subscript out of bounds (ind.col).", (long long)c, (long long)src->m);
     cols[(size_t)j] = (int32_t)c;
   }
-  std::unique_ptr<bsn_bed, void (*)(bsn_bed *)> b(new bsn_bed(), bed_free);
-  image_alloc(b.get(), n, m, src->bits);
+  bool rows_ident = n == src->n;
+  for (int64_t i = 0; rows_ident && i < n; i++) rows_ident = rows[(size_t)i] == (int32_t)i;
+  const bool in_place = reuse && reuse->n == n && reuse->bits == src->bits && reuse->cap_m >= m && reuse->d_img;
+  std::unique_ptr<bsn_bed, void (*)(bsn_bed *)> fresh(nullptr, bed_free);
+  bsn_bed *b = reuse;
+  if (in_place) {
+    BSN_HIP(hipStreamSynchronize(b->stream));
+    b->m = m;
+    b->na_cnt.clear();
+  } else {
+    fresh.reset(new bsn_bed());
+    b = fresh.get();
+    image_alloc(b, n, m, src->bits);
+  }
   b->v_off = src->v_off;
   b->v_step = src->v_step;
   DevBuf<int32_t> d_rows, d_cols;
   BSN_HIP(hipStreamSynchronize(src->stream));   // whatever still writes the source image
   // the index lists go through the new handle's pinned staging buffers (no blocking copy from pageable memory)
-  copy_h2d(b.get(), d_rows.ensure((size_t)n), rows.data(), (size_t)n * 4);
-  copy_h2d(b.get(), d_cols.ensure((size_t)m), cols.data(), (size_t)m * 4);
+  if (!rows_ident) copy_h2d(b, d_rows.ensure((size_t)n), rows.data(), (size_t)n * 4);
+  copy_h2d(b, d_cols.ensure((size_t)m), cols.data(), (size_t)m * 4);
   BSN_HIP(hipMemsetAsync(b->d_img + b->m * b->pitch, 0, (size_t)(kPadRows * b->pitch), b->stream));
   const int64_t gy = m < 65535 ? m : 65535, gz = (m + 65534) / 65535;
-  hipLaunchKernelGGL(k_gather_image, dim3((unsigned)((b->pitch + 255) / 256), (unsigned)gy, (unsigned)gz), dim3(256), 0,
-                     b->stream, src->d_img, src->pitch, src->bits, d_rows.p, n, d_cols.p, m, b->d_img, b->pitch);
+  if (rows_ident && b->pitch == src->pitch)
+    hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((b->pitch / 16 + 255) / 256), (unsigned)gy, (unsigned)gz), dim3(256), 0,
+                       b->stream, src->d_img, src->pitch, d_cols.p, m, b->d_img);
+  else
+    hipLaunchKernelGGL(k_gather_image, dim3((unsigned)((b->pitch + 255) / 256), (unsigned)gy, (unsigned)gz), dim3(256), 0,
+                       b->stream, src->d_img, src->pitch, src->bits, d_rows.p, n, d_cols.p, m, b->d_img, b->pitch);
   BSN_HIP(hipGetLastError());
+  if (in_place) smaj_refresh(b);
   BSN_HIP(hipStreamSynchronize(b->stream));
-  return b.release();
+  if (in_place) return b;
+  return fresh.release();
 }
 
 void to_bytes(bsn_bed *b, const int32_t *d_rows, int64_t n, const int32_t *d_cols, int64_t m,

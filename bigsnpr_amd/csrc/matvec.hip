@@ -835,6 +835,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_prodT(const uint8_t *__restrict_
   int ch_end = ch_begin + cps;
   if (ch_end > nchunks) ch_end = nchunks;
   if (ch_begin >= ch_end) return;   // (never: the launch geometry gives every slab at least one chunk)
+  if (wg_base >= rows_t) return;    // a workgroup wholly past the copy's rows (a segment's padding blocks): nothing to read or write
   // chunk ch of the slab: the workgroup's 512 sample rows x 128 B are ONE contiguous 64-KB run of the copy
   const int64_t chunk_stride = rows_t * (KC / 4);
   const uint8_t *const base0 = simg + ((chunk0 + ch_begin) * rows_t + wg_base) * (KC / 4);
@@ -1749,9 +1750,12 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
     smaj_cps = (int)((nchunks + ky - 1) / ky);
     ky = (int)((nchunks + smaj_cps - 1) / smaj_cps);
   }
-  if (ky > steps) ky = (int)steps;
-  if (ky > 64) ky = 64;
+  if (!smaj) {   // (k_prodT's slab count and chunks per slab were fixed together above: clamping one would drop chunks)
+    if (ky > steps) ky = (int)steps;
+    if (ky > 64) ky = 64;
+  }
   if (ky < 1) ky = 1;
+  if (smaj && (int64_t)ky * smaj_cps < m_pad / 512) fail("internal: the slabs of k_prodT do not cover the variants");
   if (b->bits == 2 && pick_nb((nvec < vmax ? nvec : vmax) * S) == 1) {
     // (one column block: the kernel is bound by HBM; with two it is bound by instruction issue, more slabs only help
     // there — 400 000 x 125 000, 16 vectors: 4 slabs 3.45 ms, 5: 3.19, 9: 3.13, 11: 3.12 — and the rule above stays)

@@ -85,7 +85,14 @@ def _no_missing(G, what, ind_row=None, ind_col=None):
         if len(cache) >= 4:
             cache.pop(next(iter(cache)))
         cache[key] = np.isnan(snp_colstats(G, ind_row, None)["sumX"])
-    bad = cache[key] if ind_col is None else cache[key][np.asarray(ind_col, dtype=np.int64)]
+    if ind_col is None:
+        bad = cache[key]
+    else:
+        ic = np.asarray(ind_col, dtype=np.int64)
+        if ic.size and (ic.min() < 0 or ic.max() >= cache[key].size):   # (numpy would wrap a negative index silently)
+            raise IndexError("Tested %d < %d. Subscript out of bounds (ind.col)."
+                             % (int(ic.max() if ic.max() >= cache[key].size else ic.min()), cache[key].size))
+        bad = cache[key][ic]
     if bad.any():
         raise ValueError("%s: the selected rows and columns of the FBM hold missing values (bigstatsr would return "
                          "NA); impute first (snp_fastImputeSimple) or exclude them." % what)

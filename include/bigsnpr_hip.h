@@ -331,6 +331,11 @@ typedef struct bsn_svd_info {
   int32_t exchange_mode;
   int32_t n_exchange[4];
   double exchange_ms[4];
+  /* 1 when ind_col was not a contiguous range and the solve ran on a compacted copy of the selected variants (kept on
+   * the handle, re-gathered in place by the next solve over another list: the rounds of bed_autoSVD); compact_ms =
+   * host wall time of making / finding that copy inside this call (0.0x ms when the same list was solved before) */
+  int32_t compacted;
+  double compact_ms;
 } bsn_svd_info;
 /* Returns 0 on success, 1 on error, and 2 when the solve ran to the end of its basis without all
  * k residuals meeting tol (outputs are filled with the best available triplets, bsn_last_error()
