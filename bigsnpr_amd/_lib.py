@@ -234,6 +234,12 @@ class PinnedPool:
         # 400K x 1M, k = 20 solve are 224 MB
         self.free = []
         self.keep = int(os.environ.get("BSN_RESULT_POOL_KEEP", 1 << 30)) if keep is None else keep
+        # ... but never less than what the caller's own pattern needs: the largest total of blocks that were alive at
+        # once (bed_cor at config C5 hands back @i + @x = 2.4 GB per call: with a fixed 1-GiB cap every call page-locked
+        # its result afresh, 339 -> 463 ms), up to BSN_RESULT_POOL_MAX (8 GiB)
+        self.keep_max = int(os.environ.get("BSN_RESULT_POOL_MAX", 8 << 30))
+        self.live = 0
+        self.peak_live = 0
         # re-entrant: __del__ of a block may run on any thread, also on THIS one inside empty() (a cyclic-GC pass
         # triggered by an allocation under the lock finalises a block, whose _give_back takes the lock again)
         self.lock = threading.RLock()
@@ -256,12 +262,17 @@ class PinnedPool:
                 # (ulimit -l, fragmentation) the result goes to ordinary memory through the staging buffers
                 return np.empty(shape, dtype=dtype)
             addr, sz = p.value, size
+        with self.lock:
+            self.live += sz
+            self.peak_live = max(self.peak_live, self.live)
         blk = _PinnedBlock(self, addr, sz)
         return np.asarray(blk)[:n].view(dtype).reshape(shape)
 
     def _give_back(self, addr, size):
         with self.lock:
-            keep = sum(sz for _, sz in self.free) + size <= self.keep
+            self.live -= size
+            limit = max(self.keep, min(self.peak_live, self.keep_max))
+            keep = sum(sz for _, sz in self.free) + size <= limit
             if keep:
                 self.free.append((addr, size))
         if not keep:
@@ -270,6 +281,7 @@ class PinnedPool:
     def drain(self):
         with self.lock:
             blocks, self.free = self.free, []
+            self.peak_live = self.live
         for addr, _ in blocks:
             load().bsn_host_free(vp(addr))
 
