@@ -44,7 +44,8 @@ class SvdInfo(C.Structure):
                 ("slices_max", C.c_int32), ("wide_steps", C.c_int32), ("wide_cprod_ms", C.c_double),
                 ("wide_prod_ms", C.c_double), ("n_wide_cprod", C.c_int32), ("n_wide_prod", C.c_int32),
                 ("lead_rel_resid", C.c_double), ("exchange_mode", C.c_int32), ("n_exchange", C.c_int32 * 4),
-                ("exchange_ms", C.c_double * 4), ("compacted", C.c_int32), ("compact_ms", C.c_double)]
+                ("exchange_ms", C.c_double * 4), ("compacted", C.c_int32), ("compact_ms", C.c_double),
+                ("out_of_core", C.c_int32)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check that every symbol

@@ -389,7 +389,7 @@ void bed_free(bsn_bed *b) {
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->ev_up) (void)hipEventDestroy(b->ev_up);
   if (b->stream_up) (void)hipStreamDestroy(b->stream_up);
-  if (b->stream) (void)hipStreamDestroy(b->stream);
+  if (b->stream && !b->stream_borrowed) (void)hipStreamDestroy(b->stream);
   delete b;
 }
 
@@ -399,10 +399,10 @@ __global__ void k_fill_f64(double *p, int64_t n, double v) {
 }
 
 void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
-             int64_t m, const double *center, const double *scale, bool defer_scale) {
+             int64_t m, const double *center, const double *scale, bool defer_scale, bool allow_streamed) {
   if (n <= 0 || m <= 0) fail("'ind.row' and 'ind.col' can't be empty.");
   if (bed->n >= (int64_t)1 << 31 || bed->m >= (int64_t)1 << 31) fail("dimension too large");
-  require_resident(bed, "this function");
+  if (!allow_streamed) require_resident(bed, "this function");
   BSN_HIP(hipSetDevice(bed->device));
   op->bed = bed;
   op->n = n;
@@ -485,6 +485,37 @@ void require_resident(const bsn_bed *b, const char *what) {
          what, (double)b->m * (double)b->pitch / 1e9);
 }
 
+// ---- out-of-core handles: the resident slab image --------------------------------------------------------------------
+// One image of slab_cols variants lives on the handle (with its page-locked staging buffers) and is filled with one
+// slab of the file at a time.  It works on the HANDLE's stream: whatever the caller queues there — the kernels of a
+// one-shot entry point, the passes of a solve (svd.hip) — is ordered with the uploads without further ado.
+bsn_bed *slab_image(bsn_bed *b) {
+  BSN_HIP(hipSetDevice(b->device));
+  if (!b->slab_img) {
+    std::unique_ptr<bsn_bed, void (*)(bsn_bed *)> im(new bsn_bed(), bed_free);
+    image_alloc(im.get(), b->n, b->slab_cols);
+    (void)hipStreamDestroy(im->stream);
+    im->stream = b->stream;
+    im->stream_borrowed = true;
+    b->slab_img = im.release();
+  }
+  if (!b->slab_stage) b->slab_stage = new FileStage();
+  return b->slab_img;
+}
+int64_t slab_count(const bsn_bed *b) { return (b->m + b->slab_cols - 1) / b->slab_cols; }
+// slab sl of the file into the slab image (pread into pinned buffers, double-buffered against the DMA, recode, zero
+// pad rows); returns its number of variants, *j0 = its first variant
+int64_t slab_upload(bsn_bed *b, int64_t sl, int64_t *j0_out) {
+  bsn_bed *img = slab_image(b);
+  const int64_t j0 = sl * b->slab_cols, cnt = std::min(b->slab_cols, b->m - j0);
+  if (cnt <= 0) fail("internal: slab %lld of %lld", (long long)sl, (long long)slab_count(b));
+  img->m = cnt;
+  img->na_cnt.clear();
+  image_from_file(img, b->fd_file, 3 + j0 * b->n_byte, b->n_byte, (FileStage *)b->slab_stage);
+  if (j0_out) *j0_out = j0;
+  return cnt;
+}
+
 // ---- out-of-core handles: the one-shot entry points over slabs of variants --------------------------------------
 // The selected variants are grouped by slab (order inside a slab = order in ind_col); `f(slab image, positions in
 // ind_col, local variant indices)` runs per non-empty slab on a resident image of that slab, in ascending slab order.
@@ -494,14 +525,7 @@ struct SlabWalk {
   bsn_bed *img;        // the resident slab image: kept on the handle between calls, like its staging buffers
   FileStage *stage;
   SlabWalk(bsn_bed *b) : bed(b) {
-    BSN_HIP(hipSetDevice(b->device));
-    if (!b->slab_img) {
-      std::unique_ptr<bsn_bed, void (*)(bsn_bed *)> im(new bsn_bed(), bed_free);
-      image_alloc(im.get(), b->n, b->slab_cols);
-      b->slab_img = im.release();
-    }
-    if (!b->slab_stage) b->slab_stage = new FileStage();
-    img = b->slab_img;
+    img = slab_image(b);
     stage = (FileStage *)b->slab_stage;
   }
   template <class F>
@@ -517,11 +541,8 @@ struct SlabWalk {
     for (int64_t sl = 0; sl < nslab; sl++) {
       const std::vector<int64_t> &P = pos[(size_t)sl];
       if (P.empty()) continue;
-      const int64_t j0 = sl * bed->slab_cols, cnt = std::min(bed->slab_cols, bed->m - j0);
-      img->m = cnt;
-      img->na_cnt.clear();
-      // upload (pread into pinned buffers, double-buffered against the DMA) + recode + zero pad rows
-      image_from_file(img, bed->fd_file, 3 + j0 * bed->n_byte, bed->n_byte, stage);
+      const int64_t j0 = sl * bed->slab_cols;
+      slab_upload(bed, sl);
       local.resize(P.size());
       for (size_t k = 0; k < P.size(); k++) local[k] = (ind_col ? ind_col[P[k]] : P[k]) - j0;
       f(img, P, local);

@@ -253,6 +253,7 @@ struct bsn_bed {
   bsn_bed *sub = nullptr;
   uint64_t sub_key = 0;
   int device = 0;
+  bool stream_borrowed = false;      // `stream` belongs to another handle (the slab image of an out-of-core handle)
   hipStream_t stream = nullptr;
   hipStream_t stream_up = nullptr;   // second stream (created on first use): uploads beside the kernels of `stream`
   hipEvent_t ev_up = nullptr;
@@ -346,7 +347,13 @@ void copy_d2h(bsn_bed *b, void *dst, const void *d_src, size_t bytes);
 
 // api.hip: operator over a sub-view; defer_scale leaves centre / scale unset (stats_pending path)
 void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
-             int64_t m, const double *center, const double *scale, bool defer_scale = false);
+             int64_t m, const double *center, const double *scale, bool defer_scale = false,
+             bool allow_streamed = false);
+// api.hip: the resident slab image of an out-of-core handle (on the handle's stream), the number of slabs, and the
+// upload of one slab into it (returns its number of variants)
+bsn_bed *slab_image(bsn_bed *b);
+int64_t slab_count(const bsn_bed *b);
+int64_t slab_upload(bsn_bed *b, int64_t sl, int64_t *j0_out = nullptr);
 
 // comm.hip: RCCL collectives on device buffers of doubles, enqueued on `st`
 // (exchange timing) a pair of events around `what` on `st`, filed under class cls; no-ops unless c->timing
@@ -364,6 +371,8 @@ void comm_all_gather(bsn_comm *c, const double *d_send, double *d_recv, int64_t 
 // matvec.hip
 void op_poll_stats(bsn_op *op);  // after a stream synchronisation: pick up the missing-value total
 void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy);
+// Y = beta Y + A~ X (the slabs of an out-of-core solve add up their products on the device)
+void op_prod_acc(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy, double beta);
 // The product pass in SEGMENTS of sample blocks (sharded solve, svd.hip: the reduce-scatter of a finished segment runs
 // on a second stream while the next segment computes).  The samples are seen as `pieces` equal pieces (the ranks' sample
 // blocks) of `stride` workgroup blocks of 512 samples each; segment s covers blocks [off, off + bs) of EVERY piece, and

@@ -1934,6 +1934,10 @@ void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, 
   prod_planes(op, d_X, nullptr, ldx, nvec, d_Y, ldy, 1, kLutRaw, kLutNA, 1, 0.0, op->slices);
 }
 
+void op_prod_acc(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy, double beta) {
+  prod_planes(op, d_X, nullptr, ldx, nvec, d_Y, ldy, 1, kLutRaw, kLutNA, 1, beta, op->slices);
+}
+
 bool op_prod_segments(bsn_op *op, const double *d_X, int64_t ldx, int nvec, int pieces, int stride, int nseg,
                       const ProdSegment *segs, const std::function<void(int)> &after) {
   if (!op->rows_identity || op->prof_kind_override == 3) return false;

@@ -509,6 +509,7 @@ struct HipSvdBackend : SvdBackend {
   bool fused_stats = false;
   int warm_launches = 0, warm_den = 16;
   bool subset(bool on) override {
+    if (ooc) return false;   // (a warm start on the leading variants would walk the first slab twice: not worth the special case)
     if (on) {
       m_op_full = op->m;
       // small matrices: a full pass is cheap and the thinned matrix too noisy.  The thinned operator is
@@ -652,8 +653,88 @@ struct HipSvdBackend : SvdBackend {
   }
   // the newest basis block with all n rows: Q itself on one GPU, the gathered copy otherwise
   const double *newest_block(int p0) const { return dist ? Qfull.p : Q.p + (int64_t)p0 * nr; }
+  // ---- out-of-core handle (round 5): both passes of a block step WALK THE FILE in slabs of variants --------------
+  // The reference maps a .bed of any size and solves on it (src/bed-acc.h:46, R/autoSVD.R:205-219).  Here a file
+  // whose image does not fit the device is served slab by slab (bsn_internal.hpp): every slab is uploaded into the
+  // one resident slab image (pread -> page-locked double buffer -> DMA, on the solve's stream) and the same streaming
+  // kernels run on it — Z[slab rows] = A_slab' Q for the crossproduct pass, W += A_slab Z[slab rows] for the product
+  // pass (added on the device).  The counts of the codes ride along the first crossproduct walk slab by slab.
+  // Each pass moves the whole file over PCIe (about 40 GB/s against 4 - 5 TB/s from HBM): the solve is paced by the
+  // link, 2.5 s per pass per 100 GB; what it buys is that no matrix is refused for its size.
+  bool ooc = false;
+  std::unique_ptr<bsn_op> sop;        // the operator over the resident slab
+  long long ooc_na_total = 0, ooc_n_bad = 0;
+  bool ooc_stats_walk = false;        // this crossproduct walk also counts the codes (first full pass of the solve)
+  void slab_operator(int64_t j0, int64_t cnt, bool with_scaling) {
+    bsn_bed *img = slab_image(op->bed);
+    if (!sop) sop.reset(new bsn_op());
+    sop->bed = img;
+    sop->n = n;
+    sop->m = cnt;
+    sop->rows_identity = true;
+    sop->cols_contig = true;
+    sop->col0 = 0;
+    sop->no_na = false;
+    sop->slices = op->slices;
+    sop->profile = op->profile;
+    sop->prof_kind_override = op->prof_kind_override;
+    sop->preq_X = nullptr;
+    sop->d_center.ensure((size_t)op->bed->slab_cols);
+    sop->d_scale.ensure((size_t)op->bed->slab_cols);
+    if (with_scaling) {
+      BSN_HIP(hipMemcpyAsync(sop->d_center.p, op->d_center.p + j0, (size_t)cnt * 8, hipMemcpyDeviceToDevice, st));
+      BSN_HIP(hipMemcpyAsync(sop->d_scale.p, op->d_scale.p + j0, (size_t)cnt * 8, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  void At_Qblock_ooc(int p0, int cb) {
+    const int64_t nslab = slab_count(op->bed);
+    const bool stats = op->stats_pending;
+    if (stats) {
+      ooc_na_total = ooc_n_bad = 0;
+      op->d_na.ensure((size_t)op->m);
+    }
+    for (int64_t sl = 0; sl < nslab; sl++) {
+      int64_t j0 = 0;
+      const int64_t cnt = slab_upload(op->bed, sl, &j0);
+      slab_operator(j0, cnt, !stats);
+      sop->stats_pending = stats;
+      sop->na_poll = false;
+      op_cprod(sop.get(), newest_block(p0), n, cb, Z.p + (int64_t)p0 * m_local + j0, m_local);
+      if (stats) {   // the slab's scaling and missing-value counts join the whole matrix's
+        BSN_HIP(hipMemcpyAsync(op->d_center.p + j0, sop->d_center.p, (size_t)cnt * 8, hipMemcpyDeviceToDevice, st));
+        BSN_HIP(hipMemcpyAsync(op->d_scale.p + j0, sop->d_scale.p, (size_t)cnt * 8, hipMemcpyDeviceToDevice, st));
+        BSN_HIP(hipMemcpyAsync(op->d_na.p + j0, sop->d_na.p, (size_t)cnt * 4, hipMemcpyDeviceToDevice, st));
+        sync_stream();
+        if (sop->h_na_total && sop->h_na_total[0] >= 0) {
+          ooc_na_total += sop->h_na_total[0];
+          ooc_n_bad += sop->h_na_total[1];
+        }
+      } else {
+        sync_stream();   // the slab image is overwritten by the next upload
+      }
+    }
+    if (stats) {
+      op->stats_pending = false;
+      if (!op->h_na_total) BSN_HIP(hipHostMalloc((void **)&op->h_na_total, 2 * sizeof(long long), hipHostMallocDefault));
+      op->h_na_total[0] = ooc_na_total;
+      op->h_na_total[1] = ooc_n_bad;
+    }
+    op->passes++;
+  }
+  void A_Zblock_ooc(int p0, int cb) {
+    const int64_t nslab = slab_count(op->bed);
+    for (int64_t sl = 0; sl < nslab; sl++) {
+      int64_t j0 = 0;
+      const int64_t cnt = slab_upload(op->bed, sl, &j0);
+      slab_operator(j0, cnt, true);
+      op_prod_acc(sop.get(), Z.p + (int64_t)p0 * m_local + j0, m_local, cb, Wc, n, sl == 0 ? 0.0 : 1.0);
+      sync_stream();
+    }
+    op->passes++;
+  }
   void At_Qblock(int p0, int cb) override {
     Tick tk(this, 1);
+    if (ooc) return At_Qblock_ooc(p0, cb);
     op_cprod(op, newest_block(p0), n, cb, Z.p + (int64_t)p0 * m_local, m_local);
   }
   // The product pass of a sharded solve in up to four SEGMENTS of sample blocks (every rank's sample block cut at the
@@ -732,6 +813,7 @@ struct HipSvdBackend : SvdBackend {
     if (S < 1) S = 1;
     if (S > 7) S = 7;
     op->slices = S;
+    if (sop) sop->slices = S;
     if (S < min_slices) min_slices = S;
   }
   int n_seg_passes = 0;   // product passes that ran in segments (diagnostics / tests)
@@ -740,6 +822,7 @@ struct HipSvdBackend : SvdBackend {
   void A_Zblock(int p0, int cb) override {
     Tick tk(this, 2);
     mx_valid = false;
+    if (ooc) return A_Zblock_ooc(p0, cb);
     if (dist && product_in_segments(p0, cb)) return;
     op_prod(op, Z.p + (int64_t)p0 * m_local, m_local, cb, dist ? Wfull.p : Wc, n);
     if (dist) {
@@ -934,7 +1017,7 @@ struct HipSvdBackend : SvdBackend {
       mx_valid = !dist;
       spec_rounded = false;
       round_W(cb);
-      op_cprod_prequant(op, dist ? Qfull.p : Wc, n, cb);
+      if (!ooc) op_cprod_prequant(op, dist ? Qfull.p : Wc, n, cb);
       spec_rounded = true;
       BSN_HIP(hipEventSynchronize(ws.ev_small));
       n_sync++;
@@ -1200,6 +1283,20 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     auto since = [&]() {
       return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     };
+    // (round 5) an out-of-core handle: the passes of the solve walk the file in slabs (HipSvdBackend, "out-of-core handle")
+    const bool ooc = bed->streamed();
+    if (ooc) {
+      if (o->comm || o->allreduce) fail("an out-of-core handle cannot be one shard of a sharded solve: shard the file instead");
+      bool all = n == bed->n && m == bed->m;
+      for (int64_t i = 0; all && ind_row && i < n; i++) all = ind_row[i] == i;
+      for (int64_t j = 0; all && ind_col && j < m; j++) all = ind_col[j] == j;
+      if (!all)
+        fail("bed_randomSVD on an out-of-core handle (the file's image does not fit the device: it streams its file) "
+             "covers all samples and all variants; a subset small enough for the device is served by a handle of its own "
+             "(snp_subset / bsn_bed_subset_payload)");
+      ind_row = nullptr;
+      ind_col = nullptr;
+    }
     // (round 5) a list of variants that is not a contiguous range: the solve runs on a compacted copy of the selection
     bool compacted = false;
     double t_compact = 0.0;
@@ -1228,7 +1325,7 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     int32_t n_bad = 0;
     bool fused = false;
     if (o->binom_scaling) {
-      fill_op(op, bed, ind_row, n, ind_col, m, nullptr, nullptr, true);
+      fill_op(op, bed, ind_row, n, ind_col, m, nullptr, nullptr, true, ooc);
       if (op->rows_identity) {
         // the counts ride along the first crossproduct pass; until they are known the general kernels run
         op->stats_pending = true;
@@ -1245,13 +1342,14 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
         if (o->scale_out) std::copy(sc.begin(), sc.end(), o->scale_out);
       }
     } else {
-      fill_op(op, bed, ind_row, n, ind_col, m, center, scale);
+      fill_op(op, bed, ind_row, n, ind_col, m, center, scale, false, ooc);
     }
     const double t_create = since();
     op->profile = true;
     if (o->slices > 7) fail("slices must be in 1..7");
     HipSvdBackend bk(*bed->svd_ws);
     bk.op = op;
+    bk.ooc = ooc;
     bk.st = bed->stream;
     bk.n = n;
     bk.m_local = m;
@@ -1455,6 +1553,16 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       double pms[kProfKinds];
       int pc[kProfKinds];
       prof_collect(op, pms, pc);
+      if (bk.sop) {   // out-of-core: the launches ran on the slab operator, one per slab
+        double p2[kProfKinds];
+        int c2[kProfKinds];
+        prof_collect(bk.sop.get(), p2, c2);
+        for (int t = 0; t < kProfKinds; t++) {
+          pms[t] += p2[t];
+          pc[t] += c2[t];
+          if (bk.sop->prof_kernel[t]) op->prof_kernel[t] = bk.sop->prof_kernel[t];
+        }
+      }
       info->wide_cprod_ms = pms[4];
       info->wide_prod_ms = pms[5];
       info->n_wide_cprod = pc[4];
@@ -1479,6 +1587,7 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
         info->tiled = 2;   // (one launch of two column blocks per product pass: k_prodT)
       info->segmented_passes = bk.n_seg_passes;
       info->compact_gathers = bk.n_compact_gathers;
+      info->out_of_core = ooc ? 1 : 0;
       info->compacted = compacted ? 1 : 0;
       info->compact_ms = t_compact;
       info->exchange_mode = bk.exchange_mode;

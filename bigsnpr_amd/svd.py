@@ -86,6 +86,7 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
                 wide_cprod_ms=info.wide_cprod_ms, wide_prod_ms=info.wide_prod_ms,
                 n_wide_cprod=int(info.n_wide_cprod), n_wide_prod=int(info.n_wide_prod),
                 lead_rel_resid=info.lead_rel_resid, compacted=bool(info.compacted), compact_ms=info.compact_ms,
+                out_of_core=bool(info.out_of_core),
                 exchange_mode=("none", "whole pass", "segments, one stream", "segments, reduce-scatters on a second stream")[
                     max(0, min(3, int(info.exchange_mode)))],
                 exchange_ms=dict(zip(("reduce_scatter", "all_gather", "small", "exposed_wait"), [float(x) for x in info.exchange_ms])),

@@ -185,7 +185,17 @@ SEXP _bigsnpr_read_bed_scaled(SEXP obj_bed, SEXP ind_row, SEXP ind_col, SEXP cen
  *                     ms$center, ms$scale, k, tol, verbose), class = "big_SVD")
  *   }
  * center = scale = NULL selects bed_scaleBinom evaluated inside the solve (its code counts ride
- * along the first crossproduct pass); the values used come back in the list either way. */
+ * along the first crossproduct pass); the values used come back in the list either way.
+ *
+ * What a caller gets (round 5): d to 1e-9 of the reference's; u and v as an fp64 Lanczos solve
+ * stopped at the same tol leaves them — the early block steps run on 24-bit panels (bsn_svd_options.vec_floor,
+ * 2.5e-7), so the rounding of the panels is not visible in the vectors: at 400K x 1M, k = 20 the leading half of the
+ * vectors lies within 1.6e-7 (u) / 8e-9 (v) of a tol-1e-10 solve, all of them within 1.3e-5 / 1.2e-6 (the k-th pair
+ * is converged to tol, like RSpectra's).  `tol` may carry up to three more numbers for callers who want another
+ * point of the accuracy / cost frontier:  tol = c(tol, slices, block, vec.floor)  — slices: int8 digits of the panels
+ * at every step (0 = automatic), block: vectors per pass (0 = automatic), vec.floor: residual floor wanted for the
+ * vectors (0 = default, < 0 = none: every step on `slices` digits, round 4's 16-bit behaviour: 15 % faster, leading
+ * vectors at 2e-5). */
 static SEXP random_svd(bsn_bed *img, SEXP ind_row, SEXP ind_col, SEXP center, SEXP scale, SEXP k_,
                        SEXP tol, SEXP verbose) {
   R_xlen_t n = XLENGTH(ind_row), m = XLENGTH(ind_col);
@@ -194,6 +204,12 @@ static SEXP random_svd(bsn_bed *img, SEXP ind_row, SEXP ind_col, SEXP center, SE
   bsn_svd_options o;
   memset(&o, 0, sizeof(o));
   o.k = k; o.tol = Rf_asReal(tol); o.verbose = Rf_asLogical(verbose);
+  if (TYPEOF(tol) == REALSXP) {   /* tol = c(tol, slices, block, vec.floor) */
+    const R_xlen_t nt = XLENGTH(tol);
+    if (nt > 1) o.slices = (int32_t) REAL(tol)[1];
+    if (nt > 2) o.block = (int32_t) REAL(tol)[2];
+    if (nt > 3) o.vec_floor = REAL(tol)[3];
+  }
   bsn_svd_info info;
   SEXP d = PROTECT(Rf_allocVector(REALSXP, k));
   SEXP u = PROTECT(Rf_allocMatrix(REALSXP, (int) n, k)), v = PROTECT(Rf_allocMatrix(REALSXP, (int) m, k));

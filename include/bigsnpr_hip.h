@@ -336,6 +336,9 @@ typedef struct bsn_svd_info {
    * host wall time of making / finding that copy inside this call (0.0x ms when the same list was solved before) */
   int32_t compacted;
   double compact_ms;
+  /* 1 when the handle is out of core (bsn_bed_is_streamed): both passes of every block step walked the file in slabs
+   * of variants through the resident slab image — PCIe-bound (the whole file per pass), same kernels, same arithmetic */
+  int32_t out_of_core;
 } bsn_svd_info;
 /* Returns 0 on success, 1 on error, and 2 when the solve ran to the end of its basis without all
  * k residuals meeting tol (outputs are filled with the best available triplets, bsn_last_error()

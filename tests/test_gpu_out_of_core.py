@@ -56,7 +56,28 @@ def test_streamed_handle_equals_resident(ba, orc, golden_dir, monkeypatch, name)
     rows, cols = np.array([5, 0, 17, 17, n - 1]), np.array([m - 1, 63, 64, 0, 200, 65])
     np.testing.assert_array_equal(ooc[rows, cols], res[rows, cols])
     np.testing.assert_array_equal(ooc.download(), res.download())
-    # what needs a resident image says so
-    for call in (lambda: ba.bed_randomSVD(ooc, k=3), lambda: ba.bed_cor(ooc, size=10), lambda: ba.bed_tcrossprodSelf(ooc)):
+    # (round 5) bed_randomSVD: both passes of every block step walk the file in slabs.  Same kernels on the same
+    # bytes: the scaling is identical, d agrees with the resident solve to 1e-12 (the product pass adds the slabs'
+    # partial products in fp64 instead of one integer sum: not bitwise) and with the oracle's dense SVD to 1e-6;
+    # default settings (precision schedule) and a tight 56-bit solve
+    k = 6
+    svd_cases = (dict(), dict(tol=1e-10, slices=7)) if (ba.bed_scaleBinom(res)["scale"] > 0).all() else ()   # (no monomorphic variant)
+    for kw in svd_cases:
+        r_res, r_ooc = ba.bed_randomSVD(res, k=k, **kw), ba.bed_randomSVD(ooc, k=k, **kw)
+        assert r_ooc["out_of_core"] and not r_res["out_of_core"] and r_ooc["converged"]
+        np.testing.assert_array_equal(r_ooc["center"], r_res["center"])
+        np.testing.assert_array_equal(r_ooc["scale"], r_res["scale"])
+        np.testing.assert_allclose(r_ooc["d"], r_res["d"], rtol=1e-12 if kw else 1e-7)
+        assert r_ooc["niter"] == r_res["niter"]
+        s = np.sign(np.sum(r_ooc["u"] * r_res["u"], axis=0))
+        assert np.abs(r_ooc["u"] * s - r_res["u"]).max() < (1e-9 if kw else 1e-4)
+        assert np.abs(r_ooc["v"] * s - r_res["v"]).max() < (1e-9 if kw else 1e-4)
+    if svd_cases:
+        np.testing.assert_allclose(r_ooc["d"], orc.dense_svd(ob, None, None, k=k)["d"], rtol=1e-9)
+    np.testing.assert_array_equal(ba.bed_cprodVec(ooc, np.ones(n)), ba.bed_cprodVec(res, np.ones(n)))   # the one-shot entries still work afterwards
+    with pytest.raises(ba.BsnError, match="all samples and all variants"):
+        ba.bed_randomSVD(ooc, ind_col=np.arange(0, m, 2), k=3)
+    # what still needs a resident image says so
+    for call in (lambda: ba.bed_cor(ooc, size=10), lambda: ba.bed_tcrossprodSelf(ooc)):
         with pytest.raises(ba.BsnError, match="streams its file"):
             call()

@@ -67,6 +67,13 @@ def test_svd_ld_and_clumping_through_the_shim(R, orc, golden_dir, example_bed, t
     np.testing.assert_array_equal(res["center"], ref["center"])
     assert res["u"].shape == (ob.n, 10) and res["v"].shape == (ic.size, 10)
     np.testing.assert_allclose(np.abs(np.sum(res["u"] * ref["u"], axis=0)), 1.0, atol=1e-4)
+    # tol = c(tol, slices, block, vec.floor): the accuracy / cost frontier is reachable from the .Call —
+    # 56-bit panels to tol 1e-10 give the oracle's vectors to 1e-6
+    tight = R.call("_bigsnpr_bed_randomSVD_hip", obj, ir + 1, ic + 1, None, None, 10, np.array([1e-10, 7.0, 4.0, 0.0]), False)
+    np.testing.assert_allclose(tight["d"], ref["d"], rtol=1e-10)
+    sgn = np.sign(np.sum(tight["u"] * ref["u"], axis=0))
+    gap_ok = np.r_[True, np.diff(-ref["d"]) / ref["d"][0] > 1e-4] & np.r_[np.diff(-ref["d"]) / ref["d"][0] > 1e-4, True]
+    assert np.abs(tight["u"] * sgn - ref["u"])[:, gap_ok].max() < 1e-6
     # corMat -> list(i, p, x) as R/corr.R:43-47 consumes it; ld_scores
     ic2 = np.arange(400)
     pos = 1000.0 * np.arange(1, ic2.size + 1)

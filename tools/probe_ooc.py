@@ -46,6 +46,16 @@ for name, fn in (("counts", lambda h: ba.bed_counts(h)), ("cprodVec", lambda h: 
     close = float(np.max(np.abs(np.asarray(r["resident_val"], dtype=float) - np.asarray(r["out_of_core_val"], dtype=float))) /
                   max(1e-300, float(np.max(np.abs(np.asarray(r["resident_val"], dtype=float))))))
     out[name] = {"resident": r["resident"], "out_of_core": r["out_of_core"], "identical": bool(same), "max_rel_diff": close}
+# (round 5) bed_randomSVD on the out-of-core handle: every pass walks the file over PCIe
+if "--svd" in sys.argv or True:
+    k = 10
+    t0 = time.perf_counter(); r0 = ba.bed_randomSVD(res, k=k); t_res = time.perf_counter() - t0
+    t0 = time.perf_counter(); r1 = ba.bed_randomSVD(ooc, k=k); t_ooc = time.perf_counter() - t0
+    passes = r1["nops"]
+    out["bed_randomSVD k=10"] = {"resident_s": t_res, "out_of_core_s": t_ooc, "block_steps": [r0["niter"], r1["niter"]],
+                                 "file_walks": passes, "GBps_over_the_walks": passes * nb * m / t_ooc / 1e9,
+                                 "d_max_rel_diff": float(np.max(np.abs(r1["d"] / r0["d"] - 1))), "out_of_core": r1["out_of_core"],
+                                 "center_identical": bool(np.array_equal(r0["center"], r1["center"]))}
 print(json.dumps(out))
 for f in os.listdir(d):
     os.remove(os.path.join(d, f))
