@@ -505,13 +505,18 @@ bsn_bed *slab_image(bsn_bed *b) {
 int64_t slab_count(const bsn_bed *b) { return (b->m + b->slab_cols - 1) / b->slab_cols; }
 // slab sl of the file into the slab image (pread into pinned buffers, double-buffered against the DMA, recode, zero
 // pad rows); returns its number of variants, *j0 = its first variant
-int64_t slab_upload(bsn_bed *b, int64_t sl, int64_t *j0_out) {
+void slab_upload_range(bsn_bed *b, int64_t j0, int64_t cnt) {
   bsn_bed *img = slab_image(b);
-  const int64_t j0 = sl * b->slab_cols, cnt = std::min(b->slab_cols, b->m - j0);
-  if (cnt <= 0) fail("internal: slab %lld of %lld", (long long)sl, (long long)slab_count(b));
+  if (j0 < 0 || cnt <= 0 || j0 + cnt > b->m || cnt > b->slab_cols)
+    fail("internal: variants %lld .. %lld into a slab image of %lld", (long long)j0, (long long)(j0 + cnt), (long long)b->slab_cols);
   img->m = cnt;
   img->na_cnt.clear();
   image_from_file(img, b->fd_file, 3 + j0 * b->n_byte, b->n_byte, (FileStage *)b->slab_stage);
+}
+int64_t slab_upload(bsn_bed *b, int64_t sl, int64_t *j0_out) {
+  const int64_t j0 = sl * b->slab_cols, cnt = std::min(b->slab_cols, b->m - j0);
+  if (cnt <= 0) fail("internal: slab %lld of %lld", (long long)sl, (long long)slab_count(b));
+  slab_upload_range(b, j0, cnt);
   if (j0_out) *j0_out = j0;
   return cnt;
 }

@@ -354,6 +354,7 @@ void fill_op(bsn_op *op, bsn_bed *bed, const int64_t *ind_row, int64_t n, const 
 bsn_bed *slab_image(bsn_bed *b);
 int64_t slab_count(const bsn_bed *b);
 int64_t slab_upload(bsn_bed *b, int64_t sl, int64_t *j0_out = nullptr);
+void slab_upload_range(bsn_bed *b, int64_t j0, int64_t cnt);   // any run of at most slab_cols variants
 
 // comm.hip: RCCL collectives on device buffers of doubles, enqueued on `st`
 // (exchange timing) a pair of events around `what` on `st`, filed under class cls; no-ops unless c->timing

@@ -1319,9 +1319,71 @@ int bsn_cormat_free(bsn_cor *c) {
   return guarded([&] { delete c; });
 }
 
+static void ld_scores_resident(bsn_bed *bed_in, const int64_t *ind_row_in, int64_t n, const int64_t *ind_col_in, int64_t m,
+                               double size, const double *pos, double *out);
+
+// (round 5) LD scores on an OUT-OF-CORE handle.  The score of a variant only needs the variants inside its window,
+// so the selection is cut into runs of target variants; each run is uploaded together with its halo (the window of
+// its first variant to the left, of its last to the right) into the resident slab image, scored there by the resident
+// code path — the same pairs in the same order: identical values — and keeps its targets' scores.
+static void ld_scores_streamed(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                               double size, const double *pos, double *out) {
+  if (m <= 0 || n <= 0) fail("'ind.row' and 'ind.col' can't be empty.");
+  auto col = [&](int64_t t) -> int64_t { return ind_col ? ind_col[t] : t; };
+  for (int64_t t = 0; t < m; t++) {
+    if (col(t) < 0 || col(t) >= bed->m) fail("Tested %lld < %lld. Subscript out of bounds (ind.col).", (long long)col(t), (long long)bed->m);
+    if (t > 0 && col(t) <= col(t - 1))
+      fail("LD scores on an out-of-core handle (it streams its file) need 'ind.col' in increasing file order");
+    if (t > 0 && pos[t] < pos[t - 1]) fail("'pos' is not sorted.");
+  }
+  const int64_t cap = bed->slab_cols;
+  bsn_bed *img = slab_image(bed);
+  std::vector<int64_t> loc;
+  std::vector<double> part;
+  int64_t a = 0;
+  while (a < m) {
+    int64_t lo = a;
+    while (lo > 0 && pos[lo - 1] >= pos[a] - size) lo--;
+    // the longest run of targets [a, b) whose halo still fits the slab image
+    int64_t b = a, hi = a;
+    for (;;) {
+      int64_t h = std::max(hi, b);
+      while (h + 1 < m && pos[h + 1] <= pos[b] + size) h++;
+      if (col(h) - col(lo) + 1 > cap) break;
+      hi = h;
+      b++;
+      if (b >= m) break;
+    }
+    if (b == a)
+      fail("LD window around variant %lld spans %lld variants of the file: more than the %lld of the out-of-core slab "
+           "image; raise BSN_IMAGE_BUDGET or use a smaller window",
+           (long long)col(a), (long long)(col(std::max(hi, a)) - col(lo) + 1), (long long)cap);
+    const int64_t base = col(lo), cnt = col(hi) - base + 1, ml = hi - lo + 1;
+    slab_upload_range(bed, base, cnt);
+    loc.resize((size_t)ml);
+    for (int64_t t = 0; t < ml; t++) loc[(size_t)t] = col(lo + t) - base;
+    part.resize((size_t)ml);
+    ld_scores_resident(img, ind_row, n, loc.data(), ml, size, pos + lo, part.data());
+    for (int64_t t = a; t < b; t++) out[t] = part[(size_t)(t - lo)];
+    a = b;
+  }
+}
+
 int bsn_ld_scores(bsn_bed *bed_in, const int64_t *ind_row_in, int64_t n, const int64_t *ind_col_in, int64_t m,
                   double size, const double *pos, double *out) {
   return guarded([&] {
+    if (bed_in->streamed()) {
+      BSN_HIP(hipSetDevice(bed_in->device));
+      ld_scores_streamed(bed_in, ind_row_in, n, ind_col_in, m, size, pos, out);
+      return;
+    }
+    ld_scores_resident(bed_in, ind_row_in, n, ind_col_in, m, size, pos, out);
+  });
+}
+
+static void ld_scores_resident(bsn_bed *bed_in, const int64_t *ind_row_in, int64_t n, const int64_t *ind_col_in, int64_t m,
+                               double size, const double *pos, double *out) {
+  {
     const RowView rv = row_view(bed_in, ind_row_in, n, ind_col_in, m);
     bsn_bed *bed = rv.bed;
     const int64_t *ind_row = rv.ind_row, *ind_col = rv.ind_col;
@@ -1340,7 +1402,7 @@ int bsn_ld_scores(bsn_bed *bed_in, const int64_t *ind_row_in, int64_t n, const i
     }
     copy_d2h(bed, out, d_ld.p, (size_t)m * 8);
     BSN_HIP(hipStreamSynchronize(bed->stream));
-  });
+  }
 }
 
 // ---- greedy clumping inside one chromosome --------------------------------------------------

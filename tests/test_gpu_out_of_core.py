@@ -2,8 +2,8 @@
 of any size (src/bed-acc.h:46, src/bed-acc-xptr.cpp:14-35) — but walked in slabs of variants by the one-shot entry
 points.  BSN_IMAGE_BUDGET forces the path on the reference's own example files with slabs of 64 variants: counts,
 colstats, MAF, scaling, the `[` accessor and bed_cprodVec are IDENTICAL to the resident handle's (same kernels on the
-same bytes), bed_prodVec — a sum over the slabs instead of one pass — agrees to 1e-13 and with the oracle; everything
-else names the reason it needs a resident image."""
+same bytes), bed_prodVec — a sum over the slabs instead of one pass — agrees to 1e-13 and with the oracle; (round 5)
+bed_randomSVD and bed_ld_scores walk the file too; what is left names the reason it needs a resident image."""
 import os
 
 import numpy as np
@@ -77,6 +77,16 @@ def test_streamed_handle_equals_resident(ba, orc, golden_dir, monkeypatch, name)
     np.testing.assert_array_equal(ba.bed_cprodVec(ooc, np.ones(n)), ba.bed_cprodVec(res, np.ones(n)))   # the one-shot entries still work afterwards
     with pytest.raises(ba.BsnError, match="all samples and all variants"):
         ba.bed_randomSVD(ooc, ind_col=np.arange(0, m, 2), k=3)
+    # (round 5) bed_ld_scores: runs of target variants with their window halos through the slab image — identical
+    # scores, all variants and an increasing subset, windows of 7 / 20 variants against slabs of 64
+    posv = 1000.0 * np.arange(m)
+    for ic in (None, np.sort(rng.choice(m, m // 2, replace=False))):
+        pv = posv if ic is None else posv[ic]
+        for size_kb in (7, 20):
+            np.testing.assert_array_equal(ba.bed_ld_scores(ooc, ind_col=ic, size=size_kb, infos_pos=pv),
+                                          ba.bed_ld_scores(res, ind_col=ic, size=size_kb, infos_pos=pv))
+    with pytest.raises(ba.BsnError, match="more than the"):
+        ba.bed_ld_scores(ooc, size=100, infos_pos=posv)            # a window of 201 variants does not fit 64
     # what still needs a resident image says so
     for call in (lambda: ba.bed_cor(ooc, size=10), lambda: ba.bed_tcrossprodSelf(ooc)):
         with pytest.raises(ba.BsnError, match="streams its file"):
