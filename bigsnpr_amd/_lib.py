@@ -64,6 +64,12 @@ SIGNATURES = {
     "bsn_comm_abort": (C.c_int, [vp]),
     "bsn_comm_destroy": (C.c_int, [vp]),
     "bsn_ld_last_stats": (C.c_int, [f64p]),
+    "bsn_robust_scale_tau2": (C.c_int, [vp, i64, i64, C.c_int32, C.c_double, C.c_double, f64p, f64p]),
+    "bsn_robust_pair_scales": (C.c_int, [vp, i64, i64, C.c_int32, C.c_double, C.c_double, f64p, f64p]),
+    "bsn_robust_mc_count": (C.c_int, [vp, i64, vp, i64, C.c_double, C.POINTER(C.c_int64)]),
+    "bsn_robust_scale_cols": (C.c_int, [vp, i64, i64, C.c_int32, f64p]),
+    "bsn_robust_rotate": (C.c_int, [vp, i64, i64, C.c_int32, f64p]),
+    "bsn_robust_wdist": (C.c_int, [vp, i64, i64, C.c_int32, f64p, f64p, f64p]),
     "bsn_bed_open": (C.c_int, [C.c_char_p, i64, i64, C.POINTER(vp)]),
     "bsn_bed_from_host": (C.c_int, [u8p, i64, i64, i64, C.POINTER(vp)]),
     "bsn_bed_from_fbm": (C.c_int, [u8p, i64, i64, i64, C.POINTER(vp)]),

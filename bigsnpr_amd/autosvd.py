@@ -93,10 +93,59 @@ def covrob_ogk(U, niter=2, beta=0.9):
     return dict(center=center, cov=cov, weights=keep)
 
 
-def dist_ogk(U, niter=2, beta=0.9):
-    """squared robust Mahalanobis distances (bigutilsr::dist_ogk)"""
+def covrob_ogk_device(U, niter=2, beta=0.9, c1=4.5, c2=3.0):
+    """covrob_ogk with its robust scales on the device (csrc/robust.hip, bsn_robust_*): the same loop, statement for
+    statement — the p + p (p - 1) scales of a round are one batch each (medians by radix select), the m x p working
+    matrix lives in HBM, the host keeps the p x p matrices and the final moments.  Values equal to the host path's to
+    rounding (the sums are taken in another order): tests/test_gpu_autosvd.py."""
+    import ctypes as C
+    from scipy.stats import chi2
+    from . import _lib
+    from ._lib import check, f64p, ptr
+    L = _lib.load()
     U = np.asarray(U, dtype=np.float64)
-    est = covrob_ogk(U, niter, beta)
+    n, p = U.shape
+    if p > 64:
+        raise ValueError("the device path of dist_ogk holds at most 64 columns")
+    Z = _lib.DeviceArray.from_numpy(U)
+    npair = p * (p - 1) // 2
+    try:
+        for _ in range(niter):
+            d = np.empty(p)
+            check(L.bsn_robust_scale_tau2(Z.ptr, n, n, p, c1, c2, None, ptr(d, f64p)))
+            d[d <= 0] = 1.0
+            check(L.bsn_robust_scale_cols(Z.ptr, n, n, p, ptr(d, f64p)))
+            R = np.eye(p)
+            if npair:
+                ss, sd = np.empty(npair), np.empty(npair)
+                check(L.bsn_robust_pair_scales(Z.ptr, n, n, p, c1, c2, ptr(ss, f64p), ptr(sd, f64p)))
+                t = 0
+                for i in range(p):
+                    for j in range(i):
+                        R[i, j] = R[j, i] = (ss[t] ** 2 - sd[t] ** 2) / 4
+                        t += 1
+            _, E = np.linalg.eigh(R)
+            E = np.asfortranarray(E[:, ::-1])
+            check(L.bsn_robust_rotate(Z.ptr, n, n, p, ptr(E, f64p)))
+        mu, sig = np.empty(p), np.empty(p)
+        check(L.bsn_robust_scale_tau2(Z.ptr, n, n, p, c1, c2, ptr(mu, f64p), ptr(sig, f64p)))
+        sig[sig <= 0] = 1.0
+        wdist = np.empty(n)
+        check(L.bsn_robust_wdist(Z.ptr, n, n, p, ptr(mu, f64p), ptr(sig, f64p), ptr(wdist, f64p)))
+    finally:
+        Z.free()
+    d0 = np.median(wdist) * chi2.ppf(beta, p) / chi2.ppf(0.5, p)
+    keep = wdist <= d0
+    center = U[keep].mean(0)
+    cov = np.cov(U[keep], rowvar=False).reshape(p, p)
+    return dict(center=center, cov=cov, weights=keep)
+
+
+def dist_ogk(U, niter=2, beta=0.9, device=False):
+    """squared robust Mahalanobis distances (bigutilsr::dist_ogk).  device=True: the robust scales on the GPU
+    (covrob_ogk_device; what snp_autoSVD / bed_autoSVD use — their loadings come from a solve on that GPU)."""
+    U = np.asarray(U, dtype=np.float64)
+    est = covrob_ogk_device(U, niter, beta) if device else covrob_ogk(U, niter, beta)
     Xc = U - est["center"]
     return np.einsum("ij,ij->i", Xc @ np.linalg.pinv(est["cov"]), Xc)
 
@@ -121,14 +170,16 @@ def rollmean(x, size):
     return num / den
 
 
-def medcouple(x):
+def medcouple(x, device=False):
     """Medcouple (Brys, Hubert & Struyf 2004): the median of the kernel
         h(xi, xj) = ((xi - med) - (med - xj)) / (xi - xj),   xi >= med >= xj,
     over all such pairs; for pairs tied AT the median (xi = xj = med) the kernel is defined through
     their order among the m ties, h = sign(m - 1 - i - j) with i, j the positions among the tied values
     on each side (the convention of robustbase::mc and of the original paper).  The kernel is monotone
     in both arguments, so #{h <= t} is a sum of searchsorted counts and the median is found by bisection
-    on t, followed by a snap to the nearest attained kernel value (the median IS a kernel value)."""
+    on t, followed by a snap to the nearest attained kernel value (the median IS a kernel value).
+    device=True: the counts of the bisection — one binary search per value above the median — on the GPU
+    (bsn_robust_mc_count; what snp_autoSVD / bed_autoSVD use); same integers, same result."""
     x = np.sort(np.asarray(x, dtype=np.float64))
     n = x.size
     if n < 3:
@@ -147,6 +198,11 @@ def medcouple(x):
     ii, jj = np.meshgrid(np.arange(k0), np.arange(k0), indexing="ij")
     tie = np.sign(k0 - 1 - ii - jj).ravel() if k0 else np.zeros(0)
     total = upp.size * lop.size + n_plus + n_minus + tie.size
+    dev = None
+    if device and upp.size * lop.size >= 1 << 24:
+        import ctypes as C
+        from . import _lib
+        dev = (_lib.DeviceArray.from_numpy(upp), _lib.DeviceArray.from_numpy(np.ascontiguousarray(lop)), _lib.load(), C.c_int64())
 
     def count_le(t):  # number of pairs with h <= t
         if t >= 1:
@@ -155,7 +211,12 @@ def medcouple(x):
             return 0
         # regular pairs: (u - l) / (u + l) <= t  <=>  l >= u (1 - t) / (1 + t)
         c = 0
-        if t > -1:
+        if t > -1 and dev is not None:
+            import ctypes as C
+            from . import _lib
+            _lib.check(dev[2].bsn_robust_mc_count(dev[0].ptr, upp.size, dev[1].ptr, lop.size, float(t), C.byref(dev[3])))
+            c = int(dev[3].value)
+        elif t > -1:
             thr = upp * (1 - t) / (1 + t)
             c = int(np.sum(lop.size - np.searchsorted(lop, thr, side="left")))
         return c + n_minus + int(np.sum(tie <= t))       # the +1 pairs only at t >= 1
@@ -208,7 +269,7 @@ def medcouple(x):
     return 0.5 * (kth(total // 2) + kth(total // 2 + 1))
 
 
-def tukey_mc_up(x, coef=None, alpha=0.05, a=-4.0, b=3.0):
+def tukey_mc_up(x, coef=None, alpha=0.05, a=-4.0, b=3.0, device=False):
     """Upper fence Q3 + coef * exp(b MC | -a MC) * IQR.  With coef = NULL the coefficient is
     the one for which a sample of m = length(x) normal values has probability `alpha` of
     containing at least one value above the fence: per-value tail p = 1 - (1 - alpha)^(1/m),
@@ -223,7 +284,7 @@ def tukey_mc_up(x, coef=None, alpha=0.05, a=-4.0, b=3.0):
         q75 = norm.ppf(0.75)
         p = -np.expm1(np.log1p(-alpha) / x.size)
         coef = (norm.isf(p) - q75) / (2 * q75)
-    mc = medcouple(x)
+    mc = medcouple(x, device=device)
     return q3 + coef * iqr * (np.exp(b * mc) if mc >= 0 else np.exp(-a * mc))
 
 
@@ -277,13 +338,13 @@ def _auto_svd(svd_fun, clump_fun, maf_nok, ind_col, infos_chr, infos_pos, thr_r2
         if it > max_iter:
             printf2("Maximum number of iterations reached.\n")
             break
-        S = np.sqrt(dist_ogk(obj["v"]))
+        S = np.sqrt(dist_ogk(obj["v"], device=obj["v"].shape[1] <= 64))
         S2 = np.full(S.size, np.nan)
         chr_keep = infos_chr[ind_keep]
         for c in np.unique(chr_keep):
             idx = np.nonzero(chr_keep == c)[0]
             S2[idx] = rollmean(S[idx], roll_size)
-        thr = tukey_mc_up(S2, alpha=alpha_tukey)
+        thr = tukey_mc_up(S2, alpha=alpha_tukey, device=True)
         excl = np.nonzero(S2 > thr)[0]
         printf2("%d outlier variant%s detected..\n", excl.size, "s" if excl.size > 1 else "")
         if excl.size > 0:

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbigsnpr_hip.so")
-SOURCES = ["image.hip", "matvec.hip", "svd.hip", "ld.hip", "api.hip", "comm.hip", "tcross.hip"]
+SOURCES = ["image.hip", "matvec.hip", "svd.hip", "ld.hip", "api.hip", "comm.hip", "tcross.hip", "robust.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC]

@@ -65,7 +65,7 @@ void fail(const char *fmt, ...) {
   throw Error(buf);
 }
 
-static void require_gpu() {
+void require_gpu() {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0)

@@ -22,6 +22,7 @@ struct Error : std::runtime_error {
 };
 void set_error(const char *msg);
 [[noreturn]] void fail(const char *fmt, ...);
+void require_gpu();   // api.hip: fails ("no CPU fallback") without a HIP device
 
 #define BSN_HIP(expr)                                                             \
   do {                                                                            \

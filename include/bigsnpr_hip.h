@@ -428,6 +428,28 @@ int bsn_clumping_chr_cached(bsn_bed *bed, const int64_t *ind_row, int64_t n, con
                             const int32_t *ordInd, const int32_t *rankInd, const double *pos,
                             int64_t n_grid, const double *sizes, const double *thrs, int32_t *keep);
 
+/* ---- robust statistics of the outlier step of snp_autoSVD / bed_autoSVD (round 5) ----------------------------------
+ * R/autoSVD.R:142-148,295-301: bigutilsr::dist_ogk(obj.svd$v) — the orthogonalised Gnanadesikan-Kettenring estimator
+ * (Maronna & Zamar 2002; robustbase::covOGK with scaleTau2) — needs, per round, p + p (p - 1) robust scales of vectors as
+ * long as the number of variants: two medians and two weighted sums each, the bulk of the function's wall time once its
+ * solves run on the GPU.  These entry points compute them for whole batches of columns of a DEVICE matrix (column-major,
+ * leading dimension ld >= m; bsn_malloc / bsn_memcpy_h2d): medians by radix select, sums in a fixed order.  The loop
+ * around them (p x p eigen-decompositions, hard rejection, Mahalanobis distances) is host code (bigsnpr_amd/autosvd.py,
+ * an R shim would keep bigutilsr's own).  Small host vectors in and out. */
+/* robustbase::scaleTau2(x, c1, c2, mu.too = TRUE, consistency = TRUE) of every column: mu_out / s_out [ncol] (either may be NULL) */
+int bsn_robust_scale_tau2(const double *d_X, int64_t m, int64_t ld, int32_t ncol, double c1, double c2, double *mu_out, double *s_out);
+/* the same scale of Z_i + Z_j and Z_i - Z_j for every pair i > j of the p <= 64 columns, pairs in the order
+ * (1,0), (2,0), (2,1), (3,0) ...: s_sum_out / s_diff_out [p (p - 1) / 2] */
+int bsn_robust_pair_scales(const double *d_Z, int64_t m, int64_t ld, int32_t p, double c1, double c2, double *s_sum_out, double *s_diff_out);
+/* medcouple of tukey_mc_up (Brys, Hubert & Struyf 2004): number of pairs (u, l), u from d_up [nu], l from the ASCENDING
+ * d_lo [nl] (both positive distances to the median), with (u - l) / (u + l) <= t, -1 < t < 1 — the count the bisection
+ * on t evaluates ~50 times per call */
+int bsn_robust_mc_count(const double *d_up, int64_t nu, const double *d_lo, int64_t nl, double t, int64_t *count_out);
+int bsn_robust_scale_cols(double *d_Z, int64_t m, int64_t ld, int32_t p, const double *div /* [p] */);      /* Z[, j] /= div[j] */
+int bsn_robust_rotate(double *d_Z, int64_t m, int64_t ld, int32_t p, const double *E /* p x p, column-major */); /* Z <- Z E */
+/* out[i] = sum_j ((Z[i, j] - mu[j]) / sig[j])^2, to the host */
+int bsn_robust_wdist(const double *d_Z, int64_t m, int64_t ld, int32_t p, const double *mu, const double *sig, double *out);
+
 /* ---- device memory + timing helpers for hosts without a HIP binding -------- */
 int bsn_malloc(void **d_ptr, int64_t bytes);
 int bsn_free(void *d_ptr);

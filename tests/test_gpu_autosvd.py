@@ -139,3 +139,50 @@ def test_subset_identical_to_the_oracle_loop_on_oracle_components(env, orc, exam
         for r, row in enumerate(ref_lrldr):
             assert (got["lrldr"]["Chr"][r], got["lrldr"]["Start"][r], got["lrldr"]["Stop"][r], got["lrldr"]["Iter"][r]) == row
         np.testing.assert_allclose(got["d"], ref_svd["d"], rtol=1e-7)
+
+
+def test_dist_ogk_on_the_device_equals_both_host_restatements():
+    """Round 5: the robust scales of bigutilsr::dist_ogk — medians by radix select, fixed-order sums — on
+    the device (csrc/robust.hip) against the product's host path and the oracle's independent restatement: loadings
+    with outliers, odd and even lengths, ties, a column with MAD 0 (scaleTau2 returns 0 there), k up to 20, and the size
+    at which snp_autoSVD calls it."""
+    from bigsnpr_amd import autosvd as prod
+    from oracle import autosvd_oracle as orc_a
+    rng = np.random.default_rng(5)
+    cases = []
+    for m, p in ((1001, 3), (1000, 5), (20000, 10), (4097, 20), (257, 2), (64, 1)):
+        U = rng.normal(size=(m, p)) * rng.uniform(0.5, 2.0, size=p)
+        U[: max(2, m // 50)] += 4.0                                  # a block of outlying variants (a long-range LD region)
+        cases.append(U)
+    T = np.round(rng.normal(size=(5000, 4)) * 3) / 3                 # heavy ties
+    cases.append(T)
+    C = rng.normal(size=(3000, 3)); C[:, 1] = np.where(rng.uniform(size=3000) < 0.7, 0.5, C[:, 1])   # MAD of column 1 is 0
+    cases.append(C)
+    for U in cases:
+        dev = prod.dist_ogk(U, device=True)
+        host = prod.dist_ogk(U)
+        np.testing.assert_allclose(dev, host, rtol=1e-9, atol=1e-12)
+        if U.shape[0] <= 5000:
+            np.testing.assert_allclose(dev, orc_a.dist_ogk(U), rtol=1e-8, atol=1e-12)
+    # the scales themselves, column by column, against the host's scale_tau2 (mu too)
+    import ctypes as C_
+    from bigsnpr_amd import _lib
+    X = rng.standard_t(3, size=(30001, 7))
+    dX = _lib.DeviceArray.from_numpy(X)
+    mu, s = np.empty(7), np.empty(7)
+    _lib.check(_lib.load().bsn_robust_scale_tau2(dX.ptr, X.shape[0], X.shape[0], 7, 4.5, 3.0, _lib.ptr(mu, _lib.f64p), _lib.ptr(s, _lib.f64p)))
+    ref = [prod.scale_tau2(X[:, j], mu_too=True) for j in range(7)]
+    np.testing.assert_allclose(mu, [r[0] for r in ref], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(s, [r[1] for r in ref], rtol=1e-12)
+    dX.free()
+
+
+def test_medcouple_counts_on_the_device():
+    """tukey_mc_up with the counts of the medcouple's bisection on the GPU (bsn_robust_mc_count): the same integers as
+    numpy.searchsorted gives the host path, hence the same fence — skewed data, ties at the median, both parities"""
+    from bigsnpr_amd import autosvd as prod
+    rng = np.random.default_rng(9)
+    for x in (rng.lognormal(size=30001), rng.chisquare(3, size=20000), np.round(rng.normal(size=25000), 2),
+              np.r_[rng.normal(size=9000), np.zeros(50)]):
+        assert prod.medcouple(x, device=True) == prod.medcouple(x)
+        assert prod.tukey_mc_up(x, device=True) == prod.tukey_mc_up(x)

@@ -23,8 +23,13 @@ def timed(name, fn):
 autosvd.snp_MAF = timed("snp_MAF", autosvd.snp_MAF)
 autosvd.snp_clumping = timed("snp_clumping", autosvd.snp_clumping)
 autosvd.big_randomSVD = timed("big_randomSVD", autosvd.big_randomSVD)
-t0 = time.perf_counter()
-res = ba.snp_autoSVD(gb, chrom, pos, k=10, verbose=True)
-tot = time.perf_counter() - t0
-print("total %.2f s; %s; other (outlier detection, host) %.2f s; kept %d of %d variants"
-      % (tot, ", ".join("%s %.2f s" % kv for kv in T.items()), tot - sum(T.values()), res["subset"].size, a.m))
+autosvd.dist_ogk = timed("dist_ogk", autosvd.dist_ogk)
+autosvd.rollmean = timed("rollmean", autosvd.rollmean)
+autosvd.tukey_mc_up = timed("tukey_mc_up", autosvd.tukey_mc_up)
+for rep in ("first call (imports, first launches, allocations)", "second call"):
+    T.clear()
+    t0 = time.perf_counter()
+    res = ba.snp_autoSVD(gb, chrom, pos, k=10, verbose=rep.startswith("first"))
+    tot = time.perf_counter() - t0
+    print("%s: total %.3f s; %s; rest of the host loop %.3f s; kept %d of %d variants"
+          % (rep, tot, ", ".join("%s %.3f s" % kv for kv in T.items()), tot - sum(T.values()), res["subset"].size, a.m))
