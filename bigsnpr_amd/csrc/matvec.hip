@@ -1445,6 +1445,19 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
     if constexpr (STATS || NPLANE == 3) {
       fail("internal: no three-block counting kernel");
     } else {
+#ifdef BSN_ABLATION
+      // shape sweep of the three-block kernel (profiling build only; correct results): BSN_NB3 bit 0: without the explicit
+      // MFMA / decode pipeline, bit 1: 8-wave workgroups (two per CU), bit 3: 4 tiles per wave in 8-wave workgroups
+      static const int nb3v = getenv("BSN_NB3") ? atoi(getenv("BSN_NB3")) : 0;
+      if (op->cols_contig && (nb3v & 11)) {
+        if ((nb3v & 11) == 1) BSN_CPROD(3, true, 0, 2, 16, 0, false, 0, b->d_img);
+        else if ((nb3v & 11) == 2) BSN_CPROD(3, true, 0, 2, 8, 0, false, 3, b->d_img);
+        else if ((nb3v & 11) == 3) BSN_CPROD(3, true, 0, 2, 8, 0, false, 0, b->d_img);
+        else BSN_CPROD(3, true, 0, 4, 8, 0, false, 0, b->d_img);
+        BSN_HIP(hipGetLastError());
+        return;
+      }
+#endif
       if (op->cols_contig) BSN_CPROD(3, true, 0, 2, 16, 0, false, 3, b->d_img);
       else BSN_CPROD(3, false, 0, 2, 16, 0, false, 0, b->d_img);
     }
@@ -1809,10 +1822,22 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
 #define BSN_PRODT_(NBV, HASQV, TAGV, GRID, BS, STRIDE, OFF)                                                          \
   BSN_KLAUNCH((k_prodT<NBV, HASQV, 2, 16, TAGV>), GRID, dim3(1024), 0, b->stream, b->d_smaj, b->rows_smaj, op->col0 / 512, \
               nchunks, smaj_cps, q, acc, npad, lutQ, BS, STRIDE, OFF)
+#ifdef BSN_ABLATION
+      static const int nb3p = getenv("BSN_NB3") ? atoi(getenv("BSN_NB3")) : 0;   // bit 2: k_prodT<3> without the explicit pipeline
+#define BSN_PRODT3(HASQV, GRID, BS, STRIDE, OFF)                                                                      \
+  do {                                                                                                               \
+    if (nb3p & 4)                                                                                                    \
+      BSN_KLAUNCH((k_prodT<3, HASQV, 2, 16, 0, 0>), GRID, dim3(1024), 0, b->stream, b->d_smaj, b->rows_smaj, op->col0 / 512, \
+                  nchunks, smaj_cps, q, acc, npad, lutQ, BS, STRIDE, OFF);                                           \
+    else BSN_PRODT_(3, HASQV, 0, GRID, BS, STRIDE, OFF);                                                             \
+  } while (0)
+#else
+#define BSN_PRODT3(HASQV, GRID, BS, STRIDE, OFF) BSN_PRODT_(3, HASQV, 0, GRID, BS, STRIDE, OFF)
+#endif
 #define BSN_PRODT(HASQV, TAGV, GRID, BS, STRIDE, OFF)                                                                \
   do {                                                                                                               \
     if (NB == 2) BSN_PRODT_(2, HASQV, TAGV, GRID, BS, STRIDE, OFF);                                                  \
-    else BSN_PRODT_(3, HASQV, 0, GRID, BS, STRIDE, OFF);                                                             \
+    else BSN_PRODT3(HASQV, GRID, BS, STRIDE, OFF);                                                                   \
   } while (0)
       // (workgroup shapes 4 x 8 / 4 x 4 / 2 x 8 / 4 x 16 tiles x waves, chunks of 256 variants: all slower, profiles/r04_sample_major.txt)
       if (sg) {
@@ -1842,6 +1867,7 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
       if (has_q) { if (warm) BSN_PRODT(true, 1, grid, 0, 0, 0); else BSN_PRODT(true, 0, grid, 0, 0, 0); }
       else { if (warm) BSN_PRODT(false, 1, grid, 0, 0, 0); else BSN_PRODT(false, 0, grid, 0, 0, 0); }
 #undef BSN_PRODT
+#undef BSN_PRODT3
 #undef BSN_PRODT_
       BSN_HIP(hipGetLastError());
     } else if (NB > 2) {
