@@ -38,6 +38,7 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 I8_PEAK_TOPS = 5000.0      # MI355X_MICROARCH.md / SURVEY.md §8d: dense int8 MFMA peak (2x the 2.5 PFLOP/s bf16)
+FP4_PEAK_TOPS = 10000.0    # MI355X_MICROARCH.md: dense FP6 / FP4 MFMA peak (block-scaled f8f6f4 forms)
 
 
 def parse():
@@ -770,16 +771,20 @@ def ld_bench(a, ba, L, rank=0, world=1, dist=None, torch=None):
     # (src/corr.cpp:54-75 restated as six GEMMs over the samples; one when no value is missing)
     ops = st["products"] * 2.0 * n * st["tile_pairs"] * 64 * 64
     achieved = ops / (st["stats_ms"] * 1e-3) / 1e12
+    on_fp4 = "FP4" in st["kernel"]      # the six products on the FP4 matrix pipe (exact for these plane values): priced against ITS peak
+    peak = FP4_PEAK_TOPS if on_fp4 else I8_PEAK_TOPS
     return {"metric": "variant pairs/sec for bed_ld_scores, window %d variants" % W,
             "value": world * pairs / res["bed_ld_scores"], "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * res["bed_ld_scores"], "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "i8 planes, exact int32 MFMA accumulation, fp64 epilogue", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": ("fp4 (E2M1) planes holding the exact integers 0 / 1 / 2 / 4, fp32 MFMA accumulation (exact: sums < 2^24), fp64 epilogue"
+                      if on_fp4 else "i8 planes, exact int32 MFMA accumulation, fp64 epilogue"), "data": "synthetic",
             "config": {"workload": "bed_ld_scores / bed_cor on synthetic %dx%d 2-bit image, window %d variants (config C5)"
                                    % (n, m, W), "n": n, "m": m, "window": W,
                        "parallelism": "one chromosome per GPU, no collective" if world > 1 else "single GPU"},
             "pairs": pairs, "bed_cor_ms": 1e3 * res["bed_cor"],
-            "roofline": {"bound": "mfma", "kernel": st["kernel"], "achieved": achieved, "peak": I8_PEAK_TOPS,
-                         "unit": "TOP/s", "frac": achieved / I8_PEAK_TOPS, "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": st["kernel"], "achieved": achieved, "peak": peak,
+                         "unit": "TOP/s", "frac": achieved / peak, "frac_of_int8_peak": achieved / I8_PEAK_TOPS, "traffic": None,
                          "ops_all_launches": ops, "ms_all_launches": st["stats_ms"], "launches": st["launches"],
                          "tile_pairs": st["tile_pairs"], "products": st["products"],
                          "note": "achieved = useful int8 ops of the %d launches of one call / their summed HIP-event time"

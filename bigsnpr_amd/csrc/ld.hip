@@ -360,6 +360,147 @@ __global__ __launch_bounds__(256, 2) void k_pair_stats_b(const uint8_t *__restri
   }
 }
 
+// (Round 5) The same six products on the FP4 matrix pipe.  The plane values 0, 1, 2, 4 are exact in FP4 (E2M1: 0b0000,
+// 0b0010, 0b0100, 0b0110), gfx950's block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales (E8M0 127) contracts
+// 128 samples per instruction where v_mfma_i32_16x16x64_i8 contracts 64, at 1.85 x the rate (tools/ubench/fp4_mfma.hip:
+// same issue cycles, twice the K), and its fp32 accumulation of small integers is exact up to 2^24 (checked there with
+// sums of 1.1e7): the pair statistics, at most 4 n, are exact for n <= 4 194 303 samples.  Same workgroup shape as
+// k_pair_stats_b (128 x 32 variant pairs, the column operand decoded once per workgroup through LDS); an iteration of
+// 256 samples is TWO K-steps, wave w decodes (K-step w >> 1, column sub-tile w & 1).  A lane's 32 samples of a K-step
+// are two dwords of 2-bit codes -> four dwords of nibbles per plane: the codes at positions 4 k and 4 k + 1 (2 and 3) of
+// a dword share an output byte, low and high nibble, each through one byte look-up (v_perm) with the plane's table —
+// the order of the samples inside the lane differs from the file's, identically for both operands, and a contraction
+// does not see it.  Sums leave the registers as integers (exact conversion) through the same fp64 epilogue.
+// Measured at C5 (profiles/r05_ld.txt, one box): bed_ld_scores 251 ms against 292 ms on the int8 kernel (- 14 %),
+// bed_cor 297 against 339 ms; counters: 1.198e9 MFMA per launch of 4 096 blocks at 16.0 pipe cycles each, matrix pipe 42 %
+// busy at 2.36 GHz, 6.65 VALU per MFMA — the decode, not the matrix pipe, paces it now.  A square
+// 64 x 64 block per workgroup (each wave 16 row variants x all 64 column variants: 4.2 VALU per MFMA) was built and
+// measured: 265 ms — twice the LDS operand reads per wave and ten spilled registers cost more than the decode it saves.
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr uint32_t kF4X = 0x00040200u, kF4Xh = 0x00402000u;     // code 0, 1, 2, 3 -> 0, 1.0, 2.0, 0 (low / high nibble)
+constexpr uint32_t kF4M = 0x00020202u, kF4Mh = 0x00202020u;     //                 -> 1.0, 1.0, 1.0, 0
+struct PlanesF4 {
+  v4i x, x2, m;
+};
+constexpr uint32_t kF4X2 = 0x00060200u, kF4X2h = 0x00602000u;   //                 -> 0, 1.0, 4.0, 0
+__device__ __forceinline__ PlanesF4 decode_f4(uint32_t w0, uint32_t w1) {
+  const uint32_t a0 = w0 & 0x03030303u, a1 = (w0 >> 2) & 0x03030303u, a2 = (w0 >> 4) & 0x03030303u, a3 = (w0 >> 6) & 0x03030303u;
+  const uint32_t b0 = w1 & 0x03030303u, b1 = (w1 >> 2) & 0x03030303u, b2 = (w1 >> 4) & 0x03030303u, b3 = (w1 >> 6) & 0x03030303u;
+  PlanesF4 p;
+  p.x = v4i{(int)(lut4b(kF4X, a0) | lut4b(kF4Xh, a1)), (int)(lut4b(kF4X, a2) | lut4b(kF4Xh, a3)),
+            (int)(lut4b(kF4X, b0) | lut4b(kF4Xh, b1)), (int)(lut4b(kF4X, b2) | lut4b(kF4Xh, b3))};
+  // (x^2 from x — 1.0 stays, 2.0 = 0b0100 becomes 4.0 = 0b0110: x | ((x >> 1) & 0x2222...), two instructions instead of
+  // three — keeps x alive longer: ten spilled registers at three waves per SIMD, 305 instead of 251 ms.  Measured, not kept.)
+  p.x2 = v4i{(int)(lut4b(kF4X2, a0) | lut4b(kF4X2h, a1)), (int)(lut4b(kF4X2, a2) | lut4b(kF4X2h, a3)),
+             (int)(lut4b(kF4X2, b0) | lut4b(kF4X2h, b1)), (int)(lut4b(kF4X2, b2) | lut4b(kF4X2h, b3))};
+  p.m = v4i{(int)(lut4b(kF4M, a0) | lut4b(kF4Mh, a1)), (int)(lut4b(kF4M, a2) | lut4b(kF4Mh, a3)),
+            (int)(lut4b(kF4M, b0) | lut4b(kF4Mh, b1)), (int)(lut4b(kF4M, b2) | lut4b(kF4Mh, b3))};
+  return p;
+}
+__device__ __forceinline__ v4f mfma_f4(const v4i &a, const v4i &b, const v4f &c) {
+  const v8i a8 = {a.x, a.y, a.z, a.w, 0, 0, 0, 0}, b8 = {b.x, b.y, b.z, b.w, 0, 0, 0, 0};
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, c, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+__global__ __launch_bounds__(256, 3) void k_pair_stats_f4(const uint8_t *__restrict__ img, int64_t pitch,
+                                                       const int32_t *__restrict__ cols,
+                                                       const int2 *__restrict__ pairs,
+                                                       const uint32_t *__restrict__ rowmask, BandOut bo) {
+  __shared__ uint4 sB[2][2][2][3][64];   // [buffer][K-step][sub-tile][plane x, x2, m][lane]: 24 KB
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int2 pr = pairs[blockIdx.x];
+  const int64_t ca0 = cols[pr.x * TR], cb0 = cols[pr.y * TC];
+  const int my_ks = __builtin_amdgcn_readfirstlane(wave >> 1), my_s = __builtin_amdgcn_readfirstlane(wave & 1);
+  uint32_t va[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) va[s] = (uint32_t)(((int64_t)cols[pr.x * TR + wave * 32 + s * 16 + r16] - ca0) * pitch + g * 16);
+  const uint32_t vb = (uint32_t)(((int64_t)cols[pr.y * TC + my_s * 16 + r16] - cb0) * pitch + g * 16);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(img + ca0 * pitch), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)(img + cb0 * pitch), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void *)rowmask, 0, 0x7fffffff, 0x00020000);
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+  v4f acc[2][2][6];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int p = 0; p < 6; p++) acc[i][j][p] = v4f{0.f, 0.f, 0.f, 0.f};
+  const int nit = (int)(pitch / 64);
+  auto stash = [&](int buf, const v2u &b, const v4u &mk) {   // this wave's (K-step, sub-tile) of the column operand -> LDS
+    const uint32_t m0 = my_ks == 0 ? mk.x : mk.z, m1 = my_ks == 0 ? mk.y : mk.w;
+    const PlanesF4 P = decode_f4(b.x | ~m0, b.y | ~m1);
+    sB[buf][my_ks][my_s][0][lane] = uint4{(uint32_t)P.x[0], (uint32_t)P.x[1], (uint32_t)P.x[2], (uint32_t)P.x[3]};
+    sB[buf][my_ks][my_s][1][lane] = uint4{(uint32_t)P.x2[0], (uint32_t)P.x2[1], (uint32_t)P.x2[2], (uint32_t)P.x2[3]};
+    sB[buf][my_ks][my_s][2][lane] = uint4{(uint32_t)P.m[0], (uint32_t)P.m[1], (uint32_t)P.m[2], (uint32_t)P.m[3]};
+  };
+  v4u a[2], mk, an[2], mkn;
+  v2u b, bn;
+  const int wsel = my_ks * 8;
+#pragma unroll
+  for (int s = 0; s < 2; s++) a[s] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)va[s], 0, 0);
+  b = __builtin_amdgcn_raw_buffer_load_b64(rsB, (int)vb, wsel, 0);
+  mk = __builtin_amdgcn_raw_buffer_load_b128(rsM, g * 16, 0, 0);
+  stash(0, b, mk);
+  __syncthreads();
+  for (int it = 0; it < nit; it++) {
+    const int kbn = (it + 1 < nit ? it + 1 : it) * 64;   // (past the end the last one again: no branch around loads)
+#pragma unroll
+    for (int s = 0; s < 2; s++) an[s] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)va[s], kbn, 0);
+    bn = __builtin_amdgcn_raw_buffer_load_b64(rsB, (int)vb, kbn + wsel, 0);
+    mkn = __builtin_amdgcn_raw_buffer_load_b128(rsM, g * 16, kbn, 0);
+    const int buf = it & 1;
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+      const uint32_t m0 = d == 0 ? mk.x : mk.z, m1 = d == 0 ? mk.y : mk.w;
+      PlanesF4 A[2];
+#pragma unroll
+      for (int s = 0; s < 2; s++) A[s] = decode_f4((d == 0 ? a[s].x : a[s].z) | ~m0, (d == 0 ? a[s].y : a[s].w) | ~m1);
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const uint4 bx = sB[buf][d][j][0][lane], bx2 = sB[buf][d][j][1][lane], bm = sB[buf][d][j][2][lane];
+        const v4i Bx = {(int)bx.x, (int)bx.y, (int)bx.z, (int)bx.w}, Bx2 = {(int)bx2.x, (int)bx2.y, (int)bx2.z, (int)bx2.w},
+                  Bm = {(int)bm.x, (int)bm.y, (int)bm.z, (int)bm.w};
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          acc[i][j][0] = mfma_f4(A[i].x, Bx, acc[i][j][0]);
+          acc[i][j][1] = mfma_f4(A[i].x, Bm, acc[i][j][1]);
+          acc[i][j][2] = mfma_f4(A[i].x2, Bm, acc[i][j][2]);
+          acc[i][j][3] = mfma_f4(A[i].m, Bx, acc[i][j][3]);
+          acc[i][j][4] = mfma_f4(A[i].m, Bx2, acc[i][j][4]);
+          acc[i][j][5] = mfma_f4(A[i].m, Bm, acc[i][j][5]);
+        }
+      }
+    }
+    stash(buf ^ 1, bn, mkn);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; s++) a[s] = an[s];
+    mk = mkn;
+  }
+  int32_t st[16][6];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int p = 0; p < 6; p++) st[(i * 2 + j) * 4 + r][p] = (int32_t)acc[i][j][p][r];
+#pragma unroll 1
+  for (int e = 0; e < 16; e++) {
+    const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
+    const int row = wave * 32 + i * 16 + 4 * g + r, col = j * 16 + r16;
+    const int64_t j0 = (int64_t)pr.x * TR + row, jj = (int64_t)pr.y * TC + col;
+    if (j0 >= bo.m || jj >= j0 || jj < bo.lo[j0]) continue;
+    bo.band[j0 * bo.W + (j0 - jj - 1)] =
+        pair_value(bo.mode, (double)st[e][0], (double)st[e][1], (double)st[e][2], (double)st[e][3], (double)st[e][4],
+                   st[e][5], bo.thr, bo.v1, bo.v2, j0, jj, bo.nrows);
+  }
+}
+
 // Cross product only (variants without missing values, FBM clumping): one wave owns the whole
 // 64 x 64 tile pair for its share of the samples (4 x 4 MFMA sub-tiles, so each decoded operand
 // feeds four MFMAs instead of two) and adds its int32 partial with atomics (K is split over
@@ -1101,8 +1242,16 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
     for (int64_t p0 = qA; p0 < qB; p0 += batch) {
       const int64_t np = std::min(batch, qB - p0);
       BSN_HIP(hipEventRecord(e0, bed->stream));
-      hipLaunchKernelGGL(k_pair_stats_b, dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
-                         J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, bo);
+      // the FP4 matrix pipe while the sums stay exact in fp32 (at most 4 n < 2^24); BSN_LD_I8=1: the int8 kernel
+      static const bool i8_only = getenv("BSN_LD_I8") != nullptr;
+      const bool f4 = bed->pitch * 4 <= 4194303 && !i8_only;
+      ls.kernel = f4 ? 6 : 4;
+      if (f4)
+        hipLaunchKernelGGL(k_pair_stats_f4, dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
+                           J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, bo);
+      else
+        hipLaunchKernelGGL(k_pair_stats_b, dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
+                           J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, bo);
       BSN_HIP(hipGetLastError());
       BSN_HIP(hipEventRecord(e1, bed->stream));
       BSN_HIP(hipEventSynchronize(e1));
@@ -1111,7 +1260,6 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
       ms_total += ms;
       ls.launches += 1;
     }
-    ls.kernel = 4;
     ls.tile_pairs += (double)(qB - qA) - (double)(pB - pA);   // blocks of 128 x 32 = the area of a 64 x 64 tile pair
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

@@ -384,6 +384,9 @@ def last_stats():
     names = ("k_pair_stats<6 products, fused fp64 epilogue>", "k_pair_stats<6 products, K split> + k_band_fill",
              "k_pair_xy64 (cross product only: no missing values) + k_band_fill",
              "k_pair_stats8 (dosage bytes with missing values: 8 products) + k_band_fill8na",
-             "k_pair_stats_b<6 products, column operand decoded once per workgroup through LDS, fused fp64 epilogue>")
+             "k_pair_stats_b<6 products, column operand decoded once per workgroup through LDS, fused fp64 epilogue>",
+             "(unused)",
+             "k_pair_stats_f4<6 products on the FP4 matrix pipe (v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales, exact), "
+             "column operand decoded once per workgroup through LDS, fused fp64 epilogue>")
     return dict(pairs=out[0], tile_pairs=out[1], stats_ms=out[2], launches=int(out[3]), kernel=names[int(out[4])],
                 products={2: 1, 3: 8}.get(int(out[4]), 6))
