@@ -204,16 +204,18 @@ __global__ void k_tcross_reduce(const double *__restrict__ part, int64_t nn, int
 
 using namespace bsn;
 
-extern "C" int bsn_bed_tcrossprod(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
-                                  int64_t m, const double *center, const double *scale, int64_t block_size,
-                                  double *K) {
-  return guarded([&] {
-    (void)block_size;  // the reference's RAM block size: nothing is materialised here
-    require_bits(bed, 2, "bed_tcrossprodSelf");
-    if ((double)n * (double)n * 8.0 > 64e9) fail("n x n result does not fit: use bed_randomSVD");
+__global__ void k_add_into(double *__restrict__ dst, const double *__restrict__ src, int64_t count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) dst[i] += src[i];
+}
+
+// K (n x n, device) = A~ A~' over the selected variants of a RESIDENT image
+static void tcross_resident(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                            const double *center, const double *scale, DevBuf<double> &d_K) {
+  {
     bsn_op op;
     fill_op(&op, bed, ind_row, n, ind_col, m, center, scale);
-    DevBuf<double> d_T, d_K, d_part;
+    DevBuf<double> d_T, d_part;
     d_T.ensure((size_t)4 * m);
     hipLaunchKernelGGL(k_scaled_table, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, bed->stream, op.d_center.p,
                        op.d_scale.p, m, d_T.p);
@@ -258,6 +260,56 @@ extern "C" int bsn_bed_tcrossprod(bsn_bed *bed, const int64_t *ind_row, int64_t 
                          n * n, (int)nslab, d_K.p);
       BSN_HIP(hipGetLastError());
     }
-    copy_d2h(bed, K, d_K.p, (size_t)n * n * 8);
+    BSN_HIP(hipStreamSynchronize(bed->stream));   // (the operator and the work buffers are released on return)
+  }
+}
+
+extern "C" int bsn_bed_tcrossprod(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col,
+                                  int64_t m, const double *center, const double *scale, int64_t block_size,
+                                  double *K) {
+  return guarded([&] {
+    (void)block_size;  // the reference's RAM block size: nothing is materialised here
+    require_bits(bed, 2, "bed_tcrossprodSelf");
+    if ((double)n * (double)n * 8.0 > 64e9) fail("n x n result does not fit: use bed_randomSVD");
+    if (n <= 0 || m <= 0) fail("'ind.row' and 'ind.col' can't be empty.");
+    DevBuf<double> d_K;
+    if (!bed->streamed()) {
+      tcross_resident(bed, ind_row, n, ind_col, m, center, scale, d_K);
+      copy_d2h(bed, K, d_K.p, (size_t)n * n * 8);
+      return;
+    }
+    // (round 5) out-of-core handle: K is a sum over the variants — the file is walked in slabs, every slab adds the
+    // K of its selected variants on the device (R/bed-tcrossprodSelf.R:40-49 walks blocks of columns just so)
+    BSN_HIP(hipSetDevice(bed->device));
+    const int64_t nslab = slab_count(bed);
+    std::vector<std::vector<int64_t>> pos((size_t)nslab);
+    for (int64_t t = 0; t < m; t++) {
+      const int64_t c = ind_col ? ind_col[t] : t;
+      if (c < 0 || c >= bed->m) fail("Tested %lld < %lld. Subscript out of bounds (ind.col).", (long long)c, (long long)bed->m);
+      pos[(size_t)(c / bed->slab_cols)].push_back(t);
+    }
+    DevBuf<double> d_sum;
+    d_sum.ensure((size_t)n * n);
+    BSN_HIP(hipMemsetAsync(d_sum.p, 0, (size_t)n * n * 8, bed->stream));
+    std::vector<int64_t> loc;
+    std::vector<double> ce, sc;
+    for (int64_t sl = 0; sl < nslab; sl++) {
+      const std::vector<int64_t> &P = pos[(size_t)sl];
+      if (P.empty()) continue;
+      int64_t j0 = 0;
+      slab_upload(bed, sl, &j0);
+      loc.resize(P.size());
+      ce.resize(P.size());
+      sc.resize(P.size());
+      for (size_t t = 0; t < P.size(); t++) {
+        loc[t] = (ind_col ? ind_col[P[t]] : P[t]) - j0;
+        ce[t] = center ? center[P[t]] : 0.0;
+        sc[t] = scale ? scale[P[t]] : 1.0;
+      }
+      tcross_resident(slab_image(bed), ind_row, n, loc.data(), (int64_t)loc.size(), ce.data(), sc.data(), d_K);
+      hipLaunchKernelGGL(k_add_into, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, bed->stream, d_sum.p, d_K.p, n * n);
+      BSN_HIP(hipGetLastError());
+    }
+    copy_d2h(bed, K, d_sum.p, (size_t)n * n * 8);
   });
 }

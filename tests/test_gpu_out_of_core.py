@@ -87,7 +87,11 @@ def test_streamed_handle_equals_resident(ba, orc, golden_dir, monkeypatch, name)
                                           ba.bed_ld_scores(res, ind_col=ic, size=size_kb, infos_pos=pv))
     with pytest.raises(ba.BsnError, match="more than the"):
         ba.bed_ld_scores(ooc, size=100, infos_pos=posv)            # a window of 201 variants does not fit 64
+    # (round 5) bed_tcrossprodSelf: K is a sum over the variants — every slab adds its part on the device
+    if svd_cases:
+        (K1, a1), (K0, a0) = ba.bed_tcrossprodSelf(ooc), ba.bed_tcrossprodSelf(res)
+        assert np.abs(K1 - K0).max() <= 1e-11 * np.abs(K0).max()
+        np.testing.assert_array_equal(a1["center"], a0["center"])
     # what still needs a resident image says so
-    for call in (lambda: ba.bed_cor(ooc, size=10), lambda: ba.bed_tcrossprodSelf(ooc)):
-        with pytest.raises(ba.BsnError, match="streams its file"):
-            call()
+    with pytest.raises(ba.BsnError, match="streams its file"):
+        ba.bed_cor(ooc, size=10)
