@@ -18,6 +18,7 @@
 
 #include <cstdlib>
 
+#include <cstring>
 #include "bsn_internal.hpp"
 
 namespace bsn {
@@ -1369,7 +1370,89 @@ struct bsn_cor {
   std::vector<std::unique_ptr<Piece>> pieces;
   int64_t nnz = 0;
   int has_nan = 0;   // an NaN among the stored correlations (a variant without variation, R/corr.R:53-54)
+  // (round 5) the result of an out-of-core handle: assembled on the host from the runs of target variants
+  bool on_host = false;
+  std::vector<int32_t> h_i;
+  std::vector<double> h_x;
 };
+
+static void cormat_resident(bsn_bed *bed_in, const int64_t *ind_row_in, int64_t n, const int64_t *ind_col_in, int64_t m,
+                            double size, const double *thr, const double *pos, int fill_diag, int32_t *p_out,
+                            int64_t *nnz_out, bsn_cor **out);
+
+// (round 5) snp_cor / bed_cor on an OUT-OF-CORE handle: corMat pairs every variant with the EARLIER variants of its
+// window (src/corr.cpp:52-53), so a run of target variants needs a halo to the left only.  Each run is uploaded with
+// that halo into the resident slab image and goes through the resident code path; the columns of its targets — row
+// indices shifted back to the caller's numbering — are appended to a result kept on the host.  Same pairs, same
+// epilogue: @p, @i, @x identical to the resident handle's.
+static void cormat_streamed(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                            double size, const double *thr, const double *pos, int fill_diag, int32_t *p_out,
+                            int64_t *nnz_out, bsn_cor **out) {
+  if (m <= 0 || n <= 0) fail("'ind.row' and 'ind.col' can't be empty.");
+  auto col = [&](int64_t t) -> int64_t { return ind_col ? ind_col[t] : t; };
+  for (int64_t t = 0; t < m; t++) {
+    if (col(t) < 0 || col(t) >= bed->m) fail("Tested %lld < %lld. Subscript out of bounds (ind.col).", (long long)col(t), (long long)bed->m);
+    if (t > 0 && col(t) <= col(t - 1))
+      fail("snp_cor on an out-of-core handle (it streams its file) needs 'ind.col' in increasing file order");
+    if (t > 0 && pos[t] < pos[t - 1]) fail("'pos' is not sorted.");
+  }
+  const int64_t cap = bed->slab_cols;
+  bsn_bed *img = slab_image(bed);
+  std::unique_ptr<bsn_cor> C(new bsn_cor());
+  C->on_host = true;
+  std::vector<int64_t> loc;
+  std::vector<int32_t> p_loc, i_loc;
+  std::vector<double> x_loc;
+  p_out[0] = 0;
+  int64_t a = 0, nnz = 0;
+  while (a < m) {
+    int64_t lo = a;
+    while (lo > 0 && pos[lo - 1] >= pos[a] - size) lo--;
+    int64_t b = a;
+    while (b < m && col(b) - col(lo) + 1 <= cap) b++;   // the longest run of targets behind that halo that fits
+    if (b == a)
+      fail("LD window before variant %lld spans %lld variants of the file: more than the %lld of the out-of-core slab "
+           "image; raise BSN_IMAGE_BUDGET or use a smaller window",
+           (long long)col(a), (long long)(col(a) - col(lo) + 1), (long long)cap);
+    const int64_t base = col(lo), ml = b - lo;
+    slab_upload_range(bed, base, col(b - 1) - base + 1);
+    loc.resize((size_t)ml);
+    for (int64_t t = 0; t < ml; t++) loc[(size_t)t] = col(lo + t) - base;
+    p_loc.resize((size_t)ml + 1);
+    int64_t nz_loc = 0;
+    bsn_cor *piece = nullptr;
+    cormat_resident(img, ind_row, n, loc.data(), ml, size, thr, pos + lo, fill_diag, p_loc.data(), &nz_loc, &piece);
+    std::unique_ptr<bsn_cor> hold(piece);
+    i_loc.resize((size_t)std::max<int64_t>(nz_loc, 1));
+    x_loc.resize((size_t)std::max<int64_t>(nz_loc, 1));
+    {
+      int64_t at = 0;
+      for (const auto &P : piece->pieces) {
+        if (P->nnz > 0) {
+          copy_d2h(img, i_loc.data() + at, P->d_i.p, (size_t)P->nnz * 4);
+          copy_d2h(img, x_loc.data() + at, P->d_x.p, (size_t)P->nnz * 8);
+        }
+        at += P->nnz;
+      }
+      BSN_HIP(hipStreamSynchronize(img->stream));
+    }
+    for (int64_t t = a; t < b; t++) {           // the targets' columns, rows in the caller's numbering
+      const int64_t c0 = p_loc[(size_t)(t - lo)], c1 = p_loc[(size_t)(t - lo + 1)];
+      for (int64_t e = c0; e < c1; e++) {
+        C->h_i.push_back((int32_t)(i_loc[(size_t)e] + lo));
+        C->h_x.push_back(x_loc[(size_t)e]);
+        if (x_loc[(size_t)e] != x_loc[(size_t)e]) C->has_nan = 1;
+      }
+      nnz += c1 - c0;
+      if (nnz > 0x7fffffffLL) fail("more than 2^31 - 1 non-zero correlations");
+      p_out[t + 1] = (int32_t)nnz;
+    }
+    a = b;
+  }
+  C->nnz = nnz;
+  *nnz_out = nnz;
+  *out = C.release();
+}
 
 extern "C" {
 
@@ -1377,6 +1460,21 @@ int bsn_cormat(bsn_bed *bed_in, const int64_t *ind_row_in, int64_t n, const int6
                double size, const double *thr, const double *pos, int fill_diag, int32_t *p_out,
                int64_t *nnz_out, bsn_cor **out) {
   return guarded([&] {
+    if (bed_in->streamed()) {
+      BSN_HIP(hipSetDevice(bed_in->device));
+      cormat_streamed(bed_in, ind_row_in, n, ind_col_in, m, size, thr, pos, fill_diag, p_out, nnz_out, out);
+      return;
+    }
+    cormat_resident(bed_in, ind_row_in, n, ind_col_in, m, size, thr, pos, fill_diag, p_out, nnz_out, out);
+  });
+}
+
+}  // extern "C"
+
+static void cormat_resident(bsn_bed *bed_in, const int64_t *ind_row_in, int64_t n, const int64_t *ind_col_in, int64_t m,
+                            double size, const double *thr, const double *pos, int fill_diag, int32_t *p_out,
+                            int64_t *nnz_out, bsn_cor **out) {
+  {
     std::unique_ptr<bsn_cor> C(new bsn_cor());
     BandJob &J = C->job;
     const RowView rv = row_view(bed_in, ind_row_in, n, ind_col_in, m);
@@ -1432,8 +1530,10 @@ int bsn_cormat(bsn_bed *bed_in, const int64_t *ind_row_in, int64_t n, const int6
     J.d_stats.release();
     *nnz_out = nnz;
     *out = C.release();
-  });
+  }
 }
+
+extern "C" {
 
 int bsn_ld_last_stats(double *out) {
   return guarded([&] {
@@ -1447,6 +1547,13 @@ int bsn_ld_last_stats(double *out) {
 
 int bsn_cormat_fetch(bsn_cor *c, int32_t *i_out, double *x_out) {
   return guarded([&] {
+    if (c->on_host) {
+      if (c->nnz > 0) {
+        std::memcpy(i_out, c->h_i.data(), (size_t)c->nnz * 4);
+        std::memcpy(x_out, c->h_x.data(), (size_t)c->nnz * 8);
+      }
+      return;
+    }
     BSN_HIP(hipSetDevice(c->job.bed->device));
     int64_t at = 0;
     for (const auto &P : c->pieces) {

@@ -87,11 +87,20 @@ def test_streamed_handle_equals_resident(ba, orc, golden_dir, monkeypatch, name)
                                           ba.bed_ld_scores(res, ind_col=ic, size=size_kb, infos_pos=pv))
     with pytest.raises(ba.BsnError, match="more than the"):
         ba.bed_ld_scores(ooc, size=100, infos_pos=posv)            # a window of 201 variants does not fit 64
+    # ... and bed_cor: runs of targets with their LEFT halo (corMat pairs a variant with the earlier ones of its window);
+    # the result is assembled on the host: @p, @i, @x identical, also with thresholds and for an increasing subset
+    for ic in (None, np.sort(rng.choice(m, m // 2, replace=False))):
+        pv = posv if ic is None else posv[ic]
+        for kw in (dict(size=7), dict(size=20, alpha=0.2), dict(size=12, thr_r2=0.05, fill_diag=False)):
+            c1, c0 = ba.bed_cor(ooc, ind_col=ic, infos_pos=pv, **kw), ba.bed_cor(res, ind_col=ic, infos_pos=pv, **kw)
+            np.testing.assert_array_equal(c1.p, c0.p)
+            np.testing.assert_array_equal(c1.i, c0.i)
+            np.testing.assert_array_equal(c1.x, c0.x)
     # (round 5) bed_tcrossprodSelf: K is a sum over the variants — every slab adds its part on the device
     if svd_cases:
         (K1, a1), (K0, a0) = ba.bed_tcrossprodSelf(ooc), ba.bed_tcrossprodSelf(res)
         assert np.abs(K1 - K0).max() <= 1e-11 * np.abs(K0).max()
         np.testing.assert_array_equal(a1["center"], a0["center"])
-    # what still needs a resident image says so
+    # what still needs a resident image says so (the rank-ordered sweep of clumping sees the whole chromosome)
     with pytest.raises(ba.BsnError, match="streams its file"):
-        ba.bed_cor(ooc, size=10)
+        ba.bed_clumping(ooc, thr_r2=0.2, size=10, infos_pos=posv, infos_chr=np.ones(m, dtype=int))
