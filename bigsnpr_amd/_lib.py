@@ -45,7 +45,7 @@ class SvdInfo(C.Structure):
                 ("wide_prod_ms", C.c_double), ("n_wide_cprod", C.c_int32), ("n_wide_prod", C.c_int32),
                 ("lead_rel_resid", C.c_double), ("exchange_mode", C.c_int32), ("n_exchange", C.c_int32 * 4),
                 ("exchange_ms", C.c_double * 4), ("compacted", C.c_int32), ("compact_ms", C.c_double),
-                ("out_of_core", C.c_int32)]
+                ("out_of_core", C.c_int32), ("na_free_steps", C.c_double * 2), ("na_skip", C.c_int32)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check that every symbol

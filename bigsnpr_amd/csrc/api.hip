@@ -385,6 +385,8 @@ void bed_free(bsn_bed *b) {
   if (b->d_tiled) (void)hipFree(b->d_tiled);
   if (b->d_smaj) (void)hipFree(b->d_smaj);
   if (b->d_lut) (void)hipFree(b->d_lut);
+  if (b->h_na_blocks) (void)hipHostFree(b->h_na_blocks);
+  if (b->d_na_blocks) (void)hipFree(b->d_na_blocks);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->ev_up) (void)hipEventDestroy(b->ev_up);

@@ -143,6 +143,9 @@ struct bsn_op {
   bool rows_identity = true;   // ind_row == 0..n_file-1
   bool cols_contig = true;     // ind_col == col0 .. col0+m-1
   bool no_na = false;          // every selected variant is known to have no missing genotype
+  // the kernels that issue the missing-value plane only for K-steps with a missing code (k_cprod / k_prodT NASKIP),
+  // set from the handle's measured share of K-steps without one (op_na_blocks, matvec.hip)
+  bool na_skip_c = false, na_skip_p = false;
   // centre / scale are not set yet: the next crossproduct pass counts the codes of every selected
   // variant on the side and derives the binomial scaling from them (bsn_bed_randomsvd)
   bool stats_pending = false;
@@ -263,6 +266,14 @@ struct bsn_bed {
   // by-product of every full-row count (and at creation for FBM / NA-free synthetic images).
   // An operator whose variants are all known to be complete skips the missing-value plane.
   std::vector<int32_t> na_cnt;
+  // Share of the K-steps of the two streaming products that carry NO missing code (round 5, matvec.hip op_na_blocks):
+  // sampled once per image by a small kernel queued on the handle's stream, picked up from pinned memory by a later
+  // launch (no synchronisation).  state 0 = not measured, 1 = queued, 2 = known.  [0] crossproduct (16 variants x
+  // 64 samples per step), [1] product on the sample-major copy (16 samples x 64 variants).
+  int na_blocks_state = 0;
+  long long *h_na_blocks = nullptr;   // pinned: free / sampled steps of the two shapes, then the arrival flag
+  long long *d_na_blocks = nullptr;
+  double na_free[2] = {0.0, 0.0};
   // Workspace of bsn_bed_randomsvd, kept between solves on this handle (basis, panels, quantised
   // operands: ~4 GB at 400K x 1M) instead of being allocated and freed by every solve; released by
   // bsn_bed_release_workspace or with the handle.
@@ -372,6 +383,7 @@ void comm_all_gather(bsn_comm *c, const double *d_send, double *d_recv, int64_t 
 
 // matvec.hip
 void op_poll_stats(bsn_op *op);  // after a stream synchronisation: pick up the missing-value total
+void op_na_blocks(bsn_op *op);   // queue / pick up the handle's share of K-steps without a missing code; sets op->na_skip_*
 void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy);
 // Y = beta Y + A~ X (the slabs of an out-of-core solve add up their products on the device)
 void op_prod_acc(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy, double beta);

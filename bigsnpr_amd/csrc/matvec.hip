@@ -236,11 +236,23 @@ __global__ __launch_bounds__(64) void k_quant(const double *__restrict__ X, int6
       shi2 += B >> 24; slo2 += B & 0xFFFFFF;
       // scaled product: the genotype plane is the raw code (3 for a missing value), so the
       // missing-value plane carries c w - 3 w, in exact integers: 3 A + (B - 3 A) - B == 0
-      if (raw3) B -= 3 * A;
+      if (raw3 & 1) B -= 3 * A;
       const int pos = PERM ? ((e & 3) * 4 + (e >> 2)) : e;
+#ifdef BSN_ABLATION
+      // BSN_DIGITS=2 (timing only: the finalize kernels read balanced base-256 digits): sign x 7-bit magnitude chunks
+      const bool sm = (raw3 >> 8) == 2;
+      const long long sgA = A < 0 ? -1 : 1, sgB = B < 0 ? -1 : 1;
+      long long mA = A < 0 ? -A : A, mB = B < 0 ? -B : B;
+#endif
 #pragma unroll
       for (int s = 0; s < S; s++) {
+#ifdef BSN_ABLATION
+        const int8_t da = sm ? (int8_t)(sgA * (mA & 0x7F)) : (int8_t)(A & 0xFF), db = sm ? (int8_t)(sgB * (mB & 0x7F)) : (int8_t)(B & 0xFF);
+        mA >>= 7;
+        mB >>= 7;
+#else
         const int8_t da = (int8_t)(A & 0xFF), db = (int8_t)(B & 0xFF);
+#endif
         A = (A - da) >> 8;
         B = (B - db) >> 8;
         pk[0][s][pos >> 2] |= (uint32_t)(uint8_t)da << (8 * (pos & 3));
@@ -250,7 +262,14 @@ __global__ __launch_bounds__(64) void k_quant(const double *__restrict__ X, int6
     for (int p = 0; p < nplanes; p++)
 #pragma unroll
       for (int s = 0; s < S; s++) {
-        int8_t *dst = q + ((kb * nplanes + p) * ncol + (v * S + s)) * 16;
+#ifdef BSN_ABLATION
+        // BSN_DIGITS=1 (timing only): slice-major columns — digit s of all vectors side by side, so that with 16 vectors
+        // of three digits every column block holds ONE digit position
+        const int col = (raw3 >> 8) == 1 ? s * (int)gridDim.y + v : v * S + s;
+#else
+        const int col = v * S + s;
+#endif
+        int8_t *dst = q + ((kb * nplanes + p) * ncol + col) * 16;
         *(uint4 *)dst = p == 0 ? uint4{pk[0][s][0], pk[0][s][1], pk[0][s][2], pk[0][s][3]}
                                : uint4{pk[1][s][0], pk[1][s][1], pk[1][s][2], pk[1][s][3]};
       }
@@ -288,8 +307,14 @@ __global__ __launch_bounds__(64) void k_quant(const double *__restrict__ X, int6
 // <..., TAG = 1> so that a kernel trace does not average them into the full passes.
 // TILED (with CONTIG, col0 a multiple of 64): `img` is the streaming-layout copy (bsn_internal.hpp): variant
 // a, byte o of its row at ((a >> 6) * (pitch >> 8) + (o >> 8)) * 16384 + (a & 63) * 256 + (o & 255).
+// NASKIP (round 5; RAW0 with two planes): the missing-value plane of a K-step — half its MFMAs and four of its
+// decode instructions — is only issued when one of the 64 samples x 16 variants of the step carries a missing code:
+// a wave-uniform branch on the ballot of (w & w >> 1 & 0x5555...).  The sums are the same integers (the plane of a
+// step without a missing code is zero).  Chosen by the host from the measured share of such steps (op_na_blocks):
+// at 1 % scattered missing values no step is free and the branch only costs; on nearly complete or batch-structured
+// data most are.
 template <int NB, int NPLANE, int KC, bool RAW0, bool STATS, bool CONTIG, int ABL = 0, int TILES = 2,
-          int WAVES = 8, int MINW = 1, int TAG = 0, bool TILED = false, int SGB = 0>
+          int WAVES = 8, int MINW = 1, int TAG = 0, bool TILED = false, int SGB = 0, bool NASKIP = false>
 __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__restrict__ img, int64_t pitch,
                                                const int32_t *__restrict__ cols, int64_t col0,
                                                int64_t m, const int8_t *__restrict__ xq,
@@ -406,8 +431,12 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_cprod(const uint8_t *__res
         st_hi[t] += __popc(w);              // all bits set (low + high)
         st_na[t] += __popc(lo & (w >> 1));  // both bits of a genotype
       }
+      static_assert(!NASKIP || (RAW0 && NPLANE == 2 && !STATS), "the skip is for the missing-value plane of the plain pass");
+      bool plane1 = true;
+      if constexpr (NASKIP) plane1 = __builtin_amdgcn_ballot_w64(((w & (w >> 1)) & 0x55555555u) != 0u) != 0ull;
 #pragma unroll
       for (int p = 0; p < NPLANE; p++) {
+        if (NASKIP && p == 1 && !plane1) continue;
         const uint32_t lut = p == 0 ? lutA : p == 1 ? lutB : lutC;
         v4i a;
         if (ABL & 2) {  // ablation: no decode, raw bits as operand
@@ -806,7 +835,8 @@ __global__ __launch_bounds__(256) void k_prod(const uint8_t *__restrict__ img, i
 // The variants are split into gridDim.y slabs of `cps` chunks (int32 partial sums per slab, added by k_prod_final in
 // exact int64 like k_prod's): 782 workgroups of 512 samples alone would fill 3.05 rounds of 256 CUs.
 // The copy is CHUNK-MAJOR (bsn_bed::d_smaj): byte of the operator's first variant in a sample row (col0 / 4, a multiple of 16).
-template <int NB, bool HASQ, int TILES = 2, int WAVES = 16, int TAG = 0, int SGB = 3>
+// NASKIP: as in k_cprod — the missing-value plane of a K-step (16 samples x 64 variants) only when it has a missing code.
+template <int NB, bool HASQ, int TILES = 2, int WAVES = 16, int TAG = 0, int SGB = 3, bool NASKIP = false>
 __global__ __launch_bounds__(64 * WAVES) void k_prodT(const uint8_t *__restrict__ simg, int64_t rows_t, int64_t chunk0,
                                                       int nchunks, int cps,
                                                       const int8_t *__restrict__ wq, int32_t *__restrict__ acc_out,
@@ -920,11 +950,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_prodT(const uint8_t *__restrict_
             acc[t][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b, acc[t][nb], 0, 0, 0);
           }
           if constexpr (HASQ) {
-            const v4i a1 = {(int)lut4(lutQ, s0), (int)lut4(lutQ, s1), (int)lut4(lutQ, s2), (int)lut4(lutQ, s3)};
+            static_assert(!NASKIP || HASQ, "the skip is for the missing-value plane");
+            bool plane1 = true;
+            if constexpr (NASKIP) plane1 = __builtin_amdgcn_ballot_w64(((w & (w >> 1)) & 0x55555555u) != 0u) != 0ull;
+            if (plane1) {
+              const v4i a1 = {(int)lut4(lutQ, s0), (int)lut4(lutQ, s1), (int)lut4(lutQ, s2), (int)lut4(lutQ, s3)};
 #pragma unroll
-            for (int nb = 0; nb < NB; nb++) {
-              const v4i b = {(int)bv[1][nb].x, (int)bv[1][nb].y, (int)bv[1][nb].z, (int)bv[1][nb].w};
-              acc[t][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b, acc[t][nb], 0, 0, 0);
+              for (int nb = 0; nb < NB; nb++) {
+                const v4i b = {(int)bv[1][nb].x, (int)bv[1][nb].y, (int)bv[1][nb].z, (int)bv[1][nb].w};
+                acc[t][nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b, acc[t][nb], 0, 0, 0);
+              }
             }
           }
         }
@@ -1303,7 +1338,13 @@ static void quantise(bsn_op *op, const double *d_X, int64_t ldx, int64_t len, in
   hipStream_t st = op->bed->stream;
   const bool bytes = op->bed->bits == 8;
   const double vstep = bytes ? op->bed->v_step : 1.0, voff = bytes ? op->bed->v_off : 0.0;
-  const int raw3 = (!bytes && mode == 1) ? 1 : 0;
+  int raw3 = (!bytes && mode == 1) ? 1 : 0;
+#ifdef BSN_ABLATION
+  // energy experiments of round 5 (profiles/r05_power.txt): BSN_DIGITS=1 slice-major digit columns, =2 sign x 7-bit
+  // magnitude digits.  The streaming kernels run on these operands at their real cost; the RESULTS are wrong (the
+  // finalize kernels read vector-major balanced digits), so this exists in the profiling build only.
+  if (const char *dg = getenv("BSN_DIGITS")) raw3 |= atoi(dg) << 8;
+#endif
   if (bytes) permute = 0;  // the byte image holds the samples of a 16-block in natural order
   // meta: kMetaVecs records, then the slice maxima of k_absmax (kMetaVecs x 256 x 2 doubles)
   double *part = (double *)(meta + kMetaVecs);
@@ -1441,6 +1482,27 @@ static void launch_cprod(bsn_op *op, int NB, const int8_t *q, int32_t *acc, uint
   // tiles on the plain image, 8 x 4 on the tiled copy (2 % faster there; the counting variant needs 150 registers with
   // 4 tiles and keeps 2); two column blocks — 16 waves x 2 tiles share one digit panel (half the L2 reads of it), with
   // the explicit MFMA / decode interleave + raised priority through the MFMA phase (SGB = 3: 2 %).
+  if constexpr (NPLANE == 2 && RAW0 && !STATS) {
+    if (op->na_skip_c && NB >= 2) {   // the missing-value plane only where a K-step has a missing code (op_na_blocks)
+      if (NB == 3) {
+        if (op->cols_contig) BSN_KLAUNCH((k_cprod<3, 2, KC, true, false, true, 0, 2, 16, 1, 0, false, 0, true>),
+                                         dim3((unsigned)((op->m + 511) / 512)), dim3(1024), 0, b->stream, b->d_img, b->pitch,
+                                         cols, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad);
+        else BSN_KLAUNCH((k_cprod<3, 2, KC, true, false, false, 0, 2, 16, 1, 0, false, 0, true>),
+                         dim3((unsigned)((op->m + 511) / 512)), dim3(1024), 0, b->stream, b->d_img, b->pitch, cols, op->col0,
+                         op->m, q, acc, op->m, l0, l1, l2, counts, npad);
+      } else {
+        if (op->cols_contig) BSN_KLAUNCH((k_cprod<2, 2, KC, true, false, true, 0, 2, 16, 1, 0, false, 0, true>),
+                                         dim3((unsigned)((op->m + 511) / 512)), dim3(1024), 0, b->stream, b->d_img, b->pitch,
+                                         cols, op->col0, op->m, q, acc, op->m, l0, l1, l2, counts, npad);
+        else BSN_KLAUNCH((k_cprod<2, 2, KC, true, false, false, 0, 2, 16, 1, 0, false, 0, true>),
+                         dim3((unsigned)((op->m + 511) / 512)), dim3(1024), 0, b->stream, b->d_img, b->pitch, cols, op->col0,
+                         op->m, q, acc, op->m, l0, l1, l2, counts, npad);
+      }
+      BSN_HIP(hipGetLastError());
+      return;
+    }
+  }
   if (NB == 3) {   // three column blocks: 16 waves x 2 tiles on the plain image (contiguous or gathered variants)
     if constexpr (STATS || NPLANE == 3) {
       fail("internal: no three-block counting kernel");
@@ -1557,6 +1619,96 @@ void op_poll_stats(bsn_op *op) {
   if (t == 0 && !getenv("BSN_FORCE_NA_PLANE")) op->no_na = true;  // complete data: skip the missing-value plane from now on
 }
 
+// ---------------------------------------------------------------------------
+// How many K-steps of the streaming products carry no missing code?  (round 5, VERDICT r4 #5b)  The missing-value plane
+// is half the MFMAs of k_cprod / k_prodT; a K-step whose 1 024 genotypes hold no missing code adds zeros through it.
+// At 1 % scattered missing values no step is free (0.99^1024); on nearly complete data (1e-4: 90 %) or on data whose
+// missing values come in batches (arrays merged over sample sets) most are.  k_na_blocks tests a SAMPLE of steps with
+// exactly the kernels' test, in the kernels' two step shapes, on the variant-major image:
+//   crossproduct  wave = 16 variants (lane & 15) x one 64-byte segment (4 x 16 B, lane >> 4): dword d of every lane is
+//                 K-step d — four steps per wave
+//   product       wave = one dword column (16 samples) x 256 variants of one half chunk: lane (c, g), step d reads
+//                 variant j0 + 64 g + 16 d + c — four steps per wave
+// out: {free, sampled} steps of the two shapes, then 1 (the arrival flag of the pinned copy).
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__global__ __launch_bounds__(64) void k_na_blocks(const uint8_t *__restrict__ img, int64_t pitch, int64_t m,
+                                                  unsigned long long *out) {
+  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+  const uint32_t h = hash32((uint32_t)blockIdx.x * 0x9E3779B1u + 0x7F4A7C15u), h2 = hash32(h ^ 0x85EBCA6Bu);
+  const int64_t nseg = pitch / 64, ngrp = m / 16, nhalf = m / 256, ndw = pitch / 4;
+  int free_c = 0, free_p = 0, tot_c = 0, tot_p = 0;
+  if (ngrp > 0 && nseg > 0) {
+    const int64_t grp = (int64_t)(((uint64_t)h * (uint64_t)ngrp) >> 32), seg = (int64_t)(((uint64_t)h2 * (uint64_t)nseg) >> 32);
+    const uint4 w = *(const uint4 *)(img + (grp * 16 + c) * pitch + seg * 64 + g * 16);
+    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int d = 0; d < 4; d++)
+      free_c += __builtin_amdgcn_ballot_w64(((ws[d] & (ws[d] >> 1)) & 0x55555555u) != 0u) == 0ull;
+    tot_c = 4;
+  }
+  if (nhalf > 0 && ndw > 0) {
+    const int64_t hc = (int64_t)(((uint64_t)h2 * (uint64_t)nhalf) >> 32), dw = (int64_t)(((uint64_t)h * (uint64_t)ndw) >> 32);
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const uint32_t w = *(const uint32_t *)(img + (hc * 256 + 64 * g + 16 * d + c) * pitch + dw * 4);
+      free_p += __builtin_amdgcn_ballot_w64(((w & (w >> 1)) & 0x55555555u) != 0u) == 0ull;
+    }
+    tot_p = 4;
+  }
+  if (lane == 0) {
+    atomicAdd(&out[0], (unsigned long long)free_c);
+    atomicAdd(&out[1], (unsigned long long)tot_c);
+    atomicAdd(&out[2], (unsigned long long)free_p);
+    atomicAdd(&out[3], (unsigned long long)tot_p);
+  }
+}
+
+// BSN_NA_SKIP=0 / 1: never / always the skipping kernels (A/B runs and tests; results are the same integers either
+// way); BSN_NA_SKIP_MIN: the share of free steps from which they are used (default 0.30: they cost 4 VALU and a
+// branch per step and do without the explicit MFMA / decode schedule, profiles/r05_power.txt).
+void op_na_blocks(bsn_op *op) {
+  bsn_bed *b = op->bed;
+  op->na_skip_c = op->na_skip_p = false;
+  if (b->bits != 2 || b->generic || op->no_na || !b->d_img) return;
+  const char *fe = getenv("BSN_NA_SKIP");   // (read at every call: the tests switch it between two products)
+  const int force = fe ? atoi(fe) : -1;
+  if (force == 0) return;
+  if (force == 1) {
+    op->na_skip_c = op->na_skip_p = true;
+    return;
+  }
+  const char *me = getenv("BSN_NA_SKIP_MIN");
+  const double min_free = me ? atof(me) : 0.30;
+  if (b->na_blocks_state == 0) {
+    if (!b->h_na_blocks) BSN_HIP(hipHostMalloc((void **)&b->h_na_blocks, 5 * sizeof(long long), hipHostMallocDefault));
+    if (!b->d_na_blocks) BSN_HIP(hipMalloc((void **)&b->d_na_blocks, 5 * sizeof(long long)));
+    for (int i = 0; i < 5; i++) b->h_na_blocks[i] = -1;   // [4] stays -1 until the second copy below has landed
+    BSN_HIP(hipMemsetAsync(b->d_na_blocks, 0, 5 * sizeof(long long), b->stream));
+    constexpr int kSamples = 8192;   // waves = 32 768 steps of each shape: the share to about half a percent
+    hipLaunchKernelGGL(k_na_blocks, dim3(kSamples), dim3(64), 0, b->stream, b->d_img, b->pitch, b->m,
+                       (unsigned long long *)b->d_na_blocks);
+    BSN_HIP(hipGetLastError());
+    // the counts first, the flag word (one byte set to 1) in a copy of its own behind them: it arrives last
+    BSN_HIP(hipMemsetAsync((uint8_t *)b->d_na_blocks + 4 * sizeof(long long), 1, 1, b->stream));
+    BSN_HIP(hipMemcpyAsync(b->h_na_blocks, b->d_na_blocks, 4 * sizeof(long long), hipMemcpyDeviceToHost, b->stream));
+    BSN_HIP(hipMemcpyAsync(b->h_na_blocks + 4, b->d_na_blocks + 4, sizeof(long long), hipMemcpyDeviceToHost, b->stream));
+    b->na_blocks_state = 1;
+    return;
+  }
+  if (b->na_blocks_state == 1) {
+    if (*(volatile long long *)(b->h_na_blocks + 4) != 1) return;   // not there yet: the plain kernels meanwhile
+    const long long *v = b->h_na_blocks;
+    b->na_free[0] = v[1] > 0 ? (double)v[0] / (double)v[1] : 0.0;
+    b->na_free[1] = v[3] > 0 ? (double)v[2] / (double)v[3] : 0.0;
+    b->na_blocks_state = 2;
+  }
+  op->na_skip_c = b->na_free[0] >= min_free;
+  op->na_skip_p = b->na_free[1] >= min_free;
+}
+
 // vectors per crossproduct launch: three column blocks on a 2-bit image unless the launch also counts the codes
 static int cprod_vmax(const bsn_op *op, int S) {
   const int nbmax = (op->bed->bits == 2 && !op->stats_pending && nb3_allowed()) ? 3 : 2;
@@ -1584,6 +1736,7 @@ void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z,
   refuse_generic(b, "this function (it needs the streaming products)");
   const int S = op->slices;
   if (nvec <= 0) return;
+  op_na_blocks(op);
   const bool have_digits = op->preq_X == d_X && op->preq_ldx == ldx && op->preq_nvec == nvec && d_X != nullptr &&
                            op->preq_S == S && nvec <= cprod_vmax(op, S);
   op->preq_X = nullptr;
@@ -1721,6 +1874,7 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
   refuse_generic(b, "this function (it needs the streaming products)");
   if (nvec <= 0) return;
   op->preq_X = nullptr;
+  op_na_blocks(op);
   // k_prod addresses a 64-variant step with 32-bit offsets from its first row
   if (b->pitch >= ((int64_t)1 << 24)) fail("more than 6.7e7 samples are not supported by the product kernel");
   const int64_t npad = n_padded(b);
@@ -1834,9 +1988,15 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
 #else
 #define BSN_PRODT3(HASQV, GRID, BS, STRIDE, OFF) BSN_PRODT_(3, HASQV, 0, GRID, BS, STRIDE, OFF)
 #endif
+#define BSN_PRODT_SKIP(NBV, GRID, BS, STRIDE, OFF)                                                                   \
+  BSN_KLAUNCH((k_prodT<NBV, true, 2, 16, 0, 0, true>), GRID, dim3(1024), 0, b->stream, b->d_smaj, b->rows_smaj,       \
+              op->col0 / 512, nchunks, smaj_cps, q, acc, npad, lutQ, BS, STRIDE, OFF)
 #define BSN_PRODT(HASQV, TAGV, GRID, BS, STRIDE, OFF)                                                                \
   do {                                                                                                               \
-    if (NB == 2) BSN_PRODT_(2, HASQV, TAGV, GRID, BS, STRIDE, OFF);                                                  \
+    if (HASQV && op->na_skip_p) {   /* the missing-value plane only where a K-step has a missing code */             \
+      if (NB == 2) BSN_PRODT_SKIP(2, GRID, BS, STRIDE, OFF);                                                         \
+      else BSN_PRODT_SKIP(3, GRID, BS, STRIDE, OFF);                                                                 \
+    } else if (NB == 2) BSN_PRODT_(2, HASQV, TAGV, GRID, BS, STRIDE, OFF);                                           \
     else BSN_PRODT3(HASQV, GRID, BS, STRIDE, OFF);                                                                   \
   } while (0)
       // (workgroup shapes 4 x 8 / 4 x 4 / 2 x 8 / 4 x 16 tiles x waves, chunks of 256 variants: all slower, profiles/r04_sample_major.txt)
@@ -1867,6 +2027,7 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
       if (has_q) { if (warm) BSN_PRODT(true, 1, grid, 0, 0, 0); else BSN_PRODT(true, 0, grid, 0, 0, 0); }
       else { if (warm) BSN_PRODT(false, 1, grid, 0, 0, 0); else BSN_PRODT(false, 0, grid, 0, 0, 0); }
 #undef BSN_PRODT
+#undef BSN_PRODT_SKIP
 #undef BSN_PRODT3
 #undef BSN_PRODT_
       BSN_HIP(hipGetLastError());

@@ -1590,6 +1590,9 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       info->segmented_passes = bk.n_seg_passes;
       info->compact_gathers = bk.n_compact_gathers;
       info->out_of_core = ooc ? 1 : 0;
+      info->na_free_steps[0] = op->bed->na_free[0];
+      info->na_free_steps[1] = op->bed->na_free[1];
+      info->na_skip = (op->na_skip_c ? 1 : 0) | (op->na_skip_p ? 2 : 0);
       info->compacted = compacted ? 1 : 0;
       info->compact_ms = t_compact;
       info->exchange_mode = bk.exchange_mode;

@@ -87,6 +87,7 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
                 n_wide_cprod=int(info.n_wide_cprod), n_wide_prod=int(info.n_wide_prod),
                 lead_rel_resid=info.lead_rel_resid, compacted=bool(info.compacted), compact_ms=info.compact_ms,
                 out_of_core=bool(info.out_of_core),
+                na_free_steps=[float(x) for x in info.na_free_steps], na_skip=int(info.na_skip),
                 exchange_mode=("none", "whole pass", "segments, one stream", "segments, reduce-scatters on a second stream")[
                     max(0, min(3, int(info.exchange_mode)))],
                 exchange_ms=dict(zip(("reduce_scatter", "all_gather", "small", "exposed_wait"), [float(x) for x in info.exchange_ms])),

@@ -339,6 +339,12 @@ typedef struct bsn_svd_info {
   /* 1 when the handle is out of core (bsn_bed_is_streamed): both passes of every block step walked the file in slabs
    * of variants through the resident slab image — PCIe-bound (the whole file per pass), same kernels, same arithmetic */
   int32_t out_of_core;
+  /* share of the K-steps (1 024 genotypes each) of the two streaming products that hold NO missing code, sampled
+   * once per image ([0] crossproduct, [1] product; 0 while not measured), and na_skip: bit 0 / bit 1 = the
+   * crossproduct / the product passes of this solve ended on the kernels that issue the missing-value plane only
+   * for steps that have one (used from a share of 0.30: nearly complete or batch-structured data; same integers) */
+  double na_free_steps[2];
+  int32_t na_skip;
 } bsn_svd_info;
 /* Returns 0 on success, 1 on error, and 2 when the solve ran to the end of its basis without all
  * k residuals meeting tol (outputs are filled with the best available triplets, bsn_last_error()

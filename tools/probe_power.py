@@ -18,6 +18,10 @@ ap.add_argument("--n", type=int, default=400000)
 ap.add_argument("--m", type=int, default=500000)
 ap.add_argument("--seconds", type=float, default=5.0)
 ap.add_argument("--xkind", default="normal", help="normal | ones (0/1 panel: constant digits) | zero")
+ap.add_argument("--na16", type=int, default=655, help="missing genotypes per 65 536 of the synthetic image")
+ap.add_argument("--slices", type=int, default=2, help="8-bit digits per vector (3: the three-block kernels at 16 vectors)")
+ap.add_argument("--only16", action="store_true", help="only the 16-vector crossproduct and product")
+ap.add_argument("--tag", default="", help="copied into every line (e.g. the environment switches of this run)")
 a = ap.parse_args()
 L = _lib.load()
 
@@ -64,7 +68,7 @@ def smi_text():
         return [repr(e)]
 
 
-gb = ba.bed.synthetic(a.n, a.m)
+gb = ba.bed.synthetic(a.n, a.m, na16=a.na16)
 L.bsn_device_sync()
 bytes_pass = ((a.n + 3) // 4) * a.m
 sc = ba.bed_scaleBinom(gb)
@@ -104,13 +108,16 @@ def loop(name, fn):
     rows = s.rows[len(s.rows) // 4:]
     avg = {k: float(np.mean([r[k] for r in rows if k in r])) for k in HW if any(k in r for r in rows)}
     per = ms.value / reps
-    print(json.dumps(dict(kernel=name, xkind=a.xkind, ms=round(per, 3), TBps=round(bytes_pass / per / 1e9, 3),
+    print(json.dumps(dict(kernel=name, xkind=a.xkind, na16=a.na16, slices=a.slices, tag=a.tag, ms=round(per, 3), TBps=round(bytes_pass / per / 1e9, 3),
                           hwmon_avg=avg, smi=txt)), flush=True)
 
 
-loop("counts", lambda: ba.bed_counts(gb))
-for nv in (16, 8):
-    op = ba.ScaledOp(gb, None, None, sc["center"], sc["scale"], slices=2)
+if not a.only16:
+    loop("counts", lambda: ba.bed_counts(gb))
+for nv in ((16,) if a.only16 else (16, 8)):
+    op = ba.ScaledOp(gb, None, None, sc["center"], sc["scale"], slices=a.slices)
+    if a.only16:
+        assert gb.sample_major()   # (the product of a solve runs on the sample-major copy)
     X = ba.DeviceArray.from_numpy(panel(a.m, nv))
     R = ba.DeviceArray.from_numpy(panel(a.n, nv))
     Y = ba.DeviceArray(a.n, nv); Z = ba.DeviceArray(a.m, nv)
