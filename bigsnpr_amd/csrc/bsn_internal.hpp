@@ -383,7 +383,7 @@ void comm_all_gather(bsn_comm *c, const double *d_send, double *d_recv, int64_t 
 
 // matvec.hip
 void op_poll_stats(bsn_op *op);  // after a stream synchronisation: pick up the missing-value total
-void op_na_blocks(bsn_op *op);   // queue / pick up the handle's share of K-steps without a missing code; sets op->na_skip_*
+void op_na_blocks(bsn_op *op, int digit_cols);   // queue / pick up the handle's share of K-steps without a missing code; sets op->na_skip_*
 void op_prod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy);
 // Y = beta Y + A~ X (the slabs of an out-of-core solve add up their products on the device)
 void op_prod_acc(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Y, int64_t ldy, double beta);

@@ -1669,10 +1669,11 @@ __global__ __launch_bounds__(64) void k_na_blocks(const uint8_t *__restrict__ im
 // BSN_NA_SKIP=0 / 1: never / always the skipping kernels (A/B runs and tests; results are the same integers either
 // way); BSN_NA_SKIP_MIN: the share of free steps from which they are used (default 0.30: they cost 4 VALU and a
 // branch per step and do without the explicit MFMA / decode schedule, profiles/r05_power.txt).
-void op_na_blocks(bsn_op *op) {
+void op_na_blocks(bsn_op *op, int digit_cols) {
   bsn_bed *b = op->bed;
   op->na_skip_c = op->na_skip_p = false;
-  if (b->bits != 2 || b->generic || op->no_na || !b->d_img) return;
+  // (one column block — the one-shot products, 8-vector solves — has no skipping kernel: nothing to measure for)
+  if (b->bits != 2 || b->generic || op->no_na || !b->d_img || digit_cols <= 16) return;
   const char *fe = getenv("BSN_NA_SKIP");   // (read at every call: the tests switch it between two products)
   const int force = fe ? atoi(fe) : -1;
   if (force == 0) return;
@@ -1736,7 +1737,7 @@ void op_cprod(bsn_op *op, const double *d_X, int64_t ldx, int nvec, double *d_Z,
   refuse_generic(b, "this function (it needs the streaming products)");
   const int S = op->slices;
   if (nvec <= 0) return;
-  op_na_blocks(op);
+  op_na_blocks(op, nvec * S);
   const bool have_digits = op->preq_X == d_X && op->preq_ldx == ldx && op->preq_nvec == nvec && d_X != nullptr &&
                            op->preq_S == S && nvec <= cprod_vmax(op, S);
   op->preq_X = nullptr;
@@ -1874,7 +1875,7 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
   refuse_generic(b, "this function (it needs the streaming products)");
   if (nvec <= 0) return;
   op->preq_X = nullptr;
-  op_na_blocks(op);
+  op_na_blocks(op, nvec * S);
   // k_prod addresses a 64-variant step with 32-bit offsets from its first row
   if (b->pitch >= ((int64_t)1 << 24)) fail("more than 6.7e7 samples are not supported by the product kernel");
   const int64_t npad = n_padded(b);
