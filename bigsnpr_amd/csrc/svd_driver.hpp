@@ -343,6 +343,15 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
       }
     // Rt: cb x cb (rn rows used): W_in = Q C2 + W_out Rt
     if (rn < 0) rn = orth(p, cb, C2, Rt, /*try_fused=*/!fused_failed);
+    // The complement of span(Q) in R^n has n - p directions, whatever the deficiency tests make of a rounded panel: on
+    // 16-bit products the projected block of a nearly full space is two genuine directions and six of rounding noise,
+    // all above the absolute threshold.  Without this bound a matrix with fewer rows than the basis limit (34 x 1701,
+    // k = 6, block 8) asked for a restart at p = 32 for ever — the noise directions did not fit below the cap —
+    // and ended on their coupling block as its "residual" (found by tests/test_gpu_random_shapes.py, offset 3000).
+    // Only against n: a basis of ALL of R^n gives exact Ritz pairs of A A' whatever its vectors are (the products are
+    // exact for the stored basis).  The other bound, rank(A) + block < n, is a statement about exact arithmetic: there
+    // the coupling block of the noise directions stays in, it is what tells an inexact exhaustion from an exact one.
+    if ((int64_t)p + rn > bk.n) rn = bk.n > p ? (int)(bk.n - p) : 0;
     pp = p;
     const bool exhausted = (rn == 0) || (p >= dim);  // Krylov space is invariant: Ritz pairs exact
     // the coupling block of the FULL next block measures the residuals, whether or not the basis has

@@ -118,6 +118,19 @@ def test_svd_tiny_matrices(ba, orc):
         np.testing.assert_allclose(res["d"], ref["d"], rtol=1e-8, atol=1e-8 * ref["d"][0])
 
 
+def test_svd_of_fewer_samples_than_the_basis_holds(ba, orc):
+    """a 34-sample selection of 135 x 1702 (random shapes, seed offset 3000): the basis reaches the whole of R^34; on
+    16- and 24-bit products the solve ends there with exact Ritz pairs instead of restarting on rounding noise"""
+    gb, ob = ba.bed.synthetic(135, 1702, seed=196, na16=6000), orc.fake_bed(135, 1702, seed=196, na16=6000)
+    ir = np.sort(np.random.default_rng(3).choice(135, 34, replace=False))
+    ic = np.nonzero(orc.bed_scaleBinom(ob, ir, None)["scale"] > 0)[0]
+    ref = orc.dense_svd(ob, ir, ic, k=6)
+    for block, slices in ((0, 2), (0, 0), (4, 3), (16, 2), (3, 0)):
+        res = ba.bed_randomSVD(gb, ind_row=ir, ind_col=ic, k=6, block=block, slices=slices)
+        assert res["converged"], (block, slices)
+        np.testing.assert_allclose(res["d"], ref["d"], rtol=1e-6)
+
+
 def test_empty_selection_errors(ba, orc):
     g = np.random.default_rng(8).integers(0, 3, size=(20, 8))
     ob, gb = _bed_from_matrix(ba, orc, g)

@@ -350,3 +350,23 @@ def test_precision_schedule_gives_the_vectors_of_wide_panels(nt, fused):
     assert out["split"][0][lead].max() < 1e-6 and out["split"][0][lead].max() < sn / 8, (out["split"][0][lead].max(), sn)
     assert sn > 3e-6, sn                       # the 16-bit floor is visible on this matrix ...
     assert ss < 3.0 * sw and ss < sn / 30, (sn, sw, ss)   # ... and gone with the early steps on 24 bits
+
+
+def test_fewer_rows_than_the_basis_limit_on_rounded_products(nt):
+    """34 x 1701, k = 6 (tests/test_gpu_random_shapes.py at seed offset 3000): the basis can hold the whole of R^34.
+    On 16-bit products the projected block at p = 32 is two genuine directions and six of rounding noise; the new
+    block is bounded by dim - p, the space is then exhausted with exact Ritz pairs — no restarts, no residual made
+    of noise."""
+    rng = np.random.default_rng(19)
+    A = rng.integers(0, 3, size=(34, 1701)).astype(float)
+    A = (A - A.mean(axis=0)) / np.maximum(A.std(axis=0), 1e-9)
+    dref = np.linalg.svd(A, compute_uv=False)
+    try:
+        for S in (2, 3, 0):
+            nt.nt_set_slices(S)
+            for block in (8, 4, 16, 3):
+                r = host_svd(nt, A, 6, tol=1e-4, block=block)
+                assert r["converged"] and r["restarts"] == 0 and r["basis"] == 34, (S, block, r["resid"], r["restarts"])
+                assert np.abs(r["d"] / dref[:6] - 1).max() < 1e-8
+    finally:
+        nt.nt_set_slices(0)
