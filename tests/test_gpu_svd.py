@@ -281,12 +281,17 @@ def test_exhausted_space_on_rounded_products(ba, orc):
         res = ba.bed_randomSVD(gb, k=16, block=block, seed=11)
         assert res["converged"]
         np.testing.assert_allclose(res["d"], ref["d"], rtol=1e-9)
-    # digits fixed by the caller: no second solve; the result says what it is
+    # digits fixed by the caller: no second solve.  Since round 5 an exhaustion that the coupling block calls inexact is
+    # answered by a thick restart (the restarted basis picks up what the rounded one lost): the solve converges within
+    # what 16-bit products resolve — or says that it did not; never a wrong value under "converged"
     import warnings
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         res = ba.bed_randomSVD(gb, k=16, block=8, slices=2, seed=11)
-    assert not res["converged"] and any("did not converge" in str(x.message) for x in w)
+    if res["converged"]:
+        np.testing.assert_allclose(res["d"], ref["d"], rtol=2e-5)
+    else:
+        assert any("did not converge" in str(x.message) for x in w)
 
 
 def test_column_list_solve_runs_on_a_compacted_copy(ba, monkeypatch):
