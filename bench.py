@@ -75,9 +75,12 @@ def parse():
                     help="svd: skip the accuracy record (u / v of the last timed solve against a 56-bit tol-1e-10 solve, outside "
                          "the timed region)")
     ap.add_argument("--ingest-gb", type=float, default=8.0, help="size of the .bed file written and re-opened")
-    ap.add_argument("--allow-fallback", action="store_true",
-                    help="N > 1 without a working RCCL communicator: take the host all-reduce hook over gloo (labelled in "
-                         "config.parallelism) instead of exiting with status 3")
+    ap.add_argument("--no-fallback", action="store_true",
+                    help="N > 1 without a working RCCL communicator: exit with status 3 instead of taking the host all-reduce "
+                         "hook over gloo (the default since round 5: a run that cannot use RCCL at all still ends with ONE line, "
+                         "labelled FALLBACK in config.parallelism and carrying the reason under \"fallback\" — a number that "
+                         "says what it is instead of no number)")
+    ap.add_argument("--allow-fallback", action="store_true", help="(the default now; kept for older command lines)")
     ap.add_argument("--shard-of", type=int, default=0,
                     help="one GPU, N given: solve on the FIRST of N column shards (m / N variants) with the solver told the "
                          "total (--m): the per-rank work of an N-GPU run — warm start, block size and step count as there; "
@@ -181,6 +184,7 @@ def main():
     comm = None
     hook = None
     exchange_report = None
+    fallback_reason = None
 
     def host_bcast(obj):                # rank 0's object on every rank (gloo)
         box = [obj]
@@ -218,14 +222,15 @@ def main():
                 if comm is not None:
                     comm.close()
                 comm = None
-                if not a.allow_fallback:
-                    # a scaling number measured over gloo and the host would not be an RCCL / xGMI number
-                    log("in-library RCCL communicator unavailable (%s); not falling back (--allow-fallback to take "
-                        "the host all-reduce hook over gloo instead)" % err)
+                if a.no_fallback:
+                    # a scaling number measured over gloo and the host is not an RCCL / xGMI number
+                    log("in-library RCCL communicator unavailable (%s); not falling back (--no-fallback)" % err)
                     dist.barrier()
                     dist.destroy_process_group()
                     sys.exit(3)
-                log("in-library RCCL communicator unavailable (%s): falling back to the host all-reduce hook (gloo)" % err)
+                log("in-library RCCL communicator unavailable (%s): falling back to the host all-reduce hook (gloo) — the "
+                    "line of this run is NOT an RCCL / xGMI number and says so" % err)
+                fallback_reason = str(err) if err is not None else "another rank has no communicator"
                 import ctypes as _C
                 import numpy as _np
 
@@ -439,6 +444,9 @@ def main():
                                    ("single GPU holding shard 1 of %d (per-rank work of an %d-GPU run, no exchange)"
                                     % (a.shard_of, a.shard_of) if a.shard_of > 1 else "single GPU"))},
         "passes_per_solve": passes / a.steps,
+        # N > 1 without any working RCCL exchange: the panels went through the host and gloo — not an xGMI measurement
+        "fallback": None if hook is None else {"transport": "host all-reduce over gloo (device -> host -> gloo -> device per panel)",
+                                               "reason": fallback_reason},
         "ind_col": None if ind_col is None else {
             "selected_variants": m_local, "of": m_image,
             "path": ("compacted copy of the selection (gathered once, %.1f ms in the first solve; the timed solves found it on the "

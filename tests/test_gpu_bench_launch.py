@@ -1,7 +1,8 @@
 """bench.py as the driver launches it for N > 1 (`python -m torch.distributed.run --nproc-per-node N bench.py
---gpus N ...`), on the one GPU of the test box: two ranks share device 0 and RCCL refuses that.  By default the
-script must then EXIT NON-ZERO on every rank (a scaling number produced over gloo is not an RCCL number); with
-`--allow-fallback` it takes — on every rank together — the host all-reduce hook.  What is checked is
+--gpus N ...`), on the one GPU of the test box: two ranks share device 0 and RCCL refuses that.  The script then
+takes — on every rank together — the host all-reduce hook over gloo and SAYS SO in its one line (`fallback`,
+`config.parallelism`: not an RCCL number, but a run that ends with a line; round 5); with `--no-fallback` it exits
+non-zero on every rank instead.  What is checked is
 the launch path around the solver: rendezvous, column sharding, the one JSON line on rank 0's stdout, whole-job
 aggregation, and that the sharded solve finds the singular values of the single-rank one."""
 import json
@@ -36,7 +37,7 @@ def _port():
 
 def test_two_ranks_without_rccl_do_not_fall_back_silently():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", _port(), "bench.py", "--gpus", "2"] + ARGS,
+                        "--master-addr", "127.0.0.1", "--master-port", _port(), "bench.py", "--gpus", "2", "--no-fallback"] + ARGS,
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert r.returncode != 0
     assert "not falling back" in r.stderr
@@ -47,9 +48,10 @@ def test_two_ranks_on_one_gpu_fall_back_and_agree():
     one, _ = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS)
     port = _port()
     two, err = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                     "--master-addr", "127.0.0.1", "--master-port", port, "bench.py", "--gpus", "2", "--allow-fallback"]
+                     "--master-addr", "127.0.0.1", "--master-port", port, "bench.py", "--gpus", "2"]
                     + ARGS)
     assert "falling back to the host all-reduce hook" in err
+    assert two["fallback"] and two["fallback"]["reason"] and one["fallback"] is None
     assert two["n_gpus"] == 2 and two["steps"] == 2 and two["warmup"] == 1
     assert two["config"]["m_total"] == 60000 and two["config"]["m_per_gpu"] == 30000
     assert "FALLBACK" in two["config"]["parallelism"]
