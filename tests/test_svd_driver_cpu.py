@@ -392,3 +392,69 @@ def test_an_inexact_exhaustion_is_restarted(nt):
             assert np.abs(res["d"] / d_true - 1).max() < 2e-5
     finally:
         nt.nt_set_slices(0)
+
+
+def test_sharded_random_shapes_in_threads(nt):
+    """2 - 4 ranks as threads of this process (the all-reduce hook sums the ranks' buffers in a fixed order behind a
+    barrier), ragged column shards down to a single column, every block size, exact / 16-bit / 24-bit products: every
+    rank ends with the same bits, converged, the values of a dense solver.  (2 000 further draws of this sweep were
+    clean; one vector per pass may skip a member of a cluster — checked as in tests/test_gpu_random_shapes.py.)"""
+    import threading
+    rng = np.random.default_rng(5)
+    try:
+        for trial in range(40):
+            R = int(rng.integers(2, 5))
+            shape = trial % 3
+            if shape == 0:
+                n, m = int(rng.integers(8, 80)), int(rng.integers(60, 900))
+            elif shape == 1:
+                n, m = int(rng.integers(100, 600)), int(rng.integers(R * 4, 90))
+            else:
+                n, m = int(rng.integers(60, 300)), int(rng.integers(60, 400))
+            r = int(rng.integers(1, 8))
+            A = rng.normal(size=(n, r)) @ rng.normal(size=(r, m)) * 3 + rng.normal(size=(n, m))
+            A -= A.mean(0)
+            k = int(rng.integers(1, min(min(n, m) - 1, 16) + 1))
+            block = int(rng.choice([1, 2, 3, 4, 8, 16]))
+            nt.nt_set_slices(int(rng.choice([0, 2, 3])))
+            cuts = np.concatenate([[0], np.sort(rng.choice(np.arange(1, m), R - 1, replace=False)), [m]])
+            bar = threading.Barrier(R)
+            bufs, results, errs = [None] * R, [None] * R, []
+
+            def make_ar(rank):
+                def ar(buf, count, ctx):
+                    a = np.ctypeslib.as_array(buf, shape=(count,))
+                    bufs[rank] = a
+                    bar.wait()
+                    tot = np.zeros(count)
+                    for q in range(R):
+                        tot += bufs[q]          # the same order on every rank
+                    bar.wait()
+                    a[:] = tot
+                    bar.wait()
+                return ar
+
+            def work(rank):
+                try:
+                    results[rank] = host_svd(nt, A[:, cuts[rank]:cuts[rank + 1]], k, tol=1e-4, block=block, m_total=m,
+                                             ar=make_ar(rank), seed=trial + 1)
+                except Exception as e:      # pragma: no cover
+                    errs.append(repr(e))
+                    bar.abort()
+
+            th = [threading.Thread(target=work, args=(q,)) for q in range(R)]
+            [t.start() for t in th]
+            [t.join(120) for t in th]
+            assert not errs and all(x is not None for x in results), (trial, errs)
+            res = results[0]
+            for q in range(1, R):
+                assert np.array_equal(results[q]["u"], res["u"]) and np.array_equal(results[q]["d"], res["d"])
+            assert res["converged"], (trial, R, n, m, k, block)
+            d_true = np.linalg.svd(A, compute_uv=False)
+            sig = d_true[:k] > 1e-3 * d_true[0]
+            if block == 1:
+                assert np.abs(res["d"][sig][:, None] / d_true[None, :] - 1).min(axis=1).max() < 1e-4
+            else:
+                assert np.abs(res["d"][sig] / d_true[:k][sig] - 1).max() < 1e-4, (trial, R, n, m, k, block)
+    finally:
+        nt.nt_set_slices(0)
