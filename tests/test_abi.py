@@ -90,3 +90,49 @@ def test_host_api_argument_checks(lib):
         ba.sub_bed("toto.txt")
     with pytest.raises(ValueError, match="Replacement must be an extension starting with '.'"):
         ba.sub_bed("toto.bed", "_QC")
+
+
+def test_ctypes_signatures_match_the_header_prototypes(lib):
+    """every prototype of include/bigsnpr_hip.h against the argument table the host mirror binds it with
+    (bigsnpr_amd/_lib.py SIGNATURES): the same number of arguments and, argument by argument, the same machine class —
+    pointer, 32-bit integer, 64-bit integer, double.  A 64-bit count bound as c_int32 works until the first large
+    matrix."""
+    import ctypes as C
+    hdr = open(os.path.join(ROOT, "include", "bigsnpr_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    hdr = re.sub(r"//[^\n]*", "", hdr)
+
+    def c_class(decl):
+        decl = decl.strip()
+        if "*" in decl or re.search(r"\bbsn_[a-z_]+_fn\b", decl) or "[" in decl:
+            return "ptr"
+        base = re.sub(r"\b(const|unsigned|signed|struct)\b", "", decl).split()
+        t = base[0] if base else ""
+        if decl.startswith("unsigned") and t in ("", "int"):
+            return "i32"
+        return {"double": "f64", "float": "f32", "int64_t": "i64", "uint64_t": "i64", "size_t": "i64", "long": "i64",
+                "int32_t": "i32", "uint32_t": "i32", "int": "i32", "uint8_t": "i8", "char": "i8"}[t]
+
+    def py_class(t):
+        if t is None:
+            return "void"
+        if isinstance(t, type) and (issubclass(t, (C._Pointer, C.c_void_p, C.c_char_p, C._CFuncPtr)) or hasattr(t, "contents")):
+            return "ptr"
+        return {C.c_double: "f64", C.c_float: "f32", C.c_int64: "i64", C.c_uint64: "i64", C.c_size_t: "i64",
+                C.c_long: "i64", C.c_longlong: "i64", C.c_ulonglong: "i64", C.c_int32: "i32", C.c_uint32: "i32",
+                C.c_int: "i32", C.c_uint: "i32"}[t]
+
+    protos = re.findall(r"([A-Za-z_][A-Za-z_0-9 \*]*?)\b(bsn_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr)
+    seen = 0
+    for ret, name, args in protos:
+        if name not in lib.SIGNATURES or "typedef" in ret:
+            continue
+        res, argtypes = lib.SIGNATURES[name]
+        args = args.strip()
+        c_args = [] if args in ("", "void") else [c_class(a) for a in args.split(",")]
+        p_args = [py_class(t) for t in argtypes]
+        assert c_args == p_args, (name, c_args, p_args)
+        want = "ptr" if "*" in ret else ("void" if ret.split()[-1] == "void" else c_class(ret.replace("extern", "")))
+        assert py_class(res) == want, (name, ret, res)
+        seen += 1
+    assert seen == len(lib.SIGNATURES), (seen, len(lib.SIGNATURES))
