@@ -17,6 +17,14 @@ inline void eig_sym(int n, std::vector<double> &V, std::vector<double> &d) {
   std::vector<double> e((size_t)n, 0.0);
   auto A = [&](int i, int j) -> double & { return V[(size_t)i + (size_t)j * n]; };
   if (n == 0) return;
+  // A NaN or an infinity makes every convergence test below false: the deflation search then ran past the end of d
+  // (heap overflow; found by a sweep over matrices scaled by 1e120, whose Gram matrices overflow).  Such a matrix has
+  // no decomposition: the eigenvalues come back NaN and the caller says so.
+  for (size_t t = 0; t < (size_t)n * (size_t)n; t++)
+    if (!std::isfinite(V[t])) {
+      d.assign((size_t)n, std::nan(""));
+      return;
+    }
   // --- tridiagonalise (rows processed from the bottom) --------------------------
   for (int j = 0; j < n; j++) d[j] = A(n - 1, j);
   for (int i = n - 1; i > 0; i--) {
@@ -97,7 +105,7 @@ inline void eig_sym(int n, std::vector<double> &V, std::vector<double> &d) {
   for (int l = 0; l < n; l++) {
     tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
     int m = l;
-    while (m < n) {
+    while (m < n - 1) {   // (e[n - 1] == 0 ends the search there at the latest; the bound holds whatever the values are)
       if (std::fabs(e[m]) <= eps * tst1) break;
       m++;
     }

@@ -29,6 +29,8 @@
 // decisions.  The backend interface keeps this file free of HIP so that the identical
 // driver is exercised on CPU (tests/native) with a host backend.
 #pragma once
+#include <string>
+#include <stdexcept>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -196,6 +198,7 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
 
   // orthonormalise W (cb columns) against Q[:, :p] and itself; returns rank r and the
   // cb x cb upper factor Rt with W_in = Q C + W_out Rt  (first r rows of Rt meaningful)
+  const double defic = 1e-22;   // "no direction left" in a projected panel: relative to the squared pre-projection scale
   auto orth = [&](int p, int cb, std::vector<double> &Cacc, std::vector<double> &Rout, bool try_fused = true) -> int {
     if (try_fused) {
       const int rf = bk.orth_fused(p, cb, Cacc, Rout);
@@ -221,7 +224,7 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
       // absolute deficiency test against the pre-projection scale (Krylov exhaustion)
       if (pass == 0) {
         int keep = 0;
-        while (keep < r && G[(size_t)keep + (size_t)keep * r] > 1e-22 * w0 && w0 > 0) keep++;
+        while (keep < r && G[(size_t)keep + (size_t)keep * r] > defic * w0 && w0 > 0) keep++;
         if (keep < r) {
           // shrink: keep the leading `keep` columns only
           std::vector<double> G2((size_t)keep * keep);
@@ -232,7 +235,7 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
         }
       }
       if (r == 0) return 0;
-      int rk = chol_upper(r, G, R, 1e-22);
+      int rk = chol_upper(r, G, R, pass == 0 ? defic : 1e-22);
       if (rk < r) {
         std::vector<double> G2((size_t)rk * rk);
         for (int j = 0; j < rk; j++)
@@ -329,6 +332,25 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
     if (rn == -1) {
       bk.ZtZ(p, p0, cb, blk.data());
       bk.QtQ(p, p0, cb, blk2.data());
+    }
+    // NaN / Inf in the projected blocks: in the operator's centre or scale (a scale of 0), in a start block handed in,
+    // or an overflow (entries beyond 1e150 square out of range).  Nothing below is defined on them — say so here
+    for (size_t t = 0; t < blk.size(); t++)
+      if (!std::isfinite(blk[t]) || !std::isfinite(blk2[t]))
+        throw std::runtime_error("the projected matrices of the partial SVD hold NaN or Inf: non-finite values in the matrix, "
+                                 "its centre or scale (a scale of 0?), or entries whose squares overflow");
+    if (res.niter == 1) {
+      // ... and the scale of the matrix.  Z'Z of the random start block is of the order sigma^2; the next Gram matrix
+      // W'W is of the order sigma^4 and must neither overflow nor fall into the denormals: a matrix scaled by 1e120
+      // came back "converged" with d = 0, one scaled by 1e-100 with d wrong by a factor of two (both found by the
+      // same sweep).  Genotypes over a standard deviation are within 1e-2 .. 1e2; anything beyond 1e+-70 is refused.
+      double gmax = 0;
+      for (int j = 0; j < cb; j++) gmax = std::max(gmax, std::fabs(blk[(size_t)(p0 + j) + (size_t)j * p]));
+      if (gmax > 1e140 || (gmax > 0 && gmax < 1e-140))
+        throw std::runtime_error("the matrix of the partial SVD is of the order of 1e" +
+                                 std::to_string((int)std::lround(0.5 * std::log10(gmax))) +
+                                 ": outside 1e-70 .. 1e70 its Gram matrices overflow or underflow in double precision; rescale it "
+                                 "(center / scale of the operator) and scale d back");
     }
     for (int j = 0; j < cb; j++)
       for (int i = 0; i < p; i++) Gat(i, p0 + j) = Gat(p0 + j, i) = blk[(size_t)i + (size_t)j * p];
@@ -446,7 +468,8 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
       }
     }
     bool done = false;
-    double worst_sig = 0;   // the same over the triplets that are not numerically zero (theta > 1e-10 theta_max)
+    const double negligible = std::max(1e-10, 4.0 * opt.resid_floor * opt.resid_floor);
+    double worst_sig = 0;   // the same over the triplets that are not numerically zero (theta > negligible theta_max)
     if (pp >= k) {
       double worst = 0, lead = 0;
       for (int t = 0; t < k; t++) {
@@ -462,8 +485,15 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
         double rel = std::sqrt(rs) / std::max(std::fabs(theta), 1e-300);
         worst = std::max(worst, rel);
         if (t < klead) lead = std::max(lead, rel);
-        if (theta > 1e-10 * eval[pp - 1]) worst_sig = std::max(worst_sig, rel);
+        if (theta > negligible * eval[pp - 1]) worst_sig = std::max(worst_sig, rel);
       }
+      // Triplets whose Ritz value is numerically zero — theta below (2 resid_floor)^2 of the largest, at least 1e-10:
+      // sigma below 1e-5 .. 4e-5 of sigma_1 — are what k > rank(A) asks for.  Their vectors are any null vectors and
+      // their relative residuals mean nothing; on rounded products the directions behind them are what the rounding
+      // of the stored basis left of range(A), and they never stop coming.  The convergence test is over the others:
+      // a matrix of rank 4 asked for 5 - 7 triplets on 16-bit products went through 100 restarts (4 000 block steps)
+      // and came back with invented singular values (98 and 296 beside the true 207 .. 151; once under "converged").
+      worst = worst_sig;
       res.max_rel_resid = worst;
       res.lead_rel_resid = lead;
       rho_lead = lead;

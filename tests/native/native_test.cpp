@@ -318,7 +318,15 @@ void nt_svd_host(const double *A, int64_t n, int64_t m_local, int64_t m_total, i
     o.vec_floor = g_vec_floor;
     o.noise_gain = g_noise_gain;
   }
-  SvdResult r = block_lanczos_svd(bk, o, d, u, v);
+  SvdResult r;
+  try {
+    r = block_lanczos_svd(bk, o, d, u, v);
+  } catch (const std::exception &) {   // (the HIP library turns it into an error code and bsn_last_error())
+    for (int t = 0; t < 8; t++) info[t] = 0;
+    info[5] = 1;   // the driver refused the input
+    *resid = std::nan("");
+    return;
+  }
   g_sched_n = 0;
   for (int S : bk.sched_log)
     if (g_sched_n < 64) g_sched_log[g_sched_n++] = S;

@@ -131,6 +131,32 @@ def test_svd_of_fewer_samples_than_the_basis_holds(ba, orc):
         np.testing.assert_allclose(res["d"], ref["d"], rtol=1e-6)
 
 
+def test_svd_refuses_scalings_that_are_not_finite_or_out_of_range(ba):
+    """a scale of 0 (a monomorphic variant under a caller's scaling) makes the scaled matrix non-finite: RSpectra fails on
+    such input, and so does this solve — with a message, and with the handle usable afterwards (before round 5 the
+    NaN reached the host eigen-solver, whose deflation search ran past its arrays); a scaling that puts the matrix at
+    1e120 is refused for the overflow of its Gram matrices instead of coming back "converged" with zeros"""
+    gb = ba.bed.synthetic(400, 900, seed=3)
+
+    def scaled(factor, zero_at=None):
+        def fun(obj, ind_row=None, ind_col=None, ncores=1):
+            ms = ba.bed_scaleBinom(obj, ind_row, ind_col)
+            ms = dict(center=np.array(ms["center"]), scale=np.array(ms["scale"]) * factor)
+            if zero_at is not None:
+                ms["scale"][zero_at] = 0.0
+            return ms
+        return fun
+
+    with pytest.raises(ba.BsnError, match="NaN or Inf"):
+        ba.bed_randomSVD(gb, fun_scaling=scaled(1.0, zero_at=7), k=5)
+    with pytest.raises(ba.BsnError, match="1e-70 .. 1e70"):
+        ba.bed_randomSVD(gb, fun_scaling=scaled(1e-120), k=5)
+    ref = ba.bed_randomSVD(gb, k=5)
+    assert ref["converged"]
+    big = ba.bed_randomSVD(gb, fun_scaling=scaled(1e-40), k=5)      # inside the range: d scales with the matrix
+    np.testing.assert_allclose(big["d"], ref["d"] * 1e40, rtol=1e-6)
+
+
 def test_empty_selection_errors(ba, orc):
     g = np.random.default_rng(8).integers(0, 3, size=(20, 8))
     ob, gb = _bed_from_matrix(ba, orc, g)
