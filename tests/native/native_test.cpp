@@ -337,6 +337,8 @@ void nt_svd_host(const double *A, int64_t n, int64_t m_local, int64_t m_total, i
   info[2] = r.basis;
   info[3] = r.converged;
   info[4] = r.restarts;
+  info[6] = r.exhausted;
+  info[7] = r.exhausted && r.exhausted_resid > 1e-9 ? 1 : 0;   // (what makes the HIP wrapper solve again on 56-bit products)
   *resid = r.max_rel_resid;
 }
 }

@@ -43,7 +43,8 @@ def host_svd(nt, A, k, tol=1e-10, block=8, m_total=None, ar=None, max_basis=0, s
                    u.ctypes.data_as(C.POINTER(C.c_double)), v.ctypes.data_as(C.POINTER(C.c_double)),
                    info.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(resid))
     return dict(d=d, u=u.T, v=v.T, niter=info[0], nops=info[1], basis=info[2],
-                converged=bool(info[3]), resid=resid.value, restarts=int(info[4]), refused=bool(info[5]))
+                converged=bool(info[3]), resid=resid.value, restarts=int(info[4]), refused=bool(info[5]),
+                exhausted=bool(info[6]), resolve=bool(info[7]))
 
 
 def test_eig_sym_matches_numpy(nt):
