@@ -236,7 +236,17 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
       }
       if (r == 0) return 0;
       int rk = chol_upper(r, G, R, pass == 0 ? defic : 1e-22);
+      // the rows of the factor that couple EVERY column of the panel to the directions kept: a dependent column is
+      // not a new direction, but it still has components along the kept ones, and the residual estimate of the step is
+      // made of them.  (Dropping them — only the kept columns' couplings survived — let a 17 x 277 matrix with
+      // 16 vectors per pass end "converged" after one step, 3.4 % off: the one direction R^17 had left was coupled to
+      // all 16 columns, the estimate saw the first.)
+      const int rc = r;
+      std::vector<double> Rrows;
       if (rk < r) {
+        Rrows.assign((size_t)rk * rc, 0.0);
+        for (int j = 0; j < rc; j++)
+          for (int i = 0; i < rk; i++) Rrows[(size_t)i + (size_t)j * rk] = R[(size_t)i + (size_t)j * rc];
         std::vector<double> G2((size_t)rk * rk);
         for (int j = 0; j < rk; j++)
           for (int i = 0; i < rk; i++) G2[(size_t)i + (size_t)j * rk] = G[(size_t)i + (size_t)j * r];
@@ -246,12 +256,16 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
       }
       inv_upper(r, R, Ri);
       bk.W_times(r, r, Ri.data());
-      // Rout <- R * Rout (leading r x cb part)
+      // Rout <- R * Rout (leading r x cb part; R = the r x rc coupling rows when columns were dropped)
       std::vector<double> Rn((size_t)cb * cb, 0.0);
       for (int j = 0; j < cb; j++)
         for (int i = 0; i < r; i++) {
           double s = 0;
-          for (int t = i; t < r; t++) s += R[(size_t)i + (size_t)t * r] * Rout[(size_t)t + (size_t)j * cb];
+          if (Rrows.empty()) {
+            for (int t = i; t < r; t++) s += R[(size_t)i + (size_t)t * r] * Rout[(size_t)t + (size_t)j * cb];
+          } else {
+            for (int t = i; t < rc; t++) s += Rrows[(size_t)i + (size_t)t * r] * Rout[(size_t)t + (size_t)j * cb];
+          }
           Rn[(size_t)i + (size_t)j * cb] = s;
         }
       Rout.swap(Rn);
@@ -468,7 +482,7 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
       }
     }
     bool done = false;
-    const double negligible = std::max(1e-10, 4.0 * opt.resid_floor * opt.resid_floor);
+    const double negligible = std::max(1e-10, 64.0 * opt.resid_floor * opt.resid_floor);
     double worst_sig = 0;   // the same over the triplets that are not numerically zero (theta > negligible theta_max)
     if (pp >= k) {
       double worst = 0, lead = 0;
@@ -487,8 +501,8 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
         if (t < klead) lead = std::max(lead, rel);
         if (theta > negligible * eval[pp - 1]) worst_sig = std::max(worst_sig, rel);
       }
-      // Triplets whose Ritz value is numerically zero — theta below (2 resid_floor)^2 of the largest, at least 1e-10:
-      // sigma below 1e-5 .. 4e-5 of sigma_1 — are what k > rank(A) asks for.  Their vectors are any null vectors and
+      // Triplets whose Ritz value is numerically zero — theta below (8 resid_floor)^2 of the largest, at least 1e-10:
+      // sigma below 1e-5 (24-bit products and wider) .. 1.5e-4 (16-bit) of sigma_1 — are what k > rank(A) asks for.  Their vectors are any null vectors and
       // their relative residuals mean nothing; on rounded products the directions behind them are what the rounding
       // of the stored basis left of range(A), and they never stop coming.  The convergence test is over the others:
       // a matrix of rank 4 asked for 5 - 7 triplets on 16-bit products went through 100 restarts (4 000 block steps)
