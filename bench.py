@@ -35,6 +35,8 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    # a rank still blocked 20 s after its communicator was aborted ends with status 86 (the library leaves that to its caller)
+    os.environ.setdefault("BSN_WATCHDOG_EXIT", "1")
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 I8_PEAK_TOPS = 5000.0      # MI355X_MICROARCH.md / SURVEY.md §8d: dense int8 MFMA peak (2x the 2.5 PFLOP/s bf16)

@@ -907,6 +907,7 @@ int bsn_bed_streaming_kernels(bsn_bed *bed, char *buf, int64_t len) {
   return guarded([&] {
     if (!buf || len < 1) fail("bsn_bed_streaming_kernels: no buffer");
     buf[0] = 0;
+    if (bed->last_solve_on_sub && bed->sub) bed = bed->sub;   // the last solve ran on the compacted copy: its operator lives there
     if (!bed->svd_op) return;
     static const char *kinds[kProfKinds] = {"cprod", "prod", "cprod_stats", "warm", "cprod_wide", "prod_wide"};
     std::string out;
@@ -956,6 +957,9 @@ int bsn_bed_release_workspace(bsn_bed *bed) {
       bed_free(bed->sub);
       bed->sub = nullptr;
       bed->sub_key = 0;
+      bed->sub_cols.clear();
+      bed->sub_rows.clear();
+      bed->last_solve_on_sub = false;
     }
     if (bed->slab_img) {   // out-of-core handle: the resident slab image and its page-locked staging buffers
       bed_free(bed->slab_img);

@@ -219,6 +219,7 @@ struct bsn_bed {
   // 100 KB apart.  Built on demand when the device has the room, freed with the handle.
   uint8_t *d_tiled = nullptr;
   bool tiled_tried = false;
+  size_t tiled_cap = 0;   // bytes of the allocation behind d_tiled (an in-place re-gather rebuilds the copy inside it)
   // Second copy of a 2-bit image in SAMPLE-MAJOR order (image.hip, image_smaj; round 4): the variants are the contiguous
   // index — four per byte, same device coding, variant 4 k + e in bits 2 e — and the copy is laid out CHUNK-MAJOR: the
   // 128 bytes "variants 512 ch .. 512 ch + 511 of sample i" sit at (ch * rows_smaj + i) * 128, rows_smaj = n rounded up
@@ -256,6 +257,8 @@ struct bsn_bed {
   // allocation (the rounds of autoSVD only remove variants), freed with the handle / bsn_bed_release_workspace.
   bsn_bed *sub = nullptr;
   uint64_t sub_key = 0;
+  std::vector<int64_t> sub_cols, sub_rows;   // the lists behind sub_key (compared on a key match: a 64-bit hash can collide)
+  bool last_solve_on_sub = false;            // bsn_bed_streaming_kernels reports the sub-handle's launches then
   int device = 0;
   bool stream_borrowed = false;      // `stream` belongs to another handle (the slab image of an out-of-core handle)
   hipStream_t stream = nullptr;

@@ -86,6 +86,14 @@ __global__ __launch_bounds__(256) void k_tile_image(const uint8_t *__restrict__ 
   }
 }
 
+static void tile_launch(bsn_bed *b) {
+  const int64_t nvb = (b->m + 63) / 64;
+  const int64_t gy = nvb < 65535 ? nvb : 65535, gz = (nvb + 65534) / 65535;
+  hipLaunchKernelGGL(k_tile_image, dim3((unsigned)(b->pitch >> 8), (unsigned)gy, (unsigned)gz), dim3(256), 0,
+                     b->stream, b->d_img, b->pitch, b->m, b->d_tiled);
+  BSN_HIP(hipGetLastError());
+}
+
 bool image_tile(bsn_bed *b) {
   if (b->d_tiled) return true;
   if (b->streamed()) return false;
@@ -103,11 +111,27 @@ bool image_tile(bsn_bed *b) {
     b->d_tiled = nullptr;
     return false;
   }
-  const int64_t gy = nvb < 65535 ? nvb : 65535, gz = (nvb + 65534) / 65535;
-  hipLaunchKernelGGL(k_tile_image, dim3((unsigned)(b->pitch >> 8), (unsigned)gy, (unsigned)gz), dim3(256), 0,
-                     b->stream, b->d_img, b->pitch, b->m, b->d_tiled);
-  BSN_HIP(hipGetLastError());
+  b->tiled_cap = bytes;
+  tile_launch(b);
   return true;
+}
+
+// the image changed in place (image_gather with `reuse`): an existing streaming-layout copy holds the PREVIOUS selection.
+// It is rebuilt inside its allocation when the new selection fits, dropped otherwise (the next solve asks for a new one).
+// (Round 5 left it alone: a later solve on the one-block kernels — vec_floor < 0, slices fixed by the caller, BSN_NO_SMAJ,
+// no room for the sample-major copy — then streamed the old selection's genotypes without any error.)
+static void tiled_refresh(bsn_bed *b) {
+  b->tiled_tried = false;
+  if (!b->d_tiled) return;
+  const size_t bytes = (size_t)((b->m + 63) / 64) * 64 * (size_t)b->pitch;
+  if (bytes <= b->tiled_cap) {
+    tile_launch(b);
+    return;
+  }
+  BSN_HIP(hipStreamSynchronize(b->stream));
+  (void)hipFree(b->d_tiled);
+  b->d_tiled = nullptr;
+  b->tiled_cap = 0;
 }
 
 // ---- sample-major copy (bsn_internal.hpp) ------------------------------------------------------------------
@@ -911,7 +935,10 @@ bsn_bed *image_gather(bsn_bed *src, const int64_t *ind_row, int64_t n, const int
     hipLaunchKernelGGL(k_gather_image, dim3((unsigned)((b->pitch + 255) / 256), (unsigned)gy, (unsigned)gz), dim3(256), 0,
                        b->stream, src->d_img, src->pitch, src->bits, d_rows.p, n, d_cols.p, m, b->d_img, b->pitch);
   BSN_HIP(hipGetLastError());
-  if (in_place) smaj_refresh(b);
+  if (in_place) {
+    smaj_refresh(b);
+    tiled_refresh(b);
+  }
   BSN_HIP(hipStreamSynchronize(b->stream));
   if (in_place) return b;
   return fresh.release();

@@ -1883,8 +1883,11 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
   // has its sample-major copy: the product runs as k_prodT (k_cprod's shape, contraction over the contiguous index).
   const bool smaj_ok = b->bits == 2 && b->d_smaj != nullptr && op->cols_contig && (op->col0 & 511) == 0 && mode == 1 &&
                        lutP == kLutRaw && lutQ == kLutNA && !getenv("BSN_NO_SMAJ");
-  const int vmax = std::min(kMetaVecs, (smaj_ok && nb3_allowed() && nvec * S > 32 ? kMaxCols : 32) / S);
-  const bool smaj = smaj_ok && nvec <= vmax && pick_nb(nvec * S) >= 2;   // (ONE launch: the geometry below is k_prodT's)
+  const int vmax_smaj = std::min(kMetaVecs, (smaj_ok && nb3_allowed() && nvec * S > 32 ? kMaxCols : 32) / S);
+  const bool smaj = smaj_ok && nvec <= vmax_smaj && pick_nb(nvec * S) >= 2;   // (ONE launch: the geometry below is k_prodT's)
+  // (a panel that needs several launches stays on k_prod, which has two column blocks at most: 16 vectors x 56 bits with
+  // the copy in place used to cut itself into launches of three — "three column blocks without the sample-major copy")
+  const int vmax = smaj ? vmax_smaj : std::max(1, std::min(kMetaVecs, 32 / S));
   if (sg && !smaj) return;   // (nothing queued: the caller takes the plain pass)
   const int64_t m_pad = round_up(op->m, smaj ? 512 : 64);
   VecMeta *meta = meta_buffer(op);

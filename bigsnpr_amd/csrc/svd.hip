@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <functional>
 
 #include "bsn_internal.hpp"
 #include "orth_small.hpp"
@@ -734,6 +735,7 @@ struct HipSvdBackend : SvdBackend {
   }
   void At_Qblock(int p0, int cb) override {
     Tick tk(this, 1);
+    if (progress) progress();
     if (ooc) return At_Qblock_ooc(p0, cb);
     op_cprod(op, newest_block(p0), n, cb, Z.p + (int64_t)p0 * m_local, m_local);
   }
@@ -816,6 +818,7 @@ struct HipSvdBackend : SvdBackend {
     if (sop) sop->slices = S;
     if (S < min_slices) min_slices = S;
   }
+  std::function<void()> progress;   // called once per pass (the exchange watchdog's deadline moves with it)
   int n_seg_passes = 0;   // product passes that ran in segments (diagnostics / tests)
   int exchange_mode = 0;  // bsn_svd_info::exchange_mode
   int n_compact_gathers = 0;   // basis blocks all-gathered as 16-bit integers
@@ -1168,23 +1171,46 @@ struct ExchangeWatchdog {
   std::mutex mu;
   std::condition_variable cv;
   bool done = false;
+  std::chrono::steady_clock::time_point deadline;
   std::atomic<int> fired{0};
   ExchangeWatchdog(bsn_comm *c_, int ms_) : c(c_), ms(ms_) {
     if (!c || ms <= 0) return;
+    deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(ms);
     th = std::thread([this] {
       std::unique_lock<std::mutex> lk(mu);
-      if (cv.wait_for(lk, std::chrono::milliseconds(ms), [this] { return done; })) return;
+      // the deadline moves with the solve's progress (kick): wait until it has really passed
+      for (;;) {
+        const auto dl = deadline;
+        if (cv.wait_until(lk, dl, [this] { return done; })) return;
+        if (std::chrono::steady_clock::now() >= deadline) break;
+      }
+      if (done) return;   // (checked under the lock: a solve that returned while the deadline passed keeps its communicator)
       fired.store(1);
       lk.unlock();
       const bool could = comm_abort(c);
-      std::fprintf(stderr, "[bsn svd] rank %d: the sharded solve did not return within %d ms: communicator %s\n", c->rank, ms,
+      std::fprintf(stderr, "[bsn svd] rank %d: the sharded solve made no progress for %d ms: communicator %s\n", c->rank, ms,
                    could ? "aborted" : "cannot be aborted (no ncclCommAbort)");
       lk.lock();
       if (cv.wait_for(lk, std::chrono::seconds(20), [this] { return done; })) return;
-      std::fprintf(stderr, "[bsn svd] rank %d: still blocked 20 s after the abort: giving up (exit status 86)\n", c->rank);
-      std::fflush(stderr);
-      _exit(86);
+      // Still blocked 20 s after the abort (a transport without ncclCommAbort, a wedged device).  Ending the host process
+      // — R, Python — from inside a library is the caller's decision: BSN_WATCHDOG_EXIT=1 (bench.py sets it: a run that
+      // cannot finish must not outlive its driver's patience) asks for exit status 86; otherwise the call stays blocked
+      // and says so.
+      const char *ex = getenv("BSN_WATCHDOG_EXIT");
+      if (ex && atoi(ex) != 0) {
+        std::fprintf(stderr, "[bsn svd] rank %d: still blocked 20 s after the abort: giving up (exit status 86, BSN_WATCHDOG_EXIT)\n", c->rank);
+        std::fflush(stderr);
+        _exit(86);
+      }
+      std::fprintf(stderr, "[bsn svd] rank %d: still blocked 20 s after the abort (BSN_WATCHDOG_EXIT=1 would end the process here)\n", c->rank);
     });
+  }
+  // progress of the solve (a block step's pass has been queued and the previous one synchronised): the deadline is per
+  // step, not per solve — a legitimately long sharded solve is not aborted
+  void kick() {
+    if (!th.joinable()) return;
+    std::lock_guard<std::mutex> lk(mu);
+    deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(ms);
   }
   ~ExchangeWatchdog() {
     if (!th.joinable()) return;
@@ -1245,7 +1271,13 @@ static bsn_bed *compacted_view(bsn_bed *bed, const int64_t *ind_row, int64_t n, 
     for (int64_t i = 0; rows_ident && i < n; i++) rows_ident = ind_row[i] == i;
   if (!rows_ident && ind_row) mix(ind_row, (size_t)n);
   if (key == 0) key = 1;
-  if (bed->sub && bed->sub_key == key && bed->sub->n == n && bed->sub->m == m) return bed->sub;
+  // the same selection again: the key AND the lists themselves (8 m bytes kept on the handle; a hash can collide)
+  const bool keep_rows = !rows_ident && ind_row;
+  if (bed->sub && bed->sub_key == key && bed->sub->n == n && bed->sub->m == m && (int64_t)bed->sub_cols.size() == m &&
+      std::memcmp(bed->sub_cols.data(), ind_col, (size_t)m * 8) == 0 &&
+      (keep_rows ? ((int64_t)bed->sub_rows.size() == n && std::memcmp(bed->sub_rows.data(), ind_row, (size_t)n * 8) == 0)
+                 : bed->sub_rows.empty()))
+    return bed->sub;
   BSN_HIP(hipSetDevice(bed->device));
   const bool in_place = bed->sub && bed->sub->n == n && bed->sub->cap_m >= m;
   if (!in_place) {
@@ -1253,6 +1285,8 @@ static bsn_bed *compacted_view(bsn_bed *bed, const int64_t *ind_row, int64_t n, 
       bed_free(bed->sub);
       bed->sub = nullptr;
       bed->sub_key = 0;
+      bed->sub_cols.clear();
+      bed->sub_rows.clear();
     }
     size_t free_b = 0, total_b = 0;
     BSN_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -1263,12 +1297,20 @@ static bsn_bed *compacted_view(bsn_bed *bed, const int64_t *ind_row, int64_t n, 
   try {
     fresh = image_gather(bed, rows_ident ? nullptr : ind_row, n, ind_col, m, in_place ? bed->sub : nullptr);
   } catch (const std::exception &) {
-    if (in_place) throw;
+    if (in_place) {   // the old copy is half overwritten: it answers to no list any more
+      bed->sub_key = 0;
+      bed->sub_cols.clear();
+      bed->sub_rows.clear();
+      throw;
+    }
     (void)hipGetLastError();
     return nullptr;   // (no room after all)
   }
   bed->sub = fresh;
   bed->sub_key = key;
+  bed->sub_cols.assign(ind_col, ind_col + m);
+  if (keep_rows) bed->sub_rows.assign(ind_row, ind_row + n);
+  else bed->sub_rows.clear();
   return fresh;
 }
 
@@ -1302,7 +1344,9 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     // (round 5) a list of variants that is not a contiguous range: the solve runs on a compacted copy of the selection
     bool compacted = false;
     double t_compact = 0.0;
+    bed->last_solve_on_sub = false;
     if (bsn_bed *sub = compacted_view(bed, ind_row, n, ind_col, m)) {
+      bed->last_solve_on_sub = true;
       if (ind_row == nullptr && n != bed->n) fail("internal: row count of a compacted solve");
       bed = sub;
       ind_row = nullptr;
@@ -1452,6 +1496,7 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     if (wd_ms == 0)
       if (const char *e = getenv("BSN_EXCHANGE_TIMEOUT_MS")) wd_ms = atoi(e);
     ExchangeWatchdog watchdog(bk.comm, wd_ms);
+    if (bk.comm && wd_ms > 0) bk.progress = [&watchdog] { watchdog.kick(); };
     if (bk.comm) {
       double junk_ms[kCommClasses];
       int junk_n[kCommClasses];
@@ -1479,13 +1524,17 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
              ex.what());
       throw;
     }
-    if (r.exhausted && r.exhausted_resid > 1e-9 && o->slices <= 0 && op->slices < 7) {
+    // ... and (round 6) whenever requested triplets lie below what the rounded products resolve — sigma below
+    // 1.5e-4 sigma_1 on 16-bit panels: the driver leaves them out of its convergence test (they cannot meet it there) and
+    // says so; their VALUES need the wide products.  Rare: k beyond the numerical rank at 16 bits.
+    if (((r.exhausted && r.exhausted_resid > 1e-9) || r.below_resolution > 0) && o->slices <= 0 && op->slices < 7) {
       // a Krylov space exhausted on rounded products (svd_driver.hpp): only matrices whose rank fits the basis get
       // here, so the second solve — 56-bit digits, at most four vectors per pass — is cheap, and it is run whenever
       // the coupling block is not negligible, met tolerance or not: a matrix this small deserves its exact values
       if (o->verbose)
-        std::fprintf(stderr, "[bsn svd] Krylov space exhausted with a relative residual of %.3g on %d-bit products: "
-                             "again with 56-bit products\n", r.max_rel_resid, 8 * op->slices);
+        std::fprintf(stderr, "[bsn svd] %s on %d-bit products (relative residual %.3g, %d requested triplets below their resolution): "
+                             "again with 56-bit products\n", r.exhausted ? "Krylov space exhausted" : "triplets below the products' resolution",
+                     8 * op->slices, r.max_rel_resid, r.below_resolution);
       op->slices = 7;
       so.slices_base = so.slices_max = 7;
       so.vec_floor = 0.0;
@@ -1534,7 +1583,17 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       if (o->center_out) copy_d2h(bed, o->center_out, op->d_center.p, (size_t)m * 8);
       if (o->scale_out) copy_d2h(bed, o->scale_out, op->d_scale.p, (size_t)m * 8);
     }
-    if (!r.converged) {
+    if (r.converged && r.below_resolution > 0) {
+      // (the digits were fixed by the caller: no second solve) the triplets the test left out are not vouched for
+      unconverged = true;
+      r.converged = 0;
+      char buf[320];
+      std::snprintf(buf, sizeof(buf),
+                    "%d of the %d requested singular triplets lie below what %d-bit products resolve (sigma below %.1e sigma_1): "
+                    "their values are not converged; ask for more digits (slices) or fewer triplets",
+                    r.below_resolution, so.k, 8 * op->slices, std::sqrt(64.0) * so.resid_floor);
+      set_error(buf);
+    } else if (!r.converged) {
       unconverged = true;
       char buf[256];
       std::snprintf(buf, sizeof(buf),

@@ -170,6 +170,12 @@ struct SvdResult {
   double lead_rel_resid = 0;   // the same over the leading half of the k pairs
   int wide_steps = 0;          // block steps that ran with more than slices_base digits (precision schedule)
   int slices_used_max = 0;
+  // of the k requested triplets, those whose Ritz value lies between the hard zero (1e-10 theta_1: below what fp64 Gram
+  // matrices resolve) and what the ROUNDED products resolve ((8 resid_floor)^2 theta_1): they were left out of the
+  // convergence test because on these products they cannot meet it — which says nothing about their values.  A caller
+  // that can should solve again on wider products (svd.hip does, in its automatic mode; with the digits fixed by the
+  // caller the solve is reported as not converged).  0 on exact products.
+  int below_resolution = 0;
 };
 
 // d: k singular values (descending); u: n x k; v: m_local x k (column-major, host)
@@ -312,6 +318,7 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
   std::vector<double> Rlast;  // coupling block (r_next x cb) of the newest complete block
   int rr_rank = 0;            // independent directions the last Rayleigh-Ritz step worked with (== pp normally)
   int rl_rows = 0, rl_cols = 0;
+  int exhausted_restarts = 0;   // thick restarts taken while the space was exhausted by count (p >= dim)
 
   while (cb > 0) {
     const int p0 = p - cb;
@@ -403,7 +410,12 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
     // steps over a wide spectrum, or rounded products — such a space is only nearly invariant, the coupling block says
     // by how much, and a thick restart continues from the Ritz vectors with what the old basis lost: 316 x 23, k = 18,
     // block 1 on exact products ended at its 24th vector with residuals of 1.5e-2, and converges after one restart)
-    const bool want_restart = rn > cap - p && rn > 0 && pp >= k && res.restarts < opt.max_restarts;
+    // (at most two restarts from the exhausted-by-count state: what floating point lost of an invariant space comes back
+    // with one or two; a matrix whose ROUNDED products keep handing over noise directions there would otherwise use up
+    // all max_restarts before it ends with exhausted = 1 — which is what sends the caller to the 56-bit solve anyway)
+    const bool by_count = p >= dim;
+    const bool want_restart = rn > cap - p && rn > 0 && pp >= k && res.restarts < opt.max_restarts &&
+                              (!by_count || exhausted_restarts < 2);
     if (rn > cap - p) rn = cap - p;
     if (rn < 0) rn = 0;
 
@@ -482,10 +494,12 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
       }
     }
     bool done = false;
-    const double negligible = std::max(1e-10, 64.0 * opt.resid_floor * opt.resid_floor);
+    const double hard_zero = 1e-10;
+    const double negligible = std::max(hard_zero, 64.0 * opt.resid_floor * opt.resid_floor);
     double worst_sig = 0;   // the same over the triplets that are not numerically zero (theta > negligible theta_max)
     if (pp >= k) {
       double worst = 0, lead = 0;
+      int n_soft = 0;
       for (int t = 0; t < k; t++) {
         int col = pp - 1 - t;
         double theta = eval[col];
@@ -500,13 +514,19 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
         worst = std::max(worst, rel);
         if (t < klead) lead = std::max(lead, rel);
         if (theta > negligible * eval[pp - 1]) worst_sig = std::max(worst_sig, rel);
+        else if (theta > hard_zero * eval[pp - 1]) n_soft++;
       }
+      res.below_resolution = n_soft;
       // Triplets whose Ritz value is numerically zero — theta below (8 resid_floor)^2 of the largest, at least 1e-10:
       // sigma below 1e-5 (24-bit products and wider) .. 1.5e-4 (16-bit) of sigma_1 — are what k > rank(A) asks for.  Their vectors are any null vectors and
       // their relative residuals mean nothing; on rounded products the directions behind them are what the rounding
       // of the stored basis left of range(A), and they never stop coming.  The convergence test is over the others:
       // a matrix of rank 4 asked for 5 - 7 triplets on 16-bit products went through 100 restarts (4 000 block steps)
       // and came back with invented singular values (98 and 296 beside the true 207 .. 151; once under "converged").
+      // What the exemption must NOT do is vouch for a triplet that is merely small: sigma = 1e-4 sigma_1 is a legitimate
+      // request that 16-bit products cannot serve (300 x 400, sigma = 100 .. 40 and a 1e-2 tail, k = 6 came
+      // back "converged" with the tail 10 % off).  Triplets between the hard zero and the products' resolution are
+      // counted (below_resolution) and the caller decides: wider products, or "not converged".
       worst = worst_sig;
       res.max_rel_resid = worst;
       res.lead_rel_resid = lead;
@@ -592,6 +612,7 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
               Mat(i, j) = Mk[(size_t)i + (size_t)j * keep];
             }
           res.restarts++;
+          if (by_count) exhausted_restarts++;
           if (opt.verbose)
             std::fprintf(stderr, "[bsn svd] basis full at %d: restart with %d Ritz vectors\n", pp, keep);
           p = keep;

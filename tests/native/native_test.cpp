@@ -338,7 +338,9 @@ void nt_svd_host(const double *A, int64_t n, int64_t m_local, int64_t m_total, i
   info[3] = r.converged;
   info[4] = r.restarts;
   info[6] = r.exhausted;
-  info[7] = r.exhausted && r.exhausted_resid > 1e-9 ? 1 : 0;   // (what makes the HIP wrapper solve again on 56-bit products)
+  // (what makes the HIP wrapper solve again on 56-bit products: bit 0 an inexact exhaustion, bit 1 requested triplets
+  // below what the rounded products resolve)
+  info[7] = (r.exhausted && r.exhausted_resid > 1e-9 ? 1 : 0) | (r.below_resolution > 0 ? 2 : 0);
   *resid = r.max_rel_resid;
 }
 }

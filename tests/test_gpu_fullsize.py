@@ -68,21 +68,31 @@ def test_c3_randomsvd_full_size_properties(ba):
     tight = ba.bed_randomSVD(gb, k=k, tol=1e-10, slices=7, block=5)
     assert tight["converged"]
     np.testing.assert_allclose(d, tight["d"], rtol=1e-6)
-    # ... and (round 5) the VECTORS of the default solve against the tight solve's: per vector || x sign - x_tight ||
-    # within the Davis-Kahan bound of the solve's own residual estimate + the floor of its precision schedule (2.5e-7:
-    # the early block steps run on 24-bit panels), for the leading half with the leading half's estimate; measured at
-    # this size: u 1.2e-6 / v 6.6e-8 over the leading half (16-bit panels at every step: 3.5e-5 / 1.2e-6)
+    # ... and the VECTORS of the default solve against the tight solve's (round 5: precision schedule, the early block steps
+    # on 24-bit panels).  What an fp64 solve stopped at the SAME tol leaves is measured, not assumed (round 6):
+    # the same Krylov trajectory — same block, same start, same tol — on 56-bit panels.  The default's leading half must be
+    # within 1.5 x of that solve's angle or inside north_star's 1e-6, per vector; measured at this size (two matrices):
+    # default 1.56e-7 / 2.34e-7 against 1.33e-7 / 2.27e-7 for the 56-bit trajectory (u; v 8.4e-9 / 1.2e-8 against 7.2e-9 /
+    # 1.2e-8) — the arithmetic is not what limits the vectors, the Lanczos process at tol 1e-4 is
+    # (profiles/r06_vectors_c3.txt; 16-bit panels at every step: 2.2e-5).
     assert res["slices_max"] == 3 and 1 <= res["wide_steps"] < res["niter"]
+    same = ba.bed_randomSVD(gb, k=k, slices=7, block=res["block"])          # tol 1e-4 as the default
+    assert same["converged"] and same["niter"] == res["niter"]
     lam = tight["d"] ** 2
     amp = np.array([lam[i] / np.min(np.abs(lam[i] - np.delete(lam, i))) for i in range(k)])
     h = (k + 1) // 2
+
+    def angles(x, ref):
+        s = np.sign(np.sum(x * ref, axis=0))
+        return np.linalg.norm(x * s - ref, axis=0)
     for name in ("u", "v"):
-        s = np.sign(np.sum(res[name] * tight[name], axis=0))
-        a = np.linalg.norm(res[name] * s - tight[name], axis=0)
+        a, a56 = angles(res[name], tight[name]), angles(same[name], tight[name])
+        # every vector inside the Davis-Kahan bound of the solve's own residual estimate + its 16-bit floor
         assert np.all(a <= 2.0 * (res["max_rel_resid"] + 1.2 * 2.0 ** -16) * amp), (name, a)
-        assert np.all(a[:h] <= 2.0 * (res["lead_rel_resid"] + 2.5e-7) * amp[:h]), (name, a[:h])
-        assert a[:h].max() <= (3e-6 if name == "u" else 3e-7), (name, a[:h])
-        print("[C3 %s vs 56-bit tol-1e-10 solve] leading half %.2e, all %.2e" % (name, a[:h].max(), a.max()))
+        assert np.all(a[:h] <= np.maximum(1e-6, 1.5 * a56[:h])), (name, a[:h], a56[:h])
+        assert a[:h].max() <= 1e-6, (name, a[:h])                              # north_star, at this matrix
+        print("[C3 %s vs 56-bit tol-1e-10 solve] default: leading half %.2e, all %.2e; 56-bit panels on the same trajectory: "
+              "%.2e, %.2e" % (name, a[:h].max(), a.max(), a56[:h].max(), a56.max()))
 
 
 def test_c5_ld_window_full_size_spot_checks(ba):

@@ -338,3 +338,31 @@ def test_column_list_solve_runs_on_a_compacted_copy(ba, monkeypatch):
     monkeypatch.delenv("BSN_NO_COMPACT")
     c = ba.bed_randomSVD(gb, ind_col=lists[1], k=k)
     assert c["compacted"]
+
+
+@pytest.mark.parametrize("how", ["vec_floor", "no_smaj", "slices2_block8"])
+def test_in_place_regather_rebuilds_the_tiled_copy(ba, monkeypatch, how):
+    """a solve that does not take the sample-major copy (every step on the narrow panels, BSN_NO_SMAJ,
+    slices fixed by the caller at block 8) asks for the TILED copy of the compacted sub-image.  When the next list is
+    gathered in place into the same allocation — the shrinking rounds of bed_autoSVD — that copy used to keep the previous
+    selection and the streaming kernels read it: wrong d, u, v without any error.  Every list of a shrinking sequence must
+    equal the gather-list path bit for bit, and the one-block kernels must really have run on a tiled copy."""
+    n, m, k = 3000, 40000, 10
+    gb = ba.bed.synthetic(n, m, seed=11)
+    rng = np.random.default_rng(11)
+    first = np.sort(rng.choice(m, 16000, replace=False))
+    lists = [first, np.sort(rng.choice(first, 12000, replace=False)), np.sort(rng.choice(first, 9000, replace=False))]
+    kw = {"vec_floor": dict(vec_floor=-1.0), "no_smaj": dict(), "slices2_block8": dict(slices=2, block=8)}[how]
+    monkeypatch.setenv("BSN_COMPACT_MIN_BYTES", "0")
+    if how == "no_smaj":
+        monkeypatch.setenv("BSN_NO_SMAJ", "1")
+    for t, ic in enumerate(lists):
+        monkeypatch.delenv("BSN_NO_COMPACT", raising=False)
+        a = ba.bed_randomSVD(gb, ind_col=ic, k=k, **kw)
+        assert a["compacted"] and a["converged"]
+        assert a["tiled"] == 1, "the solve was meant to run on the tiled copy of the sub-image"
+        monkeypatch.setenv("BSN_NO_COMPACT", "1")
+        b = ba.bed_randomSVD(gb, ind_col=ic, k=k, **kw)
+        assert not b["compacted"]
+        for f in ("d", "u", "v", "center", "scale"):
+            np.testing.assert_array_equal(a[f], b[f], err_msg="%s: list %d, %s" % (how, t, f))

@@ -44,7 +44,7 @@ def host_svd(nt, A, k, tol=1e-10, block=8, m_total=None, ar=None, max_basis=0, s
                    info.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(resid))
     return dict(d=d, u=u.T, v=v.T, niter=info[0], nops=info[1], basis=info[2],
                 converged=bool(info[3]), resid=resid.value, restarts=int(info[4]), refused=bool(info[5]),
-                exhausted=bool(info[6]), resolve=bool(info[7]))
+                exhausted=bool(info[6]), resolve=bool(info[7]), below_resolution=bool(info[7] & 2))
 
 
 def test_eig_sym_matches_numpy(nt):
@@ -511,6 +511,9 @@ def test_more_triplets_than_rank_on_rounded_products(nt):
                     kk = min(k, 4)
                     np.testing.assert_allclose(r["d"][:kk], d_true[:kk], rtol=1e-6)
                     assert np.all(r["d"][4:] < 1e-3 * d_true[0])
+                    # (round 6: triplets between the hard zero, 1e-10 theta_1, and the products' resolution raise
+                    # below_resolution — here the null directions come out at either side of 1e-10; never for k <= rank)
+                    assert not (r["below_resolution"] and k <= 4), (sched, block, k)
     finally:
         nt.nt_set_slices(0)
         nt.nt_set_schedule(C.c_double(0.0), 0, 0)
@@ -532,3 +535,31 @@ def test_dependent_columns_of_a_panel_keep_their_couplings(nt):
         r = host_svd(nt, A, 1, tol=1e-4, block=16, seed=seed + 1)
         assert r["converged"] and r["niter"] >= 2
         np.testing.assert_allclose(r["d"], d_true[:1], rtol=2e-5)
+
+
+def test_small_but_real_triplets_are_not_vouched_for(nt):
+    """300 x 400 with sigma = 100, 80, 60, 40 and a tail at 1e-2, k = 6 on 16-bit products.  The tail is
+    REAL (sigma = 1e-4 sigma_1) but below what 16-bit products resolve, so the convergence test leaves triplets 5 and 6 out —
+    and used to return converged = 1 with d[4:6] 10 % off.  The driver now counts such triplets (below_resolution) and the
+    caller acts on it: what svd.hip does in its automatic mode — the same solve on 56-bit products — gets them right."""
+    rng = np.random.default_rng(5)
+    U, _ = np.linalg.qr(rng.normal(size=(300, 300)))
+    V, _ = np.linalg.qr(rng.normal(size=(400, 400)))
+    sig = np.r_[100.0, 80.0, 60.0, 40.0, np.linspace(1e-2, 5e-3, 296)]
+    A = (U * sig) @ V[:, :300].T
+    k = 6
+    try:
+        nt.nt_set_slices(2)
+        r = host_svd(nt, A, k, tol=1e-4, block=8, seed=7)
+        assert r["below_resolution"], "the two tail triplets lie below the resolution of 16-bit products: the driver must say so"
+        np.testing.assert_allclose(r["d"][:4], sig[:4], rtol=1e-6)       # the four it tested are right
+        nt.nt_set_slices(7)                                               # the wrapper's second solve
+        r7 = host_svd(nt, A, k, tol=1e-4, block=4, seed=7)
+        assert r7["converged"] and not r7["below_resolution"]
+        np.testing.assert_allclose(r7["d"], sig[:k], rtol=1e-6)
+        nt.nt_set_slices(0)                                               # exact products never raise the flag
+        r0 = host_svd(nt, A, k, tol=1e-4, block=8, seed=7)
+        assert r0["converged"] and not r0["below_resolution"]
+        np.testing.assert_allclose(r0["d"], sig[:k], rtol=1e-6)
+    finally:
+        nt.nt_set_slices(0)
