@@ -91,6 +91,10 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="go through the RCCL communicator even with one rank (self-test)")
     ap.add_argument("--cpu-sample-cols", type=int, default=0)
+    ap.add_argument("--no-cold", action="store_true",
+                    help="svd: skip the `cold` record (a fresh process timing the FIRST bed_randomSVD of a new handle — the call the "
+                         "reference makes, R/autoSVD.R:205-219 — at full size and on a real .bed file; outside the timed region)")
+    ap.add_argument("--cold-child", default="", help=argparse.SUPPRESS)   # internal: "synthetic" | path of a .bed (n x m as given)
     ap.add_argument("--verbose", type=int, default=0, help="1: residual trajectory of every solve on stderr")
     ap.add_argument("--warm-start", type=int, default=0, help="warm-start iterations (0 = library default 1, -1 = none)")
     ap.add_argument("--warm-den", type=int, default=0, help="warm start on the leading 1/N of the variants (0 = 16)")
@@ -133,8 +137,63 @@ def log(msg):
 T_START = time.time()
 
 
+def cold_child(a):
+    """(internal) what a caller's first call costs, in a process of its own: library load, the handle (image generated on the
+    device, or bsn_bed_open of a real file), then the wall time of the first three bed_randomSVD calls on it.  One JSON line."""
+    t_proc = time.perf_counter()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    import bigsnpr_amd as ba
+    from bigsnpr_amd import _lib
+    L = _lib.load()
+    ba.selftest()                       # first contact with the device: runtime and code objects
+    t_lib = time.perf_counter() - t_proc
+    t0 = time.perf_counter()
+    if a.cold_child == "synthetic":
+        gb = ba.bed.synthetic(a.n, a.m or 1000000, seed=20250905, na16=a.na16)
+    else:
+        import ctypes as C
+        h = C.c_void_p()
+        _lib.check(L.bsn_bed_open(a.cold_child.encode(), a.n, a.m, C.byref(h)))
+        gb = ba.bed(_handle=h, _n=a.n, _m=a.m)
+    L.bsn_device_sync()
+    t_handle = time.perf_counter() - t0
+    ms, infos = [], []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        r = ba.bed_randomSVD(gb, k=a.k, tol=a.tol)
+        ms.append(1e3 * (time.perf_counter() - t0))
+        infos.append({"niter": r["niter"], "gpu_ms": r["gpu_ms"], "product_launches_on_k_prod": r["n_prod"] + r["n_wide_prod"] if r["tiled"] != 2 else None,
+                      "image_layout_at_exit": {0: "variant-major only", 1: "tiled copy", 2: "sample-major copy"}[r["tiled"]],
+                      "n_prod": r["n_prod"], "n_wide_prod": r["n_wide_prod"], "prod_ms": r["prod_ms"], "wide_prod_ms": r["wide_prod_ms"],
+                      "sigma1": float(r["d"][0])})
+        del r
+    real_stdout.write(json.dumps({"library_and_runtime_s": t_lib, "handle_s": t_handle, "solve_ms": ms, "solves": infos}) + "\n")
+    real_stdout.flush()
+
+
+def cold_record(a, bed_path=None, bed_n=0, bed_m=0):
+    """the reference's unit of work is ONE bed_randomSVD on a freshly opened object.  A child process (fresh
+    runtime, fresh handle, nothing allocated) times that call; reported beside the warm number, never part of `value`."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cold-child", bed_path or "synthetic", "--n", str(bed_n or a.n),
+           "--m", str(bed_m or a.m or 1000000), "--k", str(a.k), "--tol", str(a.tol), "--na16", str(a.na16)]
+    env = dict(os.environ)
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return {"error": str(e)[:300]}
+    first, warm = d["solve_ms"][0], min(d["solve_ms"][1:])
+    d.update({"first_solve_ms": first, "warm_solve_ms": warm, "first_minus_warm_ms": first - warm})
+    return d
+
+
 def main():
     a = parse()
+    if a.cold_child:
+        return cold_child(a)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -245,6 +304,14 @@ def main():
         elif comm is None:
             raise err
 
+    cold = None
+    if (world == 1 and rank == 0 and a.workload == "svd" and not a.no_cold and a.shard_of <= 1 and a.ind_col_fraction <= 0
+            and not a.force_dist):
+        cold = {"what": "a FRESH process: library + runtime, a new handle, then the first three bed_randomSVD(k = %d) calls on it; "
+                        "the first solve runs on the variant-major image alone; the sample-major copy is made behind it, for the later ones" % a.k,
+                "synthetic_full_size": cold_record(a)}
+        log("cold record (full size) done: first solve %s ms, warm %s ms" % (
+            cold["synthetic_full_size"].get("first_solve_ms"), cold["synthetic_full_size"].get("warm_solve_ms")))
     n, m_total = a.n, a.m or 1000000
     j0 = (m_total * rank) // world
     j1 = (m_total * (rank + 1)) // world
@@ -508,8 +575,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline(ba, gb, n, a.cpu_sample_cols)
             log("cpu baseline done")
         if not a.no_ingest:
-            out["ingest"] = ingest(ba, L, n, a.ingest_gb)
+            out["ingest"] = ingest(ba, L, n, a.ingest_gb, cold_hook=(lambda path, nn, mm: cold_record(a, path, nn, mm)) if cold else None)
+            if cold is not None and isinstance(out["ingest"], dict) and "cold" in out["ingest"]:
+                cold["real_bed_file"] = out["ingest"].pop("cold")
             log("ingest done")
+        if cold is not None:
+            out["cold"] = cold
     if comm is not None:
         sync()
         comm.close()
@@ -710,7 +781,7 @@ def download_cols(ba, gb, m_s):
     return out
 
 
-def ingest(ba, L, n, gb_size):
+def ingest(ba, L, n, gb_size, cold_hook=None):
     """bsn_bed_open on a real file: header check, parallel pread into two pinned buffers, 2-D DMA into
     the padded image, device-side recode.  The file holds the first columns of the benchmark matrix."""
     import numpy as np
@@ -742,7 +813,13 @@ def ingest(ba, L, n, gb_size):
             times.append(time.perf_counter() - t0)
             L.bsn_bed_close(h)
         size = 3 + n_byte * m_f
-        return {"file_GB": size / 1e9, "seconds": times, "GBps": size / 1e9 / min(times),
+        cold = None
+        if cold_hook is not None:   # a fresh process opens THIS file and solves on it (this process holds no handle on it now)
+            cold = cold_hook(path, n, m_f)
+            if isinstance(cold, dict) and "handle_s" in cold:
+                cold["open_ms"] = 1e3 * cold.pop("handle_s")
+                cold["file"] = "%d x %d .bed, %.1f GB, page cache warm" % (n, m_f, size / 1e9)
+        return {"cold": cold, "file_GB": size / 1e9, "seconds": times, "GBps": size / 1e9 / min(times),
                 "projected_s_for_100GB": 100.0 / (size / 1e9 / min(times)),
                 "note": "bsn_bed_open of a %.1f GB .bed written by this process (page cache warm); paid once per "
                         "handle, never part of `value`" % (size / 1e9)}

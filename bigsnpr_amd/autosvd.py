@@ -17,7 +17,7 @@ the tests assert the behavioural properties of tests/testthat/test-2-autoSVD.R i
 import numpy as np
 
 from .bed import ERROR_DIM, assert_lengths, bed_MAF, bed_scaleBinom, cols_along, rows_along
-from .ld import _ind, bed_clumping, big_randomSVD, snp_clumping, snp_MAF, snp_scaleBinom
+from .ld import _ind, bed_clumping, big_randomSVD, chr_groups, snp_clumping, snp_MAF, snp_scaleBinom
 from .svd import bed_randomSVD
 
 
@@ -324,7 +324,9 @@ def _auto_svd(svd_fun, clump_fun, maf_nok, ind_col, infos_chr, infos_pos, thr_r2
         printf2("\nSkipping clumping.\n")
     else:
         printf2("\nPhase of clumping (on %s) at r^2 > %s.. ", maf_nok[3], thr_r2)
-        excl = np.setdiff1d(np.arange(n_all_cols), ind_keep)
+        gone = np.ones(n_all_cols, dtype=bool)      # setdiff(seq_len(ncol), ind.keep) without sorting a million indices
+        gone[ind_keep] = False
+        excl = np.nonzero(gone)[0]
         ind_keep = clump_fun(excl)
         printf2("keep %d variants.\n", ind_keep.size)
 
@@ -341,8 +343,7 @@ def _auto_svd(svd_fun, clump_fun, maf_nok, ind_col, infos_chr, infos_pos, thr_r2
         S = np.sqrt(dist_ogk(obj["v"], device=obj["v"].shape[1] <= 64))
         S2 = np.full(S.size, np.nan)
         chr_keep = infos_chr[ind_keep]
-        for c in np.unique(chr_keep):
-            idx = np.nonzero(chr_keep == c)[0]
+        for _c, idx in chr_groups(chr_keep):
             S2[idx] = rollmean(S[idx], roll_size)
         thr = tukey_mc_up(S2, alpha=alpha_tukey, device=True)
         excl = np.nonzero(S2 > thr)[0]

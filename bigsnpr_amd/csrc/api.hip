@@ -10,6 +10,7 @@
 #include <cerrno>
 #include <cmath>
 #include <condition_variable>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -134,9 +135,12 @@ void *dev_alloc(size_t bytes, size_t *granted, int *device) {
     }
   }
   static const bool trace = getenv("BSN_ALLOC_TRACE") != nullptr;  // every real allocation on stderr
-  if (trace) std::fprintf(stderr, "[bsn alloc] hipMalloc %zu bytes (asked %zu)\n", want, bytes);
   void *p = nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(&p, want);
+  if (trace)
+    std::fprintf(stderr, "[bsn alloc] hipMalloc %zu bytes (asked %zu): %.2f ms\n", want, bytes,
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   if (e == hipErrorOutOfMemory) {  // give the cached blocks back and try once more
     (void)hipGetLastError();
     dev_cache_flush();
@@ -189,7 +193,7 @@ void dev_cache_flush() {
 
 constexpr size_t kStagePiece = 32u << 20;
 
-static void stage_init(bsn_bed *b) {
+void stage_init(bsn_bed *b) {
   for (int i = 0; i < 2; i++) {
     if (!b->h_stage[i]) BSN_HIP(hipHostMalloc((void **)&b->h_stage[i], kStagePiece, hipHostMallocDefault));
     if (!b->ev_stage[i]) BSN_HIP(hipEventCreateWithFlags(&b->ev_stage[i], hipEventDisableTiming));
@@ -375,6 +379,9 @@ void bed_free(bsn_bed *b) {
   for (int i = 0; i < 2; i++) {
     if (b->h_stage[i]) (void)hipHostFree(b->h_stage[i]);
     if (b->ev_stage[i]) (void)hipEventDestroy(b->ev_stage[i]);
+  }
+  if (b->smaj_job) {   // a background build of the sample-major copy reads d_img: let it end before the image goes
+    try { image_smaj_wait(b); } catch (...) {}
   }
   if (b->d_img) (void)hipFree(b->d_img);
   if (b->map_base) (void)munmap(b->map_base, b->map_len);
@@ -947,6 +954,7 @@ int bsn_bed_release_workspace(bsn_bed *bed) {
       bed->d_tiled = nullptr;
     }
     bed->tiled_tried = false;
+    image_smaj_wait(bed);   // (a build in flight is adopted first, then freed with the rest)
     if (bed->d_smaj) {  // likewise the sample-major copy
       BSN_HIP(hipFree(bed->d_smaj));
       bed->d_smaj = nullptr;
@@ -1444,6 +1452,31 @@ static void convert_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const 
                          int64_t m, uint8_t *out, bool packed) {
   if (n <= 0 || m <= 0) fail("'ind.row' and 'ind.col' can't be empty.");
   BSN_HIP(hipSetDevice(bed->device));
+  if (bed->streamed()) {
+    // (round 6) out of core: a column of the result depends on ONE variant, so the selected variants are served slab by
+    // slab of the file (the reference maps the file and walks it: src/read-plink.cpp:61-80, src/write-plink.cpp:13-52);
+    // every slab's columns go to their places in the caller's array — byte-identical to the resident conversion
+    auto r = to_i32(ind_row, n, bed->n, "ind.row");
+    const size_t col_bytes = packed ? (size_t)((n + 3) / 4) : (size_t)n;
+    SlabWalk walk(bed);
+    DevBuf<int32_t> d_r, d_c;
+    DevBuf<uint8_t> d_o;
+    std::vector<uint8_t> h_o;
+    copy_h2d(bed, d_r.ensure((size_t)n), r.data(), (size_t)n * 4);
+    walk.run(ind_col, m, [&](bsn_bed *img, const std::vector<int64_t> &P, const std::vector<int64_t> &local) {
+      const int64_t ml = (int64_t)P.size();
+      auto c = to_i32(local.data(), ml, img->m, "ind.col");
+      copy_h2d(bed, d_c.ensure((size_t)ml), c.data(), (size_t)ml * 4);
+      d_o.ensure(col_bytes * (size_t)ml);
+      if (packed) subset_pack(img, d_r.p, n, d_c.p, ml, d_o.p);
+      else to_bytes(img, d_r.p, n, d_c.p, ml, d_o.p);
+      h_o.resize(col_bytes * (size_t)ml);
+      copy_d2h(bed, h_o.data(), d_o.p, h_o.size());
+      BSN_HIP(hipStreamSynchronize(bed->stream));
+      for (int64_t t = 0; t < ml; t++) std::memcpy(out + (size_t)P[(size_t)t] * col_bytes, h_o.data() + (size_t)t * col_bytes, col_bytes);
+    });
+    return;
+  }
   auto r = to_i32(ind_row, n, bed->n, "ind.row");
   auto c = to_i32(ind_col, m, bed->m, "ind.col");
   DevBuf<int32_t> d_r, d_c;
@@ -1471,6 +1504,19 @@ int bsn_bed_readbina(bsn_bed *bed, const uint8_t *tab, uint8_t *out) {
     BSN_HIP(hipSetDevice(bed->device));
     DevBuf<uint8_t> d_tab, d_o;
     copy_h2d(bed, d_tab.ensure(1024), tab, 1024);
+    if (bed->streamed()) {   // (round 6) out of core: slab by slab of the file, each slab's n x cnt bytes to its place
+      const int64_t nslab = slab_count(bed);
+      for (int64_t sl = 0; sl < nslab; sl++) {
+        int64_t j0 = 0;
+        const int64_t cnt = slab_upload(bed, sl, &j0);
+        bsn_bed *img = slab_image(bed);
+        const size_t bytes = (size_t)bed->n * (size_t)cnt;
+        readbina_bytes(img, d_tab.p, d_o.ensure(bytes));
+        copy_d2h(bed, out + (size_t)j0 * (size_t)bed->n, d_o.p, bytes);
+        BSN_HIP(hipStreamSynchronize(bed->stream));
+      }
+      return;
+    }
     const size_t bytes = (size_t)bed->n * (size_t)bed->m;
     readbina_bytes(bed, d_tab.p, d_o.ensure(bytes));
     copy_d2h(bed, out, d_o.p, bytes);

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <functional>
+#include <cstdlib>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -15,6 +16,18 @@
 #include "bigsnpr_hip.h"
 
 namespace bsn {
+// Switches that only exist in the PROFILING build (python -m bigsnpr_amd.build --ablation, libbigsnpr_hip_abl.so): experiments
+// whose records are under profiles/ (BSN_ZQ_SPLIT, BSN_START_SLICES, BSN_LD_NOFUSE, BSN_LD_NO_SHARED_DECODE,
+// BSN_TCROSS_WAVES) beside BSN_TUNE / BSN_KY / BSN_KY_T / BSN_NB3 / BSN_DIGITS.  The product library does not read them
+// (README.md lists the switches it does read).
+inline const char *abl_getenv(const char *name) {
+#ifdef BSN_ABLATION
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 // ---- errors ----------------------------------------------------------------
 struct Error : std::runtime_error {
@@ -172,6 +185,7 @@ struct bsn_op {
   int prof_kind_override = -1;  // >= 0: every launch is filed under this kind (3 = warm-start launches on a subset)
   std::vector<hipEvent_t> ev_begin, ev_end;
   std::vector<int> ev_kind;
+  std::vector<char> ev_more;   // 1: a further piece of the previous launch (prof_begin)
   const void *prof_kernel[kProfKinds] = {};  // host stub of the last kernel launched under each kind
   ~bsn_op() {
     for (auto e : ev_begin) (void)hipEventDestroy(e);
@@ -247,6 +261,10 @@ struct bsn_bed {
   int64_t pitch_smaj = 0, rows_smaj = 0;
   bool smaj_tried = false;
   size_t smaj_cap = 0;              // bytes of the d_smaj allocation
+  // (round 6) the copy being made BESIDE the first solve that wants it (image.hip, image_smaj_start): a helper thread
+  // allocates it and queues k_smaj_build on a stream of its own; the passes of the solve take k_prod until an event says
+  // the copy is complete (image_smaj_poll) — same integer sums either way.  nullptr: no build in flight.
+  void *smaj_job = nullptr;         // bsn::SmajJob
   int64_t cap_m = 0;                // variants the d_img allocation holds (image_alloc)
   // Compacted sub-image (round 5, svd.hip compacted_view): a solve over a NON-contiguous list of variants — every
   // solve of bed_autoSVD / snp_autoSVD, whose ind.col is the clumped set (R/autoSVD.R:296-301) — runs on a gathered
@@ -294,6 +312,7 @@ namespace bsn {
 
 // image.hip
 void image_alloc(bsn_bed *b, int64_t n, int64_t m, int bits = 2);
+void stage_init(bsn_bed *b);   // api.hip: the two page-locked staging buffers of copy_h2d / copy_d2h (made with a large image, else on first use)
 void bed_free(bsn_bed *b);  // api.hip: everything a handle owns
 // a new handle holding the sub-matrix [ind_row, ind_col] (rows in list order, repeats allowed), same coding
 // `reuse`: a handle made by an earlier call whose allocation holds the new sub-matrix (same number of samples, at
@@ -301,7 +320,12 @@ void bed_free(bsn_bed *b);  // api.hip: everything a handle owns
 bsn_bed *image_gather(bsn_bed *src, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
                       bsn_bed *reuse = nullptr);
 bool image_tile(bsn_bed *b);  // true when the streaming-layout copy exists (builds it if memory allows)
-bool image_smaj(bsn_bed *b);  // true when the sample-major copy exists (builds it if memory allows)
+bool image_smaj(bsn_bed *b);  // true when the sample-major copy exists (builds it if memory allows; waits for a build in flight)
+// Non-blocking forms (round 6): start the build beside whatever the caller queues next — true when the copy exists or is on
+// its way —, ask whether it has arrived (cheap: an atomic and at most one hipEventQuery), wait for a build in flight.
+bool image_smaj_start(bsn_bed *b);
+bool image_smaj_poll(bsn_bed *b);
+void image_smaj_wait(bsn_bed *b);
 void image_from_host(bsn_bed *b, const uint8_t *payload, int64_t n_byte_src);
 // the two page-locked staging buffers (+ their events) of image_from_file; a caller that uploads many pieces (the slabs of an
 // out-of-core handle) keeps one set alive instead of paying two hipHostMalloc of 256 MB per piece
@@ -431,7 +455,7 @@ struct RoctxRange {
 };
 // api.hip: fails with the reason when `b` is an out-of-core handle (bsn_bed::streamed)
 void require_resident(const bsn_bed *b, const char *what);
-void prof_begin(bsn_op *op, int kind);
+void prof_begin(bsn_op *op, int kind, bool more = false);
 void prof_end(bsn_op *op);
 // sums the recorded launches: ms[kind], count[kind]; clears the records
 // kind 2: k_cprod carrying the code counts; 3: warm start; 4 / 5: the three-column-block launches of k_cprod / k_prodT

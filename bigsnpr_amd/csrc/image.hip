@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -64,6 +65,9 @@ void image_alloc(bsn_bed *b, int64_t n, int64_t m, int bits) {
   size_t bytes = (size_t)(m + kPadRows) * (size_t)b->pitch;
   BSN_HIP(hipMalloc((void **)&b->d_img, bytes));
   b->cap_m = m;
+  // a large image gets its page-locked staging buffers now (2 x 32 MB, ~ 12 ms): every entry point that moves host data
+  // needs them, and the first call on the handle — the one callers time — should not be the one that makes them
+  if (bytes >= ((size_t)1 << 30)) stage_init(b);
 }
 
 // ---- streaming layout (second copy) --------------------------------------------------------
@@ -184,18 +188,141 @@ __global__ __launch_bounds__(512) void k_smaj_build(const uint8_t *__restrict__ 
   }
 }
 
-static void smaj_launch(bsn_bed *b, int64_t pitch_t, int64_t rows_t) {
-  b->pitch_smaj = pitch_t;
-  b->rows_smaj = rows_t;
+static void smaj_launch(bsn_bed *b, int64_t pitch_t, int64_t rows_t, uint8_t *dst = nullptr, hipStream_t st = nullptr) {
+  if (!dst) {   // (the handle's own copy on the handle's stream; a background build passes its pending buffer and stream)
+    b->pitch_smaj = pitch_t;
+    b->rows_smaj = rows_t;
+  }
   const int64_t nvb = pitch_t * 4 / 512;
   const int64_t gy = nvb < 65535 ? nvb : 65535, gz = (nvb + 65534) / 65535;
-  hipLaunchKernelGGL(k_smaj_build, dim3((unsigned)(rows_t / 256), (unsigned)gy, (unsigned)gz), dim3(512), 0, b->stream,
-                     b->d_img, b->pitch, b->m, b->d_smaj, pitch_t, rows_t);
+  hipLaunchKernelGGL(k_smaj_build, dim3((unsigned)(rows_t / 256), (unsigned)gy, (unsigned)gz), dim3(512), 0, st ? st : b->stream,
+                     b->d_img, b->pitch, b->m, dst ? dst : b->d_smaj, pitch_t, rows_t);
   BSN_HIP(hipGetLastError());
+}
+
+static bool smaj_room(bsn_bed *b, size_t bytes) {
+  // leave room for the workspace of a solve and for the other entry points' buffers
+  size_t free_b = 0, total_b = 0;
+  BSN_HIP(hipMemGetInfo(&free_b, &total_b));
+  return (double)(free_b + dev_cache_held()) >= (double)bytes + 24e9;
+}
+
+// ---- the copy made beside the first solve (round 6) ---------------------------------------------------
+// The reference's unit of work is ONE bed_randomSVD on a freshly opened object (R/autoSVD.R:205-219).  Building the copy
+// inside that call cost 50 ms of transposition plus the allocation of 100 GB (50 ms .. 1.8 s depending on the box) before
+// the first pass could start.  Now a helper thread allocates and queues k_smaj_build on a low-priority stream of its own,
+// behind an event that marks what the handle's stream had queued (the image itself: generation, upload, gather); the
+// passes of the solve that would read the copy take k_prod<2> on the variant-major image until an event says it is
+// complete — the same integer sums (tests/test_gpu_smaj.py) — and k_prodT from then on.
+struct SmajJob {
+  std::thread th;
+  std::atomic<int> state{0};   // 0 the thread is allocating, 1 build queued (ev marks its end), 2 failed (no room / no memory)
+  uint8_t *buf = nullptr;
+  size_t bytes = 0;
+  int64_t pitch_t = 0, rows_t = 0;
+  hipStream_t st = nullptr;
+  hipEvent_t ev = nullptr, ev_img = nullptr;
+};
+
+static void smaj_job_finish(bsn_bed *b, bool adopt) {
+  SmajJob *j = (SmajJob *)b->smaj_job;
+  if (!j) return;
+  if (j->th.joinable()) j->th.join();
+  if (j->state.load() == 1) (void)hipEventSynchronize(j->ev);
+  if (adopt && j->state.load() == 1 && !b->d_smaj) {
+    b->d_smaj = j->buf;
+    b->smaj_cap = j->bytes;
+    b->pitch_smaj = j->pitch_t;
+    b->rows_smaj = j->rows_t;
+    j->buf = nullptr;
+  }
+  if (j->buf) (void)hipFree(j->buf);
+  if (j->ev) (void)hipEventDestroy(j->ev);
+  if (j->ev_img) (void)hipEventDestroy(j->ev_img);
+  if (j->st) (void)hipStreamDestroy(j->st);
+  delete j;
+  b->smaj_job = nullptr;
+}
+
+void image_smaj_wait(bsn_bed *b) { smaj_job_finish(b, true); }
+
+bool image_smaj_poll(bsn_bed *b) {
+  if (b->d_smaj) return true;
+  SmajJob *j = (SmajJob *)b->smaj_job;
+  if (!j) return false;
+  const int st = j->state.load(std::memory_order_acquire);
+  if (st == 0) return false;
+  if (st == 1 && hipEventQuery(j->ev) != hipSuccess) {
+    (void)hipGetLastError();   // (hipErrorNotReady is not an error of this thread)
+    return false;
+  }
+  smaj_job_finish(b, true);
+  return b->d_smaj != nullptr;
+}
+
+bool image_smaj_start(bsn_bed *b) {
+  if (b->d_smaj) return true;
+  if (b->smaj_job) return ((SmajJob *)b->smaj_job)->state.load() != 2 || image_smaj_poll(b);
+  if (b->streamed()) return false;
+  if (b->smaj_tried || b->bits != 2 || getenv("BSN_NO_SMAJ")) return false;
+  b->smaj_tried = true;
+  BSN_HIP(hipSetDevice(b->device));
+  const int64_t pitch_t = round_up((b->m + 3) / 4 + 128, 256), rows_t = round_up(b->n, 256);
+  if (rows_t / 4 > b->pitch) return false;
+  const size_t bytes = (size_t)rows_t * (size_t)pitch_t;
+  if (!smaj_room(b, bytes)) return false;
+  SmajJob *j = new SmajJob();
+  j->bytes = bytes;
+  j->pitch_t = pitch_t;
+  j->rows_t = rows_t;
+  try {
+    int lo = 0, hi = 0;
+    BSN_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least priority
+    BSN_HIP(hipStreamCreateWithPriority(&j->st, hipStreamNonBlocking, lo));
+    BSN_HIP(hipEventCreateWithFlags(&j->ev, hipEventDisableTiming));
+    BSN_HIP(hipEventCreateWithFlags(&j->ev_img, hipEventDisableTiming));
+    BSN_HIP(hipEventRecord(j->ev_img, b->stream));        // the image is complete behind this point of the handle's stream
+  } catch (...) {
+    if (j->ev) (void)hipEventDestroy(j->ev);
+    if (j->ev_img) (void)hipEventDestroy(j->ev_img);
+    if (j->st) (void)hipStreamDestroy(j->st);
+    delete j;
+    throw;
+  }
+  b->smaj_job = j;
+  const int device = b->device;
+  j->th = std::thread([b, j, device] {
+    const auto t0 = std::chrono::steady_clock::now();
+    bool ok = hipSetDevice(device) == hipSuccess && hipMalloc((void **)&j->buf, j->bytes) == hipSuccess;
+    if (getenv("BSN_ALLOC_TRACE"))
+      std::fprintf(stderr, "[bsn alloc] sample-major copy, helper thread: hipMalloc of %zu bytes %s after %.1f ms\n", j->bytes,
+                   ok ? "returned" : "FAILED", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    if (ok) {
+      ok = hipStreamWaitEvent(j->st, j->ev_img, 0) == hipSuccess;
+      if (ok) {
+        const int64_t nvb = j->pitch_t * 4 / 512;
+        const int64_t gy = nvb < 65535 ? nvb : 65535, gz = (nvb + 65534) / 65535;
+        hipLaunchKernelGGL(k_smaj_build, dim3((unsigned)(j->rows_t / 256), (unsigned)gy, (unsigned)gz), dim3(512), 0, j->st,
+                           b->d_img, b->pitch, b->m, j->buf, j->pitch_t, j->rows_t);
+        ok = hipGetLastError() == hipSuccess && hipEventRecord(j->ev, j->st) == hipSuccess;
+      }
+    }
+    if (!ok) {
+      (void)hipGetLastError();
+      if (j->buf) (void)hipFree(j->buf);
+      j->buf = nullptr;
+    }
+    j->state.store(ok ? 1 : 2, std::memory_order_release);
+  });
+  return true;
 }
 
 bool image_smaj(bsn_bed *b) {
   if (b->d_smaj) return true;
+  if (b->smaj_job) {   // a build in flight: wait for it
+    smaj_job_finish(b, true);
+    return b->d_smaj != nullptr;
+  }
   if (b->streamed()) return false;
   if (b->smaj_tried || b->bits != 2 || getenv("BSN_NO_SMAJ")) return false;
   b->smaj_tried = true;
@@ -203,10 +330,7 @@ bool image_smaj(bsn_bed *b) {
   const int64_t pitch_t = round_up((b->m + 3) / 4 + 128, 256), rows_t = round_up(b->n, 256);
   if (rows_t / 4 > b->pitch) return false;   // (never: pitch = ceil(n / 4) rounded up to 256 B)
   const size_t bytes = (size_t)rows_t * (size_t)pitch_t;
-  // leave room for the workspace of a solve and for the other entry points' buffers
-  size_t free_b = 0, total_b = 0;
-  BSN_HIP(hipMemGetInfo(&free_b, &total_b));
-  if ((double)(free_b + dev_cache_held()) < (double)bytes + 24e9) return false;
+  if (!smaj_room(b, bytes)) return false;
   if (hipMalloc((void **)&b->d_smaj, bytes) != hipSuccess) {
     (void)hipGetLastError();
     b->d_smaj = nullptr;
@@ -220,6 +344,7 @@ bool image_smaj(bsn_bed *b) {
 // the image changed in place (image_gather with `reuse`): an existing sample-major copy is rebuilt inside its
 // allocation when it fits, dropped otherwise (the next solve asks for a new one)
 static void smaj_refresh(bsn_bed *b) {
+  image_smaj_wait(b);   // (a build in flight read the image that was just replaced: finish it, then rebuild inside its allocation)
   b->smaj_tried = false;
   if (!b->d_smaj) return;
   const int64_t pitch_t = round_up((b->m + 3) / 4 + 128, 256), rows_t = round_up(b->n, 256);
@@ -910,6 +1035,7 @@ bsn_bed *image_gather(bsn_bed *src, const int64_t *ind_row, int64_t n, const int
   std::unique_ptr<bsn_bed, void (*)(bsn_bed *)> fresh(nullptr, bed_free);
   bsn_bed *b = reuse;
   if (in_place) {
+    image_smaj_wait(b);   // a background build of the copy still reads the selection that is about to be overwritten
     BSN_HIP(hipStreamSynchronize(b->stream));
     b->m = m;
     b->na_cnt.clear();

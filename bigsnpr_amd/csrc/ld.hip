@@ -1238,7 +1238,7 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
     g_ld_stats = ls;
     return;
   }
-  if (!xy_only && J.contig && J.use_mask && J.npairs_b >= 1024 && !getenv("BSN_LD_NO_SHARED_DECODE")) {
+  if (!xy_only && J.contig && J.use_mask && J.npairs_b >= 1024 && !abl_getenv("BSN_LD_NO_SHARED_DECODE")) {
     // enough blocks to fill the chip without a K split: the kernel that shares the column operand's decode
     for (int64_t p0 = qA; p0 < qB; p0 += batch) {
       const int64_t np = std::min(batch, qB - p0);
@@ -1275,7 +1275,7 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
     if (ksplit < 1) ksplit = 1;
     int64_t kbytes = round_up((bed->pitch + ksplit - 1) / ksplit, 64);
     ksplit = (int)((bed->pitch + kbytes - 1) / kbytes);
-    const bool fused = !xy_only && ksplit == 1 && !getenv("BSN_LD_NOFUSE");   // (A/B switch: K split + k_band_fill)
+    const bool fused = !xy_only && ksplit == 1 && !abl_getenv("BSN_LD_NOFUSE");   // (A/B switch: K split + k_band_fill)
     if (!fused) {
       J.d_stats.ensure((size_t)std::min(batch, J.npairs) * 6 * TB * TB);
       if (ksplit > 1 || xy_only) BSN_HIP(hipMemsetAsync(J.d_stats.p, 0, (size_t)np * 6 * TB * TB * 4, bed->stream));
@@ -1754,6 +1754,94 @@ static int64_t clump_bits(bsn_bed *bed, const int64_t *ind_row, int64_t n, const
   return Wq;
 }
 
+// (round 6) the same bit images for an OUT-OF-CORE handle (the reference maps a file of any size and clumps on it:
+// src/clumping-bed.cpp:11-91, src/bed-acc.h:46).  A bit of bitsL / bitsU is RELATIVE to its variant (bit i of bitsL[j0] =
+// neighbour j0 - 1 - i, of bitsU[j0] = neighbour j0 + 1 + i), so the images can be made run by run: a run of target
+// variants is uploaded with the window halo on both sides into the resident slab image (as bed_ld_scores does), its band
+// is computed and thresholded there by the resident code, and the rows of the targets are kept.  The rank-ordered sweep
+// then runs on the host over the whole chromosome exactly as for a resident image: identical indices.
+// cols == nullptr / contiguous: runs of the file; an arbitrary list (the batches of the wide-window path): the listed
+// variants are gathered from the mapped file into the slab image, which must hold them.
+static int64_t clump_bits_streamed(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                                   int mode, const double *aux1, const double *aux2, const double *pos, double size,
+                                   const std::vector<double> &uthr, std::vector<std::vector<u64>> &bitsL,
+                                   std::vector<std::vector<u64>> &bitsU) {
+  auto col = [&](int64_t t) -> int64_t { return ind_col ? ind_col[t] : t; };
+  bool increasing = true;
+  for (int64_t t = 0; t < m; t++) {
+    if (col(t) < 0 || col(t) >= bed->m) fail("Tested %lld < %lld. Subscript out of bounds (ind.col).", (long long)col(t), (long long)bed->m);
+    if (t > 0 && col(t) <= col(t - 1)) increasing = false;
+    if (t > 0 && pos[t] < pos[t - 1]) fail("'pos' is not sorted.");
+  }
+  std::vector<int64_t> nL, nU;
+  window_counts(pos, m, size, nL, nU);
+  int64_t Wg = 1;
+  for (int64_t j = 0; j < m; j++) Wg = std::max(Wg, std::max(nL[(size_t)j], nU[(size_t)j]));
+  const int64_t Wq = (Wg + 63) / 64;
+  bitsL.assign(uthr.size(), std::vector<u64>((size_t)m * (size_t)Wq, 0ull));
+  bitsU.assign(uthr.size(), std::vector<u64>((size_t)m * (size_t)Wq, 0ull));
+  const int64_t cap = bed->slab_cols;
+  bsn_bed *img = slab_image(bed);
+  std::vector<int64_t> loc;
+  std::vector<std::vector<u64>> bl, bu;
+  std::vector<uint8_t> gathered;
+  int64_t a = 0;
+  while (a < m) {
+    int64_t lo = a;
+    while (lo > 0 && pos[lo - 1] >= pos[a] - size) lo--;
+    // the longest run of targets [a, b) whose halo still fits the slab image (by count: a run whose file span fits too is
+    // read as one contiguous piece, any other is gathered variant by variant from the mapped file)
+    int64_t b = a, hi = a, h_fail = a;
+    for (;;) {
+      int64_t h = std::max(hi, b);
+      while (h + 1 < m && pos[h + 1] <= pos[b] + size) h++;
+      if (h - lo + 1 > cap) {
+        h_fail = h;
+        break;
+      }
+      hi = h;
+      b++;
+      if (b >= m) break;
+    }
+    if (b == a)
+      fail("clumping window around variant %lld holds %lld variants: more than the %lld of the out-of-core slab image; raise "
+           "BSN_IMAGE_BUDGET or use a smaller window", (long long)col(a), (long long)(h_fail - lo + 1), (long long)cap);
+    const int64_t ml = hi - lo + 1;
+    loc.resize((size_t)ml);
+    if (increasing && col(hi) - col(lo) + 1 <= cap) {
+      const int64_t base = col(lo), cnt = col(hi) - base + 1;
+      slab_upload_range(bed, base, cnt);
+      for (int64_t t = 0; t < ml; t++) loc[(size_t)t] = col(lo + t) - base;
+    } else {   // gather from the mapped file (pageable: staged by the runtime), in list order
+      gathered.resize((size_t)ml * (size_t)bed->n_byte);
+      for (int64_t t = 0; t < ml; t++)
+        std::memcpy(gathered.data() + (size_t)t * (size_t)bed->n_byte, bed->h_map + (size_t)col(lo + t) * (size_t)bed->n_byte, (size_t)bed->n_byte);
+      img->m = ml;
+      img->na_cnt.clear();
+      image_from_host(img, gathered.data(), bed->n_byte);
+      for (int64_t t = 0; t < ml; t++) loc[(size_t)t] = t;
+    }
+    // (a row list with repeated samples: the run is gathered once more, rows included, like the resident entry does)
+    const RowView rv = row_view(img, ind_row, n, loc.data(), ml);
+    const int64_t wq = clump_bits(rv.bed, rv.ind_row, n, rv.ind_col, ml, mode, aux1 + lo, aux2 + lo, pos + lo, size, uthr, bl, bu);
+    const int64_t wc = std::min(wq, Wq);
+    for (size_t t = 0; t < uthr.size(); t++)
+      for (int64_t j = a; j < b; j++) {
+        std::memcpy(&bitsL[t][(size_t)j * (size_t)Wq], &bl[t][(size_t)(j - lo) * (size_t)wq], (size_t)wc * 8);
+        std::memcpy(&bitsU[t][(size_t)j * (size_t)Wq], &bu[t][(size_t)(j - lo) * (size_t)wq], (size_t)wc * 8);
+      }
+    a = b;
+  }
+  return Wq;
+}
+static int64_t clump_bits_any(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t *ind_col, int64_t m,
+                              int mode, const double *aux1, const double *aux2, const double *pos, double size,
+                              const std::vector<double> &uthr, std::vector<std::vector<u64>> &bitsL,
+                              std::vector<std::vector<u64>> &bitsU) {
+  return bed->streamed() ? clump_bits_streamed(bed, ind_row, n, ind_col, m, mode, aux1, aux2, pos, size, uthr, bitsL, bitsU)
+                         : clump_bits(bed, ind_row, n, ind_col, m, mode, aux1, aux2, pos, size, uthr, bitsL, bitsU);
+}
+
 // widest window, in variants, of a two-sided window of `size`
 static int64_t window_width(const double *pos, int64_t m, double size) {
   std::vector<int64_t> lo;
@@ -1790,8 +1878,13 @@ static void clump_lazy(bsn_bed *bed, const int64_t *ind_row, int64_t n, const in
       sub_pos.resize(L.size());
       for (size_t i = 0; i < L.size(); i++) sub_pos[i] = pos[L[i]];
       const int64_t Wsub = window_width(sub_pos.data(), (int64_t)L.size(), size);
-      if ((double)L.size() * (double)Wsub * 8.0 <= budget_bytes) break;
+      // (an out-of-core handle: the kept variants and the batch, with their windows, also have to fit the slab image)
+      const bool fits_slab = !bed->streamed() || (int64_t)L.size() <= bed->slab_cols;
+      if ((double)L.size() * (double)Wsub * 8.0 <= budget_bytes && fits_slab) break;
       for (int64_t k = k_next; k < k_next + B; k++) in_batch[(size_t)ordInd[k]] = 0;
+      if (B <= 64 && !fits_slab)
+        fail("clumping: %lld kept variants and the next candidates are more than the %lld variants of the out-of-core slab image; "
+             "raise BSN_IMAGE_BUDGET or use a smaller window", (long long)n_kept, (long long)bed->slab_cols);
       if (B <= 64)
         fail("clumping: %lld kept variants within windows of up to %lld of them do not fit the device "
              "memory budget (%.1f GB); use a smaller window", (long long)n_kept, (long long)Wsub,
@@ -1809,8 +1902,8 @@ static void clump_lazy(bsn_bed *bed, const int64_t *ind_row, int64_t n, const in
       sub_a2[(size_t)i] = aux2[j];
       idx_in_L[(size_t)j] = i;
     }
-    const int64_t Wq = clump_bits(bed, ind_row, n, sub_cols.data(), ml, mode, sub_a1.data(), sub_a2.data(),
-                                  sub_pos.data(), size, uthr, bl, bu);
+    const int64_t Wq = clump_bits_any(bed, ind_row, n, sub_cols.data(), ml, mode, sub_a1.data(), sub_a2.data(),
+                                      sub_pos.data(), size, uthr, bl, bu);
     window_counts(sub_pos.data(), ml, size, nL, nU);
     KeptBits kb(ml);
     for (int64_t i = 0; i < ml; i++)
@@ -1855,7 +1948,11 @@ static void clumping_grid(bsn_bed *bed, const int64_t *ind_row, int64_t n, const
   std::vector<int64_t> dense;
   for (int64_t g = 0; g < n_grid; g++) {
     const int64_t Wg = window_width(pos, m, sizes[g]);
-    if ((double)m * (double)Wg * 8.0 <= budget)
+    // (an out-of-core handle makes its band run by run: at most one slab image's worth of variants at a time)
+    const int64_t mrows = bed->streamed() ? std::min(m, bed->slab_cols) : m;
+    // (... and a window that holds more variants than the slab image goes the way of the wide windows: kept variants + batch)
+    const bool window_fits = !bed->streamed() || 2 * Wg + 1 <= bed->slab_cols;
+    if ((double)mrows * (double)Wg * 8.0 <= budget && window_fits)
       dense.push_back(g);
     else
       clump_lazy(bed, ind_row, n, ind_col, m, mode, aux1, aux2, ordInd, pos, sizes[g], thrs[g], keep_out + g * m,
@@ -1874,7 +1971,7 @@ static void clumping_grid(bsn_bed *bed, const int64_t *ind_row, int64_t n, const
     thr_id[(size_t)g] = (int)t;
   }
   std::vector<std::vector<u64>> bitsL, bitsU;
-  const int64_t Wq = clump_bits(bed, ind_row, n, ind_col, m, mode, aux1, aux2, pos, size_max, uthr, bitsL, bitsU);
+  const int64_t Wq = clump_bits_any(bed, ind_row, n, ind_col, m, mode, aux1, aux2, pos, size_max, uthr, bitsL, bitsU);
   std::vector<int64_t> nL, nU;
   for (int64_t g : dense) {
     const u64 *BL = bitsL[(size_t)thr_id[(size_t)g]].data();
@@ -1896,6 +1993,10 @@ int bsn_clumping_chr(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int6
                      const int32_t *ordInd, const int32_t *rankInd, const double *pos, double size,
                      double thr, int32_t *keep) {
   return guarded([&] {
+    if (bed->streamed()) {   // (round 6) out of core: the band run by run on the slab image, the sweep on the host
+      clumping_grid(bed, ind_row, n, ind_col, m, mode, aux1, aux2, ordInd, rankInd, pos, 1, &size, &thr, keep);
+      return;
+    }
     const RowView rv = row_view(bed, ind_row, n, ind_col, m);
     clumping_grid(rv.bed, rv.ind_row, n, rv.ind_col, m, mode, aux1, aux2, ordInd, rankInd, pos, 1, &size, &thr, keep);
   });
@@ -1906,6 +2007,10 @@ int bsn_clumping_chr_cached(bsn_bed *bed, const int64_t *ind_row, int64_t n, con
                             const int32_t *ordInd, const int32_t *rankInd, const double *pos,
                             int64_t n_grid, const double *sizes, const double *thrs, int32_t *keep) {
   return guarded([&] {
+    if (bed->streamed()) {
+      clumping_grid(bed, ind_row, n, ind_col, m, mode, aux1, aux2, ordInd, rankInd, pos, n_grid, sizes, thrs, keep);
+      return;
+    }
     const RowView rv = row_view(bed, ind_row, n, ind_col, m);
     clumping_grid(rv.bed, rv.ind_row, n, rv.ind_col, m, mode, aux1, aux2, ordInd, rankInd, pos, n_grid, sizes, thrs,
                   keep);

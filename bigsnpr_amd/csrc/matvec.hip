@@ -1281,9 +1281,13 @@ void require_bits(const bsn_bed *b, int bits, const char *what) {
 }
 
 // ---------------------------------------------------------------------------
-void prof_begin(bsn_op *op, int kind) {
+// more = true: a further piece of the launch begun before (a product pass in segments: the kernels of its segments are
+// timed one by one — what lies between them, finalize kernels and the collective's hand-over, is not streaming time — and
+// count as ONE launch)
+void prof_begin(bsn_op *op, int kind, bool more) {
   if (!op->profile) return;
   if (op->prof_kind_override >= 0) kind = op->prof_kind_override;
+  op->ev_more.push_back(more);
   hipEvent_t a, b;
   BSN_HIP(hipEventCreate(&a));
   BSN_HIP(hipEventCreate(&b));
@@ -1305,7 +1309,7 @@ void prof_collect(bsn_op *op, double ms[kProfKinds], int count[kProfKinds]) {
     if (hipEventSynchronize(op->ev_end[i]) == hipSuccess &&
         hipEventElapsedTime(&t, op->ev_begin[i], op->ev_end[i]) == hipSuccess) {
       ms[op->ev_kind[i]] += t;
-      count[op->ev_kind[i]]++;
+      if (!op->ev_more[i]) count[op->ev_kind[i]]++;
     }
     (void)hipEventDestroy(op->ev_begin[i]);
     (void)hipEventDestroy(op->ev_end[i]);
@@ -1314,6 +1318,7 @@ void prof_collect(bsn_op *op, double ms[kProfKinds], int count[kProfKinds]) {
   op->ev_begin.clear();
   op->ev_end.clear();
   op->ev_kind.clear();
+  op->ev_more.clear();
 }
 
 // Column blocks of 16 digit columns per launch.  Three (48 columns: 16 vectors x 3 slices, the early steps of a solve
@@ -1881,6 +1886,7 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
   const int64_t npad = n_padded(b);
   // Two or three column blocks over a contiguous range of variants that starts on a 512-variant chunk, and the handle
   // has its sample-major copy: the product runs as k_prodT (k_cprod's shape, contraction over the contiguous index).
+  if (b->smaj_job) (void)image_smaj_poll(b);   // a copy being made beside this solve: has it arrived?
   const bool smaj_ok = b->bits == 2 && b->d_smaj != nullptr && op->cols_contig && (op->col0 & 511) == 0 && mode == 1 &&
                        lutP == kLutRaw && lutQ == kLutNA && !getenv("BSN_NO_SMAJ");
   const int vmax_smaj = std::min(kMetaVecs, (smaj_ok && nb3_allowed() && nvec * S > 32 ? kMaxCols : 32) / S);
@@ -1907,15 +1913,25 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
     }();
     wgx = (b->n + 511) / 512;
     const int64_t nchunks = m_pad / 512;
+    // ... less what the slabs cost: every slab writes its own n x 16 NB int32 partial sums and the finalize kernel reads them
+    // back — 0.15 % of the image's bytes per slab at 400K x 1M, 1.2 % on the 125 000-variant shard of an 8-GPU run, where
+    // 18 slabs (the best fill) measured 3.93 ms per pass against 3.80 - 3.82 with 8 - 10 (round 6, profiles/r06_shard_slabs.txt:
+    // the traffic weighs about 0.3 of its bytes — the writes drain beside the stream); the full-size choice (17) is unchanged
+    const double slab_cost = 0.3 * 2.0 * (double)npad * 16.0 * pick_nb((nvec < vmax ? nvec : vmax) * S) * 4.0 /
+                             ((double)m_pad * (double)(b->pitch));
     int best = 1;
-    double best_fill = 0.0;
+    double best_score = -1e300;
     for (int c = 1; c <= 24 && c <= nchunks; c++) {
       if (c < 6 && c < nchunks && nchunks >= 6) continue;
       const int64_t W = wgx * c;
       const double fill = (double)W / ((double)ncu * (double)((W + ncu - 1) / ncu));
-      if (fill > best_fill + 1e-9) best_fill = fill, best = c;
+      const double score = fill - slab_cost * c;
+      if (score > best_score + 1e-9) best_score = score, best = c;
     }
     ky = best;
+#ifdef BSN_ABLATION
+    if (const char *e = getenv("BSN_KY_T")) ky = std::max(1, std::min(atoi(e), (int)nchunks));  // slab sweep of k_prodT (correct results)
+#endif
     const int64_t ky_min2 = (m_pad + 2499999) / 2500000;
     if (ky < ky_min2) ky = (int)ky_min2;
     smaj_cps = (int)((nchunks + ky - 1) / ky);
@@ -2010,9 +2026,11 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
         for (int sidx = 0; sidx < sg->nseg; sidx++) {
           const ProdSegment &sgm = sg->segs[sidx];
           const dim3 gs((unsigned)(sg->pieces * sgm.bs), (unsigned)ky);
+          if (sidx > 0) prof_begin(op, NB == 3 ? 5 : 1, true);
           if (has_q) BSN_PRODT(true, 0, gs, sgm.bs, sg->stride, sgm.off);
           else BSN_PRODT(false, 0, gs, sgm.bs, sg->stride, sgm.off);
           BSN_HIP(hipGetLastError());
+          prof_end(op);
           const int64_t rows_s = (int64_t)sgm.bs * 512, tot = rows_s * sg->pieces;
           if (NB == 2)
             hipLaunchKernelGGL((k_prod_final<32>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, b->stream, acc, npad, ky,
@@ -2021,7 +2039,6 @@ static void prod_planes(bsn_op *op, const double *d_X, const double *d_W2, int64
             hipLaunchKernelGGL((k_prod_final<48>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, b->stream, acc, npad, ky,
                                S, nv, meta, sgm.d_rows, tot, sgm.d_out, (int64_t)0, sub_const, 0.0, rows_s);
           BSN_HIP(hipGetLastError());
-          if (sidx + 1 == sg->nseg) prof_end(op);
           (*sg->after)(sidx);
         }
         op->passes++;

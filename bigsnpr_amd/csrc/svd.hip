@@ -663,9 +663,37 @@ struct HipSvdBackend : SvdBackend {
   // Each pass moves the whole file over PCIe (about 40 GB/s against 4 - 5 TB/s from HBM): the solve is paced by the
   // link, 2.5 s per pass per 100 GB; what it buys is that no matrix is refused for its size.
   bool ooc = false;
+  // (round 6) a solve over a LIST of variants in file order (ind.col = ind.keep of bed_autoSVD, R/autoSVD.R:296-301): slab
+  // sl serves positions [sel_at[sl], sel_at[sl + 1]) of the list, sel_local = their indices inside the slab image
+  const int64_t *ooc_cols = nullptr;
+  std::vector<int64_t> sel_at, sel_local;
   std::unique_ptr<bsn_op> sop;        // the operator over the resident slab
   long long ooc_na_total = 0, ooc_n_bad = 0;
   bool ooc_stats_walk = false;        // this crossproduct walk also counts the codes (first full pass of the solve)
+  // positions [*at, *at + returned count) of the operator's variants live in slab sl (uploaded here); 0: none of them do
+  int64_t slab_selection(int64_t sl, int64_t *at) {
+    if (!ooc_cols) {
+      int64_t j0 = 0;
+      const int64_t cnt = slab_upload(op->bed, sl, &j0);
+      *at = j0;
+      sel_local.clear();
+      return cnt;
+    }
+    if (sel_at.empty()) {   // the list is in file order (checked by the entry point): one contiguous run of it per slab
+      const int64_t nslab = slab_count(op->bed), sc = op->bed->slab_cols;
+      sel_at.assign((size_t)nslab + 1, 0);
+      for (int64_t t = 0; t < m_local; t++) sel_at[(size_t)(ooc_cols[t] / sc) + 1]++;
+      for (int64_t q = 0; q < nslab; q++) sel_at[(size_t)q + 1] += sel_at[(size_t)q];
+    }
+    const int64_t a = sel_at[(size_t)sl], cnt = sel_at[(size_t)sl + 1] - a;
+    *at = a;
+    if (cnt <= 0) return 0;
+    int64_t j0 = 0;
+    slab_upload(op->bed, sl, &j0);
+    sel_local.resize((size_t)cnt);
+    for (int64_t t = 0; t < cnt; t++) sel_local[(size_t)t] = ooc_cols[a + t] - j0;
+    return cnt;
+  }
   void slab_operator(int64_t j0, int64_t cnt, bool with_scaling) {
     bsn_bed *img = slab_image(op->bed);
     if (!sop) sop.reset(new bsn_op());
@@ -675,6 +703,19 @@ struct HipSvdBackend : SvdBackend {
     sop->rows_identity = true;
     sop->cols_contig = true;
     sop->col0 = 0;
+    if (!sel_local.empty()) {   // a selection inside the slab: a range of it, or a gather list (padded like fill_op's)
+      bool contig = true;
+      for (int64_t t = 1; t < cnt && contig; t++) contig = sel_local[(size_t)t] == sel_local[0] + t;
+      sop->cols_contig = contig;
+      sop->col0 = contig ? sel_local[0] : 0;
+      if (!contig) {
+        const int64_t m_pad = round_up(cnt, 64);
+        std::vector<int32_t> c((size_t)m_pad, (int32_t)sel_local[0]);
+        for (int64_t t = 0; t < cnt; t++) c[(size_t)t] = (int32_t)sel_local[(size_t)t];
+        copy_h2d(op->bed, sop->d_cols.ensure((size_t)m_pad), c.data(), (size_t)m_pad * 4);
+        BSN_HIP(hipStreamSynchronize(st));   // (`c` is released on return)
+      }
+    }
     sop->no_na = false;
     sop->slices = op->slices;
     sop->profile = op->profile;
@@ -696,7 +737,8 @@ struct HipSvdBackend : SvdBackend {
     }
     for (int64_t sl = 0; sl < nslab; sl++) {
       int64_t j0 = 0;
-      const int64_t cnt = slab_upload(op->bed, sl, &j0);
+      const int64_t cnt = slab_selection(sl, &j0);
+      if (cnt <= 0) continue;
       slab_operator(j0, cnt, !stats);
       sop->stats_pending = stats;
       sop->na_poll = false;
@@ -724,11 +766,14 @@ struct HipSvdBackend : SvdBackend {
   }
   void A_Zblock_ooc(int p0, int cb) {
     const int64_t nslab = slab_count(op->bed);
+    bool first = true;
     for (int64_t sl = 0; sl < nslab; sl++) {
       int64_t j0 = 0;
-      const int64_t cnt = slab_upload(op->bed, sl, &j0);
+      const int64_t cnt = slab_selection(sl, &j0);
+      if (cnt <= 0) continue;
       slab_operator(j0, cnt, true);
-      op_prod_acc(sop.get(), Z.p + (int64_t)p0 * m_local + j0, m_local, cb, Wc, n, sl == 0 ? 0.0 : 1.0);
+      op_prod_acc(sop.get(), Z.p + (int64_t)p0 * m_local + j0, m_local, cb, Wc, n, first ? 0.0 : 1.0);
+      first = false;
       sync_stream();
     }
     op->passes++;
@@ -1331,15 +1376,21 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     const bool ooc = bed->streamed();
     if (ooc) {
       if (o->comm || o->allreduce) fail("an out-of-core handle cannot be one shard of a sharded solve: shard the file instead");
-      bool all = n == bed->n && m == bed->m;
-      for (int64_t i = 0; all && ind_row && i < n; i++) all = ind_row[i] == i;
-      for (int64_t j = 0; all && ind_col && j < m; j++) all = ind_col[j] == j;
-      if (!all)
+      bool all_rows = n == bed->n;
+      for (int64_t i = 0; all_rows && ind_row && i < n; i++) all_rows = ind_row[i] == i;
+      bool all_cols = m == bed->m, in_order = true;
+      for (int64_t j = 0; ind_col && j < m; j++) {
+        if (ind_col[j] != j) all_cols = false;
+        if (ind_col[j] < 0 || ind_col[j] >= bed->m) fail("Tested %lld < %lld. Subscript out of bounds (ind.col).", (long long)ind_col[j], (long long)bed->m);
+        if (j > 0 && ind_col[j] <= ind_col[j - 1]) in_order = false;
+      }
+      // (round 6) a LIST of variants in file order is served too — what bed_autoSVD solves over (ind.keep, sorted)
+      if (!all_rows || !in_order)
         fail("bed_randomSVD on an out-of-core handle (the file's image does not fit the device: it streams its file) "
-             "covers all samples and all variants; a subset small enough for the device is served by a handle of its own "
-             "(snp_subset / bsn_bed_subset_payload)");
+             "covers all samples, and its variants in increasing file order; a subset small enough for the device is served "
+             "by a handle of its own (snp_subset / bsn_bed_subset_payload)");
       ind_row = nullptr;
-      ind_col = nullptr;
+      if (all_cols) ind_col = nullptr;
     }
     // (round 5) a list of variants that is not a contiguous range: the solve runs on a compacted copy of the selection
     bool compacted = false;
@@ -1396,6 +1447,7 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     HipSvdBackend bk(*bed->svd_ws);
     bk.op = op;
     bk.ooc = ooc;
+    bk.ooc_cols = ooc ? ind_col : nullptr;
     bk.st = bed->stream;
     bk.n = n;
     bk.m_local = m;
@@ -1449,7 +1501,12 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       // precision schedule (svd_driver.hpp): wider panels for the early steps when the vectors are wanted beyond the floor
       // of `ss` digits; a caller who fixed the digits gets them at every step unless he also names a floor
       double vf = o->vec_floor;
-      if (vf == 0.0) vf = o->slices > 0 ? -1.0 : 2.5e-7;   // a quarter of north_star's 1e-6, as the digits sit a quarter below tol
+      // (round 6: 1e-7, a tenth of north_star's 1e-6.  Round 5's 2.5e-7 left the vectors the ARITHMETIC limits — small matrices
+      // that take 20 - 30 block steps, where the leading pairs converge far below tol — at 1.5 - 1.8e-6 on the oracle's
+      // shapes; 1e-7 keeps the panels at 24 bits one or two steps longer there (0.5 - 0.97e-6: what uniform 24-bit panels
+      // give) and leaves the 400K x 1M solve on the same three wide steps, its vectors being where the Lanczos process
+      // is at tol: profiles/r06_vectors_small.txt, r06_vectors_c3.txt)
+      if (vf == 0.0) vf = o->slices > 0 ? -1.0 : 1e-7;
       if (const char *e = getenv("BSN_VEC_FLOOR")) vf = atof(e);   // (A/B and the accuracy sweeps of the tests)
       so.slices_base = ss;
       so.slices_max = ss;
@@ -1464,12 +1521,12 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
       // pass — the one that also counts the codes — then carries `block` digit columns instead of twice as many
       // (16 vectors: one column block, 21 instead of 26 ms per 100 GB; same residuals, same vectors)
       so.slices_start = o->slices > 0 ? 0 : 1;
-      if (const char *e = getenv("BSN_START_SLICES")) so.slices_start = atoi(e);
+      if (const char *e = abl_getenv("BSN_START_SLICES")) so.slices_start = atoi(e);
       // columns standardised by bed_scaleBinom: a random vector is amplified by sqrt(n) (svd_driver.hpp)
       // (the product pass scheduled apart from the grids, svd_driver.hpp: measured at 400K x 1M — 12 ms saved, the
       // leading vectors at 9e-7 instead of 1.6e-7; at k = 10, 6e-6: the rounding of Z is heavier-tailed than the model,
       // so the split stays an experiment, BSN_ZQ_SPLIT=1)
-      so.noise_gain = (fused && getenv("BSN_ZQ_SPLIT")) ? std::sqrt((double)n) : 0.0;
+      so.noise_gain = (fused && abl_getenv("BSN_ZQ_SPLIT")) ? std::sqrt((double)n) : 0.0;
     }
     // a solve streams the image a dozen times: the ONE-block kernels, which are bound by HBM, get their layout (a
     // second copy in 64-variant x 256-B tiles, one extra pass of copying, kept on the handle) when the device has the
@@ -1482,7 +1539,20 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
     // only.  One second copy per handle: when the sample-major one is not to be had (no room, BSN_NO_SMAJ) the
     // one-block passes of the solve still get theirs.
     bool have_smaj = false;
-    if (so.block * so.slices_max > 16 && op->cols_contig && (op->col0 & 511) == 0 && m >= 4096) have_smaj = image_smaj(bed);
+    // (round 6) on one GPU the FIRST such solve of a handle runs without the copy — its product passes take k_prod<2>, the
+    // same sums, 55 ms more at 400K x 1M — and the copy is made BEHIND it (image_smaj_start at the end of this call: a helper
+    // thread allocates 100 GB and queues the transposition on a stream of its own while the caller looks at its result);
+    // later solves find it.  Inside the call the copy cost 90 ms (40 of allocation on an idle device, 51 of transposition)
+    // to save 55; allocated BESIDE the running solve the same hipMalloc took 1 - 2.5 s and held up every allocation of the
+    // solve (profiles/r06_cold.txt).  A caller that solves once never pays for it.  A sharded solve builds it up front:
+    // every rank must take the same exchange pattern, and which passes find the copy would differ between ranks.
+    const bool wants_smaj = so.block * so.slices_max > 16 && op->cols_contig && (op->col0 & 511) == 0 && m >= 4096;
+    bool smaj_after = false;
+    if (wants_smaj) {
+      if (bk.dist || getenv("BSN_SMAJ_SYNC")) have_smaj = image_smaj(bed);
+      else if (bed->d_smaj || bed->smaj_job) have_smaj = image_smaj_poll(bed) || bed->smaj_job != nullptr;
+      else have_smaj = smaj_after = !bed->smaj_tried && bed->bits == 2 && !getenv("BSN_NO_SMAJ");
+    }
     if (!have_smaj && so.block * so.slices_base <= 16 && op->cols_contig && (op->col0 & 63) == 0 && m >= 4096) image_tile(bed);
     so.resid_floor = 1.2 * std::ldexp(1.0, -8 * op->slices);
     // (two iterations since round 5: + 2.5 ms, every residual of the 400K x 1M solve 4 - 10 x lower at the same step)
@@ -1663,6 +1733,9 @@ extern "C" int bsn_bed_randomsvd(bsn_bed *bed, const int64_t *ind_row, int64_t n
         for (int c = 0; c < 4 && c < kCommClasses; c++) info->exchange_ms[c] = ems[c], info->n_exchange[c] = en[c];
       }
     }
+    // the sample-major copy for the NEXT solve, made beside the caller's own work — started last: on a box whose free
+    // memory has to be scrubbed the allocation of 100 GB takes seconds and holds up every other call into the runtime
+    if (smaj_after && !bed->d_smaj && !bed->smaj_job) (void)image_smaj_start(bed);
   });
   return rc != 0 ? rc : (unconverged ? 2 : 0);
 }

@@ -215,11 +215,31 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
     bk.WtW(cb, G.data());
     double w0 = 0;
     for (int i = 0; i < cb; i++) w0 = std::max(w0, G[(size_t)i + (size_t)i * cb]);
-    for (int pass = 0; pass < 2 && p > 0; pass++) {
+    // Projection passes.  The stored basis is orthonormal only up to the rounding of its blocks, Q'Q = I + E with
+    // |E| ~ 2^-8S of the COARSEST block — 4e-3 since round 5 starts on an 8-bit grid —, and W - Q (Q'W) leaves E times
+    // what it removed.  "Twice is enough" holds for |E| ~ 1e-5; with an 8-bit block and a panel that loses six digits in
+    // the projection (a spectrum over eight decades, 27 samples: found by the fixed sweep of tests/test_svd_driver_sweep_cpu.py,
+    // round 6) two passes left MORE of the old directions (E^2 = 1.6e-5 of the panel) than there was of the new one: the
+    // next block came out 0.6 - 0.8 inside span(Q), the Gram matrix of the basis had a condition of 1e10 and the exhausted
+    // space returned its tenth and eleventh singular values 44 % and 103 % off under "converged".  So: project until what a
+    // pass removes is at rounding level of what is LEFT of every column (at most eight passes; two when |E| is small).
+    for (int pass = 0; pass < 8 && p > 0; pass++) {
       C.assign((size_t)p * cb, 0.0);
       bk.QtW(p, cb, C.data());
       bk.W_minus_QC(p, cb, C.data());
       for (size_t t = 0; t < C.size(); t++) Cacc[t] += C[t];
+      if (pass < 1) continue;
+      G.assign((size_t)cb * cb, 0.0);
+      bk.WtW(cb, G.data());
+      bool clean = true;
+      for (int j = 0; j < cb && clean; j++) {
+        const double left = G[(size_t)j + (size_t)j * cb];
+        if (!(left > defic * w0)) continue;   // (nothing left of this column: the deficiency test below drops it)
+        double c2 = 0;
+        for (int a = 0; a < p; a++) c2 += C[(size_t)a + (size_t)j * p] * C[(size_t)a + (size_t)j * p];
+        clean = c2 <= 1e-24 * left;
+      }
+      if (clean) break;
     }
     Rout.assign((size_t)cb * cb, 0.0);
     for (int i = 0; i < cb; i++) Rout[(size_t)i + (size_t)i * cb] = 1.0;
@@ -275,10 +295,15 @@ inline SvdResult block_lanczos_svd(SvdBackend &bk, const SvdOptions &opt, double
           Rn[(size_t)i + (size_t)j * cb] = s;
         }
       Rout.swap(Rn);
-      if (pass == 0 && p > 0) {  // one more projection after the first normalisation
-        C.assign((size_t)p * r, 0.0);
-        bk.QtW(p, r, C.data());
-        bk.W_minus_QC(p, r, C.data());
+      if (pass == 0 && p > 0) {  // project again after the first normalisation (the columns have norm 1 now: until a pass removes < 1e-12)
+        for (int again = 0; again < 6; again++) {
+          C.assign((size_t)p * r, 0.0);
+          bk.QtW(p, r, C.data());
+          bk.W_minus_QC(p, r, C.data());
+          double cmax = 0;
+          for (size_t t = 0; t < C.size(); t++) cmax = std::max(cmax, std::fabs(C[t]));
+          if (cmax <= 1e-12) break;
+        }
       }
     }
     return r;

@@ -241,7 +241,7 @@ static void tcross_resident(bsn_bed *bed, const int64_t *ind_row, int64_t n, con
     const dim3 grid((unsigned)pairs.size(), (unsigned)nslab);
     const int32_t *cols = op.cols_contig ? nullptr : op.d_cols.p;
     // BSN_TCROSS_WAVES=4 selects the 4-wave shape (A/B measurements)
-    const char *we = getenv("BSN_TCROSS_WAVES");
+    const char *we = abl_getenv("BSN_TCROSS_WAVES");
     const bool w4 = we && atoi(we) == 4;
 #define BSN_TCROSS(IDENTV, WV, ROWS)                                                                              \
   hipLaunchKernelGGL((k_tcross<IDENTV, WV>), grid, dim3(64 * WV), 0, bed->stream, bed->d_img, bed->pitch, ROWS, \

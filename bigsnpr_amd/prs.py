@@ -66,6 +66,7 @@ def bed_tcrossprodSelf(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_co
     check(_lib.load().bsn_bed_tcrossprod(obj_bed.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p),
                                          ic.size, ptr(center, f64p), ptr(scale, f64p),
                                          int(block_size), K.ctypes.data_as(f64p)))
+    _lib.result_pool.kick()
     return K, dict(center=center, scale=scale)
 
 

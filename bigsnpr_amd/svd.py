@@ -22,7 +22,7 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
                   max_restarts=0, vec_floor=0.0, exchange_timing=False, exchange_timeout_ms=0):
     """Partial SVD of the scaled matrix.  Extra (non-reference) arguments: ``block``
     (vectors per streaming pass), ``slices`` (int8 slices per fp64 value), ``vec_floor`` (relative
-    residual floor wanted for the singular vectors that converge beyond ``tol``: 0 = 2.5e-7 unless
+    residual floor wanted for the singular vectors that converge beyond ``tol``: 0 = 1e-7 unless
     ``slices`` is given, < 0 = none, i.e. every step on ``slices`` digits; include/bigsnpr_hip.h); column-sharded
     multi-GPU: ``comm`` (a bigsnpr_amd.Comm: the exchange runs inside the library over RCCL),
     ``m_total`` (columns over all ranks); tests: ``allreduce`` (callable(ptr, count) summing a
@@ -66,6 +66,7 @@ def bed_randomSVD(obj_bed, fun_scaling=bed_scaleBinom, ind_row=None, ind_col=Non
     rc = L.bsn_bed_randomsvd(obj_bed.handle, ptr(ir, i64p), ir.size, ptr(ic, i64p), ic.size,
                              ptr(center, f64p), ptr(scale, f64p), C.byref(opts), ptr(d, f64p),
                              ptr(u, f64p), ptr(v, f64p), C.byref(info))
+    _lib.result_pool.kick()   # (page-locks, behind this call, result blocks for the next one)
     if rc == 2:  # RSpectra::svds warns likewise when fewer than k triplets converged
         warnings.warn("bed_randomSVD did not converge: " + L.bsn_last_error().decode(), RuntimeWarning)
     else:

@@ -277,7 +277,7 @@ typedef struct bsn_svd_options {
    * reference's fp64 Lanczos leaves its leading vectors at 1e-7.  vec_floor is the residual floor wanted instead:
    * the early block steps (while the leading half of the k pairs is still far from converged) then run on wider
    * panels — 24 bits for the default — and the late ones, whose rounding enters a converged vector with the small
-   * weight of its last components, stay narrow.  0 -> 2.5e-7 when `slices` is 0 (automatic), none when the caller
+   * weight of its last components, stay narrow.  0 -> 1e-7 when `slices` is 0 (automatic; 2.5e-7 until round 5), none when the caller
    * fixed `slices`; > 0 -> that floor (digits up to 56 bits); < 0 -> none: every step at `slices` (round 4). */
   double vec_floor;
   /* Sharded solve (comm != NULL), round 5.  exchange_timing = 1: every collective of the solve is bracketed by HIP

@@ -310,6 +310,7 @@ void nt_svd_host(const double *A, int64_t n, int64_t m_local, int64_t m_total, i
   o.max_basis = max_basis;
   o.seed = seed;
   o.max_restarts = g_max_restarts;
+  if (const char *e = getenv("NT_VERBOSE")) o.verbose = atoi(e);   // (the driver's per-step log on stderr)
   o.resid_floor = g_slices > 0 ? 1.2 * std::ldexp(1.0, -8 * g_slices) : 0.0;
   if (g_slices > 0) {
     o.slices_base = g_slices;

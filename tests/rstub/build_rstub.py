@@ -1,11 +1,11 @@
-"""Builds the test-only shared object: bindings/R/bigsnpr_hip_shim.c + the stand-in R runtime (rstub.c),
+"""Builds the test-only shared object: bindings/R/bigsnprhip/src/bigsnpr_hip_shim.c + the stand-in R runtime (rstub.c),
 linked against the product library."""
 import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SHIM = os.path.join(ROOT, "bindings", "R", "bigsnpr_hip_shim.c")
+SHIM = os.path.join(ROOT, "bindings", "R", "bigsnprhip", "src", "bigsnpr_hip_shim.c")
 SO = os.path.join(HERE, "libshim_rstub.so")
 WARN = ["-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter",
         "-Wno-cast-function-type"]   # the DL_FUNC casts of every R registration table

@@ -1,4 +1,4 @@
-/* TEST INFRASTRUCTURE — a stand-in for the part of the R runtime that bindings/R/bigsnpr_hip_shim.c calls,
+/* TEST INFRASTRUCTURE — a stand-in for the part of the R runtime that bindings/R/bigsnprhip/src/bigsnpr_hip_shim.c calls,
  * so that the shim's `.Call` entry points can be RUN on a machine without R: vectors, matrices, named
  * lists, environments with fields (the RC objects `bed` and `FBM.code256` as the shim sees them: obj$field),
  * external pointers with finalizers, R_alloc, and Rf_error as a non-local exit back to the caller of

@@ -1,4 +1,4 @@
-"""The R shim RUNNING (bindings/R/bigsnpr_hip_shim.c against the stand-in R runtime of tests/rstub): every
+"""The R shim RUNNING (bindings/R/bigsnprhip/src/bigsnpr_hip_shim.c against the stand-in R runtime of tests/rstub): every
 `.Call` target is called by its registered name with R-like arguments — 1-based integer indices, RC objects as
 environments whose `address` / `backingfile` / `code256` fields the shim reads like the reference's native code
 does (src/bed-prod-vec.cpp:23, src/colstats.cpp:13-14) — and compared with the oracle."""

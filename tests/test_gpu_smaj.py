@@ -64,6 +64,7 @@ def test_complete_data_and_solve(ba, monkeypatch):
         ref = ba.bed_randomSVD(gb, k=k, block=16)
         assert ref["tiled"] == 0
         monkeypatch.delenv("BSN_NO_SMAJ")
+        assert gb.sample_major()            # (round 6: a solve no longer builds the copy inside the call; bench.py does the same)
         res = ba.bed_randomSVD(gb, k=k, block=16)
         assert res["tiled"] == 2 and res["converged"] and res["warm_launches"] == 4
         for f in ("d", "u", "v", "center", "scale"):
@@ -77,10 +78,11 @@ def test_complete_data_and_solve(ba, monkeypatch):
         wide0 = ba.bed_randomSVD(gb, k=5, block=5, slices=7, tol=1e-8, return_uv=False)
         monkeypatch.delenv("BSN_NO_SMAJ")
         np.testing.assert_array_equal(wide["d"], wide0["d"])
-        gb.release_workspace()                               # frees the copy too; the next solve builds it again
+        gb.release_workspace()                               # frees the copy too; the next solve starts another one behind itself
         again = ba.bed_randomSVD(gb, k=k, block=16)
-        assert again["tiled"] == 2
+        assert again["tiled"] == 0 and gb.sample_major()
         np.testing.assert_array_equal(again["d"], ref["d"])
+        assert ba.bed_randomSVD(gb, k=k, block=16)["tiled"] == 2
 
 
 def test_random_small_shapes(ba, monkeypatch):
@@ -107,3 +109,46 @@ def test_random_small_shapes(ba, monkeypatch):
         sync()
         np.testing.assert_array_equal(Y.to_numpy(), ref, err_msg="n=%d m=%d nv=%d" % (n, m, nv))
         gb.close()
+
+
+def test_the_copy_made_behind_the_first_solve(ba, monkeypatch):
+    """the first 16-vector solve of a handle no longer waits for the sample-major copy — it runs on the
+    variant-major image alone (k_prod) and the copy is made BEHIND it: a helper thread allocates it and queues the
+    transposition on a stream of its own when the call returns; a solve that starts while the copy is still on its way
+    takes k_prod for its product passes until it has arrived.  Whichever pass switches over, the sums are the same
+    integers: the first solve of a fresh handle, later ones (copy on its way / in place), a solve with the copy built up
+    front (BSN_SMAJ_SYNC=1, what a sharded solve does) and a solve without any copy are bit-identical;
+    release_workspace while a build may still be in flight, and closing such a handle, are safe."""
+    n, m, k = 2500, 300000, 20
+    res = {}
+    for tag, env in (("behind", {}), ("up_front", {"BSN_SMAJ_SYNC": "1"}), ("none", {"BSN_NO_SMAJ": "1"})):
+        for kk, vv in env.items():
+            monkeypatch.setenv(kk, vv)
+        gb = ba.bed.synthetic(n, m, seed=5)
+        first = ba.bed_randomSVD(gb, k=k)
+        later = ba.bed_randomSVD(gb, k=k)          # (may start while the copy is still being made)
+        assert first["converged"] and first["block"] == 16
+        for f in ("d", "u", "v", "center", "scale"):
+            np.testing.assert_array_equal(first[f], later[f], err_msg="%s: %s of the first and of a later solve" % (tag, f))
+        if tag == "behind":
+            assert first["tiled"] != 2             # the first solve did not wait for a copy
+            assert gb.sample_major()               # (waits for the build in flight)
+            third = ba.bed_randomSVD(gb, k=k)
+            assert third["tiled"] == 2
+            np.testing.assert_array_equal(third["u"], first["u"])
+            gb.release_workspace()                 # frees the copy
+            again = ba.bed_randomSVD(gb, k=k)      # ... and starts another build behind itself
+            np.testing.assert_array_equal(again["u"], first["u"])
+            gb.release_workspace()                 # (adopts and frees a copy that may still be on its way)
+            fresh = ba.bed.synthetic(n, m, seed=5)
+            ba.bed_randomSVD(fresh, k=k)
+            fresh.close()                          # ... and so does closing the handle right behind its first solve
+        if tag == "up_front":
+            assert first["tiled"] == 2 and later["tiled"] == 2
+        res[tag] = first
+        gb.close()
+        for kk in env:
+            monkeypatch.delenv(kk)
+    for f in ("d", "u", "v"):
+        np.testing.assert_array_equal(res["behind"][f], res["up_front"][f], err_msg=f)
+        np.testing.assert_array_equal(res["behind"][f], res["none"][f], err_msg=f)

@@ -87,8 +87,9 @@ def test_release_workspace_returns_the_memory(ba):
     _lib.check(_lib.load().bsn_bed_release_workspace(gb.handle))
     base = free_bytes()
     r1 = ba.bed_randomSVD(gb, k=4)
-    assert r1["tiled"] == 2     # (round 5: the early steps of the default solve run on 24-bit panels, 8 x 3 digit columns:
-                                # the second copy of the image is the sample-major one)
+    # (round 5: the early steps of the default solve run on 24-bit panels, 8 x 3 digit columns: the second copy of the image
+    # is the sample-major one; round 6: made BEHIND the first such solve — sample_major() waits for it)
+    assert gb.sample_major() and ba.bed_randomSVD(gb, k=4)["tiled"] == 2
     used = base - free_bytes()
     assert used >= gb.hbm_bytes()                      # at least the second copy of the image
     _lib.check(_lib.load().bsn_bed_release_workspace(gb.handle))

@@ -1,4 +1,4 @@
-"""bindings/R/bigsnpr_hip_shim.c through a compiler (no R in this image): strict warnings against declarations of
+"""bindings/R/bigsnprhip/src/bigsnpr_hip_shim.c through a compiler (no R in this image): strict warnings against declarations of
 the R API it uses (tests/rstub/include, test infrastructure), its registration table against the reference's
 (tests/golden/reference_call_entries.json, made by tools/make_call_entries_fixture.py from
 src/RcppExports.cpp:597-640), and the entry points that need no GPU run against the stand-in runtime."""
@@ -64,3 +64,44 @@ def test_argument_checks_run_without_a_gpu(R):
     with pytest.raises(rshim.RError):
         R.call("_bigsnpr_bedXPtr", "/nonexistent/file.bed", 10, 10)
     R.reset()
+
+
+def test_r_package_files_agree_with_the_shim_and_the_reference(R):
+    """bindings/R/bigsnprhip is an installable package — DESCRIPTION, NAMESPACE (useDynLib with registration, cf.
+    the reference's NAMESPACE:124), src/Makevars (link line), R/zzz.R (hip_enable / hip_disable, the six-line bed_randomSVD, the
+    operator closures).  R is absent here, so the files are checked as text: the symbol list hip_enable() swaps == the
+    reference-named entries of the shim's registration table == the hot-path subset of the reference's own table (same
+    arities); every .Call in zzz.R names a registered routine and passes as many arguments as it is registered with."""
+    import re
+    pkg = os.path.join(ROOT, "bindings", "R", "bigsnprhip")
+    for f in ("DESCRIPTION", "NAMESPACE", os.path.join("src", "Makevars"), os.path.join("src", "bigsnpr_hip_shim.c"),
+              os.path.join("R", "zzz.R")):
+        assert os.path.isfile(os.path.join(pkg, f)), f
+    desc = open(os.path.join(pkg, "DESCRIPTION")).read()
+    assert re.search(r"^Package: bigsnprhip$", desc, re.M) and "NeedsCompilation: yes" in desc
+    ns = open(os.path.join(pkg, "NAMESPACE")).read()
+    assert re.search(r"^useDynLib\(bigsnprhip, \.registration = TRUE\)$", ns, re.M)
+    shim = open(os.path.join(pkg, "src", "bigsnpr_hip_shim.c")).read()
+    assert "void R_init_bigsnprhip(DllInfo *dll)" in shim          # the name useDynLib(bigsnprhip) looks for
+    mk = open(os.path.join(pkg, "src", "Makevars")).read()
+    assert "-lbigsnpr_hip" in mk and "/include" in mk and "-Wl,-rpath," in mk
+    zzz = open(os.path.join(pkg, "R", "zzz.R")).read()
+    body = zzz[zzz.index("hip_symbols <- function()"):]
+    listed = re.findall(r'"(_bigsnpr_\w+)"', body[:body.index("}")])
+    got = R.routines()
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_call_entries.json")))["entries"]
+    registered_ref_named = sorted(n for n in got if not n.endswith("_hip"))
+    assert sorted(listed) == registered_ref_named == sorted(HOT_PATH)
+    for n in listed:
+        assert got[n] == ref[n], n
+    # the commented symbol list of NAMESPACE (documentation of what .registration creates) is the whole table
+    assert sorted(set(re.findall(r"`(_bigsnpr_\w+)`", ns))) == sorted(got)
+    # every .Call of the R glue: a registered routine, called with its registered number of arguments
+    calls = re.findall(r"\.Call\(`(_bigsnpr_\w+)`((?:[^()]|\([^()]*\))*)\)", zzz)
+    assert {c[0] for c in calls} == {n for n in got if n.endswith("_hip")}
+    for name, args in calls:
+        nargs = 0 if not args.strip(", \n") else len([a for a in args.strip(", \n").split(",")])
+        assert nargs == got[name], (name, nargs, got[name])
+    # exports of NAMESPACE are defined in zzz.R
+    for ex in re.findall(r"^export\((\w+)\)$", ns, re.M):
+        assert re.search(r"^%s <- function" % ex, zzz, re.M), ex

@@ -563,3 +563,30 @@ def test_small_but_real_triplets_are_not_vouched_for(nt):
         np.testing.assert_allclose(r0["d"], sig[:k], rtol=1e-6)
     finally:
         nt.nt_set_slices(0)
+
+
+def test_careful_path_projects_until_clean_on_an_eight_bit_start_block(nt):
+    """Round 6, found by the fixed sweep (tests/test_svd_driver_sweep_cpu.py): 27 x 98 with singular values over eight decades,
+    k = 11, block 8, the wrapper's automatic mode (8-bit start grid since round 5 + precision schedule).  The stored basis is
+    orthonormal only up to the rounding of its coarsest block (|Q'Q - I| = 4e-3 with the 8-bit start block) and the panels of
+    such a spectrum lose six digits in the projection: the two projection passes of the careful path left more of the OLD
+    directions in the panel than there was of the new one (|Q'Q - I| = 0.63 .. 0.80 at steps 3 - 4), and the exhausted space
+    (all of R^27) returned sigma_10, sigma_11 44 % and 103 % off under converged = 1.  The path now projects until a pass
+    removes nothing of what is left."""
+    rng = np.random.default_rng(77)
+    for n, m in ((27, 98), (26, 115), (31, 60)):
+        q = min(n, m)
+        U, _ = np.linalg.qr(rng.normal(size=(n, q)))
+        V, _ = np.linalg.qr(rng.normal(size=(m, q)))
+        A = (U * np.logspace(0, -8, q)) @ V.T
+        d_true = np.linalg.svd(A, compute_uv=False)
+        try:
+            nt.nt_set_slices(2)
+            nt.nt_set_schedule(C.c_double(1e-7), 3, 1)
+            for k in (9, 11):
+                r = host_svd(nt, A, k, tol=1e-4, block=8, seed=57)
+                assert r["converged"]
+                np.testing.assert_allclose(r["d"], d_true[:k], rtol=1e-6)
+        finally:
+            nt.nt_set_slices(0)
+            nt.nt_set_schedule(C.c_double(0.0), 0, 0)

@@ -20,6 +20,22 @@ def timed(name, fn):
         t0 = time.perf_counter(); r = fn(*x, **k); T[name] = T.get(name, 0.0) + time.perf_counter() - t0
         return r
     return w
+# inside snp_clumping (round 6): the per-chromosome column statistics, the clumping call, and of it the HIP-event time of the
+# pair-statistics kernels (bsn_ld_last_stats)
+K = {}
+_clump_chr0 = ldm._clump_chr
+def _clump_chr(*x, **k):
+    t0 = time.perf_counter(); r = _clump_chr0(*x, **k); K["clumping_chr calls"] = K.get("clumping_chr calls", 0.0) + time.perf_counter() - t0
+    st = ldm.last_stats()
+    K["of which pair-statistics kernels"] = K.get("of which pair-statistics kernels", 0.0) + st["stats_ms"] * 1e-3
+    K["kernel"] = st["kernel"][:40]
+    return r
+ldm._clump_chr = _clump_chr
+_colstats0 = ldm.snp_colstats
+def _colstats(*x, **k):
+    t0 = time.perf_counter(); r = _colstats0(*x, **k); K["snp_colstats calls"] = K.get("snp_colstats calls", 0.0) + time.perf_counter() - t0
+    return r
+ldm.snp_colstats = _colstats
 autosvd.snp_MAF = timed("snp_MAF", autosvd.snp_MAF)
 autosvd.snp_clumping = timed("snp_clumping", autosvd.snp_clumping)
 autosvd.big_randomSVD = timed("big_randomSVD", autosvd.big_randomSVD)
@@ -27,9 +43,10 @@ autosvd.dist_ogk = timed("dist_ogk", autosvd.dist_ogk)
 autosvd.rollmean = timed("rollmean", autosvd.rollmean)
 autosvd.tukey_mc_up = timed("tukey_mc_up", autosvd.tukey_mc_up)
 for rep in ("first call (imports, first launches, allocations)", "second call"):
-    T.clear()
+    T.clear(); K.clear()
     t0 = time.perf_counter()
     res = ba.snp_autoSVD(gb, chrom, pos, k=10, verbose=rep.startswith("first"))
     tot = time.perf_counter() - t0
     print("%s: total %.3f s; %s; rest of the host loop %.3f s; kept %d of %d variants"
           % (rep, tot, ", ".join("%s %.3f s" % kv for kv in T.items()), tot - sum(T.values()), res["subset"].size, a.m))
+    print("    inside snp_clumping: " + ", ".join("%s %s" % (k_, ("%.3f s" % v) if isinstance(v, float) else v) for k_, v in K.items()))
