@@ -581,6 +581,26 @@ def main():
             log("ingest done")
         if cold is not None:
             out["cold"] = cold
+        if "accuracy" in out and a.ind_col_fraction <= 0:
+            # the accuracy record on a SECOND matrix (another seed of the generator), the worse of the two
+            # reported.  The timed image goes first (two images, a copy and a workspace do not fit one GPU).
+            try:
+                gb.close()
+                gb2 = ba.bed.synthetic(n, m_local, seed=7, na16=a.na16)
+                r2 = ba.bed_randomSVD(gb2, k=a.k, tol=a.tol, block=a.block, slices=a.slices, warm_start=a.warm_start,
+                                      warm_denominator=a.warm_den)
+                rec2, _ = accuracy(ba, gb2, a, r2, (r2["u"], r2["v"]))
+                gb2.close()
+                first = {key: out["accuracy"][key] for key in ("u_leading_half", "u_all", "v_leading_half", "v_all")}
+                out["accuracy"]["second_matrix"] = {"generator_seed": 7, **{key: rec2[key] for key in first},
+                                                    "residual_estimate": rec2["residual_estimate"]}
+                out["accuracy"]["worse_of_two_matrices"] = {key: max(first[key], rec2[key]) for key in first}
+                out["accuracy"]["leading_half_within_tolerance"] = bool(
+                    max(first["u_leading_half"], rec2["u_leading_half"]) <= 1e-6 and
+                    max(first["v_leading_half"], rec2["v_leading_half"]) <= 1e-6)
+                log("accuracy on a second matrix done")
+            except Exception as e:
+                out["accuracy"]["second_matrix"] = {"error": str(e)[:300]}
     if comm is not None:
         sync()
         comm.close()

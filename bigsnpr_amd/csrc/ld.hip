@@ -586,6 +586,86 @@ __global__ __launch_bounds__(64) void k_pair_xy64(const uint8_t *__restrict__ im
       }
 }
 
+// (round 6) The cross product alone on the FP4 matrix pipe.  With no missing value among the selected samples the codes
+// are the allele counts, and a 2-bit code in the low bits of a nibble IS code / 2 in E2M1 (0 -> 0, 1 -> 0.5, 2 -> 1.0): the
+// operand of 32 samples is  w & 0x3333.., (w >> 2) & 0x3333..  of two dwords — THREE instructions per 16 genotypes where the
+// int8 kernel spends twelve on its byte look-ups — and one v_mfma_scale_f32_16x16x128_f8f6f4 contracts 128 samples in the 16
+// pipe cycles the int8 instruction needs for 64.  The sums are sum g g' / 4: exact in fp32 while 4 n < 2^24 (the host takes
+// the int8 kernel beyond 4 194 303 samples, or with BSN_LD_I8=1); dropped samples are ANDed to code 0.  Same tile pairs,
+// same K split, same integer statistics as k_pair_xy64: the band, the clumping bits and the LD scores are bit-identical.
+__global__ __launch_bounds__(64) void k_pair_xy_f4(const uint8_t *__restrict__ img, int64_t pitch,
+                                                   const int32_t *__restrict__ cols,
+                                                   const int2 *__restrict__ pairs,
+                                                   const uint32_t *__restrict__ rowmask,
+                                                   int64_t kbytes_per_split, int32_t *__restrict__ stats) {
+  const int lane = threadIdx.x;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int2 pr = pairs[blockIdx.x];
+  const uint8_t *pa[4], *pb[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    pa[s] = img + (int64_t)cols[pr.x * TB + s * 16 + r16] * pitch + g * 16;
+    pb[s] = img + (int64_t)cols[pr.y * TB + s * 16 + r16] * pitch + g * 16;
+  }
+  int64_t b0 = (int64_t)blockIdx.y * kbytes_per_split, b1 = b0 + kbytes_per_split;
+  if (b1 > pitch) b1 = pitch;
+  if (b0 >= b1) return;
+  v4f acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+  uint4 a[4], b[4], an[4], bn[4], mk, mkn;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    a[s] = *(const uint4 *)(pa[s] + b0);
+    b[s] = *(const uint4 *)(pb[s] + b0);
+  }
+  mk = *(const uint4 *)((const uint8_t *)rowmask + b0 + g * 16);
+  auto nib = [](uint32_t w0, uint32_t w1) {
+    return v4i{(int)(w0 & 0x33333333u), (int)((w0 >> 2) & 0x33333333u), (int)(w1 & 0x33333333u), (int)((w1 >> 2) & 0x33333333u)};
+  };
+  for (int64_t kb = b0; kb < b1; kb += 64) {
+    const int64_t kn = kb + 64 < b1 ? kb + 64 : kb;  // branch-free prefetch of the next step
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      an[s] = *(const uint4 *)(pa[s] + kn);
+      bn[s] = *(const uint4 *)(pb[s] + kn);
+    }
+    mkn = *(const uint4 *)((const uint8_t *)rowmask + kn + g * 16);
+#pragma unroll
+    for (int d = 0; d < 2; d++) {   // a lane's 16 bytes are two K-steps of 32 samples (x 4 lane groups = 128)
+      const uint32_t m0 = d == 0 ? mk.x : mk.z, m1 = d == 0 ? mk.y : mk.w;
+      v4i A[4], B[4];
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        A[s] = nib((d == 0 ? a[s].x : a[s].z) & m0, (d == 0 ? a[s].y : a[s].w) & m1);   // dropped samples: code 0
+        B[s] = nib((d == 0 ? b[s].x : b[s].z) & m0, (d == 0 ? b[s].y : b[s].w) & m1);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = mfma_f4(A[i], B[j], acc[i][j]);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      a[s] = an[s];
+      b[s] = bn[s];
+    }
+    mk = mkn;
+  }
+  int32_t *out = stats + (int64_t)blockIdx.x * 6 * TB * TB;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = i * 16 + 4 * g + r, col = j * 16 + r16;
+        atomicAdd(out + row * TB + col, __float2int_rn(4.0f * acc[i][j][r]));   // (code / 2)(code' / 2) summed: exact quarters
+      }
+}
+
 // Byte image (dosage grid, bsn_bed::bits == 8): the cross product of the grid indices, sum_i k_i k'_i,
 // for a 64 x 64 tile pair.  The loaded bytes are the MFMA operands (no decode; `rowmask` zeroes the
 // samples that are not selected, and the pad samples).  |k| <= 127, so one int32 accumulator holds at most
@@ -1287,9 +1367,15 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
       if (ks4 < 1) ks4 = 1;
       int64_t kb4 = round_up((bed->pitch + ks4 - 1) / ks4, 64);
       ks4 = (int)((bed->pitch + kb4 - 1) / kb4);
-      hipLaunchKernelGGL(k_pair_xy64, dim3((unsigned)np, (unsigned)ks4), dim3(64), 0, bed->stream, bed->d_img,
-                         bed->pitch, J.d_cols.p, J.d_pairs.p + p0, J.d_mask.p, kb4, J.d_stats.p);
-      ls.kernel = 2;
+      // (round 6) on the FP4 matrix pipe while its fp32 sums are exact: 4 n < 2^24
+      const bool xy_f4 = bed->n <= 4194303 && !getenv("BSN_LD_I8");
+      if (xy_f4)
+        hipLaunchKernelGGL(k_pair_xy_f4, dim3((unsigned)np, (unsigned)ks4), dim3(64), 0, bed->stream, bed->d_img,
+                           bed->pitch, J.d_cols.p, J.d_pairs.p + p0, J.d_mask.p, kb4, J.d_stats.p);
+      else
+        hipLaunchKernelGGL(k_pair_xy64, dim3((unsigned)np, (unsigned)ks4), dim3(64), 0, bed->stream, bed->d_img,
+                           bed->pitch, J.d_cols.p, J.d_pairs.p + p0, J.d_mask.p, kb4, J.d_stats.p);
+      ls.kernel = xy_f4 ? 7 : 2;
     } else if (fused) {
       if (J.contig)
         hipLaunchKernelGGL((k_pair_stats<true, true, true>), dim3((unsigned)np, 1), dim3(256), 0, bed->stream,
