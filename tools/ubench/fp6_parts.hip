@@ -300,6 +300,130 @@ __global__ __launch_bounds__(64 * WAVES) void k(const uint8_t *__restrict__ img,
   if (r == 0x12345679u) out[0] = r;
 }
 
+// ---- (3b) the column blocks DIVIDED BETWEEN WAVES (round 6, second attempt) ---------------------------------------------
+// What sank the shapes above is the register budget: five column blocks x two planes x two tiles = 80 accumulators, two waves
+// per SIMD.  Here the blocks of the panel are divided between two KINDS of waves over the same variants: kind A owns blocks
+// [0, NBA) of TA tiles, kind B blocks [NBA, NBA + NBB) of TB tiles, with WA TA = WB TB tiles per workgroup — every genotype
+// row is loaded and decoded by one wave of each kind (twice the L1 / L2 reads and twice the 14-instruction decode, the same
+// HBM bytes and the same LDS operand traffic), every wave keeps <= 48 accumulators: four waves per SIMD like the int8 kernels.
+//   NB = 4: 8 + 8 waves of 2 tiles x 2 blocks;   NB = 5: 9 waves of 2 tiles x 3 blocks + 6 waves of 3 tiles x 2 blocks.
+template <int NBW, int T, int NBT, int NT>
+__device__ __forceinline__ void fp6_role(const uint8_t *__restrict__ img, int64_t pitch, const uint4 *__restrict__ xq4, uint4 *xs,
+                                         int64_t row0, int boff, unsigned *out) {
+  constexpr int NCOL = 16 * NBT, S8 = (NBT % 2 == 0) ? NCOL + 16 : NCOL, XS = 16 * NCOL + 8 * S8, NX = (XS + NT - 1) / NT;
+  static_assert(NX <= 4, "staging registers");
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int nchunks = (int)(pitch / 128);
+  auto addr = [&](int t, int ch, int it) -> const uint4 * {
+    return (const uint4 *)(img + (row0 + t * 16 + c) * pitch + (int64_t)ch * 128 + it * 64 + g * 16);
+  };
+  v4f acc[T][2][NBW];
+#pragma unroll
+  for (int t = 0; t < T; t++)
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+      for (int nb = 0; nb < NBW; nb++) acc[t][p][nb] = v4f{0, 0, 0, 0};
+  uint4 ga[2][T][2];
+#pragma unroll
+  for (int t = 0; t < T; t++)
+#pragma unroll
+    for (int it = 0; it < 2; it++) { ga[0][t][it] = *addr(t, 0, it); ga[1][t][it] = *addr(t, nchunks > 1 ? 1 : 0, it); }
+#pragma unroll
+  for (int x = 0; x < NX; x++) if (tid + x * NT < XS) xs[tid + x * NT] = xq4[tid + x * NT];
+  __syncthreads();
+  auto chunk = [&](auto SETC, const int ch) {
+    constexpr int SET = decltype(SETC)::value;
+    const int ch1 = ch + 1 < nchunks ? ch + 1 : nchunks - 1, ch2 = ch + 2 < nchunks ? ch + 2 : nchunks - 1;
+    auto at = [&](const int x) -> int64_t { return (int64_t)ch1 * XS + (tid + x * NT < XS ? tid + x * NT : XS - 1); };
+    uint4 xr0 = xq4[at(0)], xr1 = {0, 0, 0, 0}, xr2 = xr1, xr3 = xr1;
+    if constexpr (NX > 1) xr1 = xq4[at(1)];
+    if constexpr (NX > 2) xr2 = xq4[at(2)];
+    if constexpr (NX > 3) xr3 = xq4[at(3)];
+    __builtin_amdgcn_sched_barrier(0);
+    const uint4 *xb = xs + SET * XS;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      constexpr int dummy = 0; (void)dummy;
+      const int it = s >> 1, h = s & 1;
+      __builtin_amdgcn_sched_barrier(0);
+      v6i b[NBW];
+#pragma unroll
+      for (int nb = 0; nb < NBW; nb++) {
+        const uint4 lo = xb[(s * 4 + g) * NCOL + (boff + nb) * 16 + c];
+        const uint2 hi = ((const uint2 *)&xb[16 * NCOL])[(s * 4 + g) * S8 + (boff + nb) * 16 + c];
+        b[nb] = v6i{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y};
+      }
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        const uint32_t w0 = h == 0 ? ga[SET][t][it].x : ga[SET][t][it].z, w1 = h == 0 ? ga[SET][t][it].y : ga[SET][t][it].w;
+        const v4i x = {(int)(w0 & 0x33333333u), (int)((w0 >> 2) & 0x33333333u), (int)(w1 & 0x33333333u), (int)((w1 >> 2) & 0x33333333u)};
+        const v4i a1 = {x[0] & (int)((unsigned)x[0] >> 1), x[1] & (int)((unsigned)x[1] >> 1), x[2] & (int)((unsigned)x[2] >> 1), x[3] & (int)((unsigned)x[3] >> 1)};
+#pragma unroll
+        for (int nb = 0; nb < NBW; nb++) {
+          mfma_f6(acc[t][0][nb], x, b[nb], 0x7F7F7F7F);
+          mfma_f6(acc[t][1][nb], a1, b[nb], 0x7F7F7F7F);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < T; t++)
+#pragma unroll
+      for (int it = 0; it < 2; it++) ga[SET][t][it] = *addr(t, ch2, it);
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 *xw = xs + (SET ^ 1) * XS;
+    if (tid < XS) xw[tid] = xr0;
+    if constexpr (NX > 1) if (tid + NT < XS) xw[tid + NT] = xr1;
+    if constexpr (NX > 2) if (tid + 2 * NT < XS) xw[tid + 2 * NT] = xr2;
+    if constexpr (NX > 3) if (tid + 3 * NT < XS) xw[tid + 3 * NT] = xr3;
+    __syncthreads();
+  };
+  for (int ch = 0; ch < nchunks; ch += 2) {
+    chunk(std::integral_constant<int, 0>{}, ch);
+    if (ch + 1 < nchunks) chunk(std::integral_constant<int, 1>{}, ch + 1);
+  }
+  asm volatile("s_nop 15");
+  unsigned r = 0;
+#pragma unroll
+  for (int t = 0; t < T; t++)
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+      for (int nb = 0; nb < NBW; nb++) r ^= __float_as_uint(acc[t][p][nb][0]) ^ __float_as_uint(acc[t][p][nb][3]);
+  if (r == 0x12345679u) out[0] = r;
+}
+template <int NBA, int TA, int WA, int NBB, int TB, int WB>
+__global__ __launch_bounds__(64 * (WA + WB)) void kr(const uint8_t *__restrict__ img, int64_t pitch, const uint4 *__restrict__ xq4, unsigned *out) {
+  static_assert(WA * TA == WB * TB, "both kinds of waves cover the workgroup's tiles");
+  constexpr int NBT = NBA + NBB, NT = 64 * (WA + WB), NCOL = 16 * NBT, S8 = (NBT % 2 == 0) ? NCOL + 16 : NCOL, XS = 16 * NCOL + 8 * S8;
+  __shared__ uint4 xs[2 * XS];
+  const int wave = threadIdx.x >> 6;
+  const int64_t row_wg = (int64_t)blockIdx.x * (WA * TA * 16);
+  if (wave < WA) fp6_role<NBA, TA, NBT, NT>(img, pitch, xq4, xs, row_wg + wave * (TA * 16), 0, out);
+  else fp6_role<NBB, TB, NBT, NT>(img, pitch, xq4, xs, row_wg + (wave - WA) * (TB * 16), NBA, out);
+}
+template <int NBA, int TA, int WA, int NBB, int TB, int WB>
+void run_roles(const uint8_t *img, int64_t pitch, int64_t rows, const uint4 *xq, unsigned *out, int reps) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  constexpr int RW = WA * TA * 16, NB = NBA + NBB;
+  const unsigned grid = (unsigned)(rows / RW);
+  auto kern = kr<NBA, TA, WA, NBB, TB, WB>;
+  hipFuncAttributes fa;
+  CK(hipFuncGetAttributes(&fa, (const void *)kern));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (WA + WB)), 0, 0, img, pitch, xq, out);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < reps; i++) hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (WA + WB)), 0, 0, img, pitch, xq, out);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+  const double bytes = (double)grid * RW * pitch;
+  const double mfma = bytes * 4 / 128 / 16 * 2 * NB, cyc = mfma * 16 / 1024;
+  printf("cprod  fp6xfp4 NB=%d (%2d-bit) column blocks divided between waves: %d waves x %d tiles x %d blocks + %d x %d x %d  regs %3d scratch %3zu lds %6zu  %7.2f ms per 100 GB  %5.0f GB/s  pipe floor %5.2f ms at 1.7 GHz\n",
+         NB, 5 * NB, WA, TA, NBA, WB, TB, NBB, fa.numRegs, (size_t)fa.localSizeBytes, (size_t)fa.sharedSizeBytes, ms * 100e9 / bytes, bytes / ms / 1e6,
+         cyc / 1.7e9 * 1e3 * 100e9 / bytes);
+  fflush(stdout);
+}
+
 __global__ void fill(uint32_t *p, size_t n, int genotypes) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     uint32_t h = (uint32_t)(i * 2654435761u) ^ (uint32_t)(i >> 7), w = 0;
@@ -372,6 +496,10 @@ int main(int argc, char **argv) {
     run<1, 4, 1, 16, 0, 1, 0>(img, pitch, rows, xq, out, reps);
     run<0, 3, 2, 16, 1, 0>(img, pitch, rows, xq, out, reps);
     run<1, 4, 4, 8, 1, 0, 0>(img, pitch, rows, xq, out, reps);
+    run_roles<2, 2, 8, 2, 2, 8>(img, pitch, rows, xq, out, reps);     // 20 bits: 8 + 8 waves
+    run_roles<3, 2, 9, 2, 3, 6>(img, pitch, rows, xq, out, reps);     // 25 bits: 9 + 6 waves
+    run_roles<3, 2, 6, 2, 3, 4>(img, pitch, rows, xq, out, reps);     // 25 bits: 6 + 4 waves
+    run_roles<2, 1, 8, 1, 2, 4>(img, pitch, rows, xq, out, reps);     // 15 bits: 8 + 4 waves (one tile / two tiles)
     return 0;
   }
   for (int pass = 0; pass < 2; pass++) {
