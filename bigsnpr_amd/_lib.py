@@ -70,6 +70,11 @@ SIGNATURES = {
     "bsn_robust_scale_cols": (C.c_int, [vp, i64, i64, C.c_int32, f64p]),
     "bsn_robust_rotate": (C.c_int, [vp, i64, i64, C.c_int32, f64p]),
     "bsn_robust_wdist": (C.c_int, [vp, i64, i64, C.c_int32, f64p, f64p, f64p]),
+    "bsn_robust_dist_ogk": (C.c_int, [vp, i64, i64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, f64p, C.POINTER(C.c_int64)]),
+    "bsn_robust_rollmean": (C.c_int, [f64p, i64, f64p, C.c_int32, C.POINTER(C.c_int64), C.c_int32, f64p]),
+    "bsn_robust_sort": (C.c_int, [f64p, i64]),
+    "bsn_order_decreasing": (C.c_int, [f64p, i64, C.POINTER(C.c_int64), C.c_int32, i32p, i32p]),
+    "bsn_robust_mc_window": (C.c_int, [vp, i64, vp, i64, C.c_double, C.c_double, i64, f64p, C.POINTER(C.c_int64)]),
     "bsn_bed_open": (C.c_int, [C.c_char_p, i64, i64, C.POINTER(vp)]),
     "bsn_bed_from_host": (C.c_int, [u8p, i64, i64, i64, C.POINTER(vp)]),
     "bsn_bed_from_fbm": (C.c_int, [u8p, i64, i64, i64, C.POINTER(vp)]),

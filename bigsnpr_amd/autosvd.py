@@ -141,36 +141,105 @@ def covrob_ogk_device(U, niter=2, beta=0.9, c1=4.5, c2=3.0):
     return dict(center=center, cov=cov, weights=keep)
 
 
-def dist_ogk(U, niter=2, beta=0.9, device=False):
-    """squared robust Mahalanobis distances (bigutilsr::dist_ogk).  device=True: the robust scales on the GPU
-    (covrob_ogk_device; what snp_autoSVD / bed_autoSVD use — their loadings come from a solve on that GPU)."""
+def dist_ogk_device(U, niter=2, beta=0.9, c1=4.5, c2=3.0):
+    """dist_ogk end to end on the device (bsn_robust_dist_ogk): covrob_ogk_device's rounds, the hard rejection, centre and
+    covariance of the kept rows and the distances in one call — only p x p matrices visit the host, where at a million
+    variants the host tail of the step-by-step version (a fancy-index copy of the kept rows, np.cov, the m x p products of
+    the distances) cost more than the rounds.  Same values to rounding: tests/test_gpu_autosvd.py."""
+    import ctypes as C
+    from scipy.stats import chi2
+    from . import _lib
+    from ._lib import check, f64p, ptr
+    L = _lib.load()
     U = np.asarray(U, dtype=np.float64)
+    n, p = U.shape
+    if p > 64:
+        raise ValueError("the device path of dist_ogk holds at most 64 columns")
+    Z = _lib.DeviceArray.from_numpy(U)
+    out = np.empty(n)
+    try:
+        check(L.bsn_robust_dist_ogk(Z.ptr, n, n, p, int(niter), float(chi2.ppf(beta, p) / chi2.ppf(0.5, p)), c1, c2,
+                                    ptr(out, f64p), None))
+    finally:
+        Z.free()
+    return out
+
+
+def dist_ogk(U, niter=2, beta=0.9, device=False):
+    """squared robust Mahalanobis distances (bigutilsr::dist_ogk).  device=True: on the GPU (dist_ogk_device; what
+    snp_autoSVD / bed_autoSVD use — their loadings come from a solve on that GPU); device="steps": the robust scales
+    on the GPU and the loop around them here (covrob_ogk_device, round 5's path, kept as the comparator)."""
+    U = np.asarray(U, dtype=np.float64)
+    if device is True:
+        return dist_ogk_device(U, niter, beta)
     est = covrob_ogk_device(U, niter, beta) if device else covrob_ogk(U, niter, beta)
     Xc = U - est["center"]
     return np.einsum("ij,ij->i", Xc @ np.linalg.pinv(est["cov"]), Xc)
 
 
-def rollmean(x, size):
-    """bigutilsr::rollmean: Gaussian weights over 2*floor(size)+1 points, edge windows
-    renormalised by the weights they contain."""
+def _rollmean_weights(size):
     from scipy.stats import norm
-    x = np.asarray(x, dtype=np.float64)
-    if size == 0:
-        return x
     half = int(np.floor(size))
     length = 2 * half + 1
-    if length >= x.size:
-        raise ValueError("Parameter 'size' is too large.")
     a = 3.0 / 8 if length <= 10 else 0.5                       # stats::ppoints
     pp = (np.arange(1, length + 1) - a) / (length + 1 - 2 * a)
     lims = norm.ppf([pp[0], pp[-1]])
-    w = norm.pdf(np.linspace(lims[0], lims[1], length))
+    return norm.pdf(np.linspace(lims[0], lims[1], length)), half
+
+
+def rollmean(x, size):
+    """bigutilsr::rollmean: Gaussian weights over 2*floor(size)+1 points, edge windows
+    renormalised by the weights they contain."""
+    x = np.asarray(x, dtype=np.float64)
+    if size == 0:
+        return x
+    w, half = _rollmean_weights(size)
+    if w.size >= x.size:
+        raise ValueError("Parameter 'size' is too large.")
     num = np.convolve(x, w[::-1], mode="full")[half:half + x.size]
-    den = np.convolve(np.ones_like(x), w[::-1], mode="full")[half:half + x.size]
+    # the weights a window contains: all of them except within `half` of an end (partial sums from either side)
+    den = np.full(x.size, w.sum())
+    cs = np.cumsum(w)
+    den[:half] = cs[half:2 * half]
+    den[x.size - half:] = np.cumsum(w[::-1])[half:2 * half][::-1]
     return num / den
 
 
-def medcouple(x, device=False):
+def rollmean_groups(x, size, groups, device=False):
+    """rollmean inside every group of indices (R/autoSVD.R:143-144: per chromosome).  `groups` as chr_groups returns
+    them.  device=True and the groups consecutive index ranges (a genotype file sorted by chromosome): one launch for
+    all of them (bsn_robust_rollmean)."""
+    x = np.asarray(x, dtype=np.float64)
+    out = np.full(x.size, np.nan)
+    if size == 0:
+        for _c, idx in groups:
+            out[idx] = x[idx]
+        return out
+    w, half = _rollmean_weights(size)
+    for _c, idx in groups:
+        if w.size >= idx.size:
+            raise ValueError("Parameter 'size' is too large.")
+    starts = np.array([idx[0] for _c, idx in groups], dtype=np.int64)
+    stops = np.array([idx[-1] + 1 for _c, idx in groups], dtype=np.int64)
+    sizes = np.array([idx.size for _c, idx in groups], dtype=np.int64)
+    by_start = np.argsort(starts)
+    runs = (np.array_equal(stops - starts, sizes) and starts[by_start[0]] == 0 and stops[by_start[-1]] == x.size
+            and np.array_equal(starts[by_start][1:], stops[by_start][:-1]))
+    if device and runs and len(groups) <= 1 << 20:
+        import ctypes as C
+        from . import _lib
+        from ._lib import check, f64p, ptr
+        off = np.ascontiguousarray(np.r_[starts[by_start], x.size].astype(np.int64))
+        xc, wc = np.ascontiguousarray(x), np.ascontiguousarray(w)
+        check(_lib.load().bsn_robust_rollmean(ptr(xc, f64p), x.size, ptr(wc, f64p), int(w.size),
+                                              off.ctypes.data_as(C.POINTER(C.c_int64)), int(off.size - 1), ptr(out, f64p)))
+        return out
+    for _c, idx in groups:
+        out[idx] = rollmean(x[idx], size)
+    return out
+
+
+def medcouple(x, device=False, assume_sorted=False):
     """Medcouple (Brys, Hubert & Struyf 2004): the median of the kernel
         h(xi, xj) = ((xi - med) - (med - xj)) / (xi - xj),   xi >= med >= xj,
     over all such pairs; for pairs tied AT the median (xi = xj = med) the kernel is defined through
@@ -178,9 +247,12 @@ def medcouple(x, device=False):
     on each side (the convention of robustbase::mc and of the original paper).  The kernel is monotone
     in both arguments, so #{h <= t} is a sum of searchsorted counts and the median is found by bisection
     on t, followed by a snap to the nearest attained kernel value (the median IS a kernel value).
-    device=True: the counts of the bisection — one binary search per value above the median — on the GPU
-    (bsn_robust_mc_count; what snp_autoSVD / bed_autoSVD use); same integers, same result."""
-    x = np.sort(np.asarray(x, dtype=np.float64))
+    device=True: the counts of the bisection — one binary search per value above the median — and the window of kernel
+    values that ends it on the GPU (bsn_robust_mc_count, bsn_robust_mc_window; what snp_autoSVD / bed_autoSVD use);
+    same integers, same kernel values, same result.  assume_sorted: x is ascending already."""
+    x = np.asarray(x, dtype=np.float64)
+    if not assume_sorted:
+        x = np.sort(x)
     n = x.size
     if n < 3:
         return 0.0
@@ -221,7 +293,18 @@ def medcouple(x, device=False):
             c = int(np.sum(lop.size - np.searchsorted(lop, thr, side="left")))
         return c + n_minus + int(np.sum(tie <= t))       # the +1 pairs only at t >= 1
 
-    def window(a, b):  # every kernel value in (a, b], -1 < a < b < 1 (regular pairs and the ties among themselves)
+    def window(a, b, expect):  # every kernel value in (a, b], -1 < a < b < 1 (regular pairs and the ties among themselves)
+        t_in = tie[(tie > a) & (tie <= b)]
+        if dev is not None:
+            import ctypes as C
+            from . import _lib
+            cap = max(int(expect) - int(t_in.size), 0)
+            buf, cnt = np.empty(max(cap, 1)), C.c_int64()
+            _lib.check(dev[2].bsn_robust_mc_window(dev[0].ptr, upp.size, dev[1].ptr, lop.size, float(a), float(b), cap,
+                                                   _lib.ptr(buf, _lib.f64p), C.byref(cnt)))
+            if cnt.value != cap:                                              # (rounding moved a pair across a bound)
+                return np.zeros(0)
+            return np.concatenate([buf[:cap], t_in])
         lo_i = np.searchsorted(lop, upp * (1 - b) / (1 + b), side="left")     # h <= b  <=>  l >= this
         hi_i = np.searchsorted(lop, upp * (1 - a) / (1 + a), side="left")     # h >  a  <=>  l <  this
         cnt = np.maximum(hi_i - lo_i, 0)
@@ -229,9 +312,12 @@ def medcouple(x, device=False):
         u_rep = np.repeat(upp, cnt)
         first = np.repeat(lo_i - (np.cumsum(cnt) - cnt), cnt)                 # l index = first + running position
         l = lop[first + np.arange(tot)]
-        return np.concatenate([(u_rep - l) / (u_rep + l), tie[(tie > a) & (tie <= b)]])
+        return np.concatenate([(u_rep - l) / (u_rep + l), t_in])
 
-    def kth(k):  # k-th smallest kernel value (1-based)
+    def kth(k, pair=False):  # k-th smallest kernel value (1-based); pair: the k-th and the (k + 1)-th
+        if pair:
+            first = kth(k, pair=None)
+            return first if isinstance(first, tuple) else (first, kth(k + 1))
         a, b = -1.0, 1.0
         ca = count_le(-1.0)
         if ca >= k:
@@ -241,8 +327,11 @@ def medcouple(x, device=False):
         # wanted one picked by its rank (exact, and a fifth of the count evaluations of a bisection down to 1e-15)
         for _ in range(200):
             if -1.0 < a and b < 1.0 and cb - ca <= 400000:
-                vals = window(a, b)
+                vals = window(a, b, cb - ca)
                 if vals.size == cb - ca:                                      # (always, unless rounding moved a pair across a bound)
+                    if pair is None and k + 1 <= cb:                          # both middle values from the one window
+                        part = np.partition(vals, [k - ca - 1, k - ca])
+                        return float(part[k - ca - 1]), float(part[k - ca])
                     return float(np.partition(vals, k - ca - 1)[k - ca - 1])
             mid = 0.5 * (a + b)
             cm = count_le(mid)
@@ -266,7 +355,24 @@ def medcouple(x, device=False):
 
     if total % 2 == 1:
         return kth((total + 1) // 2)
-    return 0.5 * (kth(total // 2) + kth(total // 2 + 1))
+    m1, m2 = kth(total // 2, pair=True)
+    return 0.5 * (m1 + m2)
+
+
+def _quantile_sorted(xs, q):
+    """np.quantile(xs, q) (the default method, R's type 7) of an ASCENDING vector, bit for bit: numpy's virtual index
+    and its two-sided interpolation restated."""
+    n = xs.size
+    v = (n - 1) * q
+    lo = int(np.floor(v))
+    if lo >= n - 1:
+        return float(xs[n - 1])
+    if lo < 0:
+        return float(xs[0])
+    g = v - lo
+    a, b = float(xs[lo]), float(xs[lo + 1])
+    d = b - a
+    return b - d * (1.0 - g) if g >= 0.5 else a + d * g
 
 
 def tukey_mc_up(x, coef=None, alpha=0.05, a=-4.0, b=3.0, device=False):
@@ -278,13 +384,24 @@ def tukey_mc_up(x, coef=None, alpha=0.05, a=-4.0, b=3.0, device=False):
     from scipy.stats import norm
     x = np.asarray(x, dtype=np.float64)
     x = x[~np.isnan(x)]
-    q1, q3 = np.quantile(x, [0.25, 0.75])   # R's default quantile type 7 == numpy's default
+    if device and x.size >= 1 << 16:
+        # one device sort serves the quartiles and the medcouple (np.sort of a million values: 70 ms of host time)
+        from . import _lib
+        x = np.ascontiguousarray(x)
+        if not np.all(np.isfinite(x)):
+            raise ValueError("tukey_mc_up: infinite values")
+        _lib.check(_lib.load().bsn_robust_sort(_lib.ptr(x, _lib.f64p), x.size))
+        q1, q3 = _quantile_sorted(x, 0.25), _quantile_sorted(x, 0.75)
+        is_sorted = True
+    else:
+        q1, q3 = np.quantile(x, [0.25, 0.75])   # R's default quantile type 7 == numpy's default
+        is_sorted = False
     iqr = q3 - q1
     if coef is None:
         q75 = norm.ppf(0.75)
         p = -np.expm1(np.log1p(-alpha) / x.size)
         coef = (norm.isf(p) - q75) / (2 * q75)
-    mc = medcouple(x, device=device)
+    mc = medcouple(x, device=device, assume_sorted=is_sorted)
     return q3 + coef * iqr * (np.exp(b * mc) if mc >= 0 else np.exp(-a * mc))
 
 
@@ -341,10 +458,8 @@ def _auto_svd(svd_fun, clump_fun, maf_nok, ind_col, infos_chr, infos_pos, thr_r2
             printf2("Maximum number of iterations reached.\n")
             break
         S = np.sqrt(dist_ogk(obj["v"], device=obj["v"].shape[1] <= 64))
-        S2 = np.full(S.size, np.nan)
         chr_keep = infos_chr[ind_keep]
-        for _c, idx in chr_groups(chr_keep):
-            S2[idx] = rollmean(S[idx], roll_size)
+        S2 = rollmean_groups(S, roll_size, chr_groups(chr_keep), device=True)
         thr = tukey_mc_up(S2, alpha=alpha_tukey, device=True)
         excl = np.nonzero(S2 > thr)[0]
         printf2("%d outlier variant%s detected..\n", excl.size, "s" if excl.size > 1 else "")

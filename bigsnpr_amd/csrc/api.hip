@@ -520,6 +520,7 @@ void slab_upload_range(bsn_bed *b, int64_t j0, int64_t cnt) {
     fail("internal: variants %lld .. %lld into a slab image of %lld", (long long)j0, (long long)(j0 + cnt), (long long)b->slab_cols);
   img->m = cnt;
   img->na_cnt.clear();
+  img->counts_cache.clear();
   image_from_file(img, b->fd_file, 3 + j0 * b->n_byte, b->n_byte, (FileStage *)b->slab_stage);
 }
 int64_t slab_upload(bsn_bed *b, int64_t sl, int64_t *j0_out) {
@@ -577,6 +578,32 @@ void counts_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t 
     });
     return;
   }
+  // the counts of this row selection as an earlier call left them (BSN_NO_COUNTS_CACHE=1: always count)
+  auto &cc = bed->counts_cache;
+  const bool use_cache = n > 0 && m > 0 && !getenv("BSN_NO_COUNTS_CACHE");
+  bool rows_all = use_cache && n == bed->n;
+  for (int64_t i = 0; rows_all && ind_row && i < n; i++) rows_all = ind_row[i] == i;
+  std::vector<int64_t> lead;         // (a NULL list with n < the handle's samples: the leading n)
+  const int64_t *rows = ind_row;
+  if (use_cache && !rows_all && !ind_row) {
+    lead.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) lead[(size_t)i] = i;
+    rows = lead.data();
+  }
+  const bool same_rows = use_cache && (int64_t)cc.cnt.size() == 4 * bed->m &&
+                         (rows_all ? cc.rows_all
+                                   : (!cc.rows_all && (int64_t)cc.rows.size() == n && std::memcmp(cc.rows.data(), rows, (size_t)n * 8) == 0));
+  if (same_rows) {
+    bool known = true;
+    for (int64_t j = 0; known && j < m; j++) {
+      const int64_t c = ind_col ? ind_col[j] : j;
+      known = c >= 0 && c < bed->m && cc.cnt[(size_t)4 * c] >= 0;
+    }
+    if (known) {
+      for (int64_t j = 0; j < m; j++) std::memcpy(res + 4 * j, &cc.cnt[(size_t)4 * (ind_col ? ind_col[j] : j)], 16);
+      return;
+    }
+  }
   bsn_op op;
   fill_op(&op, bed, ind_row, n, ind_col, m, nullptr, nullptr, true);
   DevBuf<int32_t> d_counts;
@@ -586,6 +613,15 @@ void counts_host(bsn_bed *bed, const int64_t *ind_row, int64_t n, const int64_t 
   if (op.rows_identity) {  // remember which variants are complete
     if ((int64_t)bed->na_cnt.size() != bed->m) bed->na_cnt.assign((size_t)bed->m, -1);
     for (int64_t j = 0; j < m; j++) bed->na_cnt[(size_t)(ind_col ? ind_col[j] : j)] = res[4 * j + 3];
+  }
+  if (use_cache) {
+    if (!same_rows) {
+      cc.clear();
+      cc.rows_all = rows_all;
+      if (!rows_all) cc.rows.assign(rows, rows + n);
+      cc.cnt.assign((size_t)4 * bed->m, -1);
+    }
+    for (int64_t j = 0; j < m; j++) std::memcpy(&cc.cnt[(size_t)4 * (ind_col ? ind_col[j] : j)], res + 4 * j, 16);
   }
 }
 

@@ -287,6 +287,19 @@ struct bsn_bed {
   // by-product of every full-row count (and at creation for FBM / NA-free synthetic images).
   // An operator whose variants are all known to be complete skips the missing-value plane.
   std::vector<int32_t> na_cnt;
+  // code counts per variant as the last count entries returned them, for ONE row selection (round 6: snp_autoSVD asks for the
+  // column statistics of the same rows three times — snp_MAF, snp_clumping, the scaling function: R/autoSVD.R:103-127 — and
+  // each is a pass over the whole image).  cnt[4 j] < 0: not known.  Dropped wherever na_cnt is (the image changed).
+  struct CountsCache {
+    bool rows_all = false;
+    std::vector<int64_t> rows;      // the selection when it is not all rows in file order
+    std::vector<int32_t> cnt;       // 4 per variant of the handle
+    void clear() {
+      rows_all = false;
+      rows.clear();
+      cnt.clear();
+    }
+  } counts_cache;
   // Share of the K-steps of the two streaming products that carry NO missing code (round 5, matvec.hip op_na_blocks):
   // sampled once per image by a small kernel queued on the handle's stream, picked up from pinned memory by a later
   // launch (no synchronisation).  state 0 = not measured, 1 = queued, 2 = known.  [0] crossproduct (16 variants x

@@ -1039,6 +1039,7 @@ bsn_bed *image_gather(bsn_bed *src, const int64_t *ind_row, int64_t n, const int
     BSN_HIP(hipStreamSynchronize(b->stream));
     b->m = m;
     b->na_cnt.clear();
+    b->counts_cache.clear();
     b->na_blocks_state = 0;   // (the share of K-steps without a missing code is the old selection's)
   } else {
     fresh.reset(new bsn_bed());

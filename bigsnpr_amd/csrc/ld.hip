@@ -1904,6 +1904,7 @@ static int64_t clump_bits_streamed(bsn_bed *bed, const int64_t *ind_row, int64_t
         std::memcpy(gathered.data() + (size_t)t * (size_t)bed->n_byte, bed->h_map + (size_t)col(lo + t) * (size_t)bed->n_byte, (size_t)bed->n_byte);
       img->m = ml;
       img->na_cnt.clear();
+      img->counts_cache.clear();
       image_from_host(img, gathered.data(), bed->n_byte);
       for (int64_t t = 0; t < ml; t++) loc[(size_t)t] = t;
     }

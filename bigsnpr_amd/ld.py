@@ -266,10 +266,39 @@ def chr_groups(infos_chr, keep=None):
     return [(c, np.nonzero((infos_chr == c) & sel)[0].astype(np.int64)) for c in np.unique(infos_chr[sel])]
 
 
-def _clump_chr(im, ir, ind_chr, mode, aux1, aux2, S_chr, pos_chr, size, thr_r2):
+def _order_and_rank(S_chr):
     ord_ = _r_order_decreasing(S_chr).astype(np.int32)
     rank = np.empty(ord_.size, dtype=np.int32)
     rank[ord_] = np.arange(ord_.size, dtype=np.int32)
+    return ord_, rank
+
+
+class _OrdersAhead:
+    """order(S, decreasing = TRUE) of every chromosome BEFORE the loop that consumes them, in one device call
+    (bsn_order_decreasing: two stable radix sorts over the concatenated statistics): the stable host sort of a
+    chromosome's statistic (3 - 4 ms for 45 000 variants) otherwise sits between two GPU calls — 22 of them were a third
+    of snp_clumping's wall time at a million variants.  Statistics with NaN (R puts NA last) take the host sort."""
+
+    def __init__(self, stats):
+        self.stats = [np.ascontiguousarray(s, dtype=np.float64) for s in stats]
+        self.ord = self.rank = None
+        total = sum(s.size for s in self.stats)
+        if total >= 4096 and not any(np.isnan(s).any() for s in self.stats):
+            allS = np.concatenate(self.stats)
+            self.off = np.concatenate([[0], np.cumsum([s.size for s in self.stats])]).astype(np.int64)
+            self.ord, self.rank = np.empty(total, dtype=np.int32), np.empty(total, dtype=np.int32)
+            check(_lib.load().bsn_order_decreasing(ptr(allS, f64p), total, self.off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                   len(self.stats), ptr(self.ord, i32p), ptr(self.rank, i32p)))
+
+    def get(self, t):
+        if self.ord is None:
+            return _order_and_rank(self.stats[t])
+        a, b = int(self.off[t]), int(self.off[t + 1])
+        return self.ord[a:b], self.rank[a:b]
+
+
+def _clump_chr(im, ir, ind_chr, mode, aux1, aux2, S_chr, pos_chr, size, thr_r2, order=None):
+    ord_, rank = _order_and_rank(S_chr) if order is None else order
     keep = np.empty(ind_chr.size, dtype=np.int32)
     aux1, aux2, pos_chr = as_f64(aux1), as_f64(aux2), as_f64(pos_chr)
     assert_sorted(pos_chr)
@@ -279,6 +308,35 @@ def _clump_chr(im, ir, ind_chr, mode, aux1, aux2, S_chr, pos_chr, size, thr_r2):
                                        float(size), float(thr_r2), ptr(keep, i32p)))
     assert np.all((keep == 0) | (keep == 1))  # stopifnot(all(keep[] %in% 0:1)), R/clumping.R:134
     return ind_chr[keep == 1]
+
+
+def _clump_jobs(im, ir, jobs, mode, thr_r2, one_call=None):
+    """The chromosomes of a clumping, each (ind_chr, aux1, aux2, S_chr, pos_chr, size): R/clumping.R:95-137 loops over them.
+    On a resident handle with integer positions they go to the device as ONE call — the chromosomes laid end to end with
+    more than a window between them, one stable order by S over all of them (inside a chromosome it is the
+    chromosome's own order; variants of different chromosomes never meet in a window, so the sweep prunes the same
+    variants) — instead of 22 calls with their uploads, band allocations, bit-image downloads and tails of half-empty
+    launches (a third of snp_clumping's wall time at a million variants).  one_call=False / BSN_CLUMP_PER_CHR=1: the loop."""
+    import os
+    if not jobs:
+        return []
+    sz = jobs[0][5]
+    spans = [float(j[4][-1] - j[4][0]) for j in jobs]
+    shift = max(spans) + sz + 2.0
+    whole = all(np.all(j[4] == np.floor(j[4])) for j in jobs) and sz == np.floor(sz) and shift * (len(jobs) + 1) < 2.0 ** 52
+    if one_call is None:
+        one_call = not os.environ.get("BSN_CLUMP_PER_CHR")
+    if one_call and len(jobs) > 1 and whole and not im.streamed and all(np.all(np.diff(j[4]) >= 0) for j in jobs):
+        ind_all = np.concatenate([j[0] for j in jobs])
+        a1, a2 = np.concatenate([j[1] for j in jobs]), np.concatenate([j[2] for j in jobs])
+        S_all = np.concatenate([j[3] for j in jobs])
+        pos_all = np.concatenate([j[4] - j[4][0] + t * shift for t, j in enumerate(jobs)])
+        order = _OrdersAhead([S_all]).get(0)
+        kept = _clump_chr(im, ir, ind_all, mode, a1, a2, S_all, pos_all, sz, thr_r2, order=order)
+        return [kept]
+    ahead = _OrdersAhead([j[3] for j in jobs])
+    return [_clump_chr(im, ir, ind_chr, mode, a1, a2, S_chr, pos_chr, sz_, thr_r2, order=ahead.get(t))
+            for t, (ind_chr, a1, a2, S_chr, pos_chr, sz_) in enumerate(jobs)]
 
 
 def snp_clumping(G, infos_chr, ind_row=None, S=None, thr_r2=0.2, size=None, infos_pos=None,
@@ -301,6 +359,7 @@ def snp_clumping(G, infos_chr, ind_row=None, S=None, thr_r2=0.2, size=None, info
     sel = np.nonzero(~excl)[0].astype(np.int64)
     st_all = snp_colstats(G, ir, sel) if sel.size else None
     where = np.cumsum(~excl) - 1
+    jobs = []
     for chrom, ind_chr in chr_groups(infos_chr, ~excl):
         st = {key: val[where[ind_chr]] for key, val in st_all.items()}
         if S is None:
@@ -312,7 +371,8 @@ def snp_clumping(G, infos_chr, ind_row=None, S=None, thr_r2=0.2, size=None, info
             pos_chr, sz = np.arange(1, ind_chr.size + 1, dtype=np.float64), float(size)
         else:
             pos_chr, sz = np.asarray(infos_pos, dtype=np.float64)[ind_chr], float(size) * 1000.0
-        kept.append(_clump_chr(im, ir, ind_chr, 0, st["sumX"], st["denoX"], S_chr, pos_chr, sz, thr_r2))
+        jobs.append((ind_chr, st["sumX"], st["denoX"], S_chr, pos_chr, sz))
+    kept = _clump_jobs(im, ir, jobs, 0, thr_r2)
     return np.sort(np.concatenate(kept)) if kept else np.zeros(0, dtype=np.int64)
 
 
@@ -332,6 +392,7 @@ def bed_clumping(obj_bed, ind_row=None, S=None, thr_r2=0.2, size=None, exclude=N
     sel = np.nonzero(~excl)[0].astype(np.int64)           # (all kept variants in one call, as in snp_clumping)
     st_all = bed_colstats(obj_bed, ir, sel) if sel.size else None
     where = np.cumsum(~excl) - 1
+    jobs = []
     for chrom, ind_chr in chr_groups(infos_chr, ~excl):
         st = {key: val[where[ind_chr]] for key, val in st_all.items() if isinstance(val, np.ndarray) and val.shape[:1] == (sel.size,)}
         with np.errstate(all="ignore"):
@@ -341,8 +402,8 @@ def bed_clumping(obj_bed, ind_row=None, S=None, thr_r2=0.2, size=None, exclude=N
             S_chr = np.minimum(st["sumX"], 2.0 * st["nb_nona_col"] - st["sumX"])  # MAC
         else:
             S_chr = np.asarray(S, dtype=np.float64)[ind_chr]
-        kept.append(_clump_chr(im, ir, ind_chr, 1, center, scale, S_chr, infos_pos[ind_chr],
-                               float(size) * 1000.0, thr_r2))
+        jobs.append((ind_chr, center, scale, S_chr, infos_pos[ind_chr], float(size) * 1000.0))
+    kept = _clump_jobs(im, ir, jobs, 1, thr_r2)
     return np.sort(np.concatenate(kept)) if kept else np.zeros(0, dtype=np.int64)
 
 

@@ -455,6 +455,33 @@ int bsn_robust_scale_cols(double *d_Z, int64_t m, int64_t ld, int32_t p, const d
 int bsn_robust_rotate(double *d_Z, int64_t m, int64_t ld, int32_t p, const double *E /* p x p, column-major */); /* Z <- Z E */
 /* out[i] = sum_j ((Z[i, j] - mu[j]) / sig[j])^2, to the host */
 int bsn_robust_wdist(const double *d_Z, int64_t m, int64_t ld, int32_t p, const double *mu, const double *sig, double *out);
+/* (round 6) bigutilsr::dist_ogk end to end: squared robust Mahalanobis distances of the m rows of the DEVICE matrix d_U
+ * (m x p, p <= 64, not modified) to the host vector dist_out [m] — the OGK rounds above (niter of them), the hard
+ * rejection wdist <= median(wdist) * cut_ratio (cut_ratio = qchisq(beta, p) / qchisq(0.5, p), the caller's quantiles),
+ * centre and covariance (denominator n_kept - 1) of the kept rows, distances with the pseudo-inverse of that covariance
+ * (singular values <= 1e-15 x the largest dropped).  Only p x p matrices visit the host.  n_kept_out may be NULL.
+ * R/autoSVD.R:142,295 (`bigutilsr::dist_ogk(obj.svd$v)`) */
+int bsn_robust_dist_ogk(const double *d_U, int64_t m, int64_t ld, int32_t p, int32_t niter, double cut_ratio, double c1, double c2,
+                        double *dist_out, int64_t *n_kept_out);
+/* bigutilsr::rollmean of the HOST vector x [m] with the odd-length weight vector w [len] inside each of the consecutive
+ * groups [group_off[g], group_off[g + 1]) (NULL / 0: one group); edge windows are renormalised by the weights they
+ * contain.  R/autoSVD.R:143-144,296-297 (per chromosome) */
+int bsn_robust_rollmean(const double *x, int64_t m, const double *w, int32_t len, const int64_t *group_off, int32_t ngroups, double *out);
+/* ascending sort of a HOST vector of finite doubles in place (device radix sort): the order statistics of tukey_mc_up */
+int bsn_robust_sort(double *x, int64_t m);
+/* medcouple, the end of the bisection: the kernel values (u - l) / (u + l) in (a, b], -1 < a < b < 1, of the pairs counted
+ * by bsn_robust_mc_count, to the host in no particular order; count_out receives their number and nothing is written when
+ * it exceeds cap */
+int bsn_robust_mc_window(const double *d_up, int64_t nu, const double *d_lo, int64_t nl, double a, double b, int64_t cap, double *out,
+                         int64_t *count_out);
+
+/* R/clumping.R:106, R/bed-clumping.R:48 — `ord <- order(S.chr, decreasing = TRUE)` — for every chromosome at once: S [m]
+ * holds the statistics of the groups [group_off[g], group_off[g + 1]) one after the other (NULL / 0: one group); ord
+ * receives, group by group, the 0-based positions INSIDE the group in decreasing order of S, ties in index order (R's
+ * order is stable), rank its inverse (rank[group_off[g] + ord[group_off[g] + t]] = t): the ordInd / rankInd arguments of
+ * bsn_clumping_chr.  Two stable device radix sorts (by value, then by group); a NaN is refused (the host path puts
+ * them last, as R does). */
+int bsn_order_decreasing(const double *S, int64_t m, const int64_t *group_off, int32_t ngroups, int32_t *ord, int32_t *rank);
 
 /* ---- device memory + timing helpers for hosts without a HIP binding -------- */
 int bsn_malloc(void **d_ptr, int64_t bytes);

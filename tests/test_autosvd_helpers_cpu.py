@@ -197,3 +197,49 @@ def test_scaled_up_paths_give_the_same_numbers():
     np.testing.assert_array_equal(threaded, serial)
     for x in (rng.normal(size=1500) ** 2, np.round(rng.gamma(2.0, size=1201), 1)):
         assert abs(prod.medcouple(x) - orc_a.medcouple(x)) < 1e-12
+
+
+def test_quantile_of_a_sorted_vector_is_numpys_bit_for_bit():
+    """tukey_mc_up's device path sorts once and reads the quartiles off the sorted vector (round 6): numpy's default
+    method (R's type 7) restated, its virtual index and two-sided interpolation included"""
+    from bigsnpr_amd import autosvd as prod
+    rng = np.random.default_rng(2)
+    for _ in range(4000):
+        n = int(rng.integers(1, 400))
+        x = np.sort(rng.normal(size=n) * 10.0 ** int(rng.integers(-3, 4)))
+        q = float(rng.choice([0.25, 0.75, 0.5, 0.0, 1.0, rng.random()]))
+        assert prod._quantile_sorted(x, q) == float(np.quantile(x, q))
+    for n in (1000000, 999999, 524288):
+        x = np.sort(rng.normal(size=n))
+        for q in (0.25, 0.75):
+            assert prod._quantile_sorted(x, q) == float(np.quantile(x, q))
+
+
+def test_rollmean_in_groups_on_the_host():
+    """rollmean_groups (host path): the rolling mean inside every chromosome, whatever the order of the labels; the
+    denominators taken from partial sums of the weights equal the convolution of ones they replace"""
+    from scipy.stats import norm
+    from bigsnpr_amd import autosvd as prod
+    from bigsnpr_amd.ld import chr_groups
+    rng = np.random.default_rng(3)
+
+    def by_convolution(x, size):
+        half = int(np.floor(size)); length = 2 * half + 1
+        a = 3.0 / 8 if length <= 10 else 0.5
+        pp = (np.arange(1, length + 1) - a) / (length + 1 - 2 * a)
+        lims = norm.ppf([pp[0], pp[-1]])
+        w = norm.pdf(np.linspace(lims[0], lims[1], length))
+        return (np.convolve(x, w[::-1], mode="full")[half:half + x.size] /
+                np.convolve(np.ones_like(x), w[::-1], mode="full")[half:half + x.size])
+
+    for n, size in ((50, 3), (1000, 50), (102, 50), (12, 5.5), (7, 1)):
+        x = rng.normal(size=n)
+        np.testing.assert_allclose(prod.rollmean(x, size), by_convolution(x, size), rtol=1e-14, atol=1e-16)
+    chrom = np.repeat([1, 2, 3, 4], [300, 120, 500, 200])
+    for labels in (chrom, rng.permutation(chrom)):
+        x = rng.lognormal(size=labels.size)
+        got = prod.rollmean_groups(x, 50, chr_groups(labels))
+        for c in np.unique(labels):
+            np.testing.assert_array_equal(got[labels == c], prod.rollmean(x[labels == c], 50))
+    with pytest.raises(ValueError, match="too large"):
+        prod.rollmean_groups(np.arange(300.0), 50, chr_groups(np.repeat([1, 2, 3], 100)))

@@ -159,8 +159,10 @@ def test_dist_ogk_on_the_device_equals_both_host_restatements():
     C = rng.normal(size=(3000, 3)); C[:, 1] = np.where(rng.uniform(size=3000) < 0.7, 0.5, C[:, 1])   # MAD of column 1 is 0
     cases.append(C)
     for U in cases:
-        dev = prod.dist_ogk(U, device=True)
+        dev = prod.dist_ogk(U, device=True)              # round 6: the whole function on the device (bsn_robust_dist_ogk)
+        steps = prod.dist_ogk(U, device="steps")         # round 5: the scales on the device, the loop on the host
         host = prod.dist_ogk(U)
+        np.testing.assert_allclose(steps, host, rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(dev, host, rtol=1e-9, atol=1e-12)
         if U.shape[0] <= 5000:
             np.testing.assert_allclose(dev, orc_a.dist_ogk(U), rtol=1e-8, atol=1e-12)
@@ -186,6 +188,66 @@ def test_medcouple_counts_on_the_device():
               np.r_[rng.normal(size=9000), np.zeros(50)]):
         assert prod.medcouple(x, device=True) == prod.medcouple(x)
         assert prod.tukey_mc_up(x, device=True) == prod.tukey_mc_up(x)
+
+
+def test_the_outlier_step_on_the_device_end_to_end():
+    """Round 6: what follows dist_ogk in the reference's loop (R/autoSVD.R:142-148) on the device too — the
+    rolling mean inside every chromosome in one launch, one device sort for the quartiles and the medcouple, the window
+    of kernel values that ends the medcouple's bisection — against the host paths: the sort and the kernel values are
+    bit-identical (hence the fence is), the rolling mean agrees to rounding."""
+    import ctypes as C
+    from bigsnpr_amd import _lib, autosvd as prod
+    from bigsnpr_amd.ld import chr_groups
+    L = _lib.load()
+    rng = np.random.default_rng(21)
+    # sort: signs, ties, denormals, both zeros
+    x = np.r_[rng.normal(size=200001) * 10.0 ** rng.integers(-300, 300, size=200001), np.zeros(5), -np.zeros(3), np.round(rng.normal(size=5000), 1)]
+    y = np.ascontiguousarray(x.copy())
+    _lib.check(L.bsn_robust_sort(_lib.ptr(y, _lib.f64p), y.size))
+    assert np.array_equal(y, np.sort(x))
+    for n in (0, 1, 2):
+        z = np.ascontiguousarray(rng.normal(size=max(n, 1))[:n].copy()); zz = z.copy()
+        _lib.check(L.bsn_robust_sort(_lib.ptr(zz, _lib.f64p), n))
+        assert np.array_equal(zz, np.sort(z))
+    # rolling mean in groups: runs of chromosomes (one launch) and an interleaved order (host fallback), against rollmean per group
+    for m, nchr, size in ((300001, 22, 50), (5000, 3, 7.5), (40000, 1, 50), (2000, 4, 0)):
+        cuts = np.sort(rng.choice(np.arange(200, m - 200, 300), size=nchr - 1, replace=False)) if nchr > 1 else np.zeros(0, dtype=int)
+        chrom = np.searchsorted(cuts, np.arange(m), side="right") + 1
+        v = rng.lognormal(size=m)
+        ref = np.full(m, np.nan)
+        for c in np.unique(chrom):
+            ref[chrom == c] = prod.rollmean(v[chrom == c], size)
+        got = prod.rollmean_groups(v, size, chr_groups(chrom), device=True)
+        np.testing.assert_allclose(got, ref, rtol=1e-13, atol=0)
+        np.testing.assert_allclose(prod.rollmean_groups(v, size, chr_groups(chrom)), ref, rtol=1e-13, atol=0)
+        mixed = rng.permutation(chrom)                                # labels not in runs: the per-group host path
+        ref2 = np.full(m, np.nan)
+        for c in np.unique(mixed):
+            ref2[mixed == c] = prod.rollmean(v[mixed == c], size)
+        np.testing.assert_allclose(prod.rollmean_groups(v, size, chr_groups(mixed), device=True), ref2, rtol=1e-13, atol=0)
+    with pytest.raises(ValueError, match="too large"):
+        prod.rollmean_groups(np.arange(300.0), 50, chr_groups(np.repeat([1, 2, 3], 100)), device=True)
+    # the window of kernel values, directly: the same multiset as the host's enumeration
+    up, lo = np.sort(rng.lognormal(size=3000)), np.sort(rng.lognormal(size=2500))
+    dU, dL = _lib.DeviceArray.from_numpy(up), _lib.DeviceArray.from_numpy(lo)
+    for a, b in ((-0.2, 0.1), (0.0, 0.01), (-0.999, -0.99), (0.3, 0.3000001)):
+        h = (up[:, None] - lo[None, :]) / (up[:, None] + lo[None, :])
+        want = np.sort(h[(h > a) & (h <= b)])
+        cnt, buf = C.c_int64(), np.empty(max(want.size, 1))
+        _lib.check(L.bsn_robust_mc_window(dU.ptr, up.size, dL.ptr, lo.size, a, b, want.size, _lib.ptr(buf, _lib.f64p), C.byref(cnt)))
+        assert cnt.value == want.size and np.array_equal(np.sort(buf[:want.size]), want)
+        _lib.check(L.bsn_robust_mc_window(dU.ptr, up.size, dL.ptr, lo.size, a, b, want.size // 2, _lib.ptr(buf, _lib.f64p), C.byref(cnt)))
+        assert cnt.value == want.size                                 # over the cap: the count only
+    dU.free(); dL.free()
+    # the fence at the size snp_autoSVD calls it (device sort + counts + window) against the host path: identical
+    for x in (rng.lognormal(size=300001), rng.chisquare(3, size=1 << 17), np.round(rng.normal(size=250000), 2),
+              np.r_[rng.normal(size=90000), np.zeros(50)], np.r_[rng.gamma(2.0, size=70000), np.full(3, np.nan)]):
+        assert prod.tukey_mc_up(x, device=True) == prod.tukey_mc_up(x)
+        assert prod.tukey_mc_up(x, alpha=0.5, device=True) == prod.tukey_mc_up(x, alpha=0.5)
+    # and dist_ogk at that size, whole function against the step-by-step device path
+    U = rng.normal(size=(400000, 10)) * rng.uniform(0.5, 2.0, size=10)
+    U[5000:9000] += 3.0
+    np.testing.assert_allclose(prod.dist_ogk(U, device=True), prod.dist_ogk(U, device="steps"), rtol=1e-9, atol=1e-12)
 
 
 def _pack_bed(g):

@@ -260,3 +260,88 @@ def test_null_index_lists_mean_the_leading_rows_and_columns(ba, orc):
     np.testing.assert_array_equal(out.T, orc.read_bed(ob, ir, ic, na_val=-1))
     assert L.bsn_bed_col_counts(gb.handle, None, n + 1, None, ms, ptr(cnt, i32p)) != 0
     assert b"Subscript out of bounds" in L.bsn_last_error()
+
+
+def test_counts_remembered_per_row_selection(ba, orc, monkeypatch):
+    """round 6: a handle remembers the code counts of the last row selection (snp_autoSVD asks three times for the column
+    statistics of the same rows); every answer from memory equals a fresh count and the oracle's — other rows, column
+    subsets in any order, repeated columns, the leading-rows form of a NULL list, and an image that changed underneath
+    (a compacted solve reuses its sub-image in place)"""
+    from bigsnpr_amd import _lib
+    from bigsnpr_amd._lib import i32p, i64p, ptr
+    L = _lib.load()
+    n, m = 333, 700
+    ob = orc.fake_bed(n, m, seed=5)
+    gb = ba.bed.from_payload(ob.payload, n, m)
+    rng = np.random.default_rng(8)
+
+    def counts(ir, ic):
+        res = np.empty((len(ic), 4), dtype=np.int32)
+        ir64, ic64 = np.asarray(ir, dtype=np.int64), np.asarray(ic, dtype=np.int64)
+        _lib.check(L.bsn_bed_col_counts(gb.handle, ptr(ir64, i64p), ir64.size, ptr(ic64, i64p), ic64.size, ptr(res, i32p)))
+        return res.T
+
+    rows_a, rows_b = np.arange(n), np.sort(rng.choice(n, 200, replace=False))
+    for rows in (rows_a, rows_a, rows_b, rows_b, rows_a, rng.permutation(rows_b), np.arange(120)):
+        for cols in (np.arange(m), rng.permutation(m)[:300], np.arange(50, 250), rng.integers(0, m, size=90), np.arange(m)):
+            want = orc.bed_col_counts(ob, rows, cols)
+            np.testing.assert_array_equal(counts(rows, cols), want)           # (from memory after the first full request)
+            monkeypatch.setenv("BSN_NO_COUNTS_CACHE", "1")
+            np.testing.assert_array_equal(counts(rows, cols), want)
+            monkeypatch.delenv("BSN_NO_COUNTS_CACHE")
+    res = np.empty((m, 4), dtype=np.int32)
+    _lib.check(L.bsn_bed_col_counts(gb.handle, None, 120, None, m, ptr(res, i32p)))      # NULL lists: the leading 120 rows
+    np.testing.assert_array_equal(res.T, orc.bed_col_counts(ob, np.arange(120), np.arange(m)))
+    _lib.check(L.bsn_bed_col_counts(gb.handle, None, 120, None, m, ptr(res, i32p)))
+    np.testing.assert_array_equal(res.T, orc.bed_col_counts(ob, np.arange(120), np.arange(m)))
+    # the statistics that are derived from the counts, twice, and the MAF / colstats entries of the FBM path
+    st1, st2 = ba.bed_colstats(gb, rows_b, np.arange(m)), ba.bed_colstats(gb, rows_b, np.arange(m))
+    for key in st1:
+        np.testing.assert_array_equal(st1[key], st2[key])
+    ref = orc.bed_colstats(ob, rows_b, np.arange(m))
+    np.testing.assert_array_equal(st1["sumX"], ref["sumX"])
+    assert L.bsn_bed_col_counts(gb.handle, None, n, ptr(np.array([0, m], dtype=np.int64), i64p), 2, ptr(res, i32p)) != 0
+    assert b"Subscript out of bounds" in L.bsn_last_error()
+
+
+def test_order_decreasing_in_groups_is_rs_stable_order(ba):
+    """bsn_order_decreasing (R/clumping.R:106: order(S.chr, decreasing = TRUE) for every chromosome in one device call)
+    against numpy's stable sort per group: continuous statistics, heavy ties (MAF of few samples), both zeros, one group,
+    many groups of uneven sizes; the inverse permutation; NaN statistics take the host path inside _OrdersAhead"""
+    import ctypes as C
+    from bigsnpr_amd import _lib, ld
+    from bigsnpr_amd._lib import f64p, i32p, ptr
+    L = _lib.load()
+    rng = np.random.default_rng(12)
+    for sizes, kind in (([70000], "cont"), ([5000, 1, 17, 40000, 3000], "ties"), ([300] * 40, "ties"), ([9000, 9000], "zeros"),
+                        (list(rng.integers(1, 3000, size=300)), "cont")):
+        stats = []
+        for sz in sizes:
+            if kind == "cont":
+                v = rng.random(int(sz))
+            elif kind == "ties":
+                a = rng.integers(0, 41, size=int(sz)) / 40.0
+                v = np.minimum(a, 1 - a)
+            else:
+                v = rng.choice([0.0, -0.0, 0.25, 1e-300, -1e-300], size=int(sz))
+            stats.append(v)
+        allS = np.concatenate(stats)
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        ord_, rank = np.empty(allS.size, dtype=np.int32), np.empty(allS.size, dtype=np.int32)
+        _lib.check(L.bsn_order_decreasing(ptr(allS, f64p), allS.size, off.ctypes.data_as(C.POINTER(C.c_int64)), len(sizes),
+                                          ptr(ord_, i32p), ptr(rank, i32p)))
+        for g, v in enumerate(stats):
+            want = np.argsort(-v, kind="stable")
+            got = ord_[off[g]:off[g + 1]]
+            np.testing.assert_array_equal(got, want)
+            inv = np.empty(v.size, dtype=np.int32); inv[want] = np.arange(v.size)
+            np.testing.assert_array_equal(rank[off[g]:off[g + 1]], inv)
+        ahead = ld._OrdersAhead(stats)
+        for g, v in enumerate(stats):
+            o, r = ahead.get(g)
+            np.testing.assert_array_equal(o, np.argsort(-v, kind="stable"))
+    bad = np.array([0.5, np.nan, 0.25] * 2000)
+    assert L.bsn_order_decreasing(ptr(bad, f64p), bad.size, None, 0, ptr(np.empty(bad.size, dtype=np.int32), i32p),
+                                  ptr(np.empty(bad.size, dtype=np.int32), i32p)) != 0
+    ahead = ld._OrdersAhead([bad])
+    np.testing.assert_array_equal(ahead.get(0)[0], np.argsort(-bad, kind="stable"))

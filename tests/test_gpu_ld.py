@@ -175,6 +175,45 @@ def test_clumping_identical_to_oracle(ba, orc, golden_dir, example_bed):
     assert np.isin(keep, keep2).mean() > 0.98
 
 
+def test_clumping_all_chromosomes_in_one_call(ba, orc, monkeypatch):
+    """round 6: on a resident handle with whole-number positions the chromosomes of a clumping go to the device laid end to
+    end in ONE call (ld.py: _clump_jobs) — the same indices as the chromosome-by-chromosome loop (BSN_CLUMP_PER_CHR=1) and
+    as the oracle's loop: uneven chromosomes, tied statistics and tied positions, windows wider than a chromosome, a row
+    subset, exclusions; fractional positions and unsorted labels keep to the loop"""
+    n, m = 260, 2400
+    ob = orc.fake_bed(n, m, seed=31, na16=0)
+    gb = ba.bed.from_payload(ob.payload, n, m)
+    Go = orc.fbm_from_bed(ob)
+    G = ba.FBM_code256(Go.bytes)
+    rng = np.random.default_rng(4)
+    chrom = np.repeat([1, 2, 3, 4, 5, 6], [700, 40, 900, 3, 500, 257])
+    pos = np.concatenate([np.sort(rng.integers(1, 2_000_000, size=c)) for c in (700, 40, 900, 3, 500, 257)]).astype(float)
+    pos[100:110] = pos[100]                                            # tied positions
+    ir = np.sort(rng.choice(n, 200, replace=False))
+    excl = rng.choice(m, 300, replace=False)
+    S_tied = rng.integers(0, 6, size=m).astype(float)
+    for kw in (dict(thr_r2=0.2, infos_pos=pos), dict(thr_r2=0.05, size=150), dict(thr_r2=0.1, infos_pos=pos, size=5000),
+               dict(thr_r2=0.2, infos_pos=pos, ind_row=ir, exclude=excl), dict(thr_r2=0.3, infos_pos=pos, S=S_tied, size=300)):
+        one = ba.snp_clumping(G, chrom, **kw)
+        np.testing.assert_array_equal(one, orc.snp_clumping(Go, chrom, **kw))
+        monkeypatch.setenv("BSN_CLUMP_PER_CHR", "1")
+        np.testing.assert_array_equal(ba.snp_clumping(G, chrom, **kw), one)
+        monkeypatch.delenv("BSN_CLUMP_PER_CHR")
+    for kw in (dict(thr_r2=0.2), dict(thr_r2=0.2, ind_row=ir, exclude=excl, size=300)):
+        one = ba.bed_clumping(gb, infos_chr=chrom, infos_pos=pos, **kw)
+        np.testing.assert_array_equal(one, orc.bed_clumping(ob, chrom, pos, **kw))
+        monkeypatch.setenv("BSN_CLUMP_PER_CHR", "1")
+        np.testing.assert_array_equal(ba.bed_clumping(gb, infos_chr=chrom, infos_pos=pos, **kw), one)
+        monkeypatch.delenv("BSN_CLUMP_PER_CHR")
+    # fractional positions (kb) and labels that are not in runs: the loop, same answer as the oracle
+    np.testing.assert_array_equal(ba.snp_clumping(G, chrom, infos_pos=pos / 1000 + 0.25, size=0.5),
+                                  orc.snp_clumping(Go, chrom, infos_pos=pos / 1000 + 0.25, size=0.5))
+    mixed = rng.permutation(chrom)
+    np.testing.assert_array_equal(ba.snp_clumping(G, mixed, thr_r2=0.2, size=100), orc.snp_clumping(Go, mixed, thr_r2=0.2, size=100))
+    with pytest.raises(ValueError, match="not sorted"):
+        ba.snp_clumping(G, chrom, infos_pos=pos[::-1].copy())
+
+
 @pytest.mark.parametrize("batch", [37, 400])
 def test_clumping_wide_windows_lazy_path(ba, orc, golden_dir, example_bed, monkeypatch, batch):
     """Windows whose dense r2 band would not fit the device take the batched candidate-vs-kept path

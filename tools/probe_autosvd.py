@@ -40,9 +40,9 @@ autosvd.snp_MAF = timed("snp_MAF", autosvd.snp_MAF)
 autosvd.snp_clumping = timed("snp_clumping", autosvd.snp_clumping)
 autosvd.big_randomSVD = timed("big_randomSVD", autosvd.big_randomSVD)
 autosvd.dist_ogk = timed("dist_ogk", autosvd.dist_ogk)
-autosvd.rollmean = timed("rollmean", autosvd.rollmean)
+autosvd.rollmean_groups = timed("rollmean", autosvd.rollmean_groups)
 autosvd.tukey_mc_up = timed("tukey_mc_up", autosvd.tukey_mc_up)
-for rep in ("first call (imports, first launches, allocations)", "second call"):
+for rep in ("first call (imports, first launches, allocations)", "second call", "third call"):
     T.clear(); K.clear()
     t0 = time.perf_counter()
     res = ba.snp_autoSVD(gb, chrom, pos, k=10, verbose=rep.startswith("first"))
