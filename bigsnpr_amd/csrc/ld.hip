@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <memory>
+#include <unordered_map>
 
 #include <cstdlib>
 
@@ -593,7 +594,12 @@ __global__ __launch_bounds__(64) void k_pair_xy64(const uint8_t *__restrict__ im
 // pipe cycles the int8 instruction needs for 64.  The sums are sum g g' / 4: exact in fp32 while 4 n < 2^24 (the host takes
 // the int8 kernel beyond 4 194 303 samples, or with BSN_LD_I8=1); dropped samples are ANDed to code 0.  Same tile pairs,
 // same K split, same integer statistics as k_pair_xy64: the band, the clumping bits and the LD scores are bit-identical.
-__global__ __launch_bounds__(64) void k_pair_xy_f4(const uint8_t *__restrict__ img, int64_t pitch,
+// MASK = false when every sample of the image is selected: the pad samples are code 0 in the image and add nothing to a
+// cross product, so the keep-mask (two ANDs per operand dword: a quarter of the loop's vector instructions) is not read.
+// Three waves per SIMD are asked for by attribute: left to itself the compiler splits the kernel's ~ 150 registers between
+// the two register files and moves accumulators back and forth (56 v_accvgpr_* per 32 MFMA; 6.1 -> 4.4 -> 3.4 VALU per MFMA).
+template <bool MASK>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pair_xy_f4(const uint8_t *__restrict__ img, int64_t pitch,
                                                    const int32_t *__restrict__ cols,
                                                    const int2 *__restrict__ pairs,
                                                    const uint32_t *__restrict__ rowmask,
@@ -607,7 +613,7 @@ __global__ __launch_bounds__(64) void k_pair_xy_f4(const uint8_t *__restrict__ i
     pa[s] = img + (int64_t)cols[pr.x * TB + s * 16 + r16] * pitch + g * 16;
     pb[s] = img + (int64_t)cols[pr.y * TB + s * 16 + r16] * pitch + g * 16;
   }
-  int64_t b0 = (int64_t)blockIdx.y * kbytes_per_split, b1 = b0 + kbytes_per_split;
+  int64_t b0 = (int64_t)blockIdx.y * kbytes_per_split, b1 = b0 + kbytes_per_split;   // (multiples of 128)
   if (b1 > pitch) b1 = pitch;
   if (b0 >= b1) return;
   v4f acc[4][4];
@@ -615,44 +621,66 @@ __global__ __launch_bounds__(64) void k_pair_xy_f4(const uint8_t *__restrict__ i
   for (int i = 0; i < 4; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
-  uint4 a[4], b[4], an[4], bn[4], mk, mkn;
+  // A step is 128 bytes of every row — one whole cache line: the two halves are asked for by consecutive instructions (a
+  // step of 64 bytes left the other half of 128 lines per wave to an L1 that holds 256: every line came from L2 twice)
+  uint4 a[4][2], b[4][2], an[4][2], bn[4][2], mk[2] = {{~0u, ~0u, ~0u, ~0u}, {~0u, ~0u, ~0u, ~0u}}, mkn[2] = {mk[0], mk[1]};
 #pragma unroll
-  for (int s = 0; s < 4; s++) {
-    a[s] = *(const uint4 *)(pa[s] + b0);
-    b[s] = *(const uint4 *)(pb[s] + b0);
+  for (int s = 0; s < 4; s++)
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      a[s][h] = *(const uint4 *)(pa[s] + b0 + 64 * h);
+      b[s][h] = *(const uint4 *)(pb[s] + b0 + 64 * h);
+    }
+  if constexpr (MASK) {
+    mk[0] = *(const uint4 *)((const uint8_t *)rowmask + b0 + g * 16);
+    mk[1] = *(const uint4 *)((const uint8_t *)rowmask + b0 + 64 + g * 16);
   }
-  mk = *(const uint4 *)((const uint8_t *)rowmask + b0 + g * 16);
   auto nib = [](uint32_t w0, uint32_t w1) {
     return v4i{(int)(w0 & 0x33333333u), (int)((w0 >> 2) & 0x33333333u), (int)(w1 & 0x33333333u), (int)((w1 >> 2) & 0x33333333u)};
   };
-  for (int64_t kb = b0; kb < b1; kb += 64) {
-    const int64_t kn = kb + 64 < b1 ? kb + 64 : kb;  // branch-free prefetch of the next step
+  for (int64_t kb = b0; kb < b1; kb += 128) {
+    const int64_t kn = kb + 128 < b1 ? kb + 128 : kb;  // branch-free prefetch of the next step
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-      an[s] = *(const uint4 *)(pa[s] + kn);
-      bn[s] = *(const uint4 *)(pb[s] + kn);
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        an[s][h] = *(const uint4 *)(pa[s] + kn + 64 * h);
+        bn[s][h] = *(const uint4 *)(pb[s] + kn + 64 * h);
+      }
+    if constexpr (MASK) {
+      mkn[0] = *(const uint4 *)((const uint8_t *)rowmask + kn + g * 16);
+      mkn[1] = *(const uint4 *)((const uint8_t *)rowmask + kn + 64 + g * 16);
     }
-    mkn = *(const uint4 *)((const uint8_t *)rowmask + kn + g * 16);
 #pragma unroll
-    for (int d = 0; d < 2; d++) {   // a lane's 16 bytes are two K-steps of 32 samples (x 4 lane groups = 128)
-      const uint32_t m0 = d == 0 ? mk.x : mk.z, m1 = d == 0 ? mk.y : mk.w;
-      v4i A[4], B[4];
+    for (int h = 0; h < 2; h++)
 #pragma unroll
-      for (int s = 0; s < 4; s++) {
-        A[s] = nib((d == 0 ? a[s].x : a[s].z) & m0, (d == 0 ? a[s].y : a[s].w) & m1);   // dropped samples: code 0
-        B[s] = nib((d == 0 ? b[s].x : b[s].z) & m0, (d == 0 ? b[s].y : b[s].w) & m1);
+      for (int d = 0; d < 2; d++) {   // a lane's 16 bytes are two K-steps of 32 samples (x 4 lane groups = 128)
+        const uint32_t m0 = d == 0 ? mk[h].x : mk[h].z, m1 = d == 0 ? mk[h].y : mk[h].w;
+        v4i A[4], B[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          if constexpr (MASK) {
+            A[s] = nib((d == 0 ? a[s][h].x : a[s][h].z) & m0, (d == 0 ? a[s][h].y : a[s][h].w) & m1);   // dropped samples: code 0
+            B[s] = nib((d == 0 ? b[s][h].x : b[s][h].z) & m0, (d == 0 ? b[s][h].y : b[s][h].w) & m1);
+          } else {
+            A[s] = nib(d == 0 ? a[s][h].x : a[s][h].z, d == 0 ? a[s][h].y : a[s][h].w);
+            B[s] = nib(d == 0 ? b[s][h].x : b[s][h].z, d == 0 ? b[s][h].y : b[s][h].w);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[i][j] = mfma_f4(A[i], B[j], acc[i][j]);
       }
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+    for (int s = 0; s < 4; s++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = mfma_f4(A[i], B[j], acc[i][j]);
-    }
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-      a[s] = an[s];
-      b[s] = bn[s];
-    }
-    mk = mkn;
+      for (int h = 0; h < 2; h++) {
+        a[s][h] = an[s][h];
+        b[s][h] = bn[s][h];
+      }
+    mk[0] = mkn[0];
+    mk[1] = mkn[1];
   }
   int32_t *out = stats + (int64_t)blockIdx.x * 6 * TB * TB;
 #pragma unroll
@@ -665,6 +693,109 @@ __global__ __launch_bounds__(64) void k_pair_xy_f4(const uint8_t *__restrict__ i
         atomicAdd(out + row * TB + col, __float2int_rn(4.0f * acc[i][j][r]));   // (code / 2)(code' / 2) summed: exact quarters
       }
 }
+
+// The same cross product for FOUR tile pairs at once (round 6): a workgroup of four waves takes the 2 x 2 block of pairs
+// (I0, I0 + 1) x (J0, J0 + 1); every wave brings ONE of the four 64-variant tiles from memory — 128 bytes of each row per step,
+// whole cache lines — into LDS (raw 2-bit bytes, double-buffered, one barrier per step), and reads the two tiles of its own
+// pair from there.  k_pair_xy_f4 is bound by the vector memory path, not by its arithmetic (8 KB through L1 per 32 MFMA and
+// wave = the 64 B per clock and CU the L1 delivers at best; counters: matrix pipe 23 % busy, 92 % of the requests hit L2,
+// HBM at 1.2 TB/s — profiles/r06_ld_pmc.txt — and neither three waves per SIMD nor 3.3 instead of 6.1 VALU per MFMA moved
+// it); the block halves the bytes per MFMA.  quads[q]: {tiles I0, I1, J0, J1; pair indices of (I0,J0) (I0,J1) (I1,J0) (I1,J1)
+// in this batch, -1 = not in the band}.  Same K order per pair within a split, integer-exact sums: bit-identical output.
+struct QuadXY {
+  int t[4], p[4];
+};
+template <bool MASK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_quad_xy_f4(const uint8_t *__restrict__ img, int64_t pitch,
+                                                                                              const int32_t *__restrict__ cols,
+                                                                                              const QuadXY *__restrict__ quads,
+                                                                                              const uint32_t *__restrict__ rowmask,
+                                                                                              int64_t kbytes_per_split,
+                                                                                              int32_t *__restrict__ stats) {
+  __shared__ uint4 sT[2][4][4][2][64];   // [buffer][tile][16-row group][half line][lane]: 2 x 32 KB
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int my_pair = __builtin_amdgcn_readfirstlane(quads[blockIdx.x].p[wave]), my_tile = __builtin_amdgcn_readfirstlane(quads[blockIdx.x].t[wave]);
+  const int ta = wave >> 1, tb = 2 + (wave & 1);
+  const uint8_t *pt[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) pt[s] = img + (int64_t)cols[my_tile * TB + s * 16 + r16] * pitch + g * 16;
+  int64_t b0 = (int64_t)blockIdx.y * kbytes_per_split, b1 = b0 + kbytes_per_split;   // (multiples of 128)
+  if (b1 > pitch) b1 = pitch;
+  if (b0 >= b1) return;
+  v4f acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+  uint4 ld[4][2];
+#define BSN_QUAD_FETCH(KB)                                                                              \
+  _Pragma("unroll") for (int s = 0; s < 4; s++) _Pragma("unroll") for (int h = 0; h < 2; h++) {          \
+    uint4 v = *(const uint4 *)(pt[s] + (KB) + 64 * h);                                                  \
+    if constexpr (MASK) { /* dropped samples: code 0 (the tile is masked once, by the wave that brings it) */ \
+      const uint4 mk = *(const uint4 *)((const uint8_t *)rowmask + (KB) + 64 * h + g * 16);             \
+      v.x &= mk.x;                                                                                      \
+      v.y &= mk.y;                                                                                      \
+      v.z &= mk.z;                                                                                      \
+      v.w &= mk.w;                                                                                      \
+    }                                                                                                   \
+    ld[s][h] = v;                                                                                       \
+  }
+#define BSN_QUAD_STASH(BUF)                                                                             \
+  _Pragma("unroll") for (int s = 0; s < 4; s++) _Pragma("unroll") for (int h = 0; h < 2; h++) mine[((BUF) * 4 * 4 * 2 + s * 2 + h) * 64] = ld[s][h];
+  uint4 *const mine = &sT[0][wave][0][0][lane];   // this wave's tile, this lane's slot
+  auto nib = [](uint32_t w0, uint32_t w1) {
+    return v4i{(int)(w0 & 0x33333333u), (int)((w0 >> 2) & 0x33333333u), (int)(w1 & 0x33333333u), (int)((w1 >> 2) & 0x33333333u)};
+  };
+  BSN_QUAD_FETCH(b0)
+  BSN_QUAD_STASH(0)
+  __syncthreads();
+  int buf = 0;
+  for (int64_t kb = b0; kb < b1; kb += 128, buf ^= 1) {
+    const int64_t kn = kb + 128 < b1 ? kb + 128 : kb;   // (branch-free; the last step brings itself again)
+    BSN_QUAD_FETCH(kn)
+    if (my_pair >= 0) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        uint4 a[4], b[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          a[s] = sT[buf][ta][s][h][lane];
+          b[s] = sT[buf][tb][s][h][lane];
+        }
+#pragma unroll
+        for (int d = 0; d < 2; d++) {   // a lane's 16 bytes are two K-steps of 32 samples (x 4 lane groups = 128)
+          v4i A[4], B[4];
+#pragma unroll
+          for (int s = 0; s < 4; s++) {
+            A[s] = nib(d == 0 ? a[s].x : a[s].z, d == 0 ? a[s].y : a[s].w);
+            B[s] = nib(d == 0 ? b[s].x : b[s].z, d == 0 ? b[s].y : b[s].w);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = mfma_f4(A[i], B[j], acc[i][j]);
+        }
+      }
+    }
+    BSN_QUAD_STASH(buf ^ 1)
+    __syncthreads();
+  }
+  if (my_pair < 0) return;
+  int32_t *out = stats + (int64_t)my_pair * 6 * TB * TB;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = i * 16 + 4 * g + r, col = j * 16 + r16;
+        atomicAdd(out + row * TB + col, __float2int_rn(4.0f * acc[i][j][r]));   // (code / 2)(code' / 2) summed: exact quarters
+      }
+}
+
+#undef BSN_QUAD_FETCH
+#undef BSN_QUAD_STASH
 
 // Byte image (dosage grid, bsn_bed::bits == 8): the cross product of the grid indices, sum_i k_i k'_i,
 // for a 64 x 64 tile pair.  The loaded bytes are the MFMA operands (no decode; `rowmask` zeroes the
@@ -1028,6 +1159,7 @@ struct BandJob {
   DevBuf<long long> d_stats64;
   bool complete = false;  // no missing value among the selected samples of the selected variants
   bool use_mask = false;
+  bool all_rows = false;  // every sample of the image is selected (2-bit image)
   bool contig = false;    // every tile's variants lie within 2 GB of its first one, in ascending order
   int64_t npairs = 0, npairs_b = 0;
   // The band is held for `chunk_cols` columns at a time (a multiple of 128; >= m: the whole band, one chunk).  The
@@ -1036,6 +1168,8 @@ struct BandJob {
   // columns that fit a budget (free device memory, or BSN_LD_BAND_BUDGET bytes), compacting each block to its CSC
   // columns / adding its LD-score terms before the next — same kernels, same order of every sum.
   int64_t chunk_cols = 0;
+  std::vector<int2> pairs_host;                   // the 64 x 64 tile pairs, as on the device
+  DevBuf<QuadXY> d_quads;
   std::vector<int64_t> pair_start, pairb_start;   // first tile pair of every 64- / 128-column block of rows (+ end)
   double *band_at(int64_t c0) const { return d_band.p - c0 * W; }   // indexed with absolute columns >= c0
 };
@@ -1163,6 +1297,7 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
       }
       copy_h2d(bed, J.d_mask.ensure(mask.size()), mask.data(), mask.size() * 4);
       BSN_HIP(hipStreamSynchronize(bed->stream));
+      J.all_rows = n == bed->n;   // (no sample twice: all of them) — the FP4 cross-product kernel then skips the mask
     }
     // per-variant totals over the selected samples; when nothing is missing there, Sum x, Sum x^2 and
     // the pair count of every pair are these totals and only the cross product needs the GEMM
@@ -1196,6 +1331,7 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
   J.pair_start[(size_t)mt] = (int64_t)pairs.size();
   J.npairs = (int64_t)pairs.size();
   copy_h2d(bed, J.d_pairs.ensure(pairs.size()), pairs.data(), pairs.size() * sizeof(int2));
+  J.pairs_host = pairs;
   {
     // the same band in blocks of 128 row variants x 32 column variants (k_pair_stats_b)
     std::vector<int2> pb;
@@ -1365,17 +1501,57 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
       // one wave per workgroup here: four times the K splits of the 4-wave kernel
       int ks4 = (int)std::min<int64_t>(std::max<int64_t>(4, 8192 / np), bed->pitch / 256);
       if (ks4 < 1) ks4 = 1;
-      int64_t kb4 = round_up((bed->pitch + ks4 - 1) / ks4, 64);
+      int64_t kb4 = round_up((bed->pitch + ks4 - 1) / ks4, 128);   // (k_pair_xy_f4 walks whole cache lines)
       ks4 = (int)((bed->pitch + kb4 - 1) / kb4);
       // (round 6) on the FP4 matrix pipe while its fp32 sums are exact: 4 n < 2^24
       const bool xy_f4 = bed->n <= 4194303 && !getenv("BSN_LD_I8");
-      if (xy_f4)
-        hipLaunchKernelGGL(k_pair_xy_f4, dim3((unsigned)np, (unsigned)ks4), dim3(64), 0, bed->stream, bed->d_img,
+      // 2 x 2 blocks of tile pairs per workgroup (k_quad_xy_f4) once there are enough of them to fill the chip
+      const bool quad = xy_f4 && np >= 64 && !getenv("BSN_LD_NO_QUAD");
+      if (quad) {
+        std::vector<QuadXY> quads;
+        std::unordered_map<uint64_t, int> at;
+        const int mt = (int)((J.m + TB - 1) / TB);
+        for (int64_t p = p0; p < p0 + np; p++) {
+          const int I = J.pairs_host[(size_t)p].x, Jt = J.pairs_host[(size_t)p].y;
+          const uint64_t key = ((uint64_t)(uint32_t)(I >> 1) << 32) | (uint32_t)(Jt >> 1);
+          auto it = at.find(key);
+          if (it == at.end()) {
+            QuadXY qd;
+            qd.t[0] = (I >> 1) * 2;
+            qd.t[1] = std::min(qd.t[0] + 1, mt - 1);
+            qd.t[2] = (Jt >> 1) * 2;
+            qd.t[3] = std::min(qd.t[2] + 1, mt - 1);
+            qd.p[0] = qd.p[1] = qd.p[2] = qd.p[3] = -1;
+            it = at.emplace(key, (int)quads.size()).first;
+            quads.push_back(qd);
+          }
+          quads[(size_t)it->second].p[(I & 1) * 2 + (Jt & 1)] = (int)(p - p0);
+        }
+        const int64_t nq = (int64_t)quads.size();
+        copy_h2d(bed, J.d_quads.ensure(quads.size()), quads.data(), quads.size() * sizeof(QuadXY));
+        BSN_HIP(hipStreamSynchronize(bed->stream));   // (quads is a host vector; the event pair below times the kernel only)
+        BSN_HIP(hipEventRecord(e0, bed->stream));
+        int ksq = (int)std::min<int64_t>(std::max<int64_t>(1, 4096 / nq), bed->pitch / 1024);
+        if (ksq < 1) ksq = 1;
+        int64_t kbq = round_up((bed->pitch + ksq - 1) / ksq, 128);
+        ksq = (int)((bed->pitch + kbq - 1) / kbq);
+        if (J.all_rows)
+          hipLaunchKernelGGL(k_quad_xy_f4<false>, dim3((unsigned)nq, (unsigned)ksq), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
+                             J.d_cols.p, J.d_quads.p, J.d_mask.p, kbq, J.d_stats.p);
+        else
+          hipLaunchKernelGGL(k_quad_xy_f4<true>, dim3((unsigned)nq, (unsigned)ksq), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
+                             J.d_cols.p, J.d_quads.p, J.d_mask.p, kbq, J.d_stats.p);
+        ls.kernel = 8;
+      } else if (xy_f4 && J.all_rows)
+        hipLaunchKernelGGL(k_pair_xy_f4<false>, dim3((unsigned)np, (unsigned)ks4), dim3(64), 0, bed->stream, bed->d_img,
+                           bed->pitch, J.d_cols.p, J.d_pairs.p + p0, J.d_mask.p, kb4, J.d_stats.p);
+      else if (xy_f4)
+        hipLaunchKernelGGL(k_pair_xy_f4<true>, dim3((unsigned)np, (unsigned)ks4), dim3(64), 0, bed->stream, bed->d_img,
                            bed->pitch, J.d_cols.p, J.d_pairs.p + p0, J.d_mask.p, kb4, J.d_stats.p);
       else
         hipLaunchKernelGGL(k_pair_xy64, dim3((unsigned)np, (unsigned)ks4), dim3(64), 0, bed->stream, bed->d_img,
                            bed->pitch, J.d_cols.p, J.d_pairs.p + p0, J.d_mask.p, kb4, J.d_stats.p);
-      ls.kernel = xy_f4 ? 7 : 2;
+      if (!quad) ls.kernel = xy_f4 ? 7 : 2;
     } else if (fused) {
       if (J.contig)
         hipLaunchKernelGGL((k_pair_stats<true, true, true>), dim3((unsigned)np, 1), dim3(256), 0, bed->stream,

@@ -122,3 +122,44 @@ def test_ld_on_complete_data_uses_one_product_and_is_identical(ba, orc):
     f, g = _both_paths(lambda: ba.snp_clumping(G, chr_, thr_r2=0.05, size=40, infos_pos=bp))
     np.testing.assert_array_equal(f, g)
     np.testing.assert_array_equal(f, orc.snp_clumping(orc.fbm_from_bed(ob), chr_, thr_r2=0.05, size=40, infos_pos=bp))
+
+
+def test_cross_product_kernel_in_blocks_of_four_tile_pairs(ba, orc, monkeypatch):
+    """round 6: k_quad_xy_f4 — four tile pairs per workgroup, their tiles brought once through LDS — against the
+    one-pair-per-wave kernel (BSN_LD_NO_QUAD=1: bit-identical band), the six-product kernels and the oracle: band widths
+    from under one tile to many, an odd number of tiles, row subsets (the keep-mask applied by the loading wave), a
+    variant list that is not contiguous, clumping on an FBM"""
+    from bigsnpr_amd import ld as ldm
+    n, m = 1300, 2250                                   # 36 tiles of 64 variants (the last one ragged)
+    ob = orc.fake_bed(n, m, na16=0, seed=33)
+    gb = ba.bed.synthetic(n, m, na16=0, seed=33)
+    rng = np.random.default_rng(33)
+    ir = np.sort(rng.choice(n, 900, replace=False))
+    ic = np.sort(rng.choice(m, 2100, replace=False))
+    for rows, cols, size in ((None, None, 0.3), (ir, None, 0.07), (None, ic, 0.5), (ir, ic, 0.15)):
+        mm = m if cols is None else cols.size
+        pos = np.cumsum(rng.uniform(0.5, 1.5, mm))
+        quad = ba.bed_ld_scores(gb, rows, cols, size=size, infos_pos=pos)
+        assert "k_quad_xy_f4" in ldm.last_stats()["kernel"]
+        monkeypatch.setenv("BSN_LD_NO_QUAD", "1")
+        single = ba.bed_ld_scores(gb, rows, cols, size=size, infos_pos=pos)
+        assert "k_pair_xy_f4" in ldm.last_stats()["kernel"]
+        monkeypatch.delenv("BSN_LD_NO_QUAD")
+        np.testing.assert_array_equal(quad, single)
+        monkeypatch.setenv("BSN_FORCE_NA_PLANE", "1")
+        np.testing.assert_array_equal(quad, ba.bed_ld_scores(gb, rows, cols, size=size, infos_pos=pos))
+        monkeypatch.delenv("BSN_FORCE_NA_PLANE")
+        np.testing.assert_allclose(quad, orc.ld_scores(ob, rows, cols, size=size, infos_pos=pos), rtol=1e-12)
+    c1 = ba.bed_cor(gb, ir, None, size=0.1, infos_pos=np.arange(m, dtype=float), thr_r2=0.01)
+    monkeypatch.setenv("BSN_LD_NO_QUAD", "1")
+    c2 = ba.bed_cor(gb, ir, None, size=0.1, infos_pos=np.arange(m, dtype=float), thr_r2=0.01)
+    monkeypatch.delenv("BSN_LD_NO_QUAD")
+    for a, b in ((c1.p, c2.p), (c1.i, c2.i), (c1.x, c2.x)):
+        np.testing.assert_array_equal(a, b)
+    Go = orc.fbm_from_bed(ob)
+    G = ba.FBM_code256(Go.bytes)
+    chr_ = np.repeat([1, 2, 3], [900, 900, 450])
+    keep = ba.snp_clumping(G, chr_, thr_r2=0.1, size=200)
+    np.testing.assert_array_equal(keep, orc.snp_clumping(Go, chr_, thr_r2=0.1, size=200))
+    monkeypatch.setenv("BSN_LD_NO_QUAD", "1")
+    np.testing.assert_array_equal(ba.snp_clumping(G, chr_, thr_r2=0.1, size=200), keep)
