@@ -17,7 +17,8 @@ Extra JSON objects: "roofline" (dominant streaming kernel: algorithmic bytes per
 duration measured inside the timed solves), "cpu_baseline" (the OpenMP CPU restatement of the reference
 kernels, oracle/bsn_oracle.c, on a bounded sample of the same matrix on this host; rank 0, N = 1 only)
 and "ingest" (bsn_bed_open of a real .bed file of a bounded size: host -> HBM rate, BASELINE.md §2
-"reported separately"; never part of `value`).
+"reported separately"; never part of `value`); "cold" (the first solves of a fresh process), "accuracy" (two matrices),
+"auto_svd" (the caller of the hot path, snp_autoSVD, twice on the timed image) — all outside the timed region.
 """
 import argparse
 import json
@@ -91,6 +92,8 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="go through the RCCL communicator even with one rank (self-test)")
     ap.add_argument("--cpu-sample-cols", type=int, default=0)
+    ap.add_argument("--no-autosvd", action="store_true",
+                    help="skip the snp_autoSVD record (two calls on the timed image, outside the timed region)")
     ap.add_argument("--no-cold", action="store_true",
                     help="svd: skip the `cold` record (a fresh process timing the FIRST bed_randomSVD of a new handle — the call the "
                          "reference makes, R/autoSVD.R:205-219 — at full size and on a real .bed file; outside the timed region)")
@@ -574,6 +577,9 @@ def main():
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ba, gb, n, a.cpu_sample_cols)
             log("cpu baseline done")
+        if not a.no_autosvd and a.shard_of <= 1 and a.ind_col_fraction <= 0:
+            out["auto_svd"] = autosvd_record(ba, gb, m_local)
+            log("snp_autoSVD record done")
         if not a.no_ingest:
             out["ingest"] = ingest(ba, L, n, a.ingest_gb, cold_hook=(lambda path, nn, mm: cold_record(a, path, nn, mm)) if cold else None)
             if cold is not None and isinstance(out["ingest"], dict) and "cold" in out["ingest"]:
@@ -729,6 +735,46 @@ def wide_solves(ba, gb, a, default_info, sync, ref=None):
             res[tag]["angles_to_reference"] = _angle_record(r["u"], r["v"], ref, a.k)
         del r
     return res
+
+
+def autosvd_record(ba, gb, m):
+    """The caller of the hot path (SURVEY section 8 'next': R/autoSVD.R:67-186): snp_autoSVD(k = 10) on the timed image with 22
+    chromosomes of equal length and 500-kb windows of 250 variants a side — MAF filter, clumping, partial SVD, outlier step —
+    twice; the second call is the steady state (the first pays imports and first launches).  Outside the timed region."""
+    import numpy as np
+    from bigsnpr_amd import autosvd as av
+    try:
+        chrom = np.repeat(np.arange(1, 23), (m + 21) // 22)[:m]
+        pos = np.arange(m) * 2000.0
+        T = {}
+
+        def timed(name, fn):
+            def w(*x, **k):
+                t0 = time.perf_counter()
+                r = fn(*x, **k)
+                T[name] = T.get(name, 0.0) + time.perf_counter() - t0
+                return r
+            return w
+        names = ("snp_MAF", "snp_clumping", "big_randomSVD", "dist_ogk", "rollmean_groups", "tukey_mc_up")
+        saved = {nm: getattr(av, nm) for nm in names}
+        calls = []
+        try:
+            for nm in names:
+                setattr(av, nm, timed(nm, saved[nm]))
+            for _ in range(2):
+                T.clear()
+                t0 = time.perf_counter()
+                res = ba.snp_autoSVD(gb, chrom, pos, k=10, verbose=False)
+                calls.append((time.perf_counter() - t0, dict(T), int(res["subset"].size)))
+        finally:
+            for nm in names:
+                setattr(av, nm, saved[nm])
+        return {"what": "snp_autoSVD(k = 10, 22 chromosomes, 500-kb windows of 250 variants) on the timed image, two calls; outside the timed region",
+                "first_call_s": calls[0][0], "second_call_s": calls[1][0],
+                "stages_second_call_s": {k_: round(v, 4) for k_, v in calls[1][1].items()},
+                "kept_variants": calls[1][2], "variants": int(m)}
+    except Exception as e:
+        return {"error": str(e)[:300]}
 
 
 def cpu_baseline(ba, gb, n, sample_cols):

@@ -127,3 +127,15 @@ def test_other_workloads_print_one_line():
                     "vs_baseline", "dtype", "data", "config", "roofline"):
             assert key in rec, key
         assert rec["value"] > 0 and rec["n_gpus"] == 1 and "workload" in rec["config"]
+
+
+def test_single_gpu_line_carries_the_autosvd_record():
+    """the driver's command shape at a toy size: one line, with the objects measured outside the timed region — among them
+    `auto_svd` (round 6: snp_autoSVD twice on the timed image, stage by stage)"""
+    rec, _ = _run([sys.executable, "bench.py"] + ARGS + ["--no-cold", "--no-wide"])
+    for key in ("metric", "value", "roofline", "accuracy", "auto_svd"):
+        assert key in rec, key
+    av = rec["auto_svd"]
+    assert "error" not in av, av
+    assert av["second_call_s"] > 0 and 0 < av["kept_variants"] <= av["variants"] == 60000
+    assert {"snp_clumping", "big_randomSVD", "dist_ogk"} <= set(av["stages_second_call_s"])
