@@ -404,7 +404,11 @@ __device__ __forceinline__ v4f mfma_f4(const v4i &a, const v4i &b, const v4f &c)
   const v8i a8 = {a.x, a.y, a.z, a.w, 0, 0, 0, 0}, b8 = {b.x, b.y, b.z, b.w, 0, 0, 0, 0};
   return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, c, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
 }
-__global__ __launch_bounds__(256, 3) void k_pair_stats_f4(const uint8_t *__restrict__ img, int64_t pitch,
+// SQ = false (round 6): the bed clumping formula (mode 3, src/clumping-bed.cpp:69-73 on mean-imputed scaled values) is
+// sum x y - c' sum x m' - c sum m y + c c' sum m m' — FOUR of the six sums: the two with squares are neither multiplied nor
+// decoded (a third of the matrix instructions and of the look-ups; their accumulators are not allocated).
+template <bool SQ>
+__global__ __launch_bounds__(256, SQ ? 3 : 4) void k_pair_stats_f4(const uint8_t *__restrict__ img, int64_t pitch,
                                                        const int32_t *__restrict__ cols,
                                                        const int2 *__restrict__ pairs,
                                                        const uint32_t *__restrict__ rowmask, BandOut bo) {
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(256, 3) void k_pair_stats_f4(const uint8_t *__restr
     const uint32_t m0 = my_ks == 0 ? mk.x : mk.z, m1 = my_ks == 0 ? mk.y : mk.w;
     const PlanesF4 P = decode_f4(b.x | ~m0, b.y | ~m1);
     sB[buf][my_ks][my_s][0][lane] = uint4{(uint32_t)P.x[0], (uint32_t)P.x[1], (uint32_t)P.x[2], (uint32_t)P.x[3]};
-    sB[buf][my_ks][my_s][1][lane] = uint4{(uint32_t)P.x2[0], (uint32_t)P.x2[1], (uint32_t)P.x2[2], (uint32_t)P.x2[3]};
+    if constexpr (SQ) sB[buf][my_ks][my_s][1][lane] = uint4{(uint32_t)P.x2[0], (uint32_t)P.x2[1], (uint32_t)P.x2[2], (uint32_t)P.x2[3]};
     sB[buf][my_ks][my_s][2][lane] = uint4{(uint32_t)P.m[0], (uint32_t)P.m[1], (uint32_t)P.m[2], (uint32_t)P.m[3]};
   };
   v4u a[2], mk, an[2], mkn;
@@ -462,16 +466,18 @@ __global__ __launch_bounds__(256, 3) void k_pair_stats_f4(const uint8_t *__restr
       for (int s = 0; s < 2; s++) A[s] = decode_f4((d == 0 ? a[s].x : a[s].z) | ~m0, (d == 0 ? a[s].y : a[s].w) | ~m1);
 #pragma unroll
       for (int j = 0; j < 2; j++) {
-        const uint4 bx = sB[buf][d][j][0][lane], bx2 = sB[buf][d][j][1][lane], bm = sB[buf][d][j][2][lane];
+        const uint4 bx = sB[buf][d][j][0][lane], bm = sB[buf][d][j][2][lane];
+        uint4 bx2 = {0u, 0u, 0u, 0u};
+        if constexpr (SQ) bx2 = sB[buf][d][j][1][lane];
         const v4i Bx = {(int)bx.x, (int)bx.y, (int)bx.z, (int)bx.w}, Bx2 = {(int)bx2.x, (int)bx2.y, (int)bx2.z, (int)bx2.w},
                   Bm = {(int)bm.x, (int)bm.y, (int)bm.z, (int)bm.w};
 #pragma unroll
         for (int i = 0; i < 2; i++) {
           acc[i][j][0] = mfma_f4(A[i].x, Bx, acc[i][j][0]);
           acc[i][j][1] = mfma_f4(A[i].x, Bm, acc[i][j][1]);
-          acc[i][j][2] = mfma_f4(A[i].x2, Bm, acc[i][j][2]);
+          if constexpr (SQ) acc[i][j][2] = mfma_f4(A[i].x2, Bm, acc[i][j][2]);
           acc[i][j][3] = mfma_f4(A[i].m, Bx, acc[i][j][3]);
-          acc[i][j][4] = mfma_f4(A[i].m, Bx2, acc[i][j][4]);
+          if constexpr (SQ) acc[i][j][4] = mfma_f4(A[i].m, Bx2, acc[i][j][4]);
           acc[i][j][5] = mfma_f4(A[i].m, Bm, acc[i][j][5]);
         }
       }
@@ -728,8 +734,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int i = 0; i < 4; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
-  uint4 ld[4][2];
-#define BSN_QUAD_FETCH(KB)                                                                              \
+  // two register sets: the loads of step t + 2 are issued while step t is multiplied and the set of step t + 1 — issued a
+  // whole step earlier — goes to LDS at its end (one step of matrix work is ~ 1 000 cycles, an L2 miss twice that)
+  uint4 ldA[4][2], ldB[4][2];
+#define BSN_QUAD_FETCH(DST, KB)                                                                         \
   _Pragma("unroll") for (int s = 0; s < 4; s++) _Pragma("unroll") for (int h = 0; h < 2; h++) {          \
     uint4 v = *(const uint4 *)(pt[s] + (KB) + 64 * h);                                                  \
     if constexpr (MASK) { /* dropped samples: code 0 (the tile is masked once, by the wave that brings it) */ \
@@ -739,46 +747,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       v.z &= mk.z;                                                                                      \
       v.w &= mk.w;                                                                                      \
     }                                                                                                   \
-    ld[s][h] = v;                                                                                       \
+    DST[s][h] = v;                                                                                      \
   }
-#define BSN_QUAD_STASH(BUF)                                                                             \
-  _Pragma("unroll") for (int s = 0; s < 4; s++) _Pragma("unroll") for (int h = 0; h < 2; h++) mine[((BUF) * 4 * 4 * 2 + s * 2 + h) * 64] = ld[s][h];
+#define BSN_QUAD_STASH(SRC, BUF)                                                                        \
+  _Pragma("unroll") for (int s = 0; s < 4; s++) _Pragma("unroll") for (int h = 0; h < 2; h++) mine[((BUF) * 4 * 4 * 2 + s * 2 + h) * 64] = SRC[s][h];
   uint4 *const mine = &sT[0][wave][0][0][lane];   // this wave's tile, this lane's slot
   auto nib = [](uint32_t w0, uint32_t w1) {
     return v4i{(int)(w0 & 0x33333333u), (int)((w0 >> 2) & 0x33333333u), (int)(w1 & 0x33333333u), (int)((w1 >> 2) & 0x33333333u)};
   };
-  BSN_QUAD_FETCH(b0)
-  BSN_QUAD_STASH(0)
+#define BSN_QUAD_MULTIPLY(BUF)                                                                          \
+  if (my_pair >= 0) {                                                                                   \
+    _Pragma("unroll") for (int h = 0; h < 2; h++) {                                                     \
+      uint4 a[4], b[4];                                                                                 \
+      _Pragma("unroll") for (int s = 0; s < 4; s++) {                                                   \
+        a[s] = sT[BUF][ta][s][h][lane];                                                                 \
+        b[s] = sT[BUF][tb][s][h][lane];                                                                 \
+      }                                                                                                 \
+      _Pragma("unroll") for (int d = 0; d < 2; d++) { /* a lane's 16 bytes are two K-steps of 32 samples (x 4 lane groups = 128) */ \
+        v4i A[4], B[4];                                                                                 \
+        _Pragma("unroll") for (int s = 0; s < 4; s++) {                                                 \
+          A[s] = nib(d == 0 ? a[s].x : a[s].z, d == 0 ? a[s].y : a[s].w);                               \
+          B[s] = nib(d == 0 ? b[s].x : b[s].z, d == 0 ? b[s].y : b[s].w);                               \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) _Pragma("unroll") for (int j = 0; j < 4; j++) acc[i][j] = mfma_f4(A[i], B[j], acc[i][j]); \
+      }                                                                                                 \
+    }                                                                                                   \
+  }
+  const int64_t last = b1 - 128;
+  auto at = [&](int64_t kb) { return kb < last ? kb : last; };   // (branch-free: past the end the last step again)
+  BSN_QUAD_FETCH(ldA, b0)
+  BSN_QUAD_STASH(ldA, 0)
+  BSN_QUAD_FETCH(ldA, at(b0 + 128))
   __syncthreads();
-  int buf = 0;
-  for (int64_t kb = b0; kb < b1; kb += 128, buf ^= 1) {
-    const int64_t kn = kb + 128 < b1 ? kb + 128 : kb;   // (branch-free; the last step brings itself again)
-    BSN_QUAD_FETCH(kn)
-    if (my_pair >= 0) {
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        uint4 a[4], b[4];
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-          a[s] = sT[buf][ta][s][h][lane];
-          b[s] = sT[buf][tb][s][h][lane];
-        }
-#pragma unroll
-        for (int d = 0; d < 2; d++) {   // a lane's 16 bytes are two K-steps of 32 samples (x 4 lane groups = 128)
-          v4i A[4], B[4];
-#pragma unroll
-          for (int s = 0; s < 4; s++) {
-            A[s] = nib(d == 0 ? a[s].x : a[s].z, d == 0 ? a[s].y : a[s].w);
-            B[s] = nib(d == 0 ? b[s].x : b[s].z, d == 0 ? b[s].y : b[s].w);
-          }
-#pragma unroll
-          for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = mfma_f4(A[i], B[j], acc[i][j]);
-        }
-      }
-    }
-    BSN_QUAD_STASH(buf ^ 1)
+  for (int64_t kb = b0; kb < b1; kb += 256) {
+    // step at kb: LDS buffer 0 holds it, ldA holds the next one
+    BSN_QUAD_FETCH(ldB, at(kb + 256))
+    BSN_QUAD_MULTIPLY(0)
+    BSN_QUAD_STASH(ldA, 1)
+    __syncthreads();
+    if (kb + 128 >= b1) break;
+    // step at kb + 128: buffer 1, ldB holds the next one
+    BSN_QUAD_FETCH(ldA, at(kb + 384))
+    BSN_QUAD_MULTIPLY(1)
+    BSN_QUAD_STASH(ldB, 0)
     __syncthreads();
   }
   if (my_pair < 0) return;
@@ -796,6 +807,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 #undef BSN_QUAD_FETCH
 #undef BSN_QUAD_STASH
+#undef BSN_QUAD_MULTIPLY
 
 // Byte image (dosage grid, bsn_bed::bits == 8): the cross product of the grid indices, sum_i k_i k'_i,
 // for a 64 x 64 tile pair.  The loaded bytes are the MFMA operands (no decode; `rowmask` zeroes the
@@ -1462,9 +1474,12 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
       // the FP4 matrix pipe while the sums stay exact in fp32 (at most 4 n < 2^24); BSN_LD_I8=1: the int8 kernel
       static const bool i8_only = getenv("BSN_LD_I8") != nullptr;
       const bool f4 = bed->pitch * 4 <= 4194303 && !i8_only;
-      ls.kernel = f4 ? 6 : 4;
-      if (f4)
-        hipLaunchKernelGGL(k_pair_stats_f4, dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
+      ls.kernel = f4 ? (mode == 3 ? 9 : 6) : 4;
+      if (f4 && mode == 3)   // the bed clumping formula reads four of the six sums
+        hipLaunchKernelGGL(k_pair_stats_f4<false>, dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
+                           J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, bo);
+      else if (f4)
+        hipLaunchKernelGGL(k_pair_stats_f4<true>, dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
                            J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, bo);
       else
         hipLaunchKernelGGL(k_pair_stats_b, dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,

@@ -484,6 +484,8 @@ def last_stats():
              "k_pair_stats_f4<6 products on the FP4 matrix pipe (v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales, exact), "
              "column operand decoded once per workgroup through LDS, fused fp64 epilogue>",
              "k_pair_xy_f4 (cross product only on the FP4 matrix pipe: no missing values, codes as E2M1 nibbles) + k_band_fill",
-             "k_quad_xy_f4 (cross product only on the FP4 matrix pipe, 2 x 2 tile pairs per workgroup through LDS) + k_band_fill")
+             "k_quad_xy_f4 (cross product only on the FP4 matrix pipe, 2 x 2 tile pairs per workgroup through LDS) + k_band_fill",
+             "k_pair_stats_f4<4 of the 6 products (the bed clumping formula reads no sum of squares) on the FP4 matrix pipe, "
+             "column operand decoded once per workgroup through LDS, fused fp64 epilogue>")
     return dict(pairs=out[0], tile_pairs=out[1], stats_ms=out[2], launches=int(out[3]), kernel=names[int(out[4])],
-                products={2: 1, 3: 8, 7: 1, 8: 1}.get(int(out[4]), 6))
+                products={2: 1, 3: 8, 7: 1, 8: 1, 9: 4}.get(int(out[4]), 6))

@@ -308,3 +308,26 @@ def test_clumping_at_a_threshold_that_sits_on_a_pair(ba, orc, golden_dir, missin
         if tested == 4:
             break
     assert tested >= 2
+
+
+def test_bed_clumping_on_the_four_product_kernel(ba, orc, monkeypatch):
+    """round 6: with missing values and enough blocks to fill the chip the bed clumping band runs k_pair_stats_f4<SQ = false>
+    — the four sums src/clumping-bed.cpp:69-73 reads, the two with squares neither decoded nor multiplied — against the
+    oracle's loop (indices bit-exact), chromosome by chromosome and in one call; bed_ld_scores on the same handle keeps
+    the six-product kernel and still matches"""
+    from bigsnpr_amd import ld as ldm
+    n, m = 420, 12032
+    ob = orc.fake_bed(n, m, seed=77, na16=2000)                       # 3 % missing values
+    gb = ba.bed.from_payload(ob.payload, n, m)
+    chrom = np.repeat([1, 2], [7000, m - 7000])
+    pos = (np.arange(m) * 1000.0)
+    keep = ba.bed_clumping(gb, thr_r2=0.02, size=400, infos_chr=chrom, infos_pos=pos)
+    assert "k_pair_stats_f4" in ldm.last_stats()["kernel"]
+    np.testing.assert_array_equal(keep, orc.bed_clumping(ob, chrom, pos, thr_r2=0.02, size=400))
+    assert 1000 < keep.size < m - 1000                                   # (sampling noise of 420 samples prunes most variants at 0.02)
+    monkeypatch.setenv("BSN_CLUMP_PER_CHR", "1")
+    np.testing.assert_array_equal(ba.bed_clumping(gb, thr_r2=0.02, size=400, infos_chr=chrom, infos_pos=pos), keep)
+    monkeypatch.delenv("BSN_CLUMP_PER_CHR")
+    ld = ba.bed_ld_scores(gb, size=0.4, infos_pos=pos / 1000.0)
+    assert "k_pair_stats_f4" in ldm.last_stats()["kernel"]
+    np.testing.assert_allclose(ld, orc.ld_scores(ob, size=0.4, infos_pos=pos / 1000.0), rtol=1e-12)

@@ -10,6 +10,7 @@ from bigsnpr_amd import ld as ldm, autosvd
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=400000)
 ap.add_argument("--m", type=int, default=250000)
+ap.add_argument("--bed", action="store_true", help="bed_autoSVD (1 %% missing values: the six-product LD kernels in the clumping) instead of snp_autoSVD")
 a = ap.parse_args()
 gb = ba.bed.synthetic(a.n, a.m)
 chrom = np.repeat(np.arange(1, 23), (a.m + 21) // 22)[:a.m]
@@ -36,6 +37,18 @@ def _colstats(*x, **k):
     t0 = time.perf_counter(); r = _colstats0(*x, **k); K["snp_colstats calls"] = K.get("snp_colstats calls", 0.0) + time.perf_counter() - t0
     return r
 ldm.snp_colstats = _colstats
+if a.bed:
+    gb._map = dict(chromosome=chrom, physical_pos=pos)   # (a synthetic handle has no .bim)
+    from bigsnpr_amd import bed as bedm
+    _clump0 = ldm._clump_chr
+    autosvd.bed_MAF = timed("bed_MAF", autosvd.bed_MAF)
+    autosvd.bed_clumping = timed("bed_clumping", autosvd.bed_clumping)
+    autosvd.bed_randomSVD = timed("bed_randomSVD", autosvd.bed_randomSVD)
+    _bcs0 = ldm.bed_colstats
+    def _bcs(*x, **k):
+        t0 = time.perf_counter(); r = _bcs0(*x, **k); K["bed_colstats calls"] = K.get("bed_colstats calls", 0.0) + time.perf_counter() - t0
+        return r
+    ldm.bed_colstats = _bcs
 autosvd.snp_MAF = timed("snp_MAF", autosvd.snp_MAF)
 autosvd.snp_clumping = timed("snp_clumping", autosvd.snp_clumping)
 autosvd.big_randomSVD = timed("big_randomSVD", autosvd.big_randomSVD)
@@ -45,7 +58,8 @@ autosvd.tukey_mc_up = timed("tukey_mc_up", autosvd.tukey_mc_up)
 for rep in ("first call (imports, first launches, allocations)", "second call", "third call"):
     T.clear(); K.clear()
     t0 = time.perf_counter()
-    res = ba.snp_autoSVD(gb, chrom, pos, k=10, verbose=rep.startswith("first"))
+    res = (ba.bed_autoSVD(gb, k=10, verbose=rep.startswith("first")) if a.bed
+           else ba.snp_autoSVD(gb, chrom, pos, k=10, verbose=rep.startswith("first")))
     tot = time.perf_counter() - t0
     print("%s: total %.3f s; %s; rest of the host loop %.3f s; kept %d of %d variants"
           % (rep, tot, ", ".join("%s %.3f s" % kv for kv in T.items()), tot - sum(T.values()), res["subset"].size, a.m))
