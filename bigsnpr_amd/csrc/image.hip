@@ -368,6 +368,7 @@ static void finish_image(bsn_bed *b, int recode) {
 }
 
 void image_from_host(bsn_bed *b, const uint8_t *payload, int64_t n_byte_src) {
+  b->counts_cache.clear();   // (new bytes in the image: what earlier counts remembered is void)
   // Column chunks keep each 2-D copy below 1 GiB so that pageable (mmap'd) sources are
   // staged piecewise by the runtime.
   int64_t rows_per = (int64_t)((1ull << 30) / (size_t)n_byte_src);
@@ -394,6 +395,7 @@ FileStage::~FileStage() {
 }
 
 void image_from_file(bsn_bed *b, int fd, int64_t offset, int64_t n_byte_src, FileStage *stage) {
+  b->counts_cache.clear();   // (new bytes in the image: what earlier counts remembered is void)
   const int64_t chunk_bytes = 256ll << 20;
   int64_t cols_per = chunk_bytes / n_byte_src;
   if (cols_per < 1) cols_per = 1;
@@ -804,6 +806,7 @@ __global__ void k_generate(uint8_t *img, int64_t pitch, int64_t n, int64_t m, ui
 }
 
 void image_generate(bsn_bed *b, uint32_t seed, uint32_t npop, uint32_t na16, int64_t j_begin) {
+  b->counts_cache.clear();   // (new bytes in the image: what earlier counts remembered is void)
   int64_t dwords = b->pitch / 4;
   int64_t gy = b->m < 65535 ? b->m : 65535;
   int64_t gz = (b->m + 65534) / 65535;
