@@ -1499,8 +1499,55 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
     g_ld_stats = ls;
     return;
   }
-  for (int64_t p0 = pA; p0 < pB; p0 += batch) {
+  // (round 6) nothing in this loop waits for the device: the 2 x 2 blocks of tile pairs of ALL batches are grouped and uploaded
+  // once, every batch has its own pair of events, and the host reads them after the last launch (a batch used to end with an
+  // event wait and its own grouping + upload; measured at a million variants, same box: no difference — the band-fill kernel
+  // of a batch covered the host's preparation of the next — kept because it is the simpler order of events)
+  const bool xy_f4_all = xy_only && bed->bits == 2 && bed->n <= 4194303 && !getenv("BSN_LD_I8");
+  const bool quad_all = xy_f4_all && !getenv("BSN_LD_NO_QUAD");
+  std::vector<QuadXY> quads;
+  std::vector<int64_t> quad_off;
+  if (quad_all) {
+    std::unordered_map<uint64_t, int> at;
+    const int mt = (int)((J.m + TB - 1) / TB);
+    for (int64_t p0 = pA; p0 < pB; p0 += batch) {
+      const int64_t np = std::min(batch, pB - p0);
+      quad_off.push_back((int64_t)quads.size());
+      if (np < 64) continue;
+      at.clear();
+      const int64_t base = (int64_t)quads.size();
+      for (int64_t p = p0; p < p0 + np; p++) {
+        const int I = J.pairs_host[(size_t)p].x, Jt = J.pairs_host[(size_t)p].y;
+        const uint64_t key = ((uint64_t)(uint32_t)(I >> 1) << 32) | (uint32_t)(Jt >> 1);
+        auto it = at.find(key);
+        if (it == at.end()) {
+          QuadXY qd;
+          qd.t[0] = (I >> 1) * 2;
+          qd.t[1] = std::min(qd.t[0] + 1, mt - 1);
+          qd.t[2] = (Jt >> 1) * 2;
+          qd.t[3] = std::min(qd.t[2] + 1, mt - 1);
+          qd.p[0] = qd.p[1] = qd.p[2] = qd.p[3] = -1;
+          it = at.emplace(key, (int)((int64_t)quads.size() - base)).first;
+          quads.push_back(qd);
+        }
+        quads[(size_t)(base + it->second)].p[(I & 1) * 2 + (Jt & 1)] = (int)(p - p0);
+      }
+    }
+    quad_off.push_back((int64_t)quads.size());
+    if (!quads.empty()) {
+      copy_h2d(bed, J.d_quads.ensure(quads.size()), quads.data(), quads.size() * sizeof(QuadXY));
+      BSN_HIP(hipStreamSynchronize(bed->stream));   // (quads is a host vector)
+    }
+  }
+  std::vector<hipEvent_t> evs;
+  int64_t ib = 0;
+  for (int64_t p0 = pA; p0 < pB; p0 += batch, ib++) {
     const int64_t np = std::min(batch, pB - p0);
+    hipEvent_t b0 = nullptr, b1 = nullptr;
+    BSN_HIP(hipEventCreate(&b0));
+    BSN_HIP(hipEventCreate(&b1));
+    evs.push_back(b0);
+    evs.push_back(b1);
     // K split: enough workgroups to fill the chip when there are few tile pairs
     int ksplit = (int)std::min<int64_t>(std::max<int64_t>(1, 2048 / np), bed->pitch / 256);
     if (ksplit < 1) ksplit = 1;
@@ -1511,7 +1558,7 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
       J.d_stats.ensure((size_t)std::min(batch, J.npairs) * 6 * TB * TB);
       if (ksplit > 1 || xy_only) BSN_HIP(hipMemsetAsync(J.d_stats.p, 0, (size_t)np * 6 * TB * TB * 4, bed->stream));
     }
-    BSN_HIP(hipEventRecord(e0, bed->stream));
+    BSN_HIP(hipEventRecord(b0, bed->stream));
     if (xy_only) {
       // one wave per workgroup here: four times the K splits of the 4-wave kernel
       int ks4 = (int)std::min<int64_t>(std::max<int64_t>(4, 8192 / np), bed->pitch / 256);
@@ -1521,41 +1568,20 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
       // (round 6) on the FP4 matrix pipe while its fp32 sums are exact: 4 n < 2^24
       const bool xy_f4 = bed->n <= 4194303 && !getenv("BSN_LD_I8");
       // 2 x 2 blocks of tile pairs per workgroup (k_quad_xy_f4) once there are enough of them to fill the chip
-      const bool quad = xy_f4 && np >= 64 && !getenv("BSN_LD_NO_QUAD");
+      const bool quad = quad_all && np >= 64;
       if (quad) {
-        std::vector<QuadXY> quads;
-        std::unordered_map<uint64_t, int> at;
-        const int mt = (int)((J.m + TB - 1) / TB);
-        for (int64_t p = p0; p < p0 + np; p++) {
-          const int I = J.pairs_host[(size_t)p].x, Jt = J.pairs_host[(size_t)p].y;
-          const uint64_t key = ((uint64_t)(uint32_t)(I >> 1) << 32) | (uint32_t)(Jt >> 1);
-          auto it = at.find(key);
-          if (it == at.end()) {
-            QuadXY qd;
-            qd.t[0] = (I >> 1) * 2;
-            qd.t[1] = std::min(qd.t[0] + 1, mt - 1);
-            qd.t[2] = (Jt >> 1) * 2;
-            qd.t[3] = std::min(qd.t[2] + 1, mt - 1);
-            qd.p[0] = qd.p[1] = qd.p[2] = qd.p[3] = -1;
-            it = at.emplace(key, (int)quads.size()).first;
-            quads.push_back(qd);
-          }
-          quads[(size_t)it->second].p[(I & 1) * 2 + (Jt & 1)] = (int)(p - p0);
-        }
-        const int64_t nq = (int64_t)quads.size();
-        copy_h2d(bed, J.d_quads.ensure(quads.size()), quads.data(), quads.size() * sizeof(QuadXY));
-        BSN_HIP(hipStreamSynchronize(bed->stream));   // (quads is a host vector; the event pair below times the kernel only)
-        BSN_HIP(hipEventRecord(e0, bed->stream));
+        const int64_t nq = quad_off[(size_t)ib + 1] - quad_off[(size_t)ib];
+        const QuadXY *d_q = J.d_quads.p + quad_off[(size_t)ib];
         int ksq = (int)std::min<int64_t>(std::max<int64_t>(1, 4096 / nq), bed->pitch / 1024);
         if (ksq < 1) ksq = 1;
         int64_t kbq = round_up((bed->pitch + ksq - 1) / ksq, 128);
         ksq = (int)((bed->pitch + kbq - 1) / kbq);
         if (J.all_rows)
           hipLaunchKernelGGL(k_quad_xy_f4<false>, dim3((unsigned)nq, (unsigned)ksq), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
-                             J.d_cols.p, J.d_quads.p, J.d_mask.p, kbq, J.d_stats.p);
+                             J.d_cols.p, d_q, J.d_mask.p, kbq, J.d_stats.p);
         else
           hipLaunchKernelGGL(k_quad_xy_f4<true>, dim3((unsigned)nq, (unsigned)ksq), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
-                             J.d_cols.p, J.d_quads.p, J.d_mask.p, kbq, J.d_stats.p);
+                             J.d_cols.p, d_q, J.d_mask.p, kbq, J.d_stats.p);
         ls.kernel = 8;
       } else if (xy_f4 && J.all_rows)
         hipLaunchKernelGGL(k_pair_xy_f4<false>, dim3((unsigned)np, (unsigned)ks4), dim3(64), 0, bed->stream, bed->d_img,
@@ -1584,7 +1610,7 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
       ls.kernel = 1;
     }
     BSN_HIP(hipGetLastError());
-    BSN_HIP(hipEventRecord(e1, bed->stream));
+    BSN_HIP(hipEventRecord(b1, bed->stream));
     if (!fused) {
       hipLaunchKernelGGL(k_band_fill, dim3((unsigned)np), dim3(256), 0, bed->stream, J.d_stats.p,
                          J.d_pairs.p + p0, (int)np, J.m, J.d_lo.p, J.W, d_thr, mode, d_v1, d_v2, nrows,
@@ -1592,12 +1618,15 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
                          J.complete ? J.d_cxx.p : (const double *)nullptr);
       BSN_HIP(hipGetLastError());
     }
-    BSN_HIP(hipEventSynchronize(e1));
-    float ms = 0;
-    BSN_HIP(hipEventElapsedTime(&ms, e0, e1));
-    ms_total += ms;
     ls.launches += 1;
   }
+  if (!evs.empty()) BSN_HIP(hipStreamSynchronize(bed->stream));
+  for (size_t t = 0; t + 1 < evs.size(); t += 2) {
+    float ms = 0;
+    BSN_HIP(hipEventElapsedTime(&ms, evs[t], evs[t + 1]));
+    ms_total += ms;
+  }
+  for (hipEvent_t e : evs) (void)hipEventDestroy(e);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   ls.stats_ms = ms_total;

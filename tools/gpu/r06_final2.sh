@@ -26,7 +26,7 @@ print('alternatives', {k: (round(v['ms'],1), v.get('angles_to_reference', {}).ge
 print('cpu_baseline', d['cpu_baseline']['value'], d['cpu_baseline']['cores'], 'ingest', d.get('ingest', {}).get('GBps'))
 print('auto_svd', d.get('auto_svd'))
 P
-cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -o st -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ingest --no-wide --no-accuracy --no-cold > /dev/null 2> /tmp/pk.err
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -o st -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ingest --no-wide --no-accuracy --no-cold --no-autosvd > /dev/null 2> /tmp/pk.err
 cd "$GRAFT_REPO_ROOT"
 cp $(find /tmp/pk -name '*kernel_stats.csv' | head -1) $O/bench_kernel_stats.csv
 python tools/trace_gaps.py $(find /tmp/pk -name '*kernel_trace.csv' | head -1) > $O/bench_solve_timeline.txt; tail -3 $O/bench_solve_timeline.txt | cut -c1-250
