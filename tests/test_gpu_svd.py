@@ -324,7 +324,8 @@ def test_column_list_solve_runs_on_a_compacted_copy(ba, monkeypatch):
         a = ba.bed_randomSVD(gb, ind_col=ic, k=k)
         assert a["compacted"] and a["converged"]
         again = ba.bed_randomSVD(gb, ind_col=ic, k=k)           # the same list: the copy is found, not made
-        assert again["compacted"] and again["compact_ms"] < a["compact_ms"] + 1.0
+        # (found = no gather, no allocation; the slack only absorbs a host scheduling hiccup in the list comparison)
+        assert again["compacted"] and again["compact_ms"] < a["compact_ms"] + 5.0
         monkeypatch.setenv("BSN_NO_COMPACT", "1")
         b = ba.bed_randomSVD(gb, ind_col=ic, k=k)
         assert not b["compacted"]
