@@ -35,6 +35,8 @@ def one_draw(seed, tmp):
     n = int(rng.choice([5, 17, 63, 130, 259, 517, 1030, 2051])) + int(rng.integers(0, 4))
     m = int(rng.choice([65, 70, 127, 129, 191, 193, 320, 500, 1000, 1500])) + int(rng.integers(0, 3))
     s = int(rng.choice([1, 1, 2, 3, 4, 7]))
+    while s > 1 and 64 * s + 66 > m + 63:      # (a budget that holds the whole file gives a resident handle)
+        s -= 1
     na16 = int(rng.choice([0, 655, 6000]))
     desc = "seed %d: n=%d m=%d slabs of %d, na16=%d" % (seed, n, m, 64 * s, na16)
     gb = ba.bed.synthetic(n, m, seed=1000 + seed, na16=na16)
@@ -43,7 +45,7 @@ def one_draw(seed, tmp):
     gb.close()
     res = ba.bed(path)
     pitch = (n + 3) // 4 + 255 & ~255
-    os.environ["BSN_IMAGE_BUDGET"] = str((64 * s + 66) * pitch)
+    os.environ["BSN_IMAGE_BUDGET"] = str(min(64 * s + 66, m + 63) * pitch)
     try:
         ooc = ba.bed(path)
     finally:
@@ -95,7 +97,16 @@ def one_draw(seed, tmp):
         nc = m if ic is None else len(ic)
         ce, sa = rng.normal(size=nc), rng.uniform(0.5, 2, size=nc)
         y, x = rng.normal(size=nr), rng.normal(size=nc)
-        check("cprodVec", lambda: eq(ba.bed_cprodVec(ooc, y, ir, ic, ce, sa), ba.bed_cprodVec(res, y, ir, ic, ce, sa)))
+        repeats = ir is not None and np.unique(ir).size < ir.size
+
+        def cprod():
+            z1, z0 = ba.bed_cprodVec(ooc, y, ir, ic, ce, sa), ba.bed_cprodVec(res, y, ir, ic, ce, sa)
+            if repeats:    # (the values of a repeated sample are added up in an order of the device's choosing before they are rounded to digits)
+                assert np.abs(z1 - z0).max() <= 1e-12 * max(np.abs(z0).max(), 1e-300), "cprodVec %g" % np.abs(z1 - z0).max()
+            else:
+                eq(z1, z0)
+        check("cprodVec (rows %s, columns %s)" % ("all" if ir is None else "with repeats" if repeats else "sorted subset",
+                                                  "all" if ic is None else "sorted" if (np.diff(ic) > 0).all() else "permuted"), cprod)
 
         def prod():
             p1, p0 = ba.bed_prodVec(ooc, x, ir, ic, ce, sa), ba.bed_prodVec(res, x, ir, ic, ce, sa)
