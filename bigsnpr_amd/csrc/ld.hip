@@ -93,6 +93,10 @@ struct BandOut {
   double nrows;
   double *band;
   int mode;
+  // k_pair_stats_f4<., RAW = true> only: per-variant totals over the selected samples (sum x, sum x^2, non-missing count,
+  // by position in ind.col) and the number of sample positions the kernel walks (4 pitch: dropped and pad samples included)
+  const double *cx = nullptr, *cxx = nullptr, *cnn = nullptr;
+  double npos = 0;
 };
 
 // stats[pair][prod][row][col], prod: 0 xy, 1 x(both), 2 xx(both), 3 y(both), 4 yy(both), 5 nona
@@ -400,6 +404,30 @@ __device__ __forceinline__ PlanesF4 decode_f4(uint32_t w0, uint32_t w1) {
             (int)(lut4b(kF4M, b0) | lut4b(kF4Mh, b1)), (int)(lut4b(kF4M, b2) | lut4b(kF4Mh, b3))};
   return p;
 }
+// (Round 6, second session) The same six sums from planes that cost no look-up.  A 2-bit code in the low bits of a nibble IS
+// code / 2 in E2M1 (0, 0.5, 1.0, 1.5 for the codes 0, 1, 2, 3 = missing), its high bit alone is 1.0 = [code >= 2], and both
+// bits set is [code = 3]: with c = the raw code, H = [c >= 2], M = [c = 3] every function of a code is a combination of
+// 1, c, H, M — the allele count is x = c - 3 M, its square x^2 = c + 2 H - 5 M, "present" is 1 - M — so
+//   sum x y      = cc' - 3 cM' - 3 Mc' + 9 MM'          sum x (1 - M')   = Sx  - (cM' - 3 MM')
+//   sum x^2 (1 - M') = Sxx - (cM' + 2 HM' - 5 MM')      sum (1 - M)(1 - M') = Nx + Ny - npos + MM'      (and the mirror images)
+// with the per-variant totals Sx, Sxx, N (non-missing count) over the selected samples: SIX products again — (c, c'),
+// (c, M'), (H, M'), (M, c'), (M, H'), (M, M') — of planes that take 10 shift / and instructions per 16 genotypes where the
+// look-ups of decode_f4 take 25.  M is coded 1.0; the accumulators hold cc' / 4, cM' / 2, HM', ..., MM': multiples of
+// 1 / 4, exact in fp32 while 9 n < 2^24 (n <= 1 864 135; beyond that the look-up kernel, then the int8 kernel).  Dropped
+// samples are ORed to code 3 as before.  The recombination in the epilogue is integer arithmetic in fp64: the six sums —
+// and with them every band entry — are the ones the look-up kernel produces, bit for bit (tests/test_gpu_ld.py).
+__device__ __forceinline__ PlanesF4 decode_f4_raw(uint32_t w0, uint32_t w1, bool with_h) {
+  const uint32_t t0 = w0 >> 2, t1 = w1 >> 2;
+  const uint32_t u0 = w0 & (w0 << 1), u1 = w1 & (w1 << 1);          // bit 1 of a field: both bits set
+  PlanesF4 p;
+  p.x = v4i{(int)(w0 & 0x33333333u), (int)(t0 & 0x33333333u), (int)(w1 & 0x33333333u), (int)(t1 & 0x33333333u)};
+  if (with_h)
+    p.x2 = v4i{(int)(w0 & 0x22222222u), (int)(t0 & 0x22222222u), (int)(w1 & 0x22222222u), (int)(t1 & 0x22222222u)};
+  else
+    p.x2 = v4i{0, 0, 0, 0};
+  p.m = v4i{(int)(u0 & 0x22222222u), (int)((u0 >> 2) & 0x22222222u), (int)(u1 & 0x22222222u), (int)((u1 >> 2) & 0x22222222u)};
+  return p;
+}
 __device__ __forceinline__ v4f mfma_f4(const v4i &a, const v4i &b, const v4f &c) {
   const v8i a8 = {a.x, a.y, a.z, a.w, 0, 0, 0, 0}, b8 = {b.x, b.y, b.z, b.w, 0, 0, 0, 0};
   return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, c, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
@@ -407,7 +435,7 @@ __device__ __forceinline__ v4f mfma_f4(const v4i &a, const v4i &b, const v4f &c)
 // SQ = false (round 6): the bed clumping formula (mode 3, src/clumping-bed.cpp:69-73 on mean-imputed scaled values) is
 // sum x y - c' sum x m' - c sum m y + c c' sum m m' — FOUR of the six sums: the two with squares are neither multiplied nor
 // decoded (a third of the matrix instructions and of the look-ups; their accumulators are not allocated).
-template <bool SQ>
+template <bool SQ, bool RAW = false>
 __global__ __launch_bounds__(256, SQ ? 3 : 4) void k_pair_stats_f4(const uint8_t *__restrict__ img, int64_t pitch,
                                                        const int32_t *__restrict__ cols,
                                                        const int2 *__restrict__ pairs,
@@ -437,7 +465,7 @@ __global__ __launch_bounds__(256, SQ ? 3 : 4) void k_pair_stats_f4(const uint8_t
   const int nit = (int)(pitch / 64);
   auto stash = [&](int buf, const v2u &b, const v4u &mk) {   // this wave's (K-step, sub-tile) of the column operand -> LDS
     const uint32_t m0 = my_ks == 0 ? mk.x : mk.z, m1 = my_ks == 0 ? mk.y : mk.w;
-    const PlanesF4 P = decode_f4(b.x | ~m0, b.y | ~m1);
+    const PlanesF4 P = RAW ? decode_f4_raw(b.x | ~m0, b.y | ~m1, SQ) : decode_f4(b.x | ~m0, b.y | ~m1);
     sB[buf][my_ks][my_s][0][lane] = uint4{(uint32_t)P.x[0], (uint32_t)P.x[1], (uint32_t)P.x[2], (uint32_t)P.x[3]};
     if constexpr (SQ) sB[buf][my_ks][my_s][1][lane] = uint4{(uint32_t)P.x2[0], (uint32_t)P.x2[1], (uint32_t)P.x2[2], (uint32_t)P.x2[3]};
     sB[buf][my_ks][my_s][2][lane] = uint4{(uint32_t)P.m[0], (uint32_t)P.m[1], (uint32_t)P.m[2], (uint32_t)P.m[3]};
@@ -463,7 +491,9 @@ __global__ __launch_bounds__(256, SQ ? 3 : 4) void k_pair_stats_f4(const uint8_t
       const uint32_t m0 = d == 0 ? mk.x : mk.z, m1 = d == 0 ? mk.y : mk.w;
       PlanesF4 A[2];
 #pragma unroll
-      for (int s = 0; s < 2; s++) A[s] = decode_f4((d == 0 ? a[s].x : a[s].z) | ~m0, (d == 0 ? a[s].y : a[s].w) | ~m1);
+      for (int s = 0; s < 2; s++)
+        A[s] = RAW ? decode_f4_raw((d == 0 ? a[s].x : a[s].z) | ~m0, (d == 0 ? a[s].y : a[s].w) | ~m1, SQ)
+                   : decode_f4((d == 0 ? a[s].x : a[s].z) | ~m0, (d == 0 ? a[s].y : a[s].w) | ~m1);
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         const uint4 bx = sB[buf][d][j][0][lane], bm = sB[buf][d][j][2][lane];
@@ -496,16 +526,30 @@ __global__ __launch_bounds__(256, SQ ? 3 : 4) void k_pair_stats_f4(const uint8_t
 #pragma unroll
       for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int p = 0; p < 6; p++) st[(i * 2 + j) * 4 + r][p] = (int32_t)acc[i][j][p][r];
+        for (int p = 0; p < 6; p++) {
+          // RAW: the accumulators hold cc' / 4, cM' / 2, HM', Mc' / 2, MH', MM' (exact: powers of two back to integers)
+          const float sc = !RAW ? 1.f : p == 0 ? 4.f : (p == 1 || p == 3) ? 2.f : 1.f;
+          st[(i * 2 + j) * 4 + r][p] = (int32_t)(acc[i][j][p][r] * sc);
+        }
 #pragma unroll 1
   for (int e = 0; e < 16; e++) {
     const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
     const int row = wave * 32 + i * 16 + 4 * g + r, col = j * 16 + r16;
     const int64_t j0 = (int64_t)pr.x * TR + row, jj = (int64_t)pr.y * TC + col;
     if (j0 >= bo.m || jj >= j0 || jj < bo.lo[j0]) continue;
-    bo.band[j0 * bo.W + (j0 - jj - 1)] =
-        pair_value(bo.mode, (double)st[e][0], (double)st[e][1], (double)st[e][2], (double)st[e][3], (double)st[e][4],
-                   st[e][5], bo.thr, bo.v1, bo.v2, j0, jj, bo.nrows);
+    if constexpr (RAW) {
+      // integers in fp64 (all below 2^53): the six pairwise-complete sums from the six raw products and the totals
+      const double cc = st[e][0], cm = st[e][1], hm = st[e][2], mc = st[e][3], mh = st[e][4], mm = st[e][5];
+      const double xy = cc - 3.0 * cm - 3.0 * mc + 9.0 * mm;
+      const double xs = bo.cx[j0] - (cm - 3.0 * mm), ys = bo.cx[jj] - (mc - 3.0 * mm);
+      const double xx = SQ ? bo.cxx[j0] - (cm + 2.0 * hm - 5.0 * mm) : 0.0, yy = SQ ? bo.cxx[jj] - (mc + 2.0 * mh - 5.0 * mm) : 0.0;
+      const int nona = (int)(bo.cnn[j0] + bo.cnn[jj] - bo.npos + mm);
+      bo.band[j0 * bo.W + (j0 - jj - 1)] = pair_value(bo.mode, xy, xs, xx, ys, yy, nona, bo.thr, bo.v1, bo.v2, j0, jj, bo.nrows);
+    } else {
+      bo.band[j0 * bo.W + (j0 - jj - 1)] =
+          pair_value(bo.mode, (double)st[e][0], (double)st[e][1], (double)st[e][2], (double)st[e][3], (double)st[e][4],
+                     st[e][5], bo.thr, bo.v1, bo.v2, j0, jj, bo.nrows);
+    }
   }
 }
 
@@ -1168,6 +1212,7 @@ struct BandJob {
   DevBuf<uint32_t> d_mask;
   DevBuf<uint8_t> d_mask8;  // byte image: 0xFF per selected sample
   DevBuf<double> d_band, d_thr, d_v1, d_v2, d_cx, d_cxx, d_nna;   // d_nna: byte image, missing values per variant
+  DevBuf<double> d_cnn;     // 2-bit image: non-missing count per variant over the selected samples (raw-plane kernel)
   DevBuf<long long> d_stats64;
   bool complete = false;  // no missing value among the selected samples of the selected variants
   bool use_mask = false;
@@ -1317,19 +1362,20 @@ static void band_stats(BandJob &J, bsn_bed *bed, const int64_t *ind_row, int64_t
       std::vector<int32_t> cnt((size_t)4 * m);
       counts_host(bed, ind_row, n, ind_col, m, cnt.data());
       int64_t na = 0;
-      std::vector<double> cx((size_t)m), cxx((size_t)m);
+      std::vector<double> cx((size_t)m), cxx((size_t)m), cnn((size_t)m);
       for (int64_t j = 0; j < m; j++) {
         const int32_t *c = &cnt[(size_t)4 * j];
         na += c[3];
         cx[(size_t)j] = (double)c[1] + 2.0 * c[2];
         cxx[(size_t)j] = (double)c[1] + 4.0 * c[2];
+        cnn[(size_t)j] = (double)c[0] + (double)c[1] + (double)c[2];
       }
       J.complete = (na == 0) && !getenv("BSN_FORCE_NA_PLANE");
-      if (J.complete) {
-        copy_h2d(bed, J.d_cx.ensure((size_t)m), cx.data(), (size_t)m * 8);
-        copy_h2d(bed, J.d_cxx.ensure((size_t)m), cxx.data(), (size_t)m * 8);
-        BSN_HIP(hipStreamSynchronize(bed->stream));
-      }
+      // (with missing values the raw-plane kernel of the six sums reads the totals too)
+      copy_h2d(bed, J.d_cx.ensure((size_t)m), cx.data(), (size_t)m * 8);
+      copy_h2d(bed, J.d_cxx.ensure((size_t)m), cxx.data(), (size_t)m * 8);
+      copy_h2d(bed, J.d_cnn.ensure((size_t)m), cnn.data(), (size_t)m * 8);
+      BSN_HIP(hipStreamSynchronize(bed->stream));
     }
   }
   // tile pairs of the band
@@ -1474,8 +1520,21 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
       // the FP4 matrix pipe while the sums stay exact in fp32 (at most 4 n < 2^24); BSN_LD_I8=1: the int8 kernel
       static const bool i8_only = getenv("BSN_LD_I8") != nullptr;
       const bool f4 = bed->pitch * 4 <= 4194303 && !i8_only;
+      // planes without look-ups while 9 n < 2^24 (BSN_LD_LUT=1: the look-up kernel, for the A/B)
+      static const bool lut_only = getenv("BSN_LD_LUT") != nullptr;
+      const bool raw = f4 && bed->pitch * 4 <= 1864135 && !lut_only && J.d_cnn.p != nullptr;
       ls.kernel = f4 ? (mode == 3 ? 9 : 6) : 4;
-      if (f4 && mode == 3)   // the bed clumping formula reads four of the six sums
+      if (raw) {
+        BandOut br = bo;
+        br.cx = J.d_cx.p, br.cxx = J.d_cxx.p, br.cnn = J.d_cnn.p, br.npos = (double)(bed->pitch * 4);
+        ls.kernel = mode == 3 ? 11 : 10;
+        if (mode == 3)
+          hipLaunchKernelGGL((k_pair_stats_f4<false, true>), dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
+                             J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, br);
+        else
+          hipLaunchKernelGGL((k_pair_stats_f4<true, true>), dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
+                             J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, br);
+      } else if (f4 && mode == 3)   // the bed clumping formula reads four of the six sums
         hipLaunchKernelGGL(k_pair_stats_f4<false>, dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
                            J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, bo);
       else if (f4)

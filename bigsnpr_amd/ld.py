@@ -486,6 +486,10 @@ def last_stats():
              "k_pair_xy_f4 (cross product only on the FP4 matrix pipe: no missing values, codes as E2M1 nibbles) + k_band_fill",
              "k_quad_xy_f4 (cross product only on the FP4 matrix pipe, 2 x 2 tile pairs per workgroup through LDS) + k_band_fill",
              "k_pair_stats_f4<4 of the 6 products (the bed clumping formula reads no sum of squares) on the FP4 matrix pipe, "
-             "column operand decoded once per workgroup through LDS, fused fp64 epilogue>")
+             "column operand decoded once per workgroup through LDS, fused fp64 epilogue>",
+             "k_pair_stats_f4<RAW: 6 products of look-up-free planes (code, high bit, missing) on the FP4 matrix pipe, recombined with "
+             "the per-variant totals in the fused fp64 epilogue; column operand decoded once per workgroup through LDS>",
+             "k_pair_stats_f4<RAW: 4 products (the bed clumping formula) of look-up-free planes (code, missing) on the FP4 matrix pipe, "
+             "recombined with the per-variant totals in the fused fp64 epilogue>")
     return dict(pairs=out[0], tile_pairs=out[1], stats_ms=out[2], launches=int(out[3]), kernel=names[int(out[4])],
-                products={2: 1, 3: 8, 7: 1, 8: 1, 9: 4}.get(int(out[4]), 6))
+                products={2: 1, 3: 8, 7: 1, 8: 1, 9: 4, 11: 4}.get(int(out[4]), 6))

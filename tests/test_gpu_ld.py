@@ -331,3 +331,58 @@ def test_bed_clumping_on_the_four_product_kernel(ba, orc, monkeypatch):
     ld = ba.bed_ld_scores(gb, size=0.4, infos_pos=pos / 1000.0)
     assert "k_pair_stats_f4" in ldm.last_stats()["kernel"]
     np.testing.assert_allclose(ld, orc.ld_scores(ob, size=0.4, infos_pos=pos / 1000.0), rtol=1e-12)
+
+
+def test_raw_plane_kernel_equals_the_look_up_kernel_bit_for_bit(ba, orc, monkeypatch):
+    """round 6, second session: k_pair_stats_f4<., RAW> multiplies planes that cost no look-up — the raw code c, its high
+    bit H = [c >= 2] and M = [c = 3] — and recombines the six pairwise-complete sums of src/corr.cpp:54-75 from the six
+    products and the per-variant totals (x = c - 3 M, x^2 = c + 2 H - 5 M, present = 1 - M): integer arithmetic, so
+    every band entry is the one the look-up kernel (BSN_LD_LUT=1) writes — scores, @p / @i / @x and clumping indices
+    bit for bit; row subsets (dropped samples are ORed to missing and counted in the totals' way), an increasing column
+    subset, heavy and light missingness, ragged sizes; and against the oracle."""
+    from bigsnpr_amd import ld as ldm
+    rng = np.random.default_rng(41)
+    for n, m, na16 in ((420, 12032, 2000), (1003, 9000, 655), (259, 10250, 20000), (64, 8200, 100)):
+        ob = orc.fake_bed(n, m, seed=5 + n, na16=na16)
+        gb = ba.bed.from_payload(ob.payload, n, m)
+        pos = np.cumsum(rng.integers(1, 2000, size=m)).astype(np.float64)
+        chrom = np.repeat([1, 2], [m // 2, m - m // 2])
+        ir = np.sort(rng.choice(n, n - n // 5, replace=False))
+        ic = np.sort(rng.choice(m, m - 300, replace=False))
+        got = {}
+        for tag in ("raw", "lut"):
+            if tag == "lut":
+                monkeypatch.setenv("BSN_LD_LUT", "1")
+            # (the switch is read once per process: the A/B runs in children)
+            code = (
+                "import numpy as np, sys, pickle, bigsnpr_amd as ba\n"
+                "from bigsnpr_amd import ld as ldm\n"
+                "d = pickle.load(open(sys.argv[1], 'rb'))\n"
+                "gb = ba.bed.from_payload(d['payload'], d['n'], d['m'])\n"
+                "out = {}\n"
+                "out['ld'] = ba.bed_ld_scores(gb, size=500, infos_pos=d['pos']); out['k_ld'] = ldm.last_stats()['kernel']\n"
+                "out['ld_sub'] = ba.bed_ld_scores(gb, ind_row=d['ir'], ind_col=d['ic'], size=500, infos_pos=d['pos'][d['ic']])\n"
+                "c = ba.bed_cor(gb, size=400, infos_pos=d['pos'], alpha=0.5); out['cor'] = (c.p, c.i, c.x)\n"
+                "c = ba.bed_cor(gb, ind_row=d['ir'], size=400, infos_pos=d['pos'], thr_r2=0.01); out['cor_sub'] = (c.p, c.i, c.x)\n"
+                "out['clump'] = ba.bed_clumping(gb, thr_r2=0.02, size=500, infos_chr=d['chrom'], infos_pos=d['pos']); out['k_cl'] = ldm.last_stats()['kernel']\n"
+                "out['clump_sub'] = ba.bed_clumping(gb, ind_row=d['ir'], thr_r2=0.1, size=500, infos_chr=d['chrom'], infos_pos=d['pos'])\n"
+                "pickle.dump(out, open(sys.argv[2], 'wb'))\n")
+            import pickle, subprocess, sys, tempfile, os
+            with tempfile.TemporaryDirectory() as tmp:
+                fin, fout = os.path.join(tmp, "in.pkl"), os.path.join(tmp, "out.pkl")
+                pickle.dump(dict(payload=ob.payload, n=n, m=m, pos=pos, chrom=chrom, ir=ir, ic=ic), open(fin, "wb"))
+                r = subprocess.run([sys.executable, "-c", code, fin, fout], capture_output=True, text=True, timeout=600,
+                                   cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=dict(os.environ))
+                assert r.returncode == 0, r.stderr[-2000:]
+                got[tag] = pickle.load(open(fout, "rb"))
+            monkeypatch.delenv("BSN_LD_LUT", raising=False)
+        assert "RAW" in got["raw"]["k_ld"] and "RAW" in got["raw"]["k_cl"], (got["raw"]["k_ld"], got["raw"]["k_cl"])
+        assert "RAW" not in got["lut"]["k_ld"] and "k_pair_stats_f4" in got["lut"]["k_ld"] and "RAW" not in got["lut"]["k_cl"]
+        for key in ("ld", "ld_sub", "clump", "clump_sub"):
+            np.testing.assert_array_equal(got["raw"][key], got["lut"][key], err_msg="%s, n=%d m=%d" % (key, n, m))
+        for key in ("cor", "cor_sub"):
+            for a, b in zip(got["raw"][key], got["lut"][key]):
+                np.testing.assert_array_equal(a, b, err_msg="%s, n=%d m=%d" % (key, n, m))
+        if n <= 420:      # (the oracle's scalar loops: seconds at these sizes)
+            np.testing.assert_allclose(got["raw"]["ld"], orc.ld_scores(ob, size=500, infos_pos=pos), rtol=1e-12)
+            np.testing.assert_array_equal(got["raw"]["clump"], orc.bed_clumping(ob, chrom, pos, thr_r2=0.02, size=500))
