@@ -435,7 +435,11 @@ __device__ __forceinline__ v4f mfma_f4(const v4i &a, const v4i &b, const v4f &c)
 // SQ = false (round 6): the bed clumping formula (mode 3, src/clumping-bed.cpp:69-73 on mean-imputed scaled values) is
 // sum x y - c' sum x m' - c sum m y + c c' sum m m' — FOUR of the six sums: the two with squares are neither multiplied nor
 // decoded (a third of the matrix instructions and of the look-ups; their accumulators are not allocated).
-template <bool SQ, bool RAW = false>
+// MASK = false (RAW only): every sample of the image is selected — pad samples are code 0 in the image, and code 0 adds nothing
+// to any of the six raw products (c = H = M = 0), so the keep-mask is neither loaded nor ORed in (npos = n then).
+// PRIO > 0: s_setprio(PRIO) around the matrix instructions of a K-step (with their LDS reads), 0 again for the decode — a wave that
+// has its operands ready is issued ahead of the waves that are still decoding (measured: profiles/r06_ld_raw.txt).
+template <bool SQ, bool RAW = false, bool MASK = true, int PRIO = 0>
 __global__ __launch_bounds__(256, SQ ? 3 : 4) void k_pair_stats_f4(const uint8_t *__restrict__ img, int64_t pitch,
                                                        const int32_t *__restrict__ cols,
                                                        const int2 *__restrict__ pairs,
@@ -463,8 +467,9 @@ __global__ __launch_bounds__(256, SQ ? 3 : 4) void k_pair_stats_f4(const uint8_t
 #pragma unroll
       for (int p = 0; p < 6; p++) acc[i][j][p] = v4f{0.f, 0.f, 0.f, 0.f};
   const int nit = (int)(pitch / 64);
+  static_assert(MASK || RAW, "the look-up planes count pad samples as present: they need the keep-mask");
   auto stash = [&](int buf, const v2u &b, const v4u &mk) {   // this wave's (K-step, sub-tile) of the column operand -> LDS
-    const uint32_t m0 = my_ks == 0 ? mk.x : mk.z, m1 = my_ks == 0 ? mk.y : mk.w;
+    const uint32_t m0 = !MASK ? ~0u : my_ks == 0 ? mk.x : mk.z, m1 = !MASK ? ~0u : my_ks == 0 ? mk.y : mk.w;
     const PlanesF4 P = RAW ? decode_f4_raw(b.x | ~m0, b.y | ~m1, SQ) : decode_f4(b.x | ~m0, b.y | ~m1);
     sB[buf][my_ks][my_s][0][lane] = uint4{(uint32_t)P.x[0], (uint32_t)P.x[1], (uint32_t)P.x[2], (uint32_t)P.x[3]};
     if constexpr (SQ) sB[buf][my_ks][my_s][1][lane] = uint4{(uint32_t)P.x2[0], (uint32_t)P.x2[1], (uint32_t)P.x2[2], (uint32_t)P.x2[3]};
@@ -476,7 +481,9 @@ __global__ __launch_bounds__(256, SQ ? 3 : 4) void k_pair_stats_f4(const uint8_t
 #pragma unroll
   for (int s = 0; s < 2; s++) a[s] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)va[s], 0, 0);
   b = __builtin_amdgcn_raw_buffer_load_b64(rsB, (int)vb, wsel, 0);
-  mk = __builtin_amdgcn_raw_buffer_load_b128(rsM, g * 16, 0, 0);
+  if constexpr (MASK) mk = __builtin_amdgcn_raw_buffer_load_b128(rsM, g * 16, 0, 0);
+  else mk = v4u{~0u, ~0u, ~0u, ~0u};
+  mkn = mk;
   stash(0, b, mk);
   __syncthreads();
   for (int it = 0; it < nit; it++) {
@@ -484,16 +491,17 @@ __global__ __launch_bounds__(256, SQ ? 3 : 4) void k_pair_stats_f4(const uint8_t
 #pragma unroll
     for (int s = 0; s < 2; s++) an[s] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)va[s], kbn, 0);
     bn = __builtin_amdgcn_raw_buffer_load_b64(rsB, (int)vb, kbn + wsel, 0);
-    mkn = __builtin_amdgcn_raw_buffer_load_b128(rsM, g * 16, kbn, 0);
+    if constexpr (MASK) mkn = __builtin_amdgcn_raw_buffer_load_b128(rsM, g * 16, kbn, 0);
     const int buf = it & 1;
 #pragma unroll
     for (int d = 0; d < 2; d++) {
-      const uint32_t m0 = d == 0 ? mk.x : mk.z, m1 = d == 0 ? mk.y : mk.w;
+      const uint32_t m0 = !MASK ? ~0u : d == 0 ? mk.x : mk.z, m1 = !MASK ? ~0u : d == 0 ? mk.y : mk.w;
       PlanesF4 A[2];
 #pragma unroll
       for (int s = 0; s < 2; s++)
         A[s] = RAW ? decode_f4_raw((d == 0 ? a[s].x : a[s].z) | ~m0, (d == 0 ? a[s].y : a[s].w) | ~m1, SQ)
                    : decode_f4((d == 0 ? a[s].x : a[s].z) | ~m0, (d == 0 ? a[s].y : a[s].w) | ~m1);
+      if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         const uint4 bx = sB[buf][d][j][0][lane], bm = sB[buf][d][j][2][lane];
@@ -511,6 +519,7 @@ __global__ __launch_bounds__(256, SQ ? 3 : 4) void k_pair_stats_f4(const uint8_t
           acc[i][j][5] = mfma_f4(A[i].m, Bm, acc[i][j][5]);
         }
       }
+      if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(0);
     }
     stash(buf ^ 1, bn, mkn);
     __syncthreads();
@@ -755,7 +764,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 struct QuadXY {
   int t[4], p[4];
 };
-template <bool MASK>
+template <bool MASK, int PRIO = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_quad_xy_f4(const uint8_t *__restrict__ img, int64_t pitch,
                                                                                               const int32_t *__restrict__ cols,
                                                                                               const QuadXY *__restrict__ quads,
@@ -813,7 +822,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           A[s] = nib(d == 0 ? a[s].x : a[s].z, d == 0 ? a[s].y : a[s].w);                               \
           B[s] = nib(d == 0 ? b[s].x : b[s].z, d == 0 ? b[s].y : b[s].w);                               \
         }                                                                                               \
+        if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);                                         \
         _Pragma("unroll") for (int i = 0; i < 4; i++) _Pragma("unroll") for (int j = 0; j < 4; j++) acc[i][j] = mfma_f4(A[i], B[j], acc[i][j]); \
+        if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(0);                                            \
       }                                                                                                 \
     }                                                                                                   \
   }
@@ -1526,14 +1537,35 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
       ls.kernel = f4 ? (mode == 3 ? 9 : 6) : 4;
       if (raw) {
         BandOut br = bo;
-        br.cx = J.d_cx.p, br.cxx = J.d_cxx.p, br.cnn = J.d_cnn.p, br.npos = (double)(bed->pitch * 4);
+        // every sample selected: no keep-mask (the pad samples are code 0 and add nothing to the raw products)
+        const bool nomask = J.all_rows && !abl_getenv("BSN_LD_RAW_MASK");
+        int prio = 2;   // (profiling build: BSN_LD_RAW_PRIO=0..3)
+        if (const char *e = abl_getenv("BSN_LD_RAW_PRIO")) prio = atoi(e);
+        br.cx = J.d_cx.p, br.cxx = J.d_cxx.p, br.cnn = J.d_cnn.p, br.npos = nomask ? (double)bed->n : (double)(bed->pitch * 4);
         ls.kernel = mode == 3 ? 11 : 10;
-        if (mode == 3)
-          hipLaunchKernelGGL((k_pair_stats_f4<false, true>), dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
-                             J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, br);
-        else
-          hipLaunchKernelGGL((k_pair_stats_f4<true, true>), dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
-                             J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, br);
+#define BSN_LAUNCH_RAW(SQ_, MASK_, PRIO_)                                                                                      \
+  hipLaunchKernelGGL((k_pair_stats_f4<SQ_, true, MASK_, PRIO_>), dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, \
+                     bed->pitch, J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, br)
+#ifdef BSN_ABLATION
+#define BSN_LAUNCH_RAW_P(SQ_, MASK_)                  \
+  do {                                                \
+    if (prio == 0) BSN_LAUNCH_RAW(SQ_, MASK_, 0);     \
+    else if (prio == 1) BSN_LAUNCH_RAW(SQ_, MASK_, 1); \
+    else if (prio == 3) BSN_LAUNCH_RAW(SQ_, MASK_, 3); \
+    else BSN_LAUNCH_RAW(SQ_, MASK_, 2);               \
+  } while (0)
+#else
+#define BSN_LAUNCH_RAW_P(SQ_, MASK_) BSN_LAUNCH_RAW(SQ_, MASK_, 2)
+#endif
+        if (mode == 3) {
+          if (nomask) BSN_LAUNCH_RAW_P(false, false);
+          else BSN_LAUNCH_RAW_P(false, true);
+        } else {
+          if (nomask) BSN_LAUNCH_RAW_P(true, false);
+          else BSN_LAUNCH_RAW_P(true, true);
+        }
+#undef BSN_LAUNCH_RAW_P
+#undef BSN_LAUNCH_RAW
       } else if (f4 && mode == 3)   // the bed clumping formula reads four of the six sums
         hipLaunchKernelGGL(k_pair_stats_f4<false>, dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
                            J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, bo);
@@ -1635,7 +1667,10 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
         if (ksq < 1) ksq = 1;
         int64_t kbq = round_up((bed->pitch + ksq - 1) / ksq, 128);
         ksq = (int)((bed->pitch + kbq - 1) / kbq);
-        if (J.all_rows)
+        if (J.all_rows && abl_getenv("BSN_LD_QUAD_PRIO"))
+          hipLaunchKernelGGL((k_quad_xy_f4<false, 2>), dim3((unsigned)nq, (unsigned)ksq), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
+                             J.d_cols.p, d_q, J.d_mask.p, kbq, J.d_stats.p);
+        else if (J.all_rows)
           hipLaunchKernelGGL(k_quad_xy_f4<false>, dim3((unsigned)nq, (unsigned)ksq), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
                              J.d_cols.p, d_q, J.d_mask.p, kbq, J.d_stats.p);
         else
