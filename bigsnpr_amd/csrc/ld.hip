@@ -411,21 +411,22 @@ __device__ __forceinline__ PlanesF4 decode_f4(uint32_t w0, uint32_t w1) {
 //   sum x y      = cc' - 3 cM' - 3 Mc' + 9 MM'          sum x (1 - M')   = Sx  - (cM' - 3 MM')
 //   sum x^2 (1 - M') = Sxx - (cM' + 2 HM' - 5 MM')      sum (1 - M)(1 - M') = Nx + Ny - npos + MM'      (and the mirror images)
 // with the per-variant totals Sx, Sxx, N (non-missing count) over the selected samples: SIX products again — (c, c'),
-// (c, M'), (H, M'), (M, c'), (M, H'), (M, M') — of planes that take 10 shift / and instructions per 16 genotypes where the
+// (c, M'), (H, M'), (M, c'), (M, H'), (M, M') — of planes that take 9 shift / and instructions per 16 genotypes where the
 // look-ups of decode_f4 take 25.  M is coded 1.0; the accumulators hold cc' / 4, cM' / 2, HM', ..., MM': multiples of
 // 1 / 4, exact in fp32 while 9 n < 2^24 (n <= 1 864 135; beyond that the look-up kernel, then the int8 kernel).  Dropped
 // samples are ORed to code 3 as before.  The recombination in the epilogue is integer arithmetic in fp64: the six sums —
 // and with them every band entry — are the ones the look-up kernel produces, bit for bit (tests/test_gpu_ld.py).
 __device__ __forceinline__ PlanesF4 decode_f4_raw(uint32_t w0, uint32_t w1, bool with_h) {
-  const uint32_t t0 = w0 >> 2, t1 = w1 >> 2;
-  const uint32_t u0 = w0 & (w0 << 1), u1 = w1 & (w1 << 1);          // bit 1 of a field: both bits set
+  const uint32_t c0 = w0 & 0x33333333u, c1 = (w0 >> 2) & 0x33333333u, c2 = w1 & 0x33333333u, c3 = (w1 >> 2) & 0x33333333u;
   PlanesF4 p;
-  p.x = v4i{(int)(w0 & 0x33333333u), (int)(t0 & 0x33333333u), (int)(w1 & 0x33333333u), (int)(t1 & 0x33333333u)};
+  p.x = v4i{(int)c0, (int)c1, (int)c2, (int)c3};
   if (with_h)
-    p.x2 = v4i{(int)(w0 & 0x22222222u), (int)(t0 & 0x22222222u), (int)(w1 & 0x22222222u), (int)(t1 & 0x22222222u)};
+    p.x2 = v4i{(int)(c0 & 0x22222222u), (int)(c1 & 0x22222222u), (int)(c2 & 0x22222222u), (int)(c3 & 0x22222222u)};
   else
     p.x2 = v4i{0, 0, 0, 0};
-  p.m = v4i{(int)(u0 & 0x22222222u), (int)((u0 >> 2) & 0x22222222u), (int)(u1 & 0x22222222u), (int)((u1 >> 2) & 0x22222222u)};
+  // both bits of a code set: bit 1 of the nibble survives c & (c << 1) (the upper two bits of a nibble of c are zero, so the
+  // shift carries nothing into a neighbour): 1.0 for a missing code, 0 otherwise
+  p.m = v4i{(int)(c0 & (c0 << 1)), (int)(c1 & (c1 << 1)), (int)(c2 & (c2 << 1)), (int)(c3 & (c3 << 1))};
   return p;
 }
 __device__ __forceinline__ v4f mfma_f4(const v4i &a, const v4i &b, const v4f &c) {
