@@ -1542,6 +1542,7 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
         const bool nomask = J.all_rows && !abl_getenv("BSN_LD_RAW_MASK");
         int prio = 2;   // (profiling build: BSN_LD_RAW_PRIO=0..3)
         if (const char *e = abl_getenv("BSN_LD_RAW_PRIO")) prio = atoi(e);
+        (void)prio;
         br.cx = J.d_cx.p, br.cxx = J.d_cxx.p, br.cnn = J.d_cnn.p, br.npos = nomask ? (double)bed->n : (double)(bed->pitch * 4);
         ls.kernel = mode == 3 ? 11 : 10;
 #define BSN_LAUNCH_RAW(SQ_, MASK_, PRIO_)                                                                                      \
