@@ -1525,9 +1525,14 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
     return;
   }
   if (!xy_only && J.contig && J.use_mask && J.npairs_b >= 1024 && !abl_getenv("BSN_LD_NO_SHARED_DECODE")) {
-    // enough blocks to fill the chip without a K split: the kernel that shares the column operand's decode
-    for (int64_t p0 = qA; p0 < qB; p0 += batch) {
-      const int64_t np = std::min(batch, qB - p0);
+    // enough blocks to fill the chip without a K split: the kernel that shares the column operand's decode.
+    // (round 6, second session) ONE launch for the whole run: the fused epilogue needs no scratch, every block walks the same
+    // sample range (equal work), and a launch of 4 096 blocks on 768 resident workgroups ended with a round that was a third
+    // full — 13 such tails at C5 (BSN_LD_BATCH=<n> in the profiling build: blocks per launch, for the A/B)
+    int64_t fbatch = std::max<int64_t>(qB - qA, 1);
+    if (const char *e = abl_getenv("BSN_LD_BATCH")) fbatch = std::max<int64_t>(1, atoll(e));
+    for (int64_t p0 = qA; p0 < qB; p0 += fbatch) {
+      const int64_t np = std::min(fbatch, qB - p0);
       BSN_HIP(hipEventRecord(e0, bed->stream));
       // the FP4 matrix pipe while the sums stay exact in fp32 (at most 4 n < 2^24); BSN_LD_I8=1: the int8 kernel
       static const bool i8_only = getenv("BSN_LD_I8") != nullptr;
