@@ -250,6 +250,8 @@ constexpr int TR = 128, TC = 32;
 // (Round 4: an explicit MFMA : VALU schedule through __builtin_amdgcn_sched_group_barrier, as in k_cprod — 1 or 2 VALU
 // offered behind every MFMA, the column operand's decode pulled into the last K-step — needs 210 registers, and forced
 // back to 168 for the third wave it runs 422 - 434 ms against 292 at C5: profiles/r04_ld.txt.  Not kept.)
+// PRIO (round 6, second session): s_setprio around the matrix instructions of a K-step, as in k_pair_stats_f4 (profiles/r06_ld_raw.txt).
+template <int PRIO = 0>
 __global__ __launch_bounds__(256, 2) void k_pair_stats_b(const uint8_t *__restrict__ img, int64_t pitch,
                                                       const int32_t *__restrict__ cols,
                                                       const int2 *__restrict__ pairs,
@@ -320,6 +322,7 @@ __global__ __launch_bounds__(256, 2) void k_pair_stats_b(const uint8_t *__restri
         const uint32_t wa = d == 0 ? a[s].x : d == 1 ? a[s].y : d == 2 ? a[s].z : a[s].w;
         A[s] = decode3(wa | ~mw);
       }
+      if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         const uint4 bx = sB[buf][d][j][0][lane], bx2 = sB[buf][d][j][1][lane], bm = sB[buf][d][j][2][lane];
@@ -335,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void k_pair_stats_b(const uint8_t *__restri
           acc[i][j][5] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[i].m, Bm, acc[i][j][5], 0, 0, 0);
         }
       }
+      if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(0);
     }
     // (Placing this decode between the K-steps above, where the matrix pipe is busy, costs 24 registers — two
     // waves per SIMD instead of three — and 12 % of the time: measured.)
@@ -1573,14 +1577,24 @@ static void band_run(BandJob &J, int mode, const double *d_thr, const double *d_
         }
 #undef BSN_LAUNCH_RAW_P
 #undef BSN_LAUNCH_RAW
+      } else if (abl_getenv("BSN_LD_NOPRIO")) {   // (profiling build: the look-up / int8 kernels without the priority, for the A/B)
+        if (f4 && mode == 3)
+          hipLaunchKernelGGL(k_pair_stats_f4<false>, dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
+                             J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, bo);
+        else if (f4)
+          hipLaunchKernelGGL(k_pair_stats_f4<true>, dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
+                             J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, bo);
+        else
+          hipLaunchKernelGGL(k_pair_stats_b<0>, dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
+                             J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, bo);
       } else if (f4 && mode == 3)   // the bed clumping formula reads four of the six sums
-        hipLaunchKernelGGL(k_pair_stats_f4<false>, dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
+        hipLaunchKernelGGL((k_pair_stats_f4<false, false, true, 2>), dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
                            J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, bo);
       else if (f4)
-        hipLaunchKernelGGL(k_pair_stats_f4<true>, dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
+        hipLaunchKernelGGL((k_pair_stats_f4<true, false, true, 2>), dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
                            J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, bo);
-      else
-        hipLaunchKernelGGL(k_pair_stats_b, dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
+      else   // (the int8 kernel without the priority: with it the compiler needs 174 registers — two waves per SIMD — and it is 11 % slower)
+        hipLaunchKernelGGL(k_pair_stats_b<0>, dim3((unsigned)np), dim3(256), 0, bed->stream, bed->d_img, bed->pitch,
                            J.d_cols.p, J.d_pairs_b.p + p0, J.d_mask.p, bo);
       BSN_HIP(hipGetLastError());
       BSN_HIP(hipEventRecord(e1, bed->stream));
