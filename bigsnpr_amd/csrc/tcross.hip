@@ -47,7 +47,7 @@ constexpr int kLdsRow = kTile + 16;  // doubles per k-row in LDS: 16 of padding 
 //   the 144-double row pitch the 64 lanes of a wave then hit every bank exactly twice per store.
 //   gather (any ind.row): one byte load and one table load per value (thread = one sample of both tiles x 8
 //   variants).
-template <bool IDENT, int WAVES>
+template <bool IDENT, int WAVES, int PRIO = 0>
 __global__ __launch_bounds__(64 * WAVES, 2) void k_tcross(const uint8_t *__restrict__ img, int64_t pitch,
                                                           const int32_t *__restrict__ rows,
                                                           const int32_t *__restrict__ cols, int64_t col0, int64_t n,
@@ -164,11 +164,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_tcross(const uint8_t *__restr
       for (int t = 0; t < 4; t++) a[t] = sA[buf][k * kLdsRow + wi * 64 + t * 16 + r16];
 #pragma unroll
       for (int t = 0; t < TB; t++) b[t] = sB[buf][k * kLdsRow + wj * (16 * TB) + t * 16 + r16];
+      if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);   // (experiment, profiling build: BSN_TCROSS_PRIO=1)
 #pragma unroll
       for (int ta = 0; ta < 4; ta++)
 #pragma unroll
         for (int tb = 0; tb < TB; tb++)
           acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+      if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(0);
     }
     if (more) stash(buf ^ 1);
     __syncthreads();
@@ -246,7 +248,10 @@ static void tcross_resident(bsn_bed *bed, const int64_t *ind_row, int64_t n, con
 #define BSN_TCROSS(IDENTV, WV, ROWS)                                                                              \
   hipLaunchKernelGGL((k_tcross<IDENTV, WV>), grid, dim3(64 * WV), 0, bed->stream, bed->d_img, bed->pitch, ROWS, \
                      cols, op.col0, n, m, m_slab, d_T.p, d_pairs.p, out)
-    if (op.rows_identity) {
+    if (op.rows_identity && !w4 && abl_getenv("BSN_TCROSS_PRIO")) {
+      hipLaunchKernelGGL((k_tcross<true, 8, 2>), grid, dim3(64 * 8), 0, bed->stream, bed->d_img, bed->pitch, (const int32_t *)nullptr,
+                         cols, op.col0, n, m, m_slab, d_T.p, d_pairs.p, out);
+    } else if (op.rows_identity) {
       if (w4) BSN_TCROSS(true, 4, nullptr);
       else BSN_TCROSS(true, 8, nullptr);
     } else {
